@@ -1,0 +1,211 @@
+"""bench.py — the SpMM hot path on MI355X, BASELINE.json's metric.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2]
+
+A step is one pass of the hot path over the whole synthetic matrix:
+C = A_csr · B through `custom_mm.naive_spmm` (row-split HIP kernel).  N = 1 runs
+BASELINE.json configs[2] (1M×1M CSR at 0.01 % × 1M×256 dense fp32 — the
+configuration the metric is quoted on); N > 1 (launched by torch.distributed.run,
+one rank per GPU) runs configs[3]: the same matrix row-sharded over the ranks
+with an RCCL all-gather of C, strong scaling, `value` = whole-job GFLOP/s
+including the gather.  Inputs are generated with the pinned generator of
+SURVEY.md §8(d) and are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel
+(spmm_wave_row_kernel), from HIP events on the launch stream inside the timed
+region; `cpu_baseline` times the oracle (a CPU port of the reference's
+algorithm — test infrastructure) on a bounded sample of the same workload.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+for _p in (str(REPO), str(REPO / "matrix-multiplication_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md §Chip-level parameters
+
+WORKLOADS = {
+    # name: (M, K, density, N, description)
+    "c3": (1 << 20, 1 << 20, 1e-4, 256, "CSR 1M x 1M at 0.01% nnz x dense 1M x 256 fp32 (BASELINE.json configs[2])"),
+    "c2": (1 << 16, 1 << 16, 1e-3, 128, "CSR 64k x 64k at 0.1% nnz x dense 64k x 128 fp32 (BASELINE.json configs[1])"),
+}
+
+
+def algorithmic_bytes(nnz, M, N):
+    """per nonzero one B-row gather + col + val; per row rowptr + one C-row write."""
+    return nnz * (4 * N + 8) + 4 * (M + 1) + 4 * M * N
+
+
+def committed_traffic(workload):
+    """HBM bytes per launch from the committed PMC passes of this same command (profiles/), or None."""
+    p = REPO / "profiles" / "pmc_traffic.json"
+    if not p.exists():
+        return None
+    try:
+        rec = json.loads(p.read_text())
+        return rec.get(workload, {}).get("hbm_bytes_per_launch")
+    except (ValueError, OSError):
+        return None
+
+
+def cpu_baseline(rowptr, col, val, K, B, N, sample_rows):
+    """The oracle's OpenMP row-split SpMM (CPU port of reference src/naive_sparse_mm.cu:24-101)
+    on the first `sample_rows` rows of the same A and the same B; best of 2."""
+    import oracle
+    threads = min(16, os.cpu_count() or 1)
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    threads = int(os.environ["OMP_NUM_THREADS"])
+    rp = rowptr[:sample_rows + 1]
+    nnz = int(rp[-1])
+    best = float("inf")
+    for _ in range(2):
+        t0 = time.perf_counter()
+        oracle.spmm_csr_omp(rp, col[:nnz], val[:nnz], sample_rows, K, B)
+        best = min(best, time.perf_counter() - t0)
+    return {"value": round(2.0 * nnz * N / best / 1e9, 3), "unit": "GFLOP/s", "cores": threads, "kind": "port",
+            "sample": f"first {sample_rows} rows of the same A ({nnz} nnz) x the same B, oracle OpenMP row-split "
+                      f"SpMM, best of 2, {best:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--chunks", type=int, default=4, help="block-cyclic chunks per rank for N > 1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+
+    import custom_mm
+    import oracle  # only make_csr (the pinned generator) and the cpu_baseline leg
+    import sharded
+
+    M, K, density, N, desc = WORKLOADS[args.workload]
+    t0 = time.perf_counter()
+    rowptr, col, val = oracle.make_csr(M, K, density, seed=0)
+    B_host = np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32)
+    nnz = int(rowptr[-1])
+    gen_s = time.perf_counter() - t0
+    flops = 2.0 * nnz * N
+    bytes_alg = algorithmic_bytes(nnz, M, N)
+
+    B = torch.from_numpy(B_host).to(dev)
+    custom_mm.init_cusparse()
+    if world == 1:
+        d_rp, d_col, d_val = (torch.from_numpy(x).to(dev) for x in (rowptr, col, val))
+        C = torch.empty(M, N, device=dev)
+
+        def step():
+            custom_mm.naive_spmm(d_val, d_col, d_rp, nnz, M, K, B, C)
+        launches_per_step = 1
+        local_bytes_alg = bytes_alg
+    else:
+        op = sharded.ShardedSpMM(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), M, K, dev,
+                                 chunks=args.chunks)
+        C = op.alloc_output(N)
+
+        def step():
+            op.forward(B, out=C)
+        launches_per_step = op.chunks
+        local_bytes_alg = algorithmic_bytes(op.local_nnz, op.block_rows * op.chunks, N)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(args.steps):
+        step()
+        ev[i + 1].record()  # same (current) stream the kernels are launched on
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
+    step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+    kernel_ms = float(np.mean(step_ms)) / launches_per_step  # N = 1: one launch per step, back to back
+
+    # light in-run parity check: a few rows against the oracle (full parity lives in tests/)
+    rows = [0, M // 3, M - 1]
+    got = C[rows].cpu().numpy()
+    for i, r in enumerate(rows):
+        sl = slice(int(rowptr[r]), int(rowptr[r + 1]))
+        exp = oracle.spmm_csr(np.array([0, sl.stop - sl.start], np.int32), col[sl], val[sl], 1, K, B_host)
+        assert np.array_equal(got[i], exp[0]), f"row {r} differs from the oracle"
+
+    if rank == 0:
+        achieved = local_bytes_alg / launches_per_step / (kernel_ms * 1e-3) / 1e9
+        rec = {
+            "metric": "SpMM GFLOP/s, CSR(1M,0.01%) x dense(256)" if args.workload == "c3"
+                      else "SpMM GFLOP/s, CSR(64k,0.1%) x dense(128)",
+            "value": round(flops * args.steps / elapsed / 1e9, 2),
+            "unit": "GFLOP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": desc, "M": M, "K": K, "N": N, "nnz": nnz,
+                "generator": "numpy PCG64 seedA=0 seedB=1 (SURVEY.md 8d)",
+                "sha256_rowptr_col_val": hashlib.sha256(rowptr.tobytes() + col.tobytes() + val.tobytes()).hexdigest()[:16],
+                "parallelism": "single GPU" if world == 1 else
+                               f"A row-sharded over {world} GPUs, block-cyclic x{args.chunks}, RCCL all-gather of C",
+                "flops_per_step": flops, "algorithmic_bytes_per_step": bytes_alg,
+                "effective_GBps_whole_job": round(bytes_alg * args.steps / elapsed / 1e9, 1),
+                "input_generation_s": round(gen_s, 1),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "spmm_wave_row_kernel<1,8>" if N == 256 else "spmm_group_kernel",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": committed_traffic(args.workload) if world == 1 else None,
+                "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_bytes_per_launch": local_bytes_alg // launches_per_step,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(rowptr, col, val, K, B_host, N, sample_rows=min(M, 1 << 17))
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,194 @@
+/*
+ * mi_spmm.h — C-ABI of the MI355X (gfx950) SpMM hot path.
+ *
+ * This is the drop-in boundary below the `custom_mm` pybind module: plain
+ * pointers, sizes and a HIP stream handle; no torch types.  Every entry point
+ * enqueues work on `stream` and returns without synchronising.  Return value:
+ * 0 (MI_OK) or a negative MI_E* code; `mi_status_string` names it and
+ * `mi_last_hip_error` gives the hipError_t behind an MI_EHIP.
+ *
+ * Each entry cites the reference interface (relative to the reference repo
+ * smoorjani/matrix-multiplication) it replaces.  All device pointers must be
+ * valid for the sizes stated; index arrays are int32, values are float32.
+ */
+#ifndef MI_SPMM_H_
+#define MI_SPMM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_SPMM_ABI_VERSION 1
+
+typedef void* mi_stream_t; /* a hipStream_t; NULL = the null stream */
+
+enum {
+  MI_OK = 0,
+  MI_EINVAL = -1,   /* bad argument (null pointer, negative size, bad flag)   */
+  MI_ERANGE = -2,   /* a size does not fit the 32-bit index math of the path  */
+  MI_EHIP = -3,     /* a HIP runtime call / kernel launch failed              */
+  MI_ENOMEM = -4,   /* workspace too small                                    */
+  MI_EUNSORTED = -5 /* host inspector: COO rows not sorted (coo2csr contract) */
+};
+
+int mi_spmm_abi_version(void);
+const char* mi_status_string(int status);
+/* hipError_t (as int) recorded by the last MI_EHIP on this thread, else 0. */
+int mi_last_hip_error(void);
+const char* mi_last_hip_error_string(void);
+
+/* ------------------------------------------------------------------------ *
+ * K1 / B1 / B2 — C[M,N] = A_csr[M,K] · B[K,N], row-major B (ldb) and C (ldc).
+ * Replaces  spmm_kernel<float,SUM,true> + naive_spmm_wrapper
+ *           (src/naive_sparse_mm.cu:24-101, :104-136), reached from
+ *           custom_mm.naive_spmm (src/custom_mm.cpp:166-179), and
+ *           cusparse_mm_wrapper (src/baseline_mm.cu:167-216), reached from
+ *           custom_mm.cusparse_mmul (src/custom_mm.cpp:203-217).
+ * Per output element the products are accumulated with fused multiply-add in
+ * CSR order (p = rowptr[r] … rowptr[r+1]-1), so the result does not depend on
+ * the launch geometry.  Every element of C is written (zeros for empty rows).
+ * ------------------------------------------------------------------------ */
+int mi_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                    int64_t nnz, int32_t M, int32_t K, int32_t N,
+                    const float* B, int64_t ldb, float* C, int64_t ldc,
+                    mi_stream_t stream);
+
+/* As above with a kernel-variant override, for benchmarks and tests.
+ * variant: MI_SPMM_AUTO or one of the MI_SPMM_* ids below; an id that cannot
+ * handle the shape returns MI_EINVAL. */
+enum {
+  MI_SPMM_AUTO = 0,
+  MI_SPMM_WAVE_ROW_U4 = 1,  /* one wave per row, float4 lanes, 4 B-rows in flight  */
+  MI_SPMM_WAVE_ROW_U8 = 2,  /* … 8 in flight                                       */
+  MI_SPMM_WAVE_ROW_U16 = 3, /* … 16 in flight                                      */
+  MI_SPMM_GROUP_VEC4 = 4,   /* G = N/4 lanes per row, 64/G rows per wave            */
+  MI_SPMM_GROUP_SCALAR = 5, /* any N / alignment: one float per lane                */
+  MI_SPMM_WAVE_ROW_VL = 6,  /* wave per row, col/val via vector load + readlane     */
+  MI_SPMM_VARIANT_COUNT = 7
+};
+int mi_spmm_csr_f32_variant(int variant, const int32_t* rowptr, const int32_t* col,
+                            const float* val, int64_t nnz, int32_t M, int32_t K,
+                            int32_t N, const float* B, int64_t ldb, float* C,
+                            int64_t ldc, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * Batched form — `batch` independent products in ONE launch:
+ *   C[b] (M×N) = A[b] (M×K, CSR) · B[b] (K×N).
+ * rowptr is [batch, M+1]; entry rowptr[b*(M+1)+r] indexes into col/val with
+ * the batch item's base ALREADY included (a "rowptr of rowptrs": item b's
+ * nonzeros are rowptr[b*(M+1)] … rowptr[b*(M+1)+M]-1).  strideB / strideC are
+ * element strides between consecutive items (strideB = 0 broadcasts one B).
+ * Replaces the Python recursion + torch.stack of naive_matmul
+ * (matmuls.py:289-293) and the dead batch_idx feature of spmm_kernel
+ * (src/naive_sparse_mm.cu:36,52-53,86).
+ * ------------------------------------------------------------------------ */
+int mi_spmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col,
+                            const float* val, int64_t nnz_total, int32_t batch,
+                            int32_t M, int32_t K, int32_t N, const float* B,
+                            int64_t ldb, int64_t strideB, float* C, int64_t ldc,
+                            int64_t strideC, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * B3 / K2 executor — column-major dense operands:
+ *   C (M×N, column-major, ldc ≥ M) = A_csr (M×K) · B (K×N, column-major, ldb ≥ K)
+ * i.e. the caller holds activations X = Bᵀ as row-major [N,K] and receives
+ * Y = Cᵀ as row-major [N,M].
+ * Replaces torch_cusparse_mm_wrapper (src/baseline_mm.cu:272-321) behind
+ * custom_mm.cusparse_mmul_opt (src/custom_mm.cpp:259-270) and
+ * kernel_TiledELL / TiledSpMM_multiply (src/sparse_mm.cu:39-99, :371-385)
+ * behind custom_mm.tiledspmm_mm (src/custom_mm.cpp:337-348).
+ * `workspace` must hold mi_spmm_colmajor_workspace_bytes(M,K,N) bytes.
+ * ------------------------------------------------------------------------ */
+size_t mi_spmm_colmajor_workspace_bytes(int32_t M, int32_t K, int32_t N);
+int mi_spmm_csr_colmajor_f32(const int32_t* rowptr, const int32_t* col,
+                             const float* val, int64_t nnz, int32_t M, int32_t K,
+                             int32_t N, const float* B, int64_t ldb, float* C,
+                             int64_t ldc, void* workspace, size_t workspace_bytes,
+                             mi_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * K5 — dense fp32 product, row-major, optional batch and transposes:
+ *   C[b] (m×n) = op(A[b]) · op(B[b]),   op(X) = X or Xᵀ
+ * A[b] is stored (transa ? k×m : m×k) with leading dimension lda, B[b] is
+ * stored (transb ? n×k : k×n) with ldb, C[b] m×n with ldc; stride* are element
+ * strides between batch items (0 broadcasts).  alpha = 1, beta = 0.
+ * Replaces cublas_mm_wrapper / cublas_bmm_wrapper
+ * (src/baseline_mm.cu:52-102, :105-155) behind custom_mm.cublas_mmul /
+ * cublas_bmm (src/custom_mm.cpp:104-164).  Products are accumulated over k in
+ * increasing order with fused multiply-add (exact-fp32 MFMA), one rounding per
+ * product.
+ * ------------------------------------------------------------------------ */
+int mi_gemm_f32(int transa, int transb, int32_t m, int32_t n, int32_t k,
+                const float* A, int64_t lda, int64_t strideA, const float* B,
+                int64_t ldb, int64_t strideB, float* C, int64_t ldc,
+                int64_t strideC, int32_t batch, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * Dense → CSR on the device (exact-zero test, columns ascending within a row),
+ * batched: `batch` matrices of rows×cols (leading dimension ld, item stride
+ * `stride`).  Two steps so the caller can size col/val without a host sync
+ * per item:
+ *   1. mi_dense_to_csr_count: writes rowptr[batch*(rows+1)] as a "rowptr of
+ *      rowptrs" (see mi_spmm_csr_batched_f32); rowptr[batch*(rows+1)-1] is the
+ *      total nnz.  `workspace` ≥ mi_dense_to_csr_workspace_bytes(batch, rows).
+ *   2. mi_dense_to_csr_fill: writes col / val (capacity ≥ total nnz).
+ * Replaces dense_to_csr (src/baseline_mm.cu:218-264, cusparseDenseToSparse)
+ * and the per-slice torch `to_sparse_csr()` of naive_matmul (matmuls.py:295-296).
+ * ------------------------------------------------------------------------ */
+size_t mi_dense_to_csr_workspace_bytes(int32_t batch, int32_t rows);
+int mi_dense_to_csr_count(const float* dense, int32_t batch, int32_t rows,
+                          int32_t cols, int64_t ld, int64_t stride,
+                          int32_t* rowptr, void* workspace, size_t workspace_bytes,
+                          mi_stream_t stream);
+int mi_dense_to_csr_fill(const float* dense, int32_t batch, int32_t rows,
+                         int32_t cols, int64_t ld, int64_t stride,
+                         const int32_t* rowptr, int32_t* col, float* val,
+                         mi_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * Device CSR transpose (A M×K → Aᵀ K×M, columns ascending within each row of
+ * Aᵀ, stable): used by the backward pass  grad_B = Aᵀ · dC.
+ * `workspace` ≥ mi_csr_transpose_workspace_bytes(M, K, nnz).
+ * No counterpart in the reference (its backward re-sparsifies a strided view,
+ * matmuls.py:319-325, SURVEY.md §8a defect 1).
+ * ------------------------------------------------------------------------ */
+size_t mi_csr_transpose_workspace_bytes(int32_t M, int32_t K, int64_t nnz);
+int mi_csr_transpose_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                         int64_t nnz, int32_t M, int32_t K, int32_t* t_rowptr,
+                         int32_t* t_col, float* t_val, void* workspace,
+                         size_t workspace_bytes, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * SDDMM on A's pattern:  out[p] = Σ_j dC[row(p), j] · B[col[p], j]
+ * = the gradient of C = A·B with respect to A's stored values.
+ * ------------------------------------------------------------------------ */
+int mi_sddmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz,
+                     int32_t M, int32_t K, int32_t N, const float* dC, int64_t lddc,
+                     const float* B, int64_t ldb, float* out_val,
+                     mi_stream_t stream);
+
+/* Dense 2-D transpose  dst[cols, rows] = src[rows, cols]ᵀ (row-major, ld's). */
+int mi_transpose_f32(const float* src, int32_t rows, int32_t cols, int64_t ld_src,
+                     float* dst, int64_t ld_dst, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
+ * HOST inspector step (no GPU): COO (sorted by row) → CSR, keeping the input
+ * order inside a row.  Replaces TiledSpMM_coo2csr (src/sparse_mm.cu:110-134).
+ * rowptr has M+1 entries; col_out / val_out have nnz entries.
+ * ------------------------------------------------------------------------ */
+int mi_coo_to_csr_host(int32_t M, int64_t nnz, const int32_t* coo_row,
+                       const int32_t* coo_col, const float* coo_val,
+                       int32_t* rowptr, int32_t* col_out, float* val_out);
+
+/* Replaces dummy_kernel_launch (src/baseline_mm.cu:24-35): launches a 64×64
+ * grid on the stream; each thread writes its global id into out[4096]
+ * (the reference printf()s it). */
+int mi_dummy_kernel(int32_t* out, mi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_SPMM_H_ */

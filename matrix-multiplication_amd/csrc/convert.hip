@@ -1,0 +1,426 @@
+// Format-side kernels of the SpMM path (include/mi_spmm.h):
+//   dense 2-D transpose, column-major SpMM executor, device dense→CSR
+//   (count / scan / fill, batched), device CSR transpose, SDDMM.
+// Reference counterparts are cited at each entry point.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "mi_common.h"
+
+namespace {
+
+// --------------------------------------------------------------------------
+// Dense transpose: dst[c, r] = src[r, c]; 64×64 tiles through padded LDS so
+// both the global read and the global write are 256-B coalesced.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int rows,
+                                                        int cols, long ld_src,
+                                                        float* __restrict__ dst, long ld_dst,
+                                                        int tiles_c) {
+  __shared__ float tile[64][65];
+  const int tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+  const int r0 = tr * 64, c0 = tc * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + i * 4, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + i * 4][tx] = src[(long)r * ld_src + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + i * 4, r = r0 + tx;
+    if (c < cols && r < rows) dst[(long)c * ld_dst + r] = tile[tx][ty + i * 4];
+  }
+}
+
+int launch_transpose(const float* src, int rows, int cols, long ld_src, float* dst, long ld_dst,
+                     hipStream_t s) {
+  if (rows == 0 || cols == 0) return MI_OK;
+  const long tiles_r = (rows + 63) / 64, tiles_c = (cols + 63) / 64;
+  if (tiles_r * tiles_c > 0x7fffffffL) return MI_ERANGE;
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)(tiles_r * tiles_c)), dim3(256), 0, s, src,
+                     rows, cols, ld_src, dst, ld_dst, (int)tiles_c);
+  return mi::check_launch();
+}
+
+// --------------------------------------------------------------------------
+// Exclusive scan of n int32 counts, 2048 per block, three launches.
+// scatter variant: element i = (b, r) with r < rows goes to
+// out[b*(rows+1) + r]; the item's end slot out[b*(rows+1)+rows] gets the
+// inclusive value — the "rowptr of rowptrs" layout of the batched CSR.
+// --------------------------------------------------------------------------
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = 256 * SCAN_ITEMS;
+
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* total) {
+  __shared__ int wave_sums[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wave_sums[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int s = wave_sums[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(const int* __restrict__ in, long n,
+                                                              int* __restrict__ block_sums) {
+  const long base = (long)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i)
+    if (base + i < n) s += in[base + i];
+  int total;
+  block_exclusive_scan_256(s, &total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// Single block: exclusive scan of block_sums in place.
+__global__ __launch_bounds__(256) void scan_of_sums_kernel(int* __restrict__ block_sums, long nb) {
+  int carry = 0;
+  for (long b0 = 0; b0 < nb; b0 += 256) {
+    const long i = b0 + threadIdx.x;
+    const int v = i < nb ? block_sums[i] : 0;
+    int total;
+    const int ex = block_exclusive_scan_256(v, &total);
+    if (i < nb) block_sums[i] = carry + ex;
+    carry += total;
+  }
+}
+
+__global__ __launch_bounds__(256) void scan_scatter_kernel(const int* __restrict__ in, long n,
+                                                           const int* __restrict__ block_sums,
+                                                           int* __restrict__ out, int rows) {
+  const long base = (long)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  int v[SCAN_ITEMS];
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    v[i] = base + i < n ? in[base + i] : 0;
+    s += v[i];
+  }
+  int total;
+  int run = block_sums[blockIdx.x] + block_exclusive_scan_256(s, &total);
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    const long idx = base + i;
+    if (idx < n) {
+      const long b = idx / rows;
+      const int r = (int)(idx - b * rows);
+      out[b * ((long)rows + 1) + r] = run;
+      if (r == rows - 1) out[b * ((long)rows + 1) + rows] = run + v[i];
+    }
+    run += v[i];
+  }
+}
+
+size_t scan_workspace_ints(long n) { return (size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 1; }
+
+// counts[n] → out (rowptr-of-rowptrs with `rows` rows per item); n = batch*rows.
+int launch_scan_rowptr(const int* counts, long n, int rows, int* out, int* block_sums,
+                       hipStream_t s) {
+  const long nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (nb > 0x7fffffffL) return MI_ERANGE;
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nb), dim3(256), 0, s, counts, n,
+                     block_sums);
+  hipLaunchKernelGGL(scan_of_sums_kernel, dim3(1), dim3(256), 0, s, block_sums, nb);
+  hipLaunchKernelGGL(scan_scatter_kernel, dim3((unsigned)nb), dim3(256), 0, s, counts, n,
+                     block_sums, out, rows);
+  return mi::check_launch();
+}
+
+// --------------------------------------------------------------------------
+// Dense → CSR: one wave per dense row.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void count_nonzeros_kernel(const float* __restrict__ dense,
+                                                             long total_rows, int rows, int cols,
+                                                             long ld, long stride,
+                                                             int* __restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  const long id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (id >= total_rows) return;
+  const long b = id / rows;
+  const float* src = dense + b * stride + (id - b * rows) * ld;
+  int cnt = 0;
+  for (int c0 = 0; c0 < cols; c0 += 64) {
+    const int c = c0 + lane;
+    const bool nz = c < cols && src[c] != 0.0f;
+    cnt += __builtin_popcountll(__ballot(nz));
+  }
+  if (lane == 0) counts[id] = cnt;
+}
+
+__global__ __launch_bounds__(256) void fill_csr_kernel(const float* __restrict__ dense,
+                                                       long total_rows, int rows, int cols, long ld,
+                                                       long stride, const int* __restrict__ rowptr,
+                                                       int* __restrict__ col,
+                                                       float* __restrict__ val) {
+  const int lane = threadIdx.x & 63;
+  const long id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (id >= total_rows) return;
+  const long b = id / rows;
+  const int r = (int)(id - b * rows);
+  const float* src = dense + b * stride + (long)r * ld;
+  long out = rowptr[b * ((long)rows + 1) + r];
+  for (int c0 = 0; c0 < cols; c0 += 64) {
+    const int c = c0 + lane;
+    const float x = c < cols ? src[c] : 0.0f;
+    const bool nz = c < cols && x != 0.0f;
+    const unsigned long long mask = __ballot(nz);
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                               __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+    if (nz) {
+      col[out + rank] = c;
+      val[out + rank] = x;
+    }
+    out += __builtin_popcountll(mask);
+  }
+}
+
+// --------------------------------------------------------------------------
+// CSR transpose helpers.
+// --------------------------------------------------------------------------
+__global__ void iota_kernel(int* out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int)i;
+}
+
+__global__ void histogram_kernel(const int* __restrict__ col, long nnz, int* __restrict__ counts) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nnz) atomicAdd(&counts[col[i]], 1);
+}
+
+// q-th entry of Aᵀ comes from original entry p = perm[q]: its row in A (found
+// by binary search in rowptr) becomes the column index.
+__global__ void gather_transposed_kernel(const int* __restrict__ perm, long nnz,
+                                         const int* __restrict__ rowptr, int M,
+                                         const float* __restrict__ val, int* __restrict__ t_col,
+                                         float* __restrict__ t_val) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nnz) return;
+  const int p = perm[q];
+  int lo = 0, hi = M;  // largest r with rowptr[r] <= p
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (rowptr[mid] <= p) lo = mid;
+    else hi = mid;
+  }
+  t_col[q] = lo;
+  t_val[q] = val[p];
+}
+
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// --------------------------------------------------------------------------
+// SDDMM: one wave per row of A; lane l sums j ≡ l (mod 64) ascending, then a
+// xor-butterfly (32,16,…,1) combines the 64 partial sums.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sddmm_kernel(const int* __restrict__ rowptr,
+                                                    const int* __restrict__ col, int M, int N,
+                                                    const float* __restrict__ dC, long lddc,
+                                                    const float* __restrict__ B, long ldb,
+                                                    float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* x = dC + row * lddc;
+  const int start = rowptr[row], end = rowptr[row + 1];
+  for (int p = start; p < end; ++p) {
+    const float* y = B + (long)col[p] * ldb;
+    float s = 0.f;
+    for (int j = lane; j < N; j += 64) s = __builtin_fmaf(x[j], y[j], s);
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) s += __shfl_xor(s, w, 64);
+    if (lane == 0) out[p] = s;
+  }
+}
+
+}  // namespace
+
+// Defined in spmm_csr.hip.
+extern "C" int mi_spmm_csr_f32(const int32_t*, const int32_t*, const float*, int64_t, int32_t,
+                               int32_t, int32_t, const float*, int64_t, float*, int64_t,
+                               mi_stream_t);
+
+extern "C" {
+
+int mi_transpose_f32(const float* src, int32_t rows, int32_t cols, int64_t ld_src, float* dst,
+                     int64_t ld_dst, mi_stream_t stream) {
+  if (rows < 0 || cols < 0) return MI_EINVAL;
+  if (rows == 0 || cols == 0) return MI_OK;
+  if (!src || !dst || ld_src < cols || ld_dst < rows) return MI_EINVAL;
+  return launch_transpose(src, rows, cols, ld_src, dst, ld_dst, static_cast<hipStream_t>(stream));
+}
+
+// Column-major executor (round-1 form): bring B to row-major [K,N] and C back
+// from row-major [M,N] with two coalesced tile transposes around the row-split
+// kernel.  The transposes move 8·(K+M)·N bytes against the gather's 4·N·nnz, so
+// they are a small fraction for rows longer than a few nonzeros.
+size_t mi_spmm_colmajor_workspace_bytes(int32_t M, int32_t K, int32_t N) {
+  if (M < 0 || K < 0 || N < 0) return 0;
+  return align_up((size_t)K * N * 4) + align_up((size_t)M * N * 4);
+}
+
+int mi_spmm_csr_colmajor_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                             int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
+                             int64_t ldb, float* C, int64_t ldc, void* workspace,
+                             size_t workspace_bytes, mi_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (M < 0 || K < 0 || N < 0 || nnz < 0) return MI_EINVAL;
+  if (M == 0 || N == 0) return MI_OK;
+  if (!rowptr || !C || ldc < M) return MI_EINVAL;
+  if (K > 0 && (!B || ldb < K)) return MI_EINVAL;
+  if (workspace_bytes < mi_spmm_colmajor_workspace_bytes(M, K, N)) return MI_ENOMEM;
+  if (!workspace || !mi::aligned16(workspace)) return MI_EINVAL;
+  float* Bt = static_cast<float*>(workspace);  // [K, N] row-major
+  float* Ct = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)K * N * 4));
+  // column-major K×N with ldb  ==  row-major [N, ldb]; its transpose is [K, N].
+  int st = launch_transpose(B, N, K, ldb, Bt, N, s);
+  if (st != MI_OK) return st;
+  st = mi_spmm_csr_f32(rowptr, col, val, nnz, M, K, N, Bt, N, Ct, N, stream);
+  if (st != MI_OK) return st;
+  // row-major [M, N] → row-major [N, ldc]  ==  column-major M×N with ldc.
+  return launch_transpose(Ct, M, N, N, C, ldc, s);
+}
+
+size_t mi_dense_to_csr_workspace_bytes(int32_t batch, int32_t rows) {
+  if (batch < 0 || rows < 0) return 0;
+  const long n = (long)batch * rows;
+  return align_up((size_t)n * 4) + align_up(scan_workspace_ints(n) * 4);
+}
+
+// Replaces dense_to_csr's cusparseDenseToSparse_{bufferSize,analysis}
+// (reference src/baseline_mm.cu:232-247) for a whole batch in three launches.
+int mi_dense_to_csr_count(const float* dense, int32_t batch, int32_t rows, int32_t cols,
+                          int64_t ld, int64_t stride, int32_t* rowptr, void* workspace,
+                          size_t workspace_bytes, mi_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (batch < 0 || rows < 0 || cols < 0) return MI_EINVAL;
+  if (batch == 0) return MI_OK;
+  if (!rowptr) return MI_EINVAL;
+  const long n = (long)batch * rows;
+  if (n == 0) {  // rows == 0: every item is just its end slot
+    MI_HIP_TRY(hipMemsetAsync(rowptr, 0, sizeof(int32_t) * (size_t)batch, s));
+    return MI_OK;
+  }
+  if ((cols > 0 && !dense) || ld < cols || stride < 0) return MI_EINVAL;
+  if (workspace_bytes < mi_dense_to_csr_workspace_bytes(batch, rows)) return MI_ENOMEM;
+  if (!workspace) return MI_EINVAL;
+  int* counts = static_cast<int*>(workspace);
+  int* block_sums = reinterpret_cast<int*>(static_cast<char*>(workspace) + align_up((size_t)n * 4));
+  const long blocks = (n + 3) / 4;
+  if (blocks > 0x7fffffffL) return MI_ERANGE;
+  hipLaunchKernelGGL(count_nonzeros_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dense, n, rows,
+                     cols, ld, stride, counts);
+  int st = mi::check_launch();
+  if (st != MI_OK) return st;
+  return launch_scan_rowptr(counts, n, rows, rowptr, block_sums, s);
+}
+
+// Replaces cusparseDenseToSparse_convert (reference src/baseline_mm.cu:249-258).
+int mi_dense_to_csr_fill(const float* dense, int32_t batch, int32_t rows, int32_t cols, int64_t ld,
+                         int64_t stride, const int32_t* rowptr, int32_t* col, float* val,
+                         mi_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (batch < 0 || rows < 0 || cols < 0) return MI_EINVAL;
+  const long n = (long)batch * rows;
+  if (n == 0 || cols == 0) return MI_OK;
+  if (!dense || !rowptr || !col || !val || ld < cols || stride < 0) return MI_EINVAL;
+  const long blocks = (n + 3) / 4;
+  if (blocks > 0x7fffffffL) return MI_ERANGE;
+  hipLaunchKernelGGL(fill_csr_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dense, n, rows, cols,
+                     ld, stride, rowptr, col, val);
+  return mi::check_launch();
+}
+
+// Workspace: sorted keys | iota | permutation | column counts | scan sums | rocPRIM temp.
+static size_t transpose_sort_temp_bytes(int64_t nnz) {
+  size_t bytes = 0;
+  if (nnz > 0 &&
+      rocprim::radix_sort_pairs(nullptr, bytes, (const int*)nullptr, (int*)nullptr,
+                                (const int*)nullptr, (int*)nullptr, (size_t)nnz, 0, 32,
+                                (hipStream_t)0) != hipSuccess)
+    return 0;
+  return bytes;
+}
+
+size_t mi_csr_transpose_workspace_bytes(int32_t M, int32_t K, int64_t nnz) {
+  if (M < 0 || K < 0 || nnz < 0) return 0;
+  return 3 * align_up((size_t)nnz * 4) + align_up(((size_t)K + 1) * 4) +
+         align_up(scan_workspace_ints(K) * 4) + align_up(transpose_sort_temp_bytes(nnz));
+}
+
+int mi_csr_transpose_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
+                         int32_t M, int32_t K, int32_t* t_rowptr, int32_t* t_col, float* t_val,
+                         void* workspace, size_t workspace_bytes, mi_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (M < 0 || K < 0 || nnz < 0) return MI_EINVAL;
+  if (nnz > 0x7fffffffLL) return MI_ERANGE;
+  if (!t_rowptr) return MI_EINVAL;
+  if (nnz == 0 || K == 0) {
+    MI_HIP_TRY(hipMemsetAsync(t_rowptr, 0, sizeof(int32_t) * ((size_t)K + 1), s));
+    return MI_OK;
+  }
+  if (!rowptr || !col || !val || !t_col || !t_val) return MI_EINVAL;
+  if (workspace_bytes < mi_csr_transpose_workspace_bytes(M, K, nnz)) return MI_ENOMEM;
+  if (!workspace) return MI_EINVAL;
+  char* w = static_cast<char*>(workspace);
+  int* keys_out = reinterpret_cast<int*>(w);
+  w += align_up((size_t)nnz * 4);
+  int* iota = reinterpret_cast<int*>(w);
+  w += align_up((size_t)nnz * 4);
+  int* perm = reinterpret_cast<int*>(w);
+  w += align_up((size_t)nnz * 4);
+  int* counts = reinterpret_cast<int*>(w);
+  w += align_up(((size_t)K + 1) * 4);
+  int* block_sums = reinterpret_cast<int*>(w);
+  w += align_up(scan_workspace_ints(K) * 4);
+  size_t temp_bytes = transpose_sort_temp_bytes(nnz);
+
+  const unsigned nb = (unsigned)((nnz + 255) / 256);
+  // rows of Aᵀ: histogram of columns → exclusive scan (rows = K, one "item").
+  MI_HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int) * ((size_t)K + 1), s));
+  hipLaunchKernelGGL(histogram_kernel, dim3(nb), dim3(256), 0, s, col, nnz, counts);
+  int st = launch_scan_rowptr(counts, K, K, t_rowptr, block_sums, s);
+  if (st != MI_OK) return st;
+  // stable sort of entry ids by column: inside a row of Aᵀ entries keep
+  // ascending original order (= ascending row of A).
+  hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, s, iota, nnz);
+  int end_bit = 1;
+  while (end_bit < 32 && (1LL << end_bit) < (long long)K) ++end_bit;
+  MI_HIP_TRY(rocprim::radix_sort_pairs(w, temp_bytes, col, keys_out, iota, perm, (size_t)nnz, 0,
+                                       end_bit, s));
+  hipLaunchKernelGGL(gather_transposed_kernel, dim3(nb), dim3(256), 0, s, perm, nnz, rowptr, M, val,
+                     t_col, t_val);
+  return mi::check_launch();
+}
+
+int mi_sddmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz, int32_t M, int32_t K,
+                     int32_t N, const float* dC, int64_t lddc, const float* B, int64_t ldb,
+                     float* out_val, mi_stream_t stream) {
+  (void)K;
+  if (M < 0 || N < 0 || nnz < 0) return MI_EINVAL;
+  if (M == 0 || nnz == 0) return MI_OK;
+  if (!rowptr || !col || !out_val) return MI_EINVAL;
+  if (N > 0 && (!dC || !B || lddc < N || ldb < N)) return MI_EINVAL;
+  const long blocks = ((long)M + 3) / 4;
+  hipLaunchKernelGGL(sddmm_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), rowptr, col, M, N, dC, lddc, B, ldb, out_val);
+  return mi::check_launch();
+}
+
+}  // extern "C"

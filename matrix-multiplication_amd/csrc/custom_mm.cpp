@@ -1,0 +1,594 @@
+// custom_mm — pybind11 module with the reference's 16 entry points
+// (smoorjani/matrix-multiplication src/custom_mm.cpp:393-416, same names, same
+// positional signatures, same "caller allocates C, callee fills it and returns
+// the same tensor" convention), backed by the MI355X C-ABI library
+// libmi_spmm.so (include/mi_spmm.h).
+//
+// This layer only validates tensors, extracts pointers / leading dimensions,
+// looks up torch's current HIP stream for the tensors' device and calls the
+// C-ABI.  There is no CPU fallback: every compute entry point requires device
+// tensors and raises otherwise.
+//
+// Differences from the reference that are deliberate:
+//  * work is enqueued on torch's current stream of the tensors' device, not on
+//    the legacy default stream (reference naive_sparse_mm.cu:117,133);
+//  * dtype, device, shape and layout are checked (the reference reads
+//    data_ptr() of whatever it is given, README.md:44); strided / transposed
+//    views are handled through leading dimensions or copied, never misread;
+//  * the inspect-style registries hold tensor references (the reference keeps
+//    raw pointers and later cudaFree()s torch memory, custom_mm.cpp:249-251,
+//    :272-277), are mutex-protected, and an unknown layer name raises instead
+//    of aliasing handle 0 (custom_mm.cpp:260-263, :338-341).
+#include <torch/extension.h>
+
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+
+#include "mi_spmm.h"
+
+namespace {
+
+void check_status(int st, const char* what) {
+  if (st == MI_OK) return;
+  if (st == MI_EHIP)
+    TORCH_CHECK(false, what, ": HIP error: ", mi_last_hip_error_string());
+  if (st == MI_EINVAL) throw std::invalid_argument(std::string(what) + ": " + mi_status_string(st));
+  TORCH_CHECK(false, what, ": ", mi_status_string(st));
+}
+
+void check_device_f32(const torch::Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda(), name, " must be a device (HIP) tensor; custom_mm has no CPU path");
+  TORCH_CHECK(t.scalar_type() == torch::kFloat32, name, " must be float32, got ", t.scalar_type());
+}
+
+void check_device_i32(const torch::Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda(), name, " must be a device (HIP) tensor; custom_mm has no CPU path");
+  TORCH_CHECK(t.scalar_type() == torch::kInt32, name, " must be int32, got ", t.scalar_type());
+}
+
+void check_same_device(const torch::Tensor& a, const torch::Tensor& b, const char* what) {
+  TORCH_CHECK(a.device() == b.device(), what, ": tensors are on different devices (", a.device(),
+              " vs ", b.device(), ")");
+}
+
+mi_stream_t stream_of(const torch::Tensor& t) {
+  return static_cast<mi_stream_t>(c10::hip::getCurrentHIPStream(t.device().index()).stream());
+}
+
+// A dense operand as the C-ABI wants it: pointer, leading dimension, batch
+// stride, and whether the stored matrix is the transpose of the logical one.
+struct Operand {
+  torch::Tensor keep;  // owns the memory for the duration of the call
+  const float* ptr;
+  int64_t ld;
+  int64_t batch_stride;
+  bool stored_transposed;
+  int64_t rows, cols;  // logical (before `stored_transposed`)
+};
+
+// View the last two dims of `t` (after flattening the leading `nbatch` dims to
+// one) as row-major-with-ld, or as a transposed row-major matrix; copy only
+// when the strides fit neither.
+Operand as_operand(const torch::Tensor& t, int nbatch_dims) {
+  Operand o;
+  const int64_t d = t.dim();
+  TORCH_CHECK(d == nbatch_dims + 2, "expected a ", nbatch_dims + 2, "-d tensor, got ", d, "-d");
+  o.rows = t.size(d - 2);
+  o.cols = t.size(d - 1);
+  // Leading dims must flatten to ONE batch stride (nbatch_dims ≤ 2 here).
+  auto batch_stride_of = [&](const torch::Tensor& y, int64_t& stride) {
+    stride = 0;
+    if (nbatch_dims == 0) return true;
+    if (nbatch_dims == 1) {
+      stride = y.size(0) > 1 ? y.stride(0) : 0;
+      return stride >= 0;
+    }
+    const int64_t b0 = y.size(0), b1 = y.size(1), s0 = y.stride(0), s1 = y.stride(1);
+    if (b0 <= 1) stride = b1 > 1 ? s1 : 0;
+    else if (b1 <= 1) stride = s0;
+    else if (s0 == s1 * b1) stride = s1;
+    else return false;
+    return stride >= 0;
+  };
+  // Row-major with a leading dimension, or the transpose of one.
+  auto layout_of = [&](const torch::Tensor& y, bool& transposed, int64_t& ld) {
+    const int64_t sr = y.stride(d - 2), sc = y.stride(d - 1);
+    if ((sc == 1 || o.cols <= 1) && (o.rows <= 1 || sr >= std::max<int64_t>(o.cols, 1))) {
+      transposed = false;
+      ld = o.rows > 1 ? sr : std::max<int64_t>(o.cols, 1);
+      return true;
+    }
+    if ((sr == 1 || o.rows <= 1) && (o.cols <= 1 || sc >= std::max<int64_t>(o.rows, 1))) {
+      transposed = true;
+      ld = o.cols > 1 ? sc : std::max<int64_t>(o.rows, 1);
+      return true;
+    }
+    return false;
+  };
+  torch::Tensor x = t;
+  bool transposed = false;
+  int64_t ld = 0, bstride = 0;
+  if (!layout_of(x, transposed, ld) || !batch_stride_of(x, bstride)) {
+    x = t.contiguous();
+    TORCH_INTERNAL_ASSERT(layout_of(x, transposed, ld) && batch_stride_of(x, bstride));
+  }
+  o.keep = x;
+  o.ptr = x.data_ptr<float>();
+  o.stored_transposed = transposed;
+  o.ld = ld;
+  o.batch_stride = bstride;
+  return o;
+}
+
+int64_t batch_count(const torch::Tensor& t, int nbatch_dims) {
+  int64_t b = 1;
+  for (int i = 0; i < nbatch_dims; ++i) b *= t.size(i);
+  return b;
+}
+
+// C = op(A)·op(B) for `nbatch_dims` leading batch dims.
+torch::Tensor gemm_impl(const torch::Tensor& A, const torch::Tensor& B, torch::Tensor C,
+                        int nbatch_dims, bool transa, bool transb, const char* what) {
+  check_device_f32(A, "A");
+  check_device_f32(B, "B");
+  check_device_f32(C, "C");
+  check_same_device(A, B, what);
+  check_same_device(A, C, what);
+  TORCH_CHECK(C.is_contiguous(), what, ": C must be contiguous");
+  TORCH_CHECK(C.dim() == nbatch_dims + 2, what, ": C has the wrong rank");
+  for (int i = 0; i < nbatch_dims; ++i)
+    TORCH_CHECK(A.size(i) == B.size(i) && A.size(i) == C.size(i), what,
+                ": batch dimensions of A, B and C differ");
+  Operand a = as_operand(A, nbatch_dims);
+  Operand b = as_operand(B, nbatch_dims);
+  const int64_t m = transa ? a.cols : a.rows, ka = transa ? a.rows : a.cols;
+  const int64_t kb = transb ? b.cols : b.rows, n = transb ? b.rows : b.cols;
+  TORCH_CHECK(ka == kb, what, ": inner dimensions differ (", ka, " vs ", kb, ")");
+  TORCH_CHECK(C.size(-2) == m && C.size(-1) == n, what, ": C must be ", m, "x", n, ", got ",
+              C.size(-2), "x", C.size(-1));
+  TORCH_CHECK(m <= INT32_MAX && n <= INT32_MAX && ka <= INT32_MAX, what, ": dimension too large");
+  const int64_t batch = batch_count(C, nbatch_dims);
+  c10::hip::HIPGuard guard(C.device().index());
+  const int st = mi_gemm_f32(transa != a.stored_transposed, transb != b.stored_transposed, (int32_t)m,
+                             (int32_t)n, (int32_t)ka, a.ptr, a.ld, a.batch_stride, b.ptr, b.ld,
+                             b.batch_stride, C.data_ptr<float>(), std::max<int64_t>(n, 1), m * n,
+                             (int32_t)batch, stream_of(C));
+  check_status(st, what);
+  return C;
+}
+
+// ---- cuBLAS-named entry points (reference custom_mm.cpp:104-164) ------------
+
+torch::Tensor cublas_mmul(torch::Tensor A, torch::Tensor B, torch::Tensor C, bool transa,
+                          bool transb) {
+  return gemm_impl(A, B, C, 0, transa, transb, "cublas_mmul");
+}
+
+torch::Tensor cublas_bmm(torch::Tensor A, torch::Tensor B, torch::Tensor C, int dim, bool transa,
+                         bool transb) {
+  if (dim == 3) return gemm_impl(A, B, C, 1, transa, transb, "cublas_bmm");
+  if (dim == 4) return gemm_impl(A, B, C, 2, transa, transb, "cublas_bmm");
+  if (dim == 2) return cublas_mmul(A, B, C, transa, transb);
+  throw std::invalid_argument("Invalid dim argument.");  // reference custom_mm.cpp:162
+}
+
+// ---- CSR × dense, row-major (reference custom_mm.cpp:166-179, :203-217) -----
+
+torch::Tensor spmm_impl(const torch::Tensor& A_values, const torch::Tensor& A_columns,
+                        const torch::Tensor& A_offsets, int64_t nnzA, int64_t A_rows,
+                        int64_t A_cols, const torch::Tensor& B, torch::Tensor C, const char* what) {
+  check_device_f32(A_values, "A_values");
+  check_device_i32(A_columns, "A_columns");
+  check_device_i32(A_offsets, "A_offsets");
+  check_device_f32(B, "B");
+  check_device_f32(C, "C");
+  check_same_device(A_values, C, what);
+  check_same_device(A_columns, C, what);
+  check_same_device(A_offsets, C, what);
+  check_same_device(B, C, what);
+  TORCH_CHECK(A_rows >= 0 && A_cols >= 0 && nnzA >= 0, what, ": negative size");
+  TORCH_CHECK(A_rows <= INT32_MAX && A_cols <= INT32_MAX, what, ": dimension too large");
+  TORCH_CHECK(A_values.is_contiguous() && A_columns.is_contiguous() && A_offsets.is_contiguous(),
+              what, ": CSR arrays must be contiguous");
+  TORCH_CHECK(A_values.numel() >= nnzA && A_columns.numel() >= nnzA, what,
+              ": nnzA exceeds the CSR arrays");
+  TORCH_CHECK(A_offsets.numel() == A_rows + 1, what, ": A_offsets must have A_rows + 1 entries");
+  TORCH_CHECK(B.dim() == 2 && C.dim() == 2, what, ": B and C must be 2-d");
+  TORCH_CHECK(B.size(0) == A_cols, what, ": B must have A_cols = ", A_cols, " rows, got ", B.size(0));
+  TORCH_CHECK(C.size(0) == A_rows && C.size(1) == B.size(1), what, ": C must be ", A_rows, "x",
+              B.size(1));
+  TORCH_CHECK(C.is_contiguous(), what, ": C must be contiguous");
+  torch::Tensor Bc = (B.stride(1) == 1 || B.size(1) == 1) && (B.stride(0) >= B.size(1) || B.size(0) <= 1)
+                         ? B
+                         : B.contiguous();
+  const int64_t N = B.size(1);
+  const int64_t ldb = Bc.size(0) > 1 ? Bc.stride(0) : std::max<int64_t>(N, 1);
+  c10::hip::HIPGuard guard(C.device().index());
+  const int st = mi_spmm_csr_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
+                                 A_values.data_ptr<float>(), nnzA, (int32_t)A_rows, (int32_t)A_cols,
+                                 (int32_t)N, Bc.data_ptr<float>(), ldb, C.data_ptr<float>(),
+                                 std::max<int64_t>(N, 1), stream_of(C));
+  check_status(st, what);
+  return C;
+}
+
+torch::Tensor naive_spmm(torch::Tensor A_values, torch::Tensor A_columns, torch::Tensor A_offsets,
+                         int nnzA, int A_rows, int A_cols, torch::Tensor B, torch::Tensor C) {
+  return spmm_impl(A_values, A_columns, A_offsets, nnzA, A_rows, A_cols, B, C, "naive_spmm");
+}
+
+torch::Tensor cusparse_mmul(torch::Tensor A_values, torch::Tensor A_columns, torch::Tensor A_offsets,
+                            int nnzA, int A_rows, int A_cols, torch::Tensor B, torch::Tensor C) {
+  return spmm_impl(A_values, A_columns, A_offsets, nnzA, A_rows, A_cols, B, C, "cusparse_mmul");
+}
+
+// ---- additions to the reference surface (used by matmuls.py) -----------------
+// The reference batches by Python recursion + torch.stack with one
+// to_sparse_csr() per slice (matmuls.py:289-297) and has no working backward
+// (SURVEY.md §8a defects 1-2); these four entry points give matmuls.py the
+// one-launch batched forward and the sparse backward.  They are extra names:
+// the 16 reference names keep their exact signatures.
+
+// dense [..., rows, cols] → (values f32[nnz], columns i32[nnz], offsets i32[batch, rows+1]);
+// offsets are global over the batch ("rowptr of rowptrs", include/mi_spmm.h).
+// Device counterpart of dense_to_csr (reference src/baseline_mm.cu:218-264).
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> dense_to_csr(torch::Tensor dense) {
+  check_device_f32(dense, "dense");
+  TORCH_CHECK(dense.dim() >= 2, "dense_to_csr: expected at least a 2-d tensor");
+  torch::Tensor d = dense.contiguous();
+  const int64_t rows = d.size(-2), cols = d.size(-1);
+  const int64_t batch = rows * cols > 0 ? d.numel() / (rows * cols) : [&] {
+    int64_t b = 1;
+    for (int64_t i = 0; i + 2 < d.dim(); ++i) b *= d.size(i);
+    return b;
+  }();
+  TORCH_CHECK(rows <= INT32_MAX && cols <= INT32_MAX && batch <= INT32_MAX, "dense_to_csr: dimension too large");
+  TORCH_CHECK(d.numel() <= INT32_MAX, "dense_to_csr: more than 2^31-1 elements cannot be indexed by int32 offsets");
+  c10::hip::HIPGuard guard(d.device().index());
+  auto iopt = torch::dtype(torch::kInt32).device(d.device());
+  torch::Tensor offsets = torch::empty({batch, rows + 1}, iopt);
+  const size_t ws_bytes = mi_dense_to_csr_workspace_bytes((int32_t)batch, (int32_t)rows);
+  torch::Tensor ws = torch::empty({(int64_t)std::max<size_t>(ws_bytes, 1)}, torch::dtype(torch::kUInt8).device(d.device()));
+  check_status(mi_dense_to_csr_count(d.data_ptr<float>(), (int32_t)batch, (int32_t)rows, (int32_t)cols, cols,
+                                     rows * cols, offsets.data_ptr<int32_t>(), ws.data_ptr(), ws_bytes,
+                                     stream_of(d)),
+               "dense_to_csr(count)");
+  // one host read-back per call (not per slice) to size col / val
+  const int64_t nnz = batch > 0 ? offsets.view({-1})[batch * (rows + 1) - 1].item<int32_t>() : 0;
+  torch::Tensor columns = torch::empty({nnz}, iopt);
+  torch::Tensor values = torch::empty({nnz}, torch::dtype(torch::kFloat32).device(d.device()));
+  check_status(mi_dense_to_csr_fill(d.data_ptr<float>(), (int32_t)batch, (int32_t)rows, (int32_t)cols, cols,
+                                    rows * cols, offsets.data_ptr<int32_t>(), columns.data_ptr<int32_t>(),
+                                    values.data_ptr<float>(), stream_of(d)),
+               "dense_to_csr(fill)");
+  return std::make_tuple(values, columns, offsets);
+}
+
+// C[b] = A[b]·B[b] for a batched CSR (offsets [batch, A_rows+1], global) in one
+// launch; B is [batch, K, N] or [K, N] (shared by every item), C is [batch, M, N].
+torch::Tensor naive_spmm_batched(torch::Tensor A_values, torch::Tensor A_columns, torch::Tensor A_offsets,
+                                 int64_t nnzA, int64_t batch, int64_t A_rows, int64_t A_cols,
+                                 torch::Tensor B, torch::Tensor C) {
+  const char* what = "naive_spmm_batched";
+  check_device_f32(A_values, "A_values");
+  check_device_i32(A_columns, "A_columns");
+  check_device_i32(A_offsets, "A_offsets");
+  check_device_f32(B, "B");
+  check_device_f32(C, "C");
+  check_same_device(A_values, C, what);
+  check_same_device(A_columns, C, what);
+  check_same_device(A_offsets, C, what);
+  check_same_device(B, C, what);
+  TORCH_CHECK(batch >= 0 && A_rows >= 0 && A_cols >= 0 && nnzA >= 0, what, ": negative size");
+  TORCH_CHECK(batch <= 65535, what, ": at most 65535 items per launch");
+  TORCH_CHECK(A_values.is_contiguous() && A_columns.is_contiguous() && A_offsets.is_contiguous(), what,
+              ": CSR arrays must be contiguous");
+  TORCH_CHECK(A_offsets.numel() == batch * (A_rows + 1), what, ": A_offsets must be [batch, A_rows + 1]");
+  TORCH_CHECK(A_values.numel() >= nnzA && A_columns.numel() >= nnzA, what, ": nnzA exceeds the CSR arrays");
+  TORCH_CHECK(C.dim() == 3 && C.is_contiguous() && C.size(0) == batch && C.size(1) == A_rows, what,
+              ": C must be contiguous [batch, A_rows, N]");
+  const int64_t N = C.size(2);
+  torch::Tensor Bc = B.contiguous();
+  int64_t strideB = 0;
+  if (Bc.dim() == 3) {
+    TORCH_CHECK(Bc.size(0) == batch && Bc.size(1) == A_cols && Bc.size(2) == N, what, ": B must be [batch, A_cols, N]");
+    strideB = A_cols * N;
+  } else {
+    TORCH_CHECK(Bc.dim() == 2 && Bc.size(0) == A_cols && Bc.size(1) == N, what, ": B must be [A_cols, N]");
+  }
+  c10::hip::HIPGuard guard(C.device().index());
+  check_status(mi_spmm_csr_batched_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
+                                       A_values.data_ptr<float>(), nnzA, (int32_t)batch, (int32_t)A_rows,
+                                       (int32_t)A_cols, (int32_t)N, Bc.data_ptr<float>(), std::max<int64_t>(N, 1),
+                                       strideB, C.data_ptr<float>(), std::max<int64_t>(N, 1), A_rows * N,
+                                       stream_of(C)),
+               what);
+  return C;
+}
+
+// CSR of A (A_rows×A_cols) → CSR of Aᵀ: (values, columns, offsets[A_cols+1]).
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> csr_transpose(torch::Tensor A_values,
+                                                                      torch::Tensor A_columns,
+                                                                      torch::Tensor A_offsets, int64_t nnzA,
+                                                                      int64_t A_rows, int64_t A_cols) {
+  const char* what = "csr_transpose";
+  check_device_f32(A_values, "A_values");
+  check_device_i32(A_columns, "A_columns");
+  check_device_i32(A_offsets, "A_offsets");
+  check_same_device(A_values, A_columns, what);
+  check_same_device(A_values, A_offsets, what);
+  TORCH_CHECK(A_rows >= 0 && A_cols >= 0 && nnzA >= 0 && A_rows <= INT32_MAX && A_cols <= INT32_MAX, what, ": bad size");
+  TORCH_CHECK(A_values.is_contiguous() && A_columns.is_contiguous() && A_offsets.is_contiguous(), what,
+              ": CSR arrays must be contiguous");
+  TORCH_CHECK(A_offsets.numel() == A_rows + 1 && A_values.numel() >= nnzA && A_columns.numel() >= nnzA, what,
+              ": CSR array sizes do not match");
+  c10::hip::HIPGuard guard(A_values.device().index());
+  auto iopt = torch::dtype(torch::kInt32).device(A_values.device());
+  torch::Tensor t_off = torch::empty({A_cols + 1}, iopt);
+  torch::Tensor t_col = torch::empty({nnzA}, iopt);
+  torch::Tensor t_val = torch::empty({nnzA}, A_values.options());
+  const size_t ws_bytes = mi_csr_transpose_workspace_bytes((int32_t)A_rows, (int32_t)A_cols, nnzA);
+  torch::Tensor ws = torch::empty({(int64_t)std::max<size_t>(ws_bytes, 1)}, torch::dtype(torch::kUInt8).device(A_values.device()));
+  check_status(mi_csr_transpose_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
+                                    A_values.data_ptr<float>(), nnzA, (int32_t)A_rows, (int32_t)A_cols,
+                                    t_off.data_ptr<int32_t>(), t_col.data_ptr<int32_t>(), t_val.data_ptr<float>(),
+                                    ws.data_ptr(), ws_bytes, stream_of(A_values)),
+               what);
+  return std::make_tuple(t_val, t_col, t_off);
+}
+
+// out[p] = <dC[row(p), :], B[col[p], :]> on A's pattern: d(A·B)/d(A values).
+torch::Tensor sddmm(torch::Tensor A_columns, torch::Tensor A_offsets, int64_t nnzA, int64_t A_rows,
+                    int64_t A_cols, torch::Tensor dC, torch::Tensor B) {
+  const char* what = "sddmm";
+  check_device_i32(A_columns, "A_columns");
+  check_device_i32(A_offsets, "A_offsets");
+  check_device_f32(dC, "dC");
+  check_device_f32(B, "B");
+  check_same_device(A_columns, dC, what);
+  check_same_device(A_offsets, dC, what);
+  check_same_device(B, dC, what);
+  TORCH_CHECK(A_columns.is_contiguous() && A_offsets.is_contiguous(), what, ": CSR arrays must be contiguous");
+  TORCH_CHECK(A_offsets.numel() == A_rows + 1 && A_columns.numel() >= nnzA, what, ": CSR array sizes do not match");
+  TORCH_CHECK(dC.dim() == 2 && B.dim() == 2 && dC.size(0) == A_rows && B.size(0) == A_cols &&
+                  dC.size(1) == B.size(1),
+              what, ": dC must be [A_rows, N] and B [A_cols, N]");
+  torch::Tensor dCc = dC.contiguous(), Bc = B.contiguous();
+  const int64_t N = Bc.size(1);
+  c10::hip::HIPGuard guard(dC.device().index());
+  torch::Tensor out = torch::empty({nnzA}, dCc.options());
+  check_status(mi_sddmm_csr_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(), nnzA,
+                                (int32_t)A_rows, (int32_t)A_cols, (int32_t)N, dCc.data_ptr<float>(),
+                                std::max<int64_t>(N, 1), Bc.data_ptr<float>(), std::max<int64_t>(N, 1),
+                                out.data_ptr<float>(), stream_of(dCc)),
+               what);
+  return out;
+}
+
+// ---- inspector–executor registries -----------------------------------------
+
+struct CsrHandle {
+  int64_t M = 0, K = 0, N = 0;  // A is M×K, dense width N
+  int64_t nnz = 0;
+  torch::Tensor rowptr, col, val;  // device, int32 / int32 / float32 — owned references
+};
+
+std::mutex g_registry_mutex;
+std::unordered_map<std::string, CsrHandle> g_cusparse_layers;  // cusparse_inspect / _mmul_opt
+std::unordered_map<std::string, CsrHandle> g_tiled_layers;     // tiledspmm_*
+
+// Column-major executor shared by cusparse_mmul_opt and tiledspmm_mm:
+// C (M×N col-major) = A · B (K×N col-major); tensors of any shape with the
+// right element count are accepted, as in the reference (raw data_ptr()).
+void colmajor_mm(const CsrHandle& h, const torch::Tensor& B, torch::Tensor& C, const char* what) {
+  check_device_f32(B, "B");
+  check_device_f32(C, "C");
+  check_same_device(B, C, what);
+  check_same_device(h.val, C, what);
+  TORCH_CHECK(B.is_contiguous() && C.is_contiguous(), what, ": B and C must be contiguous");
+  TORCH_CHECK(B.numel() == h.K * h.N, what, ": B must hold K*N = ", h.K * h.N, " elements, got ",
+              B.numel());
+  TORCH_CHECK(C.numel() == h.M * h.N, what, ": C must hold M*N = ", h.M * h.N, " elements, got ",
+              C.numel());
+  c10::hip::HIPGuard guard(C.device().index());
+  const size_t ws_bytes = mi_spmm_colmajor_workspace_bytes((int32_t)h.M, (int32_t)h.K, (int32_t)h.N);
+  torch::Tensor ws = torch::empty({(int64_t)ws_bytes}, torch::dtype(torch::kUInt8).device(C.device()));
+  const int st = mi_spmm_csr_colmajor_f32(
+      h.rowptr.data_ptr<int32_t>(), h.col.data_ptr<int32_t>(), h.val.data_ptr<float>(), h.nnz,
+      (int32_t)h.M, (int32_t)h.K, (int32_t)h.N, B.data_ptr<float>(), h.K, C.data_ptr<float>(), h.M,
+      ws.data_ptr(), ws_bytes, stream_of(C));
+  check_status(st, what);
+}
+
+const CsrHandle& lookup(const std::unordered_map<std::string, CsrHandle>& reg,
+                        const std::string& layer, const char* what) {
+  auto it = reg.find(layer);
+  if (it == reg.end()) throw std::runtime_error(std::string(what) + ": Invalid handle_id! (unknown layer '" + layer + "')");
+  return it->second;
+}
+
+// reference custom_mm.cpp:236-257: (displ, colindex, value, nnz, M, N, K, layer);
+// A is M×K, dense operand width N (custom_mm.cpp:266-267 passes M, K, then K, N).
+void cusparse_inspect(torch::Tensor displ, torch::Tensor colindex, torch::Tensor value, int nnz,
+                      int M, int N, int K, std::string layer) {
+  check_device_i32(displ, "displ");
+  check_device_i32(colindex, "colindex");
+  check_device_f32(value, "value");
+  TORCH_CHECK(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "cusparse_inspect: negative size");
+  TORCH_CHECK(displ.numel() == (int64_t)M + 1, "cusparse_inspect: displ must have M + 1 entries");
+  TORCH_CHECK(colindex.numel() >= nnz && value.numel() >= nnz, "cusparse_inspect: nnz exceeds the CSR arrays");
+  CsrHandle h;
+  h.M = M;
+  h.K = K;
+  h.N = N;
+  h.nnz = nnz;
+  h.rowptr = displ.contiguous();
+  h.col = colindex.contiguous();
+  h.val = value.contiguous();
+  std::lock_guard<std::mutex> lock(g_registry_mutex);
+  g_cusparse_layers[layer] = std::move(h);
+}
+
+torch::Tensor cusparse_mmul_opt(torch::Tensor B, torch::Tensor C, std::string layer) {
+  CsrHandle h;
+  {
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    h = lookup(g_cusparse_layers, layer, "cusparse_mmul_opt");
+  }
+  colmajor_mm(h, B, C, "cusparse_mmul_opt");
+  return C;
+}
+
+void cusparse_clean() {
+  std::lock_guard<std::mutex> lock(g_registry_mutex);
+  g_cusparse_layers.clear();
+}
+
+// TiledSpMM convention (reference custom_mm.cpp:283-290): C[M×K] = A[M×N]·B[N×K],
+// B and C column-major.  In CsrHandle terms: inner dim = N, dense width = K.
+void register_tiled(int64_t M, int64_t N, int64_t K, torch::Tensor rowptr_cpu_i32,
+                    torch::Tensor col_cpu_i32, torch::Tensor val_cpu, const std::string& layer) {
+  const auto dev = torch::Device(torch::kCUDA, c10::hip::current_device());
+  CsrHandle h;
+  h.M = M;
+  h.K = N;  // inner dimension
+  h.N = K;  // dense width
+  h.nnz = val_cpu.numel();
+  h.rowptr = rowptr_cpu_i32.to(dev);
+  h.col = col_cpu_i32.to(dev);
+  h.val = val_cpu.to(dev);
+  std::lock_guard<std::mutex> lock(g_registry_mutex);
+  g_tiled_layers[layer] = std::move(h);
+}
+
+void check_host(const torch::Tensor& t, torch::ScalarType ty, const char* name) {
+  TORCH_CHECK(t.device().is_cpu(), name, " must be a CPU tensor (host inspector input)");
+  TORCH_CHECK(t.scalar_type() == ty, name, " must be ", ty, ", got ", t.scalar_type());
+}
+
+// reference custom_mm.cpp:321-335: CSR with int64 displ / colindex on the host.
+void tiledspmm_inspect_csr(int M, int N, int K, torch::Tensor displ, torch::Tensor colindex,
+                           torch::Tensor value, std::string layer) {
+  check_host(displ, torch::kInt64, "displ");
+  check_host(colindex, torch::kInt64, "colindex");
+  check_host(value, torch::kFloat32, "value");
+  TORCH_CHECK(M >= 0 && N >= 0 && K >= 0, "tiledspmm_inspect_csr: negative size");
+  TORCH_CHECK(displ.numel() == (int64_t)M + 1, "tiledspmm_inspect_csr: displ must have M + 1 entries");
+  torch::Tensor d = displ.contiguous(), c = colindex.contiguous(), v = value.contiguous();
+  const int64_t nnz = M > 0 ? d.data_ptr<int64_t>()[M] : 0;
+  TORCH_CHECK(nnz >= 0 && nnz <= INT32_MAX, "tiledspmm_inspect_csr: nnz does not fit int32");
+  TORCH_CHECK(c.numel() >= nnz && v.numel() >= nnz, "tiledspmm_inspect_csr: nnz exceeds the CSR arrays");
+  if (nnz > 0) {
+    TORCH_CHECK(c.slice(0, 0, nnz).min().item<int64_t>() >= 0 &&
+                    c.slice(0, 0, nnz).max().item<int64_t>() < N,
+                "tiledspmm_inspect_csr: column index out of range");
+  }
+  register_tiled(M, N, K, d.to(torch::kInt32), c.slice(0, 0, nnz).to(torch::kInt32),
+                 v.slice(0, 0, nnz).contiguous(), layer);
+}
+
+// reference custom_mm.cpp:293-319: COO with int32 indices on the host, sorted by row.
+void tiledspmm_inspect_coo(int M, int N, int K, int64_t nnz, torch::Tensor rowidx,
+                           torch::Tensor colidx, torch::Tensor value, std::string layer) {
+  check_host(rowidx, torch::kInt32, "rowidx");
+  check_host(colidx, torch::kInt32, "colidx");
+  check_host(value, torch::kFloat32, "value");
+  TORCH_CHECK(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "tiledspmm_inspect_coo: negative size");
+  TORCH_CHECK(rowidx.numel() >= nnz && colidx.numel() >= nnz && value.numel() >= nnz,
+              "tiledspmm_inspect_coo: nnz exceeds the COO arrays");
+  torch::Tensor r = rowidx.contiguous(), c = colidx.contiguous(), v = value.contiguous();
+  if (nnz > 0) {
+    TORCH_CHECK(c.slice(0, 0, nnz).min().item<int32_t>() >= 0 &&
+                    c.slice(0, 0, nnz).max().item<int32_t>() < N,
+                "tiledspmm_inspect_coo: column index out of range");
+  }
+  torch::Tensor rowptr = torch::empty({(int64_t)M + 1}, torch::kInt32);
+  torch::Tensor col = torch::empty({nnz}, torch::kInt32);
+  torch::Tensor val = torch::empty({nnz}, torch::kFloat32);
+  int st;
+  {
+    pybind11::gil_scoped_release nogil;  // host inspector pass
+    st = mi_coo_to_csr_host(M, nnz, r.data_ptr<int32_t>(), c.data_ptr<int32_t>(), v.data_ptr<float>(),
+                            rowptr.data_ptr<int32_t>(), col.data_ptr<int32_t>(), val.data_ptr<float>());
+  }
+  check_status(st, "tiledspmm_inspect_coo");
+  register_tiled(M, N, K, rowptr, col, val, layer);
+}
+
+void tiledspmm_mm(torch::Tensor B, torch::Tensor C, std::string layer) {
+  CsrHandle h;
+  {
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    h = lookup(g_tiled_layers, layer, "tiledspmm_mm");
+  }
+  colmajor_mm(h, B, C, "tiledspmm_mm");
+}
+
+void tiledspmm_clean() {
+  std::lock_guard<std::mutex> lock(g_registry_mutex);
+  g_tiled_layers.clear();
+}
+
+// ---- handle init / destroy (reference custom_mm.cpp:361-391) ----------------
+// There are no vendor handles on this path; init checks that the C-ABI library
+// this module was linked against has the expected ABI (printing to stderr on
+// mismatch, like the reference's init failures) and all four are idempotent.
+void init_backend(const char* name) {
+  if (mi_spmm_abi_version() != MI_SPMM_ABI_VERSION)
+    std::cerr << name << " initialization error: libmi_spmm ABI " << mi_spmm_abi_version()
+              << " != " << MI_SPMM_ABI_VERSION << std::endl;
+}
+void init_cublas_handle() { init_backend("cuBLAS-path"); }
+void destroy_cublas_handle() {}
+void init_cusparse_handle() { init_backend("cuSPARSE-path"); }
+void destroy_cusparse_handle() {}
+
+// reference baseline_mm.cu:24-35 prints every thread id of a 64×64 launch;
+// this launches the same grid, checks the ids on the host and prints one line.
+void dummy_kernel_launch() {
+  const auto dev = torch::Device(torch::kCUDA, c10::hip::current_device());
+  torch::Tensor out = torch::full({4096}, -1, torch::dtype(torch::kInt32).device(dev));
+  check_status(mi_dummy_kernel(out.data_ptr<int32_t>(), stream_of(out)), "dummy_kernel");
+  torch::Tensor host = out.cpu();  // synchronises, like the reference's cudaDeviceSynchronize
+  const bool ok = host.equal(torch::arange(4096, torch::kInt32));
+  std::cout << "dummy_kernel: 64 blocks x 64 threads ran, ids " << (ok ? "0..4095 ok" : "WRONG")
+            << std::endl;
+  TORCH_CHECK(ok, "dummy_kernel wrote wrong thread ids");
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.def("init_cublas", &init_cublas_handle, "Create cuBLAS handle.");
+  m.def("destroy_cublas", &destroy_cublas_handle, "Destroy cuBLAS handle.");
+
+  m.def("init_cusparse", &init_cusparse_handle, "Create cuSPARSE handle.");
+  m.def("destroy_cusparse", &destroy_cusparse_handle, "Destroy cuSPARSE handle.");
+
+  m.def("cublas_mmul", &cublas_mmul, "cuBLAS Torch Matrix Multiplication");
+  m.def("cublas_bmm", &cublas_bmm, "cuBLAS Batched Torch Matrix Multiplication");
+  m.def("cusparse_mmul", &cusparse_mmul, "cuSPARSE Torch Matrix Multiplication");
+
+  m.def("dummy_kernel", &dummy_kernel_launch, "Launch dummy kernel.");
+  m.def("naive_spmm", &naive_spmm, "A naive implementation of Sparse Matrix Multiplication");
+
+  m.def("tiledspmm_inspect_csr", &tiledspmm_inspect_csr, "Inspect function for TiledSpMM with CSR input");
+  m.def("tiledspmm_inspect_coo", &tiledspmm_inspect_coo, "Inspect function for TiledSpMM with COO input");
+  m.def("tiledspmm_mm", &tiledspmm_mm, "MM function for TiledSpMM");
+  m.def("tiledspmm_clean", &tiledspmm_clean, "Cleanup function for TiledSpMM");
+
+  m.def("cusparse_inspect", &cusparse_inspect, "Inspect function for CuSPARSE with CSR input");
+  m.def("cusparse_mmul_opt", &cusparse_mmul_opt, "MM function for CuSPARSE");
+  m.def("cusparse_clean", &cusparse_clean, "Cleanup function for CuSPARSE");
+
+  // additions (not in the reference): one-launch batching and the sparse backward
+  m.def("dense_to_csr", &dense_to_csr, "Device dense -> batched CSR (values, columns, offsets)");
+  m.def("naive_spmm_batched", &naive_spmm_batched, "Batched CSR x dense in one launch");
+  m.def("csr_transpose", &csr_transpose, "Device CSR transpose (values, columns, offsets)");
+  m.def("sddmm", &sddmm, "Sampled dense-dense product on a CSR pattern");
+}

@@ -1,0 +1,254 @@
+// Dense fp32 (batched, transposed) product for gfx950 — the MI355X counterpart
+// of the reference's cuBLAS entry points cublas_mm_wrapper / cublas_bmm_wrapper
+// (src/baseline_mm.cu:52-102, :105-155), i.e. what custom_mm.cublas_mmul /
+// cublas_bmm and matmuls.cublas*MM.apply (the README's BERT drop-in,
+// cublasTransbMM.apply(q, k)) run on.
+//
+//   C[b] (m×n, row-major) = op(A[b]) · op(B[b]),  alpha = 1, beta = 0
+//
+// Design: LDS-tiled, exact-fp32 matrix-core kernel.  v_mfma_f32_32x32x2_f32
+// (f32 in / f32 accumulate) is bit-for-bit a k-ordered fmaf chain, so the
+// result equals the sequential-k oracle (oracle_gemm_f32) exactly.  A block of
+// 256 threads (4 waves, 2×2) owns a BM×BN tile of C; each wave holds TM×TN
+// 32×32 accumulators.  The k-tile (BK = 32) of each operand goes through LDS in
+// the layout that makes both the global read (16 B per lane along the
+// operand's contiguous dimension) and the MFMA operand read (32 lanes on 32
+// consecutive m or n at one k) bank-conflict free:
+//    source contiguous along k  → Xs[mn][BK+1]   (A not transposed, B transposed)
+//    source contiguous along mn → Xs[BK][BMN+4]  (A transposed, B not transposed)
+// The next k-tile's global loads are issued before the MFMAs of the current
+// one (register staging), C is stored with non-temporal 128-B row segments.
+#include "mi_common.h"
+
+namespace {
+
+using mi::f32x4;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+
+// One operand's k-tile: EXT×BK elements (EXT = BM or BN), 256 threads.
+// KCONTIG: element (e, k) lives at src[e*ld + k]; else at src[k*ld + e].
+template <int EXT, bool KCONTIG>
+struct TileLoader {
+  static constexpr int VECS = EXT * BK / 4 / 256;  // float4 per thread
+  static constexpr int LDS_LD = KCONTIG ? (BK + 1) : (EXT + 4);
+  static constexpr int LDS_FLOATS = KCONTIG ? EXT * (BK + 1) : BK * (EXT + 4);
+
+  // (e, k) of the first element of this thread's v-th float4.
+  static __device__ __forceinline__ void coords(int v, int tid, int& e, int& k) {
+    const int idx = v * 256 + tid;
+    if (KCONTIG) {
+      e = idx / (BK / 4);
+      k = (idx % (BK / 4)) * 4;
+    } else {
+      k = idx / (EXT / 4);
+      e = (idx % (EXT / 4)) * 4;
+    }
+  }
+
+  // Global → registers; zero outside [0,ext_lim) × [0,k_lim).
+  static __device__ __forceinline__ void load(f32x4 (&r)[VECS], const float* src, long ld, int e0,
+                                              int k0, int ext_lim, int k_lim, bool vec_ok, int tid) {
+#pragma unroll
+    for (int v = 0; v < VECS; ++v) {
+      int e, k;
+      coords(v, tid, e, k);
+      e += e0;
+      k += k0;
+      f32x4 x = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (KCONTIG) {
+        if (e < ext_lim) {
+          const float* p = src + (long)e * ld + k;
+          if (vec_ok && k + 3 < k_lim) {
+            x = *reinterpret_cast<const f32x4*>(p);
+          } else {
+            if (k + 0 < k_lim) x.x = p[0];
+            if (k + 1 < k_lim) x.y = p[1];
+            if (k + 2 < k_lim) x.z = p[2];
+            if (k + 3 < k_lim) x.w = p[3];
+          }
+        }
+      } else {
+        if (k < k_lim) {
+          const float* p = src + (long)k * ld + e;
+          if (vec_ok && e + 3 < ext_lim) {
+            x = *reinterpret_cast<const f32x4*>(p);
+          } else {
+            if (e + 0 < ext_lim) x.x = p[0];
+            if (e + 1 < ext_lim) x.y = p[1];
+            if (e + 2 < ext_lim) x.z = p[2];
+            if (e + 3 < ext_lim) x.w = p[3];
+          }
+        }
+      }
+      r[v] = x;
+    }
+  }
+
+  // Registers → LDS.
+  static __device__ __forceinline__ void store(const f32x4 (&r)[VECS], float* lds, int tid) {
+#pragma unroll
+    for (int v = 0; v < VECS; ++v) {
+      int e, k;
+      coords(v, tid, e, k);
+      if (KCONTIG) {
+        float* p = lds + e * LDS_LD + k;  // odd row stride: 4 scalar stores, conflict-free
+        p[0] = r[v].x;
+        p[1] = r[v].y;
+        p[2] = r[v].z;
+        p[3] = r[v].w;
+      } else {
+        *reinterpret_cast<f32x4*>(lds + k * LDS_LD + e) = r[v];  // 16-B aligned rows
+      }
+    }
+  }
+
+  // MFMA operand element (e, k) from LDS.
+  static __device__ __forceinline__ float at(const float* lds, int e, int k) {
+    return KCONTIG ? lds[e * LDS_LD + k] : lds[k * LDS_LD + e];
+  }
+};
+
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int m, int n,
+    int k, long lda, long ldb, long ldc, long strideA, long strideB, long strideC, int tiles_n,
+    bool vecA, bool vecB) {
+  constexpr int TM = BM / 64;  // 32×32 tiles per wave along m (2×2 waves)
+  constexpr int TN = BN / 64;
+  typedef TileLoader<BM, !TA> LA;  // A not transposed → contiguous along k
+  typedef TileLoader<BN, TB> LB;   // B transposed     → contiguous along k
+  __shared__ float lds[LA::LDS_FLOATS + LB::LDS_FLOATS];
+  float* As = lds;
+  float* Bs = lds + LA::LDS_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile_m = blockIdx.x / tiles_n;
+  const int tile_n = blockIdx.x % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const long item = blockIdx.y;
+  A += item * strideA;
+  B += item * strideB;
+  C += item * strideC;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[LA::VECS], rb[LB::VECS];
+  LA::load(ra, A, lda, m0, 0, m, k, vecA, tid);
+  LB::load(rb, B, ldb, n0, 0, n, k, vecB, tid);
+
+  const int l31 = lane & 31, lhi = lane >> 5;
+  for (int k0 = 0; k0 < k; k0 += BK) {
+    LA::store(ra, As, tid);
+    LB::store(rb, Bs, tid);
+    __syncthreads();
+    if (k0 + BK < k) {
+      LA::load(ra, A, lda, m0, k0 + BK, m, k, vecA, tid);
+      LB::load(rb, B, ldb, n0, k0 + BK, n, k, vecB, tid);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = LA::at(As, wm * (BM / 2) + i * 32 + l31, kk + lhi);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = LB::at(Bs, wn * (BN / 2) + j * 32 + l31, kk + lhi);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // C/D layout of the 32×32 MFMA: col = lane&31, row = (reg&3) + 8·(reg>>2) + 4·(lane>>5).
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (BN / 2) + j * 32 + l31;
+      const int row_base = m0 + wm * (BM / 2) + i * 32 + 4 * lhi;
+      if (col < n) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row_base + (r & 3) + 8 * (r >> 2);
+          if (row < m) __builtin_nontemporal_store(acc[i][j][r], C + (long)row * ldc + col);
+        }
+      }
+    }
+}
+
+template <int BM, int BN, bool TA, bool TB>
+int launch(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb,
+           long ldc, long sA, long sB, long sC, int batch, bool vecA, bool vecB, hipStream_t s) {
+  const long tiles_m = (m + BM - 1) / BM, tiles_n = (n + BN - 1) / BN;
+  const long blocks = tiles_m * tiles_n;
+  if (blocks > 0x7fffffffL) return MI_ERANGE;
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB>), dim3((unsigned)blocks, (unsigned)batch),
+                     dim3(256), 0, s, A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, (int)tiles_n,
+                     vecA, vecB);
+  return mi::check_launch();
+}
+
+template <bool TA, bool TB>
+int pick_tile(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb,
+              long ldc, long sA, long sB, long sC, int batch, bool vecA, bool vecB, hipStream_t s) {
+  // Wide tiles when both extents fill them; the 64-wide n tile covers BERT's
+  // head dim (probs·V, n = 64) without wasting half the MFMAs.
+  if (n > 64 && m > 64)
+    return launch<128, 128, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, s);
+  if (m > 64)
+    return launch<128, 64, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, s);
+  if (n > 64)
+    return launch<64, 128, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, s);
+  return launch<64, 64, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, s);
+}
+
+// k == 0: C = 0 (beta = 0 semantics).
+__global__ void zero_rows_kernel(float* C, int m, int n, long ldc, long strideC) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < (long)m * n) C[blockIdx.y * strideC + (idx / n) * ldc + (idx % n)] = 0.f;
+}
+
+}  // namespace
+
+extern "C" int mi_gemm_f32(int transa, int transb, int32_t m, int32_t n, int32_t k, const float* A,
+                           int64_t lda, int64_t strideA, const float* B, int64_t ldb,
+                           int64_t strideB, float* C, int64_t ldc, int64_t strideC, int32_t batch,
+                           mi_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (m < 0 || n < 0 || k < 0 || batch < 0) return MI_EINVAL;
+  if (batch > 65535) return MI_ERANGE;
+  if (m == 0 || n == 0 || batch == 0) return MI_OK;
+  if (!C || ldc < n) return MI_EINVAL;
+  if (k == 0) {
+    const long total = (long)m * n;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)batch),
+                       dim3(256), 0, s, C, m, n, ldc, strideC);
+    return mi::check_launch();
+  }
+  if (!A || !B) return MI_EINVAL;
+  if (lda < (transa ? m : k) || ldb < (transb ? k : n)) return MI_EINVAL;
+  if (strideA < 0 || strideB < 0 || strideC < 0) return MI_EINVAL;
+  const bool vecA = (lda % 4 == 0) && (strideA % 4 == 0) && mi::aligned16(A);
+  const bool vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && mi::aligned16(B);
+#define MI_GEMM(TA_, TB_)                                                                       \
+  return pick_tile<TA_, TB_>(A, B, C, m, n, k, lda, ldb, ldc, strideA, strideB, strideC, batch, \
+                             vecA, vecB, s)
+  if (!transa && !transb) MI_GEMM(false, false);
+  if (!transa && transb) MI_GEMM(false, true);
+  if (transa && !transb) MI_GEMM(true, false);
+  MI_GEMM(true, true);
+#undef MI_GEMM
+}

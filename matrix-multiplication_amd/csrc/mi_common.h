@@ -1,0 +1,40 @@
+// Shared host-side helpers for the C-ABI translation units (not installed).
+#ifndef MI_COMMON_H_
+#define MI_COMMON_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mi_spmm.h"
+
+namespace mi {
+
+// Records a failing hipError_t for mi_last_hip_error() and maps it to MI_EHIP.
+int record_hip_error(hipError_t e);
+
+// Call after every kernel launch: picks up launch-configuration errors without
+// synchronising (the reference checks nothing after <<<>>>).
+inline int check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MI_OK : record_hip_error(e);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int pow2_ceil(int x) {
+  int p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+}  // namespace mi
+
+#define MI_HIP_TRY(expr)                                  \
+  do {                                                    \
+    hipError_t _e = (expr);                               \
+    if (_e != hipSuccess) return mi::record_hip_error(_e); \
+  } while (0)
+
+#endif  // MI_COMMON_H_

@@ -1,0 +1,391 @@
+// Row-split CSR × dense SpMM for gfx950 (MI355X), fp32.
+//
+// What it computes (contract of include/mi_spmm.h, mi_spmm_csr_f32):
+//   C[r, j] = Σ_{p = rowptr[r]}^{rowptr[r+1]-1} val[p] · B[col[p], j]
+// accumulated per output element with fused multiply-add in CSR order — the
+// per-element summation order of the reference's spmm_kernel
+// (src/naive_sparse_mm.cu:60-92), so results do not depend on launch geometry
+// and the row-sharded multi-GPU result is bit-identical to the 1-GPU one.
+//
+// Design (not a port of the reference's 32-lane, 4-byte-per-lane kernel):
+//  * wave64 owns whole output rows; a lane owns 16 B (float4) of the row, so a
+//    B-row gather for N = 256 is exactly one global_load_dwordx4 wave
+//    instruction (1 KiB, fully coalesced) and col/val are read ONCE per row
+//    (the reference re-reads them ⌈N/32⌉ times, naive_sparse_mm.cu:39,116).
+//  * col/val of a row are wave-uniform, so the wave-per-row kernels read them
+//    through the scalar unit (s_load) and form the B-row address as
+//    scalar-base + lane-offset; no shuffles (the reference spends 64
+//    __shfl_sync per 32 nonzeros, naive_sparse_mm.cu:75-80).
+//  * the kernel is a random 1 KiB-row gather from a table far larger than the
+//    256 MiB Infinity Cache: memory-level parallelism is what matters, so U
+//    independent B-row loads are issued before the first FMA consumes one.
+//  * C rows are written once with non-temporal 16-B stores.
+//  * narrower N: G = N/4 lanes per row and 64/G rows per wave (col/val are
+//    broadcast inside the G-lane group with ds_bpermute); arbitrary N or
+//    unaligned operands: the same kernel with one float per lane.
+#include "mi_common.h"
+
+namespace {
+
+using mi::f32x4;
+
+__device__ __forceinline__ f32x4 fma4(float a, f32x4 x, f32x4 acc) {
+  acc.x = __builtin_fmaf(a, x.x, acc.x);
+  acc.y = __builtin_fmaf(a, x.y, acc.y);
+  acc.z = __builtin_fmaf(a, x.z, acc.z);
+  acc.w = __builtin_fmaf(a, x.w, acc.w);
+  return acc;
+}
+
+// ---------------------------------------------------------------------------
+// One wave per row, N == 256·T exactly.  col/val through the scalar unit.
+// grid = (⌈M/4⌉, batch), block = 256 (4 waves = 4 rows).
+// ---------------------------------------------------------------------------
+template <int T, int U>
+__global__ __launch_bounds__(256) void spmm_wave_row_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col,
+    const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
+    int M, long ldb, long ldc, long strideB, long strideC) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  const long item = blockIdx.y;
+  const int* rp = rowptr + item * ((long)M + 1);
+  const float* Bl = B + item * strideB + lane * 4;
+  float* Cl = C + item * strideC + row * ldc + lane * 4;
+
+  int p = rp[row];
+  const int end = rp[row + 1];
+
+  f32x4 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (; p + U <= end; p += U) {
+    int c[U];
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      c[u] = col[p + u];
+      v[u] = val[p + u];
+    }
+    f32x4 x[U][T];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float* src = Bl + (long)c[u] * ldb;
+#pragma unroll
+      for (int t = 0; t < T; ++t) x[u][t] = *reinterpret_cast<const f32x4*>(src + t * 256);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[t] = fma4(v[u], x[u][t], acc[t]);
+    }
+  }
+  for (; p < end; ++p) {
+    const int c = col[p];
+    const float v = val[p];
+    const float* src = Bl + (long)c * ldb;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      acc[t] = fma4(v, *reinterpret_cast<const f32x4*>(src + t * 256), acc[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+    __builtin_nontemporal_store(acc[t], reinterpret_cast<f32x4*>(Cl + t * 256));
+}
+
+// ---------------------------------------------------------------------------
+// One wave per row, N == 256, col/val fetched 64 at a time with one coalesced
+// vector load each and handed to the scalar unit with v_readlane.
+// ---------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(256) void spmm_wave_row_vl_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col,
+    const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
+    int M, long ldb, long ldc, long strideB, long strideC) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  const long item = blockIdx.y;
+  const int* rp = rowptr + item * ((long)M + 1);
+  const float* Bl = B + item * strideB + lane * 4;
+  float* Cl = C + item * strideC + row * ldc + lane * 4;
+
+  const int start = rp[row];
+  const int end = rp[row + 1];
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int p = start; p < end; p += 64) {
+    const int idx = p + lane;
+    const int myc = idx < end ? col[idx] : 0;
+    const float myv = idx < end ? val[idx] : 0.f;
+    const int cnt = (end - p) < 64 ? (end - p) : 64;  // wave-uniform
+    int i = 0;
+    for (; i + U <= cnt; i += U) {
+      f32x4 x[U];
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = __builtin_amdgcn_readlane(myc, i + u);
+        v[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), i + u));
+        x[u] = *reinterpret_cast<const f32x4*>(Bl + (long)c * ldb);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc = fma4(v[u], x[u], acc);
+    }
+    for (; i < cnt; ++i) {
+      const int c = __builtin_amdgcn_readlane(myc, i);
+      const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), i));
+      acc = fma4(v, *reinterpret_cast<const f32x4*>(Bl + (long)c * ldb), acc);
+    }
+  }
+  __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(Cl));
+}
+
+// ---------------------------------------------------------------------------
+// G lanes per row (G a power of two ≤ 64), 64/G rows per wave, VEC floats per
+// lane per tile, T tiles per pass; columns beyond G·VEC·T are covered by an
+// outer pass loop (col/val re-read once per pass).  Handles every N.
+// grid = (⌈M / (4·64/G)⌉, batch), block = 256.
+// ---------------------------------------------------------------------------
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<4> {
+  typedef f32x4 type;
+  static __device__ __forceinline__ type zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ type load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void store(float* p, type v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  }
+  static __device__ __forceinline__ type fma(float a, type x, type acc) { return fma4(a, x, acc); }
+};
+template <>
+struct Vec<1> {
+  typedef float type;
+  static __device__ __forceinline__ type zero() { return 0.f; }
+  static __device__ __forceinline__ type load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, type v) { __builtin_nontemporal_store(v, p); }
+  static __device__ __forceinline__ type fma(float a, type x, type acc) { return __builtin_fmaf(a, x, acc); }
+};
+
+template <int G, int VEC, int T>
+__global__ __launch_bounds__(256) void spmm_group_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col,
+    const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
+    int M, int N, long ldb, long ldc, long strideB, long strideC) {
+  typedef Vec<VEC> V;
+  typedef typename V::type vec_t;
+  constexpr int RPW = 64 / G;  // rows per wave
+  constexpr int UI = G < 4 ? G : 4;  // B-row loads in flight per group
+  const int lane = threadIdx.x & 63;
+  const int gl = lane & (G - 1);
+  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + (lane / G);
+  const long item = blockIdx.y;
+  const int* rp = rowptr + item * ((long)M + 1);
+  const float* Bi = B + item * strideB;
+  float* Ci = C + item * strideC;
+
+  int start = 0, end = 0;
+  if (row < M) {
+    start = rp[row];
+    end = rp[row + 1];
+  }
+
+  for (int n0 = 0; n0 < N; n0 += G * VEC * T) {  // wave-uniform pass loop
+    vec_t acc[T];
+    bool on[T];
+    int coff[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      acc[t] = V::zero();
+      coff[t] = n0 + (t * G + gl) * VEC;
+      on[t] = coff[t] < N;
+    }
+    for (int p = start; p < end; p += G) {  // trip count differs between groups
+      const int idx = p + gl;
+      const int myc = idx < end ? col[idx] : 0;
+      const float myv = idx < end ? val[idx] : 0.f;
+      const int cnt = (end - p) < G ? (end - p) : G;  // group-uniform
+      int i = 0;
+      for (; i + UI <= cnt; i += UI) {
+        vec_t x[UI][T];
+        float v[UI];
+#pragma unroll
+        for (int u = 0; u < UI; ++u) {
+          const int c = __shfl(myc, i + u, G);
+          v[u] = __shfl(myv, i + u, G);
+          const float* src = Bi + (long)c * ldb;
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+            if (on[t]) x[u][t] = V::load(src + coff[t]);
+        }
+#pragma unroll
+        for (int u = 0; u < UI; ++u) {
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+            if (on[t]) acc[t] = V::fma(v[u], x[u][t], acc[t]);
+        }
+      }
+      for (; i < cnt; ++i) {
+        const int c = __shfl(myc, i, G);
+        const float v = __shfl(myv, i, G);
+        const float* src = Bi + (long)c * ldb;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+          if (on[t]) acc[t] = V::fma(v, V::load(src + coff[t]), acc[t]);
+      }
+    }
+    if (row < M) {
+      float* dst = Ci + row * ldc;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        if (on[t]) V::store(dst + coff[t], acc[t]);
+    }
+  }
+}
+
+template <int G, int VEC, int T>
+int launch_group(const int* rowptr, const int* col, const float* val, const float* B,
+                 float* C, int M, int N, long ldb, long ldc, long strideB, long strideC,
+                 int batch, hipStream_t s) {
+  constexpr int rows_per_block = 4 * (64 / G);
+  const long blocks = ((long)M + rows_per_block - 1) / rows_per_block;
+  if (blocks > 0x7fffffffL) return MI_ERANGE;
+  hipLaunchKernelGGL((spmm_group_kernel<G, VEC, T>), dim3((unsigned)blocks, (unsigned)batch),
+                     dim3(256), 0, s, rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC);
+  return mi::check_launch();
+}
+
+template <int VEC>
+int dispatch_group(const int* rowptr, const int* col, const float* val, const float* B,
+                   float* C, int M, int N, long ldb, long ldc, long strideB, long strideC,
+                   int batch, hipStream_t s) {
+  const int nv = (N + VEC - 1) / VEC;  // vector columns
+  const int G = nv >= 64 ? 64 : mi::pow2_ceil(nv);
+#define MI_GROUP(G_, T_) \
+  return launch_group<G_, VEC, T_>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, s)
+  switch (G) {
+    case 1: MI_GROUP(1, 1);
+    case 2: MI_GROUP(2, 1);
+    case 4: MI_GROUP(4, 1);
+    case 8: MI_GROUP(8, 1);
+    case 16: MI_GROUP(16, 1);
+    case 32: MI_GROUP(32, 1);
+    default: break;
+  }
+  const int tiles = (nv + 63) / 64;
+  if (tiles <= 1) MI_GROUP(64, 1);
+  if (tiles == 2) MI_GROUP(64, 2);
+  MI_GROUP(64, 4);
+#undef MI_GROUP
+}
+
+template <int T, int U>
+int launch_wave_row(const int* rowptr, const int* col, const float* val, const float* B,
+                    float* C, int M, long ldb, long ldc, long strideB, long strideC,
+                    int batch, hipStream_t s) {
+  const long blocks = ((long)M + 3) / 4;
+  if (blocks > 0x7fffffffL) return MI_ERANGE;
+  hipLaunchKernelGGL((spmm_wave_row_kernel<T, U>), dim3((unsigned)blocks, (unsigned)batch),
+                     dim3(256), 0, s, rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC);
+  return mi::check_launch();
+}
+
+template <int U>
+int launch_wave_row_vl(const int* rowptr, const int* col, const float* val, const float* B,
+                       float* C, int M, long ldb, long ldc, long strideB, long strideC,
+                       int batch, hipStream_t s) {
+  const long blocks = ((long)M + 3) / 4;
+  if (blocks > 0x7fffffffL) return MI_ERANGE;
+  hipLaunchKernelGGL((spmm_wave_row_vl_kernel<U>), dim3((unsigned)blocks, (unsigned)batch),
+                     dim3(256), 0, s, rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC);
+  return mi::check_launch();
+}
+
+int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const float* val,
+                  int64_t nnz, int32_t batch, int32_t M, int32_t K, int32_t N, const float* B,
+                  int64_t ldb, int64_t strideB, float* C, int64_t ldc, int64_t strideC,
+                  hipStream_t s) {
+  if (M < 0 || K < 0 || N < 0 || nnz < 0 || batch < 0) return MI_EINVAL;
+  if (variant < 0 || variant >= MI_SPMM_VARIANT_COUNT) return MI_EINVAL;
+  if (nnz > 0x7fffffffLL) return MI_ERANGE;  // int32 rowptr entries
+  if (batch > 65535) return MI_ERANGE;       // grid.y
+  if (M == 0 || N == 0 || batch == 0) return MI_OK;
+  if (!rowptr || !C) return MI_EINVAL;
+  if (nnz > 0 && (!col || !val || !B)) return MI_EINVAL;
+  if (ldb < N || ldc < N) return MI_EINVAL;
+
+  const bool vec4_ok = (N % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && (strideB % 4 == 0) &&
+                       (strideC % 4 == 0) && mi::aligned16(B) && mi::aligned16(C);
+  const bool wave_ok = vec4_ok && (N == 256 || N == 512 || N == 1024);
+
+  if (variant == MI_SPMM_AUTO) {
+    if (wave_ok) variant = MI_SPMM_WAVE_ROW_U8;
+    else variant = vec4_ok ? MI_SPMM_GROUP_VEC4 : MI_SPMM_GROUP_SCALAR;
+  }
+
+#define MI_WAVE(T_, U_) \
+  return launch_wave_row<T_, U_>(rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, batch, s)
+  switch (variant) {
+    case MI_SPMM_WAVE_ROW_U4:
+      if (!wave_ok) return MI_EINVAL;
+      if (N == 256) MI_WAVE(1, 4);
+      if (N == 512) MI_WAVE(2, 4);
+      MI_WAVE(4, 2);
+    case MI_SPMM_WAVE_ROW_U8:
+      if (!wave_ok) return MI_EINVAL;
+      if (N == 256) MI_WAVE(1, 8);
+      if (N == 512) MI_WAVE(2, 4);
+      MI_WAVE(4, 2);
+    case MI_SPMM_WAVE_ROW_U16:
+      if (!wave_ok) return MI_EINVAL;
+      if (N == 256) MI_WAVE(1, 16);
+      if (N == 512) MI_WAVE(2, 8);
+      MI_WAVE(4, 4);
+    case MI_SPMM_WAVE_ROW_VL:
+      if (!(vec4_ok && N == 256)) return MI_EINVAL;
+      return launch_wave_row_vl<8>(rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, batch, s);
+    case MI_SPMM_GROUP_VEC4:
+      if (!vec4_ok) return MI_EINVAL;
+      return dispatch_group<4>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, s);
+    case MI_SPMM_GROUP_SCALAR:
+      return dispatch_group<1>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, s);
+    default:
+      return MI_EINVAL;
+  }
+#undef MI_WAVE
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
+                    int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb, float* C,
+                    int64_t ldc, mi_stream_t stream) {
+  return spmm_dispatch(MI_SPMM_AUTO, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0,
+                       static_cast<hipStream_t>(stream));
+}
+
+int mi_spmm_csr_f32_variant(int variant, const int32_t* rowptr, const int32_t* col,
+                            const float* val, int64_t nnz, int32_t M, int32_t K, int32_t N,
+                            const float* B, int64_t ldb, float* C, int64_t ldc,
+                            mi_stream_t stream) {
+  return spmm_dispatch(variant, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0,
+                       static_cast<hipStream_t>(stream));
+}
+
+int mi_spmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                            int64_t nnz_total, int32_t batch, int32_t M, int32_t K, int32_t N,
+                            const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,
+                            int64_t strideC, mi_stream_t stream) {
+  if (strideB < 0 || strideC < 0) return MI_EINVAL;
+  return spmm_dispatch(MI_SPMM_AUTO, rowptr, col, val, nnz_total, batch, M, K, N, B, ldb, strideB,
+                       C, ldc, strideC, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

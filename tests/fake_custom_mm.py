@@ -1,0 +1,90 @@
+"""A stand-in for the `custom_mm` extension built on the CPU oracle — TEST ONLY.
+
+Lets the `-m "not gpu"` tests exercise matmuls.py's host logic (rank dispatch,
+output allocation, autograd formulas, broadcasting) on CPU tensors: the test
+puts this module into sys.modules['custom_mm'] before importing matmuls, so the
+default `mm_op` / `bmm_op` arguments bind to these functions.  Same names and
+positional signatures as the real module (reference src/custom_mm.cpp:393-416).
+"""
+import numpy as np
+import torch
+
+import oracle
+
+calls = []  # (name, extra) per kernel invocation, for dispatch assertions
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _write(C, arr):
+    C.copy_(torch.from_numpy(np.ascontiguousarray(arr)).reshape(C.shape))
+    return C
+
+
+def cublas_mmul(A, B, C, transa, transb):
+    calls.append(("cublas_mmul", (transa, transb)))
+    return _write(C, oracle.gemm(_np(A), _np(B), transa, transb))
+
+
+def cublas_bmm(A, B, C, dim, transa, transb):
+    calls.append(("cublas_bmm", (dim, transa, transb)))
+    if dim not in (2, 3, 4):
+        raise ValueError("Invalid dim argument.")
+    assert A.dim() == dim and B.dim() == dim
+    return _write(C, oracle.gemm(np.ascontiguousarray(_np(A)), np.ascontiguousarray(_np(B)), transa, transb))
+
+
+def _spmm(name, vals, cols, offs, nnz, rows, kcols, B, C):
+    calls.append((name, (rows, kcols)))
+    assert offs.dtype == torch.int32 and cols.dtype == torch.int32 and vals.dtype == torch.float32
+    assert offs.numel() == rows + 1 and B.shape[0] == kcols
+    return _write(C, oracle.spmm_csr(_np(offs), _np(cols)[:nnz], _np(vals)[:nnz], rows, kcols, _np(B)))
+
+
+def naive_spmm(vals, cols, offs, nnz, rows, kcols, B, C):
+    return _spmm("naive_spmm", vals, cols, offs, nnz, rows, kcols, B, C)
+
+
+def cusparse_mmul(vals, cols, offs, nnz, rows, kcols, B, C):
+    return _spmm("cusparse_mmul", vals, cols, offs, nnz, rows, kcols, B, C)
+
+
+def dense_to_csr(dense):
+    calls.append(("dense_to_csr", tuple(dense.shape)))
+    rp, c, v = oracle.dense_to_csr(_np(dense))
+    return torch.from_numpy(v.copy()), torch.from_numpy(c.copy()), torch.from_numpy(rp.copy())
+
+
+def naive_spmm_batched(vals, cols, offs, nnz, batch, rows, kcols, B, C):
+    calls.append(("naive_spmm_batched", (batch, rows, kcols)))
+    return _write(C, oracle.spmm_csr_batched(_np(offs), _np(cols)[:nnz], _np(vals)[:nnz], batch, rows, kcols,
+                                             np.ascontiguousarray(_np(B))))
+
+
+def csr_transpose(vals, cols, offs, nnz, rows, kcols):
+    calls.append(("csr_transpose", (rows, kcols)))
+    rp, c, v = oracle.csr_transpose(_np(offs), _np(cols)[:nnz], _np(vals)[:nnz], rows, kcols)
+    return torch.from_numpy(v.copy()), torch.from_numpy(c.copy()), torch.from_numpy(rp.copy())
+
+
+def sddmm(cols, offs, nnz, rows, kcols, dC, B):
+    calls.append(("sddmm", (rows, kcols)))
+    return torch.from_numpy(oracle.sddmm(_np(offs), _np(cols)[:nnz], rows, _np(dC), _np(B)).copy())
+
+
+def init_cublas():
+    pass
+
+
+def destroy_cublas():
+    pass
+
+
+def init_cusparse():
+    pass
+
+
+def destroy_cusparse():
+    pass

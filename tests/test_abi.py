@@ -1,0 +1,160 @@
+"""The drop-in boundary without a GPU: libmi_spmm.so loads and exports every
+symbol include/mi_spmm.h declares; argument validation that returns before any
+HIP call; the host inspector; the custom_mm module surface and its error
+behaviour on CPU tensors (no CPU fallback)."""
+import ctypes
+import re
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+REPO = Path(__file__).resolve().parent.parent
+HEADER = REPO / "include" / "mi_spmm.h"
+
+REFERENCE_NAMES = [  # reference src/custom_mm.cpp:393-416
+    "init_cublas", "destroy_cublas", "init_cusparse", "destroy_cusparse", "cublas_mmul", "cublas_bmm",
+    "cusparse_mmul", "dummy_kernel", "naive_spmm", "tiledspmm_inspect_csr", "tiledspmm_inspect_coo",
+    "tiledspmm_mm", "tiledspmm_clean", "cusparse_inspect", "cusparse_mmul_opt", "cusparse_clean"]
+
+
+def declared_functions():
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib(built):
+    import torch  # noqa: F401  (torch's HIP runtime first, as in the product)
+    return ctypes.CDLL(str(built / "libmi_spmm.so"))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = declared_functions()
+    assert len(names) == 19, names
+    for must in ("mi_spmm_csr_f32", "mi_spmm_csr_batched_f32", "mi_spmm_csr_colmajor_f32", "mi_gemm_f32",
+                 "mi_dense_to_csr_count", "mi_dense_to_csr_fill", "mi_csr_transpose_f32", "mi_sddmm_csr_f32",
+                 "mi_coo_to_csr_host", "mi_dummy_kernel"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} declared in include/mi_spmm.h but not exported"
+    assert lib.mi_spmm_abi_version() == 1
+
+
+def test_status_strings(lib):
+    lib.mi_status_string.restype = ctypes.c_char_p
+    assert lib.mi_status_string(0) == b"ok"
+    seen = {lib.mi_status_string(-i) for i in range(0, 6)}
+    assert len(seen) == 6 and b"unknown status" not in seen
+    assert lib.mi_status_string(-99) == b"unknown status"
+
+
+def test_argument_validation_needs_no_gpu(lib):
+    """Bad arguments and empty problems return before any HIP call."""
+    i64, i32, vp = ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p
+    lib.mi_spmm_csr_f32.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, i64, vp, i64, vp]
+    assert lib.mi_spmm_csr_f32(None, None, None, 0, -1, 4, 4, None, 4, None, 4, None) == -1   # MI_EINVAL
+    assert lib.mi_spmm_csr_f32(None, None, None, 0, 0, 4, 4, None, 4, None, 4, None) == 0     # M == 0: nothing to do
+    assert lib.mi_spmm_csr_f32(None, None, None, 2 ** 31, 4, 4, 4, None, 4, None, 4, None) == -2  # MI_ERANGE
+    assert lib.mi_spmm_csr_f32(None, None, None, 0, 4, 4, 4, None, 4, None, 4, None) == -1   # null rowptr / C
+    lib.mi_gemm_f32.argtypes = [ctypes.c_int, ctypes.c_int, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, i64,
+                                i32, vp]
+    assert lib.mi_gemm_f32(0, 0, -1, 2, 2, None, 2, 0, None, 2, 0, None, 2, 0, 1, None) == -1
+    assert lib.mi_gemm_f32(0, 0, 0, 2, 2, None, 2, 0, None, 2, 0, None, 2, 0, 1, None) == 0
+    assert lib.mi_gemm_f32(0, 0, 2, 2, 2, None, 2, 0, None, 2, 0, None, 2, 0, 70000, None) == -2
+    lib.mi_spmm_colmajor_workspace_bytes.restype = ctypes.c_size_t
+    lib.mi_spmm_colmajor_workspace_bytes.argtypes = [i32, i32, i32]
+    assert lib.mi_spmm_colmajor_workspace_bytes(10, 20, 5) >= 4 * (20 * 5 + 10 * 5)
+    lib.mi_dense_to_csr_workspace_bytes.restype = ctypes.c_size_t
+    lib.mi_dense_to_csr_workspace_bytes.argtypes = [i32, i32]
+    assert lib.mi_dense_to_csr_workspace_bytes(3, 7) >= 4 * 21
+
+
+def test_host_inspector_coo_to_csr(lib, golden, oracle_mod):
+    c = golden.case("coo")
+    M, nnz = c["a"].shape[0], len(c["val"])
+    ip = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+    fp = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    lib.mi_coo_to_csr_host.argtypes = [ctypes.c_int32, ctypes.c_int64, ip, ip, fp, ip, ip, fp]
+    rp, col, val = np.zeros(M + 1, np.int32), np.zeros(nnz, np.int32), np.zeros(nnz, np.float32)
+    assert lib.mi_coo_to_csr_host(M, nnz, c["row"], c["col"], c["val"], rp, col, val) == 0
+    assert np.array_equal(rp, c["rowptr"]) and np.array_equal(col, c["csr_col"]) and np.array_equal(val, c["csr_val"])
+    o_rp, o_col, o_val = oracle_mod.coo_to_csr(M, c["row"], c["col"], c["val"])
+    assert np.array_equal(rp, o_rp) and np.array_equal(col, o_col) and np.array_equal(val, o_val)
+    # unsorted rows are rejected (the reference silently builds a wrong CSR, src/sparse_mm.cu:110-134)
+    assert lib.mi_coo_to_csr_host(M, nnz, c["row"][::-1].copy(), c["col"], c["val"], rp, col, val) == -5
+    bad = c["row"].copy()
+    bad[0] = M
+    assert lib.mi_coo_to_csr_host(M, nnz, bad, c["col"], c["val"], rp, col, val) == -1
+
+
+@pytest.fixture(scope="module")
+def custom_mm(built):
+    sys.modules.pop("custom_mm", None)
+    import custom_mm
+    assert Path(custom_mm.__file__).parent == built
+    return custom_mm
+
+
+def test_custom_mm_surface(custom_mm):
+    for name in REFERENCE_NAMES:
+        assert callable(getattr(custom_mm, name)), name
+    for extra in ("dense_to_csr", "naive_spmm_batched", "csr_transpose", "sddmm"):
+        assert callable(getattr(custom_mm, extra)), extra
+    # positional-only, like the reference's m.def without py::arg
+    with pytest.raises(TypeError):
+        custom_mm.cublas_mmul(A=torch.zeros(1, 1))
+    # handle init / destroy are cheap, idempotent no-throw calls (reference custom_mm.cpp:361-391)
+    for _ in range(2):
+        custom_mm.init_cublas()
+        custom_mm.init_cusparse()
+        custom_mm.destroy_cusparse()
+        custom_mm.destroy_cublas()
+    custom_mm.cusparse_clean()
+    custom_mm.tiledspmm_clean()
+
+
+def test_custom_mm_has_no_cpu_path(custom_mm):
+    a, b, c = torch.rand(2, 3), torch.rand(3, 4), torch.zeros(2, 4)
+    with pytest.raises(RuntimeError, match="device"):
+        custom_mm.cublas_mmul(a, b, c, False, False)
+    with pytest.raises(RuntimeError, match="device"):
+        custom_mm.cublas_bmm(a[None], b[None], c[None], 3, False, False)
+    csr = a.to_sparse_csr()
+    args = (csr.values(), csr.col_indices().int(), csr.crow_indices().int(), 6, 2, 3, b, c)
+    with pytest.raises(RuntimeError, match="device"):
+        custom_mm.naive_spmm(*args)
+    with pytest.raises(RuntimeError, match="device"):
+        custom_mm.cusparse_mmul(*args)
+    with pytest.raises(RuntimeError, match="device"):
+        custom_mm.dense_to_csr(a)
+
+
+def test_custom_mm_error_convention(custom_mm):
+    a = torch.rand(2, 2)
+    with pytest.raises(ValueError, match="Invalid dim"):  # std::invalid_argument, reference custom_mm.cpp:162
+        custom_mm.cublas_bmm(a, a, a, 5, False, False)
+    with pytest.raises(RuntimeError, match="Invalid handle_id"):  # reference custom_mm.cpp:262,340
+        custom_mm.cusparse_mmul_opt(a, a, "no-such-layer")
+    with pytest.raises(RuntimeError, match="Invalid handle_id"):
+        custom_mm.tiledspmm_mm(a, a, "no-such-layer")
+    with pytest.raises(RuntimeError):  # host inspector inputs must be CPU int64 / float32
+        custom_mm.tiledspmm_inspect_csr(2, 2, 2, torch.zeros(3, dtype=torch.int32), torch.zeros(0, dtype=torch.int64),
+                                        torch.zeros(0), "x")
+
+
+def test_matmuls_product_path_fails_loudly_on_cpu(built):
+    """The real matmuls + real custom_mm on CPU tensors raise; nothing falls back to torch."""
+    for k in ("custom_mm", "matmuls"):
+        sys.modules.pop(k, None)
+    import matmuls
+    assert "fake" not in matmuls.custom_mm.__name__
+    a, b = torch.rand(8, 64), torch.rand(64, 8)
+    for cls in (matmuls.cublasMM, matmuls.naiveSpMM, matmuls.cusparseMM):
+        with pytest.raises(RuntimeError, match="device"):
+            cls.apply(a, b)

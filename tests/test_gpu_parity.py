@@ -1,0 +1,472 @@
+"""Parity of the HIP path with the oracle — needs the MI355X (`-m gpu`).
+
+Everything here calls the product path (custom_mm → libmi_spmm.so → HIP
+kernels, or the C-ABI directly through ctypes for the variant override) and
+compares with the CPU oracle on the same seeded inputs: bit-exact where the
+oracle states the same summation order (all SpMM / GEMM / conversion entry
+points), rtol 1e-5 / atol 1e-8 (the reference tests' torch.allclose defaults,
+tests/naive_kernel_test.py:36-37) against torch.matmul expectations and the
+committed golden fixtures.
+"""
+import ctypes
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-5, 1e-8
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X; the HIP path has no fallback"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def cmm(built):
+    for k in ("custom_mm", "matmuls"):
+        sys.modules.pop(k, None)
+    import custom_mm
+    assert custom_mm.__file__.endswith(".so") and "matrix-multiplication_amd" in custom_mm.__file__
+    custom_mm.init_cublas()
+    custom_mm.init_cusparse()
+    return custom_mm
+
+
+@pytest.fixture(scope="module")
+def mm(cmm):
+    import matmuls
+    assert matmuls.custom_mm is cmm
+    return matmuls
+
+
+@pytest.fixture(scope="module")
+def capi(built, cmm):
+    lib = ctypes.CDLL(str(built / "libmi_spmm.so"))
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    lib.mi_spmm_csr_f32_variant.argtypes = [ctypes.c_int, vp, vp, vp, i64, i32, i32, i32, vp, i64, vp, i64, vp]
+    return lib
+
+
+def t(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def run_spmm(cmm, dev, rowptr, col, val, M, K, B, op="naive_spmm"):
+    C = torch.full((M, B.shape[1]), float("nan"), device=dev)
+    out = getattr(cmm, op)(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, t(B, dev), C)
+    assert out is C or out.data_ptr() == C.data_ptr()  # same tensor returned (reference custom_mm.cpp:178,216)
+    return C.cpu().numpy()
+
+
+# ------------------------------------------------------------------ SpMM ----
+
+def test_spmm_golden_bit_exact_vs_oracle(cmm, dev, golden, oracle_mod):
+    for name in golden.cases("spmm"):
+        c = golden.case(name)
+        M, K = c["a"].shape
+        expect = oracle_mod.spmm_csr(c["rowptr"], c["col"], c["val"], M, K, c["b"])
+        for op in ("naive_spmm", "cusparse_mmul"):
+            got = run_spmm(cmm, dev, c["rowptr"], c["col"], c["val"], M, K, c["b"], op)
+            assert np.array_equal(got, expect), (name, op)
+            assert np.allclose(got, c["c"], rtol=RTOL, atol=ATOL), (name, op)
+
+
+@pytest.mark.parametrize("M,K,N,density", [
+    (512, 1024, 256, 0.1),    # reference tests/cusparse_kernel_test.py:38
+    (1024, 1024, 1024, 0.01), (1024, 2048, 512, 0.01), (2048, 1024, 512, 0.01),  # tiledsppm_kernel_test.py:34-39
+    (333, 777, 256, 0.05), (333, 777, 512, 0.05), (65, 129, 1024, 0.2), (1000, 1000, 100, 0.02),
+    (77, 300, 1, 0.1), (77, 300, 2, 0.1), (77, 300, 7, 0.1), (300, 77, 1031, 0.1), (5, 40, 2048, 0.5),
+])
+def test_spmm_every_variant_is_bit_identical(capi, dev, oracle_mod, M, K, N, density):
+    rowptr, col, val = oracle_mod.make_csr(M, K, density, seed=M + N)
+    B = np.random.Generator(np.random.PCG64(N)).random((K, N), dtype=np.float32)
+    expect = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    d = [t(x, dev) for x in (rowptr, col, val, B)]
+    ran = 0
+    for variant in range(7):
+        C = torch.full((M, N), float("nan"), device=dev)
+        st = capi.mi_spmm_csr_f32_variant(variant, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(val), M, K,
+                                          N, d[3].data_ptr(), N, C.data_ptr(), N,
+                                          torch.cuda.current_stream().cuda_stream)
+        if st == -1:  # variant does not cover this shape
+            continue
+        assert st == 0
+        ran += 1
+        assert np.array_equal(C.cpu().numpy(), expect), f"variant {variant}"
+    assert ran >= 2  # AUTO plus the generic kernel at least
+
+
+def test_spmm_edge_cases(cmm, dev, oracle_mod):
+    # nnz = 0, empty rows at both ends, a row much longer than a wave, inf/nan must not leak from unused B rows
+    M, K, N = 9, 70, 256
+    A = np.zeros((M, K), np.float32)
+    A[2, :] = np.random.Generator(np.random.PCG64(0)).random(K, dtype=np.float32)
+    A[2, 5] = 0
+    A[6, 3] = 2.0
+    rowptr, col, val = oracle_mod.dense_to_csr(A)
+    B = np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32)
+    B[5, :] = np.inf   # column 5 is referenced by no nonzero
+    B[0, 0] = np.nan   # row 0 is referenced only by row 2
+    got = run_spmm(cmm, dev, rowptr.reshape(-1), col, val, M, K, B)
+    expect = oracle_mod.spmm_csr(rowptr.reshape(-1), col, val, M, K, B)
+    assert np.array_equal(got, expect, equal_nan=True)
+    assert np.all(got[[0, 1, 3, 4, 5, 7, 8]] == 0) and np.isfinite(got[6]).all() and np.isnan(got[2, 0])
+    z = run_spmm(cmm, dev, np.zeros(M + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32), M, K, B)
+    assert np.all(z == 0)
+    # strided B (a column slice of a wider matrix) is honoured through ldb, not misread
+    Bw = torch.rand(K, 2 * N, device=dev)
+    C = torch.empty(M, N, device=dev)
+    cmm.naive_spmm(t(val, dev), t(col, dev), t(rowptr.reshape(-1), dev), len(val), M, K, Bw[:, N:], C)
+    assert np.array_equal(C.cpu().numpy(),
+                          oracle_mod.spmm_csr(rowptr.reshape(-1), col, val, M, K, Bw[:, N:].cpu().numpy()))
+    # a transposed view is copied, not read as if contiguous (reference defect 1)
+    Bt = torch.rand(N, K, device=dev)
+    cmm.naive_spmm(t(val, dev), t(col, dev), t(rowptr.reshape(-1), dev), len(val), M, K, Bt.t(), C)
+    assert np.array_equal(C.cpu().numpy(),
+                          oracle_mod.spmm_csr(rowptr.reshape(-1), col, val, M, K, Bt.t().contiguous().cpu().numpy()))
+
+
+def test_spmm_argument_errors(cmm, dev):
+    v, ci, rp = torch.rand(3, device=dev), torch.zeros(3, dtype=torch.int32, device=dev), \
+        torch.tensor([0, 3], dtype=torch.int32, device=dev)
+    B, C = torch.rand(4, 8, device=dev), torch.empty(1, 8, device=dev)
+    with pytest.raises(RuntimeError, match="rows"):
+        cmm.naive_spmm(v, ci, rp, 3, 1, 5, B, C)            # A_cols != B rows
+    with pytest.raises(RuntimeError, match="int32"):
+        cmm.naive_spmm(v, ci.long(), rp, 3, 1, 4, B, C)     # int64 indices (reference: data_ptr<int> dtype check)
+    with pytest.raises(RuntimeError, match="float32"):
+        cmm.naive_spmm(v.double(), ci, rp, 3, 1, 4, B, C)
+    with pytest.raises(RuntimeError, match="C must be"):
+        cmm.naive_spmm(v, ci, rp, 3, 1, 4, B, torch.empty(2, 8, device=dev))
+    with pytest.raises(RuntimeError, match="device"):
+        cmm.naive_spmm(v, ci, rp, 3, 1, 4, B.cpu(), C)
+
+
+def test_spmm_config_c2_full_output_bit_exact(cmm, dev, oracle_mod):
+    """BASELINE.json configs[1]: 64k×64k CSR at 0.1 % × 64k×128, pinned generator, full output."""
+    M = K = 65536
+    N = 128
+    rowptr, col, val = oracle_mod.make_csr(M, K, 1e-3, seed=0)
+    B = np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32)
+    got = run_spmm(cmm, dev, rowptr, col, val, M, K, B)
+    assert np.array_equal(got, oracle_mod.spmm_csr_omp(rowptr, col, val, M, K, B))
+
+
+def test_spmm_config_c3_full_size(cmm, dev, oracle_mod):
+    """BASELINE.json configs[2]: 1M×1M CSR at 0.01 % × 1M×256 on one GPU.  Full output against
+    the oracle (bit-exact) plus size-independent properties: row-shard equivalence and linearity."""
+    M = K = 1 << 20
+    N = 256
+    rowptr, col, val = oracle_mod.make_csr(M, K, 1e-4, seed=0)
+    assert rowptr[-1] == len(val) and 1.09e8 < len(val) < 1.11e8
+    B = np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32)
+    d_rp, d_col, d_val, d_B = (t(x, dev) for x in (rowptr, col, val, B))
+    C = torch.empty(M, N, device=dev)
+    cmm.naive_spmm(d_val, d_col, d_rp, len(val), M, K, d_B, C)
+    got = C.cpu().numpy()
+    expect = oracle_mod.spmm_csr_omp(rowptr, col, val, M, K, B)
+    assert np.array_equal(got, expect)
+    del expect
+    # a row shard computed alone gives the same bits as the same rows of the full product
+    r0, r1 = 300_000, 431_072
+    rp_s = (d_rp[r0:r1 + 1] - d_rp[r0]).contiguous()
+    p0, p1 = int(rowptr[r0]), int(rowptr[r1])
+    Cs = torch.empty(r1 - r0, N, device=dev)
+    cmm.naive_spmm(d_val[p0:p1], d_col[p0:p1], rp_s, p1 - p0, r1 - r0, K, d_B, Cs)
+    assert torch.equal(Cs, C[r0:r1])
+    # linearity in B: A·(2B) == 2·(A·B) exactly (power-of-two scaling commutes with every rounding)
+    C2 = torch.empty(M, N, device=dev)
+    cmm.naive_spmm(d_val, d_col, d_rp, len(val), M, K, d_B * 2, C2)
+    assert torch.equal(C2, C * 2)
+
+
+def test_batched_spmm_one_launch(cmm, dev, golden, oracle_mod):
+    c = golden.case("batched/bert")
+    a, b = c["a"].reshape(-1, 16, 16), c["b"].reshape(-1, 16, 8)
+    vals, cols, offs = cmm.dense_to_csr(t(a, dev))
+    o_rp, o_col, o_val = oracle_mod.dense_to_csr(a)
+    assert np.array_equal(offs.cpu().numpy(), o_rp) and np.array_equal(cols.cpu().numpy(), o_col)
+    assert np.array_equal(vals.cpu().numpy(), o_val)
+    C = torch.empty(a.shape[0], 16, 8, device=dev)
+    cmm.naive_spmm_batched(vals, cols, offs, vals.numel(), a.shape[0], 16, 16, t(b, dev), C)
+    expect = oracle_mod.spmm_csr_batched(o_rp, o_col, o_val, a.shape[0], 16, 16, b)
+    assert np.array_equal(C.cpu().numpy(), expect)
+    assert np.allclose(C.cpu().numpy().reshape(c["c"].shape), c["c"], rtol=RTOL, atol=ATOL)
+    # one B shared by every item
+    cmm.naive_spmm_batched(vals, cols, offs, vals.numel(), a.shape[0], 16, 16, t(b[0], dev), C)
+    assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr_batched(o_rp, o_col, o_val, a.shape[0], 16, 16, b[0]))
+
+
+# -------------------------------------------------- conversions / backward ----
+
+@pytest.mark.parametrize("shape,density", [((1, 1), 1.0), ((7, 5), 0.5), ((3, 64, 64), 0.3), ((2, 3, 100, 257), 0.05),
+                                           ((513, 1000), 0.01), ((4, 0, 8), 0.5), ((1, 5, 0), 0.5)])
+def test_dense_to_csr_bit_exact(cmm, dev, oracle_mod, shape, density):
+    g = np.random.Generator(np.random.PCG64(sum(shape)))
+    a = (g.random(shape, dtype=np.float32) * (g.random(shape) < density)).astype(np.float32)
+    if a.size:
+        a.flat[0] = -0.0  # negative zero is a zero (x != 0 test, like torch.to_sparse_csr)
+    vals, cols, offs = cmm.dense_to_csr(t(a, dev))
+    rp, col, val = oracle_mod.dense_to_csr(a)
+    assert offs.dtype == torch.int32 and cols.dtype == torch.int32
+    assert np.array_equal(offs.cpu().numpy(), rp)
+    assert np.array_equal(cols.cpu().numpy(), col) and np.array_equal(vals.cpu().numpy(), val)
+
+
+@pytest.mark.parametrize("M,K,density", [(300, 170, 0.05), (50, 4000, 0.01), (4000, 50, 0.3), (1, 1, 1.0), (64, 64, 0.0)])
+def test_csr_transpose_bit_exact(cmm, dev, oracle_mod, M, K, density):
+    rowptr, col, val = oracle_mod.make_csr(M, K, density, seed=3) if density > 0 else \
+        (np.zeros(M + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
+    t_val, t_col, t_off = cmm.csr_transpose(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K)
+    e_rp, e_col, e_val = oracle_mod.csr_transpose(rowptr, col, val, M, K)
+    assert np.array_equal(t_off.cpu().numpy(), e_rp) and np.array_equal(t_col.cpu().numpy(), e_col)
+    assert np.array_equal(t_val.cpu().numpy(), e_val)
+
+
+@pytest.mark.parametrize("N", [1, 8, 64, 100, 256, 300])
+def test_sddmm_bit_exact(cmm, dev, oracle_mod, N):
+    M, K = 120, 90
+    rowptr, col, val = oracle_mod.make_csr(M, K, 0.1, seed=N)
+    g = np.random.Generator(np.random.PCG64(N))
+    dC, B = g.random((M, N), dtype=np.float32), g.random((K, N), dtype=np.float32)
+    got = cmm.sddmm(t(col, dev), t(rowptr, dev), len(val), M, K, t(dC, dev), t(B, dev))
+    assert np.array_equal(got.cpu().numpy(), oracle_mod.sddmm(rowptr, col, M, dC, B))
+
+
+# ------------------------------------------------------------------ GEMM ----
+
+def gemm_ref(oracle_mod, a, b, ta, tb):
+    return oracle_mod.gemm(a, b, ta, tb)
+
+
+@pytest.mark.parametrize("ta", [False, True])
+@pytest.mark.parametrize("tb", [False, True])
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (37, 45, 53), (64, 64, 32), (65, 129, 33), (128, 128, 64), (200, 70, 130),
+                                   (130, 260, 7), (3, 300, 257)])
+def test_gemm_bit_exact_vs_oracle(cmm, dev, oracle_mod, ta, tb, m, n, k):
+    g = np.random.Generator(np.random.PCG64(m * 7 + n * 3 + k))
+    a = g.random((k, m) if ta else (m, k), dtype=np.float32)
+    b = g.random((n, k) if tb else (k, n), dtype=np.float32)
+    C = torch.full((m, n), float("nan"), device=dev)
+    out = cmm.cublas_mmul(t(a, dev), t(b, dev), C, ta, tb)
+    assert out.data_ptr() == C.data_ptr()
+    assert np.array_equal(C.cpu().numpy(), gemm_ref(oracle_mod, a, b, ta, tb))
+
+
+def test_gemm_golden_and_batched(cmm, dev, golden, oracle_mod):
+    for name in golden.cases("gemm"):
+        c = golden.case(name)
+        ta, tb = (bool(x) for x in c["flags"])
+        a, b = c["a"], c["b"]
+        if a.ndim != b.ndim:
+            continue  # mixed ranks go through matmuls (test_matmuls_on_device)
+        C = torch.empty(c["c"].shape, device=dev)
+        if a.ndim == 2:
+            cmm.cublas_mmul(t(a, dev), t(b, dev), C, ta, tb)
+        else:
+            cmm.cublas_bmm(t(a, dev), t(b, dev), C, a.ndim, ta, tb)
+        assert np.array_equal(C.cpu().numpy(), gemm_ref(oracle_mod, a, b, ta, tb)), name
+        assert np.allclose(C.cpu().numpy(), c["c"], rtol=RTOL, atol=ATOL), name
+
+
+def test_gemm_views_are_honoured(cmm, dev, oracle_mod):
+    g = torch.Generator(device="cpu").manual_seed(0)
+    a, b = torch.rand(40, 50, generator=g), torch.rand(60, 50, generator=g)
+    C = torch.empty(40, 60, device=dev)
+    # b.t() is a transposed view: must give a @ b.t(), not a misread of b's memory
+    cmm.cublas_mmul(a.to(dev), b.to(dev).t(), C, False, False)
+    assert np.array_equal(C.cpu().numpy(), oracle_mod.gemm(a.numpy(), b.numpy(), False, True))
+    # row slices with a leading dimension, batch-broadcast (stride-0) operand
+    wide = torch.rand(3, 40, 100, generator=g)
+    bb = torch.rand(50, 20, generator=g)
+    C3 = torch.empty(3, 40, 20, device=dev)
+    cmm.cublas_bmm(wide.to(dev)[:, :, 25:75], bb.to(dev).expand(3, 50, 20), C3, 3, False, False)
+    expect = oracle_mod.gemm(wide[:, :, 25:75].contiguous().numpy(), bb.expand(3, 50, 20).contiguous().numpy())
+    assert np.array_equal(C3.cpu().numpy(), expect)
+    with pytest.raises(RuntimeError, match="inner dimensions"):
+        cmm.cublas_mmul(a.to(dev), b.to(dev), C, False, False)
+    with pytest.raises(ValueError, match="Invalid dim"):
+        cmm.cublas_bmm(a.to(dev), b.to(dev), C, 7, False, False)
+
+
+def test_gemm_bert_base_attention_shapes(cmm, dev, oracle_mod):
+    """BASELINE.json configs[4]: B=32, H=12, S=512, D=64 — q·kᵀ and probs·v at full size."""
+    g = torch.Generator(device="cpu").manual_seed(0)
+    q, k, v = (torch.rand(32, 12, 512, 64, generator=g) for _ in range(3))
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    scores = torch.empty(32, 12, 512, 512, device=dev)
+    cmm.cublas_bmm(qd, kd, scores, 4, False, True)
+    assert torch.allclose(torch.matmul(qd, kd.transpose(-1, -2)), scores, rtol=RTOL, atol=ATOL)
+    for (bi, hi) in [(0, 0), (17, 5), (31, 11)]:  # oracle on three heads, bit-exact
+        assert np.array_equal(scores[bi, hi].cpu().numpy(), oracle_mod.gemm(q[bi, hi].numpy(), k[bi, hi].numpy(), False, True))
+    probs = torch.softmax(scores / 8.0, dim=-1)
+    ctxt = torch.empty(32, 12, 512, 64, device=dev)
+    cmm.cublas_bmm(probs, vd, ctxt, 4, False, False)
+    assert torch.allclose(torch.matmul(probs, vd), ctxt, rtol=RTOL, atol=ATOL)
+    p = probs[3, 7].cpu().numpy()
+    assert np.array_equal(ctxt[3, 7].cpu().numpy(), oracle_mod.gemm(p, v[3, 7].numpy()))
+
+
+# ------------------------------------------------ inspector–executor APIs ----
+
+def test_cusparse_inspect_and_mmul_opt_column_major(cmm, dev, golden, oracle_mod):
+    c = golden.case("colmajor/fc")
+    M, K = c["a"].shape
+    N = c["x"].shape[0]
+    cmm.cusparse_inspect(t(c["rowptr"], dev), t(c["col"], dev), t(c["val"], dev), len(c["val"]), M, N, K, "fc1")
+    x = t(c["x"], dev)                       # activations [N, K] row-major == B column-major K×N
+    y = torch.full((N, M), float("nan"), device=dev)
+    out = cmm.cusparse_mmul_opt(x, y, "fc1")
+    assert out.data_ptr() == y.data_ptr()
+    expect = oracle_mod.spmm_csr_colmajor(c["rowptr"], c["col"], c["val"], M, K, N, c["x"]).reshape(N, M)
+    assert np.array_equal(y.cpu().numpy(), expect)
+    assert np.allclose(y.cpu().numpy(), c["y"], rtol=RTOL, atol=ATOL)
+    cmm.cusparse_clean()
+    with pytest.raises(RuntimeError, match="Invalid handle_id"):
+        cmm.cusparse_mmul_opt(x, y, "fc1")
+
+
+@pytest.mark.parametrize("n", [128, 1024])
+def test_tiledspmm_inspect_and_multiply(cmm, dev, oracle_mod, n):
+    """reference tests/tiledsppm_kernel_test.py:34-39 shapes: C[M×K] = A[M×N]·B[N×K], column-major B and C."""
+    for idx, (M, N, K) in enumerate([(n, n, n), (n, 2 * n, n), (n, n, n // 2), (2 * n, n, n // 2)]):
+        rowptr, col, val = oracle_mod.make_csr(M, N, 0.01, seed=idx)
+        g = np.random.Generator(np.random.PCG64(idx))
+        Bcm = g.random((K, N), dtype=np.float32)  # flat column-major N×K buffer
+        expect = oracle_mod.spmm_csr_colmajor(rowptr, col, val, M, N, K, Bcm)
+        # CSR entry: int64 host tensors (reference custom_mm.cpp:321-326)
+        cmm.tiledspmm_inspect_csr(M, N, K, torch.from_numpy(rowptr.astype(np.int64)), torch.from_numpy(col.astype(np.int64)),
+                                  torch.from_numpy(val), f"csr{idx}")
+        # COO entry: int32 host tensors sorted by row (reference custom_mm.cpp:293-298)
+        rows = np.repeat(np.arange(M, dtype=np.int32), np.diff(rowptr))
+        cmm.tiledspmm_inspect_coo(M, N, K, len(val), torch.from_numpy(rows), torch.from_numpy(col), torch.from_numpy(val),
+                                  f"coo{idx}")
+        for layer in (f"csr{idx}", f"coo{idx}"):
+            C = torch.zeros(K, M, device=dev)  # callers pre-zero (reference kernel skips empty row blocks)
+            cmm.tiledspmm_mm(t(Bcm, dev), C, layer)
+            assert np.array_equal(C.cpu().numpy().reshape(-1), expect), (n, idx, layer)
+    cmm.tiledspmm_clean()
+    with pytest.raises(RuntimeError, match="Invalid handle_id"):
+        cmm.tiledspmm_mm(torch.zeros(1, device=dev), torch.zeros(1, device=dev), "csr0")
+    with pytest.raises(RuntimeError, match="sorted"):
+        cmm.tiledspmm_inspect_coo(4, 4, 4, 2, torch.tensor([3, 1], dtype=torch.int32), torch.tensor([0, 0], dtype=torch.int32),
+                                  torch.ones(2), "bad")
+
+
+def test_dummy_kernel_and_streams(cmm, dev, oracle_mod, capfd):
+    cmm.dummy_kernel()
+    assert "0..4095 ok" in capfd.readouterr().out
+    # work is enqueued on torch's CURRENT stream (the reference uses the legacy default stream)
+    M, K, N = 2000, 3000, 256
+    rowptr, col, val = oracle_mod.make_csr(M, K, 0.01, seed=9)
+    B = np.random.Generator(np.random.PCG64(9)).random((K, N), dtype=np.float32)
+    side = torch.cuda.Stream()
+    d = [t(x, dev) for x in (val, col, rowptr, B)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        C = torch.empty(M, N, device=dev)
+        cmm.naive_spmm(d[0], d[1], d[2], len(val), M, K, d[3], C)
+        side.synchronize()
+        got = C.cpu().numpy()
+    assert np.array_equal(got, oracle_mod.spmm_csr(rowptr, col, val, M, K, B))
+
+
+# --------------------------------------------------- matmuls on the device ----
+
+def fwd_bwd_device(fn, ref_fn, a, b, dev):
+    a1, b1 = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    a2, b2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    out, exp = fn(a1, b1), ref_fn(a2, b2)
+    assert out.is_cuda and out.shape == exp.shape
+    assert torch.allclose(exp, out.cpu(), rtol=RTOL, atol=ATOL)
+    dc = torch.rand(exp.shape, generator=torch.Generator().manual_seed(3))
+    out.backward(dc.to(dev))
+    exp.backward(dc)
+    assert torch.allclose(a2.grad, a1.grad.cpu(), rtol=RTOL, atol=ATOL)
+    assert torch.allclose(b2.grad, b1.grad.cpu(), rtol=RTOL, atol=ATOL)
+
+
+def test_matmuls_dense_classes_on_device(mm, dev):
+    g = torch.Generator().manual_seed(21)
+    for cls, ta, tb in [("cublasMM", 0, 0), ("cublasTransaMM", 1, 0), ("cublasTransbMM", 0, 1), ("cublasTransabMM", 1, 1)]:
+        for batch in [(), (3,), (2, 3), (2, 1, 2, 3)]:
+            m, n, k = 33, 65, 47
+            a = torch.rand(*batch, *((k, m) if ta else (m, k)), generator=g)
+            b = torch.rand(*batch, *((n, k) if tb else (k, n)), generator=g)
+            fwd_bwd_device(getattr(mm, cls).apply,
+                           lambda x, y: torch.matmul(x.transpose(-1, -2) if ta else x, y.transpose(-1, -2) if tb else y),
+                           a, b, dev)
+    # FC-layer call shape with a .t() weight view (reference benchmarks/cublas_fc_layer.py:41)
+    w = torch.rand(96, 80, generator=g)
+    fwd_bwd_device(lambda x, wt: mm.cublasMM.apply(x, wt.t()), lambda x, wt: x @ wt.t(), torch.rand(4, 10, 80, generator=g), w, dev)
+    fwd_bwd_device(mm.cublasMM.apply, torch.matmul, torch.rand(50, generator=g), torch.rand(50, 20, generator=g), dev)
+
+
+def test_matmuls_sparse_classes_on_device(mm, dev):
+    g = torch.Generator().manual_seed(22)
+
+    def sp(*shape, density=0.2):
+        return torch.rand(*shape, generator=g) * (torch.rand(*shape, generator=g) < density)
+    for cls in (mm.naiveSpMM, mm.cusparseMM):
+        fwd_bwd_device(cls.apply, torch.matmul, sp(70, 90), torch.rand(90, 256, generator=g), dev)
+        fwd_bwd_device(cls.apply, torch.matmul, sp(70, 90), torch.rand(3, 90, 33, generator=g), dev)
+        fwd_bwd_device(cls.apply, torch.matmul, sp(2, 5, 90), torch.rand(90, 64, generator=g), dev)      # FC layer shape
+        fwd_bwd_device(cls.apply, torch.matmul, sp(2, 3, 64, 64), torch.rand(2, 3, 64, 16, generator=g), dev)
+    # reference tests/naive_kernel_test.py:62-64 (torch.rand "sparse" inputs, 100 % dense)
+    fwd_bwd_device(mm.naiveSpMM.apply, torch.matmul, torch.rand(4, 2, generator=g), torch.rand(2, 3, generator=g), dev)
+    fwd_bwd_device(mm.naiveSpMM.apply, torch.matmul, torch.rand(2, 4, 2, generator=g), torch.rand(2, 2, 3, generator=g), dev)
+    fwd_bwd_device(mm.naiveSpMM.apply, lambda x, y: x @ y, torch.rand(2, 4, 2, generator=g),
+                   torch.rand(2, 4, 2, generator=g).transpose(-1, -2).contiguous(), dev)
+
+
+def test_matmuls_csr_tensor_input_on_device(mm, dev):
+    """reference tests/cusparse_kernel_test.py:46-58 incl. the (512,1024)×(1024,256) case."""
+    g = torch.Generator().manual_seed(23)
+    for (ar, ac), bshape in [((10, 10), (10, 10)), ((10, 20), (20, 10)), ((10, 10), (10, 5)), ((20, 10), (10, 5)),
+                             ((512, 1024), (1024, 256))]:
+        a = torch.rand(ar, ac, generator=g) * (torch.rand(ar, ac, generator=g) < 0.1)
+        b = torch.rand(bshape, generator=g)
+        exp = a @ b
+        a_csr = a.to(dev).to_sparse_csr().requires_grad_(True)
+        b1 = b.to(dev).requires_grad_(True)
+        our = mm.cusparseMM.apply(a_csr, b1)
+        assert torch.allclose(exp, our.cpu(), rtol=RTOL, atol=ATOL)
+        dc = torch.rand(exp.shape, generator=g)
+        our.backward(dc.to(dev))
+        a2, b2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        (a2 @ b2).backward(dc)
+        assert torch.allclose(b2.grad, b1.grad.cpu(), rtol=RTOL, atol=ATOL)
+        assert a_csr.grad.is_sparse_csr
+        assert torch.allclose(a2.grad * (a != 0), a_csr.grad.to_dense().cpu(), rtol=RTOL, atol=ATOL)
+
+
+def test_bert_large_reference_shapes(mm, dev):
+    """reference tests/naive_kernel_test.py:67-68 / tests/cublas_kernel_test.py:68-69, batch 256·16 cut to 16·16."""
+    g = torch.Generator(device=dev).manual_seed(1)
+    a = torch.rand(16, 16, 512, 512, device=dev, generator=g)
+    b = torch.rand(16, 16, 512, 64, device=dev, generator=g)
+    exp = torch.matmul(a, b)
+    assert torch.allclose(exp, mm.naiveSpMM.apply(a, b), rtol=RTOL, atol=ATOL)   # 100 % dense CSR, one launch
+    assert torch.allclose(exp, mm.cublasMM.apply(a, b), rtol=RTOL, atol=ATOL)
+    q = torch.rand(16, 16, 512, 64, device=dev, generator=g)
+    assert torch.allclose(torch.matmul(q, b.transpose(-1, -2)), mm.cublasTransbMM.apply(q, b), rtol=RTOL, atol=ATOL)
+    assert torch.allclose(torch.matmul(q, b.transpose(-1, -2)),
+                          mm.naiveSpMM.apply(q, b.transpose(-1, -2).contiguous()), rtol=RTOL, atol=ATOL)
+
+
+def test_sharded_layout_on_one_gpu(cmm, dev, oracle_mod):
+    """The row-sharded driver with world = 1: block-cyclic chunks computed in place give the
+    same bits as one launch (the N>1 collective path is covered by tests/test_sharded_cpu.py)."""
+    import sharded
+    M, K, N = 10_001, 8_000, 256
+    rowptr, col, val = oracle_mod.make_csr(M, K, 0.005, seed=4)
+    B = t(np.random.Generator(np.random.PCG64(4)).random((K, N), dtype=np.float32), dev)
+    op = sharded.ShardedSpMM(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), M, K, dev, chunks=4)
+    C = op.forward(B)
+    single = torch.empty(M, N, device=dev)
+    cmm.naive_spmm(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, B, single)
+    assert C.shape == (M, N) and torch.equal(C, single)

@@ -1,0 +1,83 @@
+"""Row-sharded SpMM over a 2-rank gloo group on the CPU (no GPU): partitioning,
+rowptr rebasing (bit-exact integers), the in-place block-cyclic all-gather, and
+equality of the gathered C with the single-rank result.  The local 2-d kernel is
+the oracle here (test stand-in for custom_mm.naive_spmm)."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _oracle_mm_op(vals, cols, offs, nnz, rows, kcols, B, C):
+    import oracle
+    C.copy_(torch.from_numpy(oracle.spmm_csr(offs.numpy(), cols.numpy()[:nnz], vals.numpy()[:nnz], rows, kcols,
+                                             B.numpy())))
+    return C
+
+
+def _worker(rank, world, port, M, K, N, chunks, out_dir):
+    for p in (str(REPO), str(REPO / "matrix-multiplication_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        import sharded
+        rowptr, col, val = oracle.make_csr(M, K, 0.05, seed=0)
+        B = torch.from_numpy(np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32))
+        op = sharded.ShardedSpMM(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), M, K, "cpu",
+                                 chunks=chunks, mm_op=_oracle_mm_op)
+        # integer artefacts: block ownership and rebased rowptrs
+        assert [b[0] for b in op.blocks] == [j * world + rank for j in range(chunks)]
+        for blk, rp, ci, v, nnz in op.blocks:
+            r0, r1 = min(blk * op.block_rows, M), min((blk + 1) * op.block_rows, M)
+            expect = (rowptr[r0:r1 + 1].astype(np.int64) - rowptr[r0]).astype(np.int32)
+            got = rp.numpy()
+            assert got.dtype == np.int32 and got[0] == 0 and len(got) == op.block_rows + 1
+            assert np.array_equal(got[:r1 - r0 + 1], expect) and np.all(got[r1 - r0:] == expect[-1])
+            assert nnz == rowptr[r1] - rowptr[r0] and np.array_equal(ci.numpy(), col[rowptr[r0]:rowptr[r1]])
+        total = torch.tensor([op.local_nnz])
+        dist.all_reduce(total)
+        assert int(total) == len(val)
+        C = op.forward(B)
+        np.save(os.path.join(out_dir, f"c_{rank}.npy"), C.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("M,chunks", [(96, 2), (101, 3), (7, 4)])
+def test_two_rank_gather_equals_single_rank(tmp_path, oracle_mod, M, chunks):
+    K, N, world = 64, 24, 2
+    mp.spawn(_worker, args=(world, _free_port(), M, K, N, chunks, str(tmp_path)), nprocs=world, join=True)
+    rowptr, col, val = oracle_mod.make_csr(M, K, 0.05, seed=0)
+    B = np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32)
+    single = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    for r in range(world):
+        got = np.load(tmp_path / f"c_{r}.npy")
+        assert got.shape == (M, N)
+        assert np.array_equal(got, single), f"rank {r}: gathered C differs from the single-rank result"
+
+
+def test_single_process_layout(oracle_mod):
+    sys.path.insert(0, str(REPO / "matrix-multiplication_amd"))
+    import sharded
+    assert sharded.block_layout(1 << 20, 8, 4) == (32768, 1 << 20)
+    assert sharded.block_layout(101, 2, 3) == (17, 102)
+    assert sharded.owned_blocks(1, 2, 3) == [1, 3, 5]
+    rp = torch.tensor([0, 2, 2, 5, 9], dtype=torch.int32)
+    assert sharded.shard_rowptr(rp, 1, 3, 4).tolist() == [0, 0, 3]
+    assert sharded.shard_rowptr(rp, 3, 6, 4).tolist() == [0, 4, 4, 4]  # padded tail rows are empty
