@@ -262,10 +262,11 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> dense_to_csr(torch::Tens
   const int64_t nnz = batch > 0 ? offsets.view({-1})[batch * (rows + 1) - 1].item<int32_t>() : 0;
   torch::Tensor columns = torch::empty({nnz}, iopt);
   torch::Tensor values = torch::empty({nnz}, torch::dtype(torch::kFloat32).device(d.device()));
-  check_status(mi_dense_to_csr_fill(d.data_ptr<float>(), (int32_t)batch, (int32_t)rows, (int32_t)cols, cols,
-                                    rows * cols, offsets.data_ptr<int32_t>(), columns.data_ptr<int32_t>(),
-                                    values.data_ptr<float>(), stream_of(d)),
-               "dense_to_csr(fill)");
+  if (nnz > 0)
+    check_status(mi_dense_to_csr_fill(d.data_ptr<float>(), (int32_t)batch, (int32_t)rows, (int32_t)cols, cols,
+                                      rows * cols, offsets.data_ptr<int32_t>(), columns.data_ptr<int32_t>(),
+                                      values.data_ptr<float>(), stream_of(d)),
+                 "dense_to_csr(fill)");
   return std::make_tuple(values, columns, offsets);
 }
 
