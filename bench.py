@@ -46,15 +46,29 @@ def algorithmic_bytes(nnz, M, N):
 
 
 def committed_traffic(workload):
-    """HBM bytes per launch from the committed PMC passes of this same command (profiles/), or None."""
+    """HBM bytes per product (= per step at N = 1) from the committed PMC passes of this same
+    command (profiles/pmc_traffic.json, written by tools/collect_profiles.py), or None."""
     p = REPO / "profiles" / "pmc_traffic.json"
     if not p.exists():
         return None
     try:
         rec = json.loads(p.read_text())
-        return rec.get(workload, {}).get("hbm_bytes_per_launch")
+        return rec.get(workload, {}).get("hbm_bytes_per_product")
     except (ValueError, OSError):
         return None
+
+
+def spmm_plan(nnz, M, K, N, B, C):
+    """Which kernel custom_mm.naive_spmm's AUTO dispatch runs for this problem and how many
+    launches it issues per product (C-ABI query, no GPU work)."""
+    import ctypes
+    lib = ctypes.CDLL(str(REPO / "matrix-multiplication_amd" / "libmi_spmm.so"))
+    i64, i32, vp = ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p
+    lib.mi_spmm_csr_f32_plan.argtypes = [i64, i32, i32, i32, vp, i64, vp, i64]
+    lib.mi_spmm_variant_name.restype = ctypes.c_char_p
+    variant = lib.mi_spmm_csr_f32_plan(nnz, M, K, N, B.data_ptr(), B.stride(0), C.data_ptr(), C.stride(0))
+    assert variant > 0, variant
+    return lib.mi_spmm_variant_name(variant).decode(), lib.mi_spmm_variant_launches(variant)
 
 
 def cpu_baseline(rowptr, col, val, K, B, N, sample_rows):
@@ -124,7 +138,7 @@ def main():
 
         def step():
             custom_mm.naive_spmm(d_val, d_col, d_rp, nnz, M, K, B, C)
-        launches_per_step = 1
+        kernel_name, launches_per_step = spmm_plan(nnz, M, K, N, B, C)
         local_bytes_alg = bytes_alg
     else:
         op = sharded.ShardedSpMM(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), M, K, dev,
@@ -133,7 +147,8 @@ def main():
 
         def step():
             op.forward(B, out=C)
-        launches_per_step = op.chunks
+        kernel_name, per_block = spmm_plan(op.blocks[0][4], op.block_rows, K, N, B, C)
+        launches_per_step = op.chunks * per_block
         local_bytes_alg = algorithmic_bytes(op.local_nnz, op.block_rows * op.chunks, N)
 
     def barrier():
@@ -157,7 +172,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
     step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
-    kernel_ms = float(np.mean(step_ms)) / launches_per_step  # N = 1: one launch per step, back to back
+    # the step's launches run back to back on this stream: their durations sum to the step's event time
+    kernels_ms_per_step = float(np.mean(step_ms))
 
     # light in-run parity check: a few rows against the oracle (full parity lives in tests/)
     rows = [0, M // 3, M - 1]
@@ -168,7 +184,7 @@ def main():
         assert np.array_equal(got[i], exp[0]), f"row {r} differs from the oracle"
 
     if rank == 0:
-        achieved = local_bytes_alg / launches_per_step / (kernel_ms * 1e-3) / 1e9
+        achieved = local_bytes_alg / (kernels_ms_per_step * 1e-3) / 1e9
         rec = {
             "metric": "SpMM GFLOP/s, CSR(1M,0.01%) x dense(256)" if args.workload == "c3"
                       else "SpMM GFLOP/s, CSR(64k,0.1%) x dense(128)",
@@ -192,12 +208,16 @@ def main():
                 "input_generation_s": round(gen_s, 1),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "spmm_wave_row_kernel<1,8>" if N == 256 else "spmm_group_kernel",
+                "bound": "hbm", "kernel": kernel_name, "launches_per_step": launches_per_step,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": committed_traffic(args.workload) if world == 1 else None,
-                "kernel_ms": round(kernel_ms, 4),
-                "algorithmic_bytes_per_launch": local_bytes_alg // launches_per_step,
+                "kernel_ms_per_step": round(kernels_ms_per_step, 4),
+                "avg_launch_ms": round(kernels_ms_per_step / launches_per_step, 4),
+                "algorithmic_bytes_per_step": local_bytes_alg,
+                "note": "achieved = algorithmic bytes of one product / summed duration of its "
+                        f"{launches_per_step} back-to-back launch(es) (HIP events on the launch stream); "
+                        "traffic = PMC bytes per product from profiles/pmc_traffic.json",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -67,12 +67,27 @@ enum {
   MI_SPMM_GROUP_VEC4 = 4,   /* G = N/4 lanes per row, 64/G rows per wave            */
   MI_SPMM_GROUP_SCALAR = 5, /* any N / alignment: one float per lane                */
   MI_SPMM_WAVE_ROW_VL = 6,  /* wave per row, col/val via vector load + readlane     */
-  MI_SPMM_VARIANT_COUNT = 7
+  MI_SPMM_PANELS_2 = 7,     /* N = 256: K cut into 2 column panels, one launch per   */
+  MI_SPMM_PANELS_3 = 8,     /*   panel (Infinity-Cache blocking of B); … 3 panels    */
+  MI_SPMM_PANELS_4 = 9,
+  MI_SPMM_PANELS_5 = 10,
+  MI_SPMM_PANELS_6 = 11,
+  MI_SPMM_PANELS_8 = 12,
+  MI_SPMM_GROUP_VEC2 = 13,  /* G = N/2 lanes per row, 8 B per lane                    */
+  MI_SPMM_VARIANT_COUNT = 14
 };
 int mi_spmm_csr_f32_variant(int variant, const int32_t* rowptr, const int32_t* col,
                             const float* val, int64_t nnz, int32_t M, int32_t K,
                             int32_t N, const float* B, int64_t ldb, float* C,
                             int64_t ldc, mi_stream_t stream);
+
+/* What MI_SPMM_AUTO resolves to for this problem (no GPU work), how many kernel
+ * launches a variant issues per product, and the kernel's name as profilers show
+ * it — so a benchmark can attribute launch durations. */
+int mi_spmm_csr_f32_plan(int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
+                         int64_t ldb, const float* C, int64_t ldc);
+int mi_spmm_variant_launches(int variant);
+const char* mi_spmm_variant_name(int variant);
 
 /* ------------------------------------------------------------------------ *
  * Batched form — `batch` independent products in ONE launch:

@@ -146,6 +146,104 @@ __global__ __launch_bounds__(256) void spmm_wave_row_vl_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Column-panel pass (Infinity-Cache blocking), N == 256.  When B is larger than
+// the 256 MiB Infinity Cache a uniformly random gather misses it ~(1 - 256MiB/|B|)
+// of the time.  Cutting K into P panels whose B slice fits the cache and running
+// one launch per panel (all CUs work on the same panel at the same time) turns
+// the gathers into cache hits; the price is that C is carried through memory
+// between passes ((2P-1) row passes instead of 1) and col is scanned P times.
+// A pass handles the nonzeros with c_lo <= col < c_hi in CSR order on top of the
+// previous pass's C, so for column-sorted rows (torch CSR, the pinned generator)
+// the per-element fmaf chain is exactly the CSR-order chain of the one-pass
+// kernel: bit-identical results.
+// ---------------------------------------------------------------------------
+template <bool FIRST, int T, int U>
+__global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col,
+    const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
+    int M, long ldb, long ldc, int c_lo, int c_hi) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long row = (long)blockIdx.x * 4 + wave;
+  if (row >= M) return;
+  const float* Bl = B + lane * 4;
+  float* Cl = C + row * ldc + lane * 4;
+  const int start = rowptr[row];
+  const int end = rowptr[row + 1];
+  f32x4 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+    acc[t] = FIRST ? f32x4{0.f, 0.f, 0.f, 0.f}
+                   : __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Cl + t * 256));
+  const unsigned width = (unsigned)(c_hi - c_lo);
+
+  for (int p = start; p < end; p += 64) {
+    const int idx = p + lane;
+    const int myc = idx < end ? col[idx] : -1;
+    const bool in = (unsigned)(myc - c_lo) < width && idx < end;
+    const float myv = in ? val[idx] : 0.f;
+    unsigned long long mask = __ballot(in);  // this chunk's nonzeros that fall in the panel
+    while (__builtin_popcountll(mask) >= U) {
+      f32x4 x[U][T];
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const int c = __builtin_amdgcn_readlane(myc, i);
+        v[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), i));
+        const float* src = Bl + (long)c * ldb;
+#pragma unroll
+        for (int t = 0; t < T; ++t) x[u][t] = *reinterpret_cast<const f32x4*>(src + t * 256);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = fma4(v[u], x[u][t], acc[t]);
+    }
+    while (mask) {
+      const int i = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const int c = __builtin_amdgcn_readlane(myc, i);
+      const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), i));
+      const float* src = Bl + (long)c * ldb;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        acc[t] = fma4(v, *reinterpret_cast<const f32x4*>(src + t * 256), acc[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+    __builtin_nontemporal_store(acc[t], reinterpret_cast<f32x4*>(Cl + t * 256));
+}
+
+template <int T, int U>
+int launch_panels_t(int panels, const int* rowptr, const int* col, const float* val, const float* B,
+                    float* C, int M, int K, long ldb, long ldc, hipStream_t s) {
+  const long blocks = ((long)M + 3) / 4;
+  if (blocks > 0x7fffffffL) return MI_ERANGE;
+  const long kp = ((long)K + panels - 1) / panels;
+  for (int q = 0; q < panels; ++q) {
+    const int lo = (int)(q * kp);
+    const int hi = (int)((q + 1) * kp < K ? (q + 1) * kp : K);
+    if (q == 0)
+      hipLaunchKernelGGL((spmm_wave_row_panel_kernel<true, T, U>), dim3((unsigned)blocks), dim3(256), 0,
+                         s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi);
+    else
+      hipLaunchKernelGGL((spmm_wave_row_panel_kernel<false, T, U>), dim3((unsigned)blocks), dim3(256), 0,
+                         s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi);
+  }
+  return mi::check_launch();
+}
+
+int launch_panels(int panels, const int* rowptr, const int* col, const float* val, const float* B,
+                  float* C, int M, int K, int N, long ldb, long ldc, hipStream_t s) {
+  if (N == 256) return launch_panels_t<1, 8>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, s);
+  if (N == 512) return launch_panels_t<2, 4>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, s);
+  return launch_panels_t<4, 2>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, s);
+}
+
+// ---------------------------------------------------------------------------
 // G lanes per row (G a power of two ≤ 64), 64/G rows per wave, VEC floats per
 // lane per tile, T tiles per pass; columns beyond G·VEC·T are covered by an
 // outer pass loop (col/val re-read once per pass).  Handles every N.
@@ -162,6 +260,20 @@ struct Vec<4> {
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
   }
   static __device__ __forceinline__ type fma(float a, type x, type acc) { return fma4(a, x, acc); }
+};
+template <>
+struct Vec<2> {
+  typedef float type __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ type zero() { return type{0.f, 0.f}; }
+  static __device__ __forceinline__ type load(const float* p) { return *reinterpret_cast<const type*>(p); }
+  static __device__ __forceinline__ void store(float* p, type v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<type*>(p));
+  }
+  static __device__ __forceinline__ type fma(float a, type x, type acc) {
+    acc.x = __builtin_fmaf(a, x.x, acc.x);
+    acc.y = __builtin_fmaf(a, x.y, acc.y);
+    return acc;
+  }
 };
 template <>
 struct Vec<1> {
@@ -306,6 +418,39 @@ int launch_wave_row_vl(const int* rowptr, const int* col, const float* val, cons
   return mi::check_launch();
 }
 
+struct Shape {
+  bool vec4_ok, vec2_ok, wave_ok;
+};
+
+Shape classify(int32_t N, int64_t ldb, int64_t ldc, int64_t strideB, int64_t strideC, const float* B,
+               const float* C) {
+  Shape sh;
+  sh.vec4_ok = (N % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && (strideB % 4 == 0) &&
+               (strideC % 4 == 0) && mi::aligned16(B) && mi::aligned16(C);
+  sh.vec2_ok = (N % 2 == 0) && (ldb % 2 == 0) && (ldc % 2 == 0) && (strideB % 2 == 0) &&
+               (strideC % 2 == 0) &&
+               ((reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 7u) == 0;
+  sh.wave_ok = sh.vec4_ok && (N == 256 || N == 512 || N == 1024);
+  return sh;
+}
+
+// The kernel AUTO resolves to.
+int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32_t K, int32_t N,
+                   int64_t ldb) {
+  // B much larger than the 256 MiB Infinity Cache and rows long enough to pay for
+  // carrying C through memory once: two column panels (measured on MI355X at
+  // |B| = 1 GiB, 105 nnz/row: 15.5 ms vs 16.4 ms one-pass; 3+ panels lose, each
+  // extra pass costs a read + write of C).  The launch must also re-touch a panel
+  // often enough to keep it resident (gathered bytes >= 8x |B|), which excludes the
+  // short row blocks of a sharded run.
+  const long b_elems = (long)K * ldb;
+  if (sh.wave_ok && batch == 1 && b_elems * 4 >= (768L << 20) && nnz >= 32L * M &&
+      nnz * (long)N >= 8 * b_elems)
+    return MI_SPMM_PANELS_2;
+  if (sh.wave_ok) return MI_SPMM_WAVE_ROW_U8;
+  return sh.vec4_ok ? MI_SPMM_GROUP_VEC4 : MI_SPMM_GROUP_SCALAR;
+}
+
 int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const float* val,
                   int64_t nnz, int32_t batch, int32_t M, int32_t K, int32_t N, const float* B,
                   int64_t ldb, int64_t strideB, float* C, int64_t ldc, int64_t strideC,
@@ -319,14 +464,9 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
   if (nnz > 0 && (!col || !val || !B)) return MI_EINVAL;
   if (ldb < N || ldc < N) return MI_EINVAL;
 
-  const bool vec4_ok = (N % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && (strideB % 4 == 0) &&
-                       (strideC % 4 == 0) && mi::aligned16(B) && mi::aligned16(C);
-  const bool wave_ok = vec4_ok && (N == 256 || N == 512 || N == 1024);
-
-  if (variant == MI_SPMM_AUTO) {
-    if (wave_ok) variant = MI_SPMM_WAVE_ROW_U8;
-    else variant = vec4_ok ? MI_SPMM_GROUP_VEC4 : MI_SPMM_GROUP_SCALAR;
-  }
+  const Shape sh = classify(N, ldb, ldc, strideB, strideC, B, C);
+  const bool vec4_ok = sh.vec4_ok, vec2_ok = sh.vec2_ok, wave_ok = sh.wave_ok;
+  if (variant == MI_SPMM_AUTO) variant = choose_variant(sh, nnz, batch, M, K, N, ldb);
 
 #define MI_WAVE(T_, U_) \
   return launch_wave_row<T_, U_>(rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, batch, s)
@@ -349,9 +489,18 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
     case MI_SPMM_WAVE_ROW_VL:
       if (!(vec4_ok && N == 256)) return MI_EINVAL;
       return launch_wave_row_vl<8>(rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, batch, s);
+    case MI_SPMM_PANELS_2: case MI_SPMM_PANELS_3: case MI_SPMM_PANELS_4: case MI_SPMM_PANELS_5:
+    case MI_SPMM_PANELS_6: case MI_SPMM_PANELS_8: {
+      if (!(wave_ok && batch == 1)) return MI_EINVAL;
+      static const int kPanels[] = {2, 3, 4, 5, 6, 8};
+      return launch_panels(kPanels[variant - MI_SPMM_PANELS_2], rowptr, col, val, B, C, M, K, N, ldb, ldc, s);
+    }
     case MI_SPMM_GROUP_VEC4:
       if (!vec4_ok) return MI_EINVAL;
       return dispatch_group<4>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, s);
+    case MI_SPMM_GROUP_VEC2:
+      if (!vec2_ok) return MI_EINVAL;
+      return dispatch_group<2>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, s);
     case MI_SPMM_GROUP_SCALAR:
       return dispatch_group<1>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, s);
     default:
@@ -386,6 +535,30 @@ int mi_spmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col, const flo
   if (strideB < 0 || strideC < 0) return MI_EINVAL;
   return spmm_dispatch(MI_SPMM_AUTO, rowptr, col, val, nnz_total, batch, M, K, N, B, ldb, strideB,
                        C, ldc, strideC, static_cast<hipStream_t>(stream));
+}
+
+int mi_spmm_csr_f32_plan(int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,
+                         const float* C, int64_t ldc) {
+  if (M < 0 || K < 0 || N < 0 || nnz < 0) return MI_EINVAL;
+  return choose_variant(classify(N, ldb, ldc, 0, 0, B, C), nnz, 1, M, K, N, ldb);
+}
+
+int mi_spmm_variant_launches(int variant) {
+  static const int kPanels[] = {2, 3, 4, 5, 6, 8};
+  if (variant >= MI_SPMM_PANELS_2 && variant <= MI_SPMM_PANELS_8) return kPanels[variant - MI_SPMM_PANELS_2];
+  return (variant > MI_SPMM_AUTO && variant < MI_SPMM_VARIANT_COUNT) ? 1 : MI_EINVAL;
+}
+
+const char* mi_spmm_variant_name(int variant) {
+  switch (variant) {
+    case MI_SPMM_AUTO: return "auto";
+    case MI_SPMM_WAVE_ROW_U4: case MI_SPMM_WAVE_ROW_U8: case MI_SPMM_WAVE_ROW_U16: return "spmm_wave_row_kernel";
+    case MI_SPMM_WAVE_ROW_VL: return "spmm_wave_row_vl_kernel";
+    case MI_SPMM_GROUP_VEC4: case MI_SPMM_GROUP_VEC2: case MI_SPMM_GROUP_SCALAR: return "spmm_group_kernel";
+    case MI_SPMM_PANELS_2: case MI_SPMM_PANELS_3: case MI_SPMM_PANELS_4: case MI_SPMM_PANELS_5:
+    case MI_SPMM_PANELS_6: case MI_SPMM_PANELS_8: return "spmm_wave_row_panel_kernel";
+    default: return "unknown";
+  }
 }
 
 }  // extern "C"

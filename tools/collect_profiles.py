@@ -1,0 +1,57 @@
+"""Copies the summaries of a tools/profile_bench.sh run from gpurun_out/<tag>/ into profiles/
+(tracked) and derives HBM traffic per product from the PMC passes:
+    python tools/collect_profiles.py <tag> <round-prefix> <workload>
+FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reads exactly half the bytes of
+16-B-per-lane coalesced reads (MI355X_MICROARCH.md §HBM), so it is doubled; WRITE_SIZE is exact."""
+import csv
+import glob
+import json
+import shutil
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+tag, prefix, workload = sys.argv[1], sys.argv[2], sys.argv[3]
+src = REPO / "gpurun_out" / tag
+dst = REPO / "profiles"
+dst.mkdir(exist_ok=True)
+shutil.copy(src / "bench.json", dst / f"{prefix}_bench_{workload}.json")
+stats = glob.glob(str(src / "stats" / "**" / "*_kernel_stats.csv"), recursive=True)[0]
+shutil.copy(stats, dst / f"{prefix}_bench_{workload}_kernel_stats.csv")
+bench = json.loads((src / "bench.json").read_text())
+launches = bench["roofline"]["launches_per_step"]
+
+per_counter = {}
+for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    f = glob.glob(str(src / name / "**" / "*_counter_collection.csv"), recursive=True)[0]
+    by_kernel = defaultdict(list)
+    with open(f) as fi, open(dst / f"{prefix}_{workload}_{name}_counter_collection.csv", "w") as fo:
+        for i, line in enumerate(fi):
+            if i == 0 or "spmm" in line:
+                fo.write(line)
+    for r in csv.DictReader(open(f)):
+        if "spmm" in r["Kernel_Name"]:
+            by_kernel[r["Kernel_Name"].split("(int const")[0].replace("void (anonymous namespace)::", "")].append(float(r["Counter_Value"]))
+    # mean per launch of each kernel instantiation; one product = one launch of each
+    per_counter[counter] = {k: sum(v) / len(v) for k, v in by_kernel.items()}
+fetch_kb = sum(per_counter["FETCH_SIZE"].values())
+write_kb = sum(per_counter["WRITE_SIZE"].values())
+assert len(per_counter["FETCH_SIZE"]) == launches or launches == 1, (per_counter, launches)
+rec_path = dst / "pmc_traffic.json"
+rec = json.loads(rec_path.read_text()) if rec_path.exists() else {}
+rec[workload] = {
+    "round": prefix,
+    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --output-format csv -- "
+               "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+    "kernels": per_counter,
+    "FETCH_SIZE_KB_raw_per_product": fetch_kb, "WRITE_SIZE_KB_raw_per_product": write_kb,
+    "correction": "gfx950: FETCH_SIZE x2 (16-B/lane coalesced reads), WRITE_SIZE exact, unit KB",
+    "read_bytes_per_product": fetch_kb * 2 * 1024, "write_bytes_per_product": write_kb * 1024,
+    "hbm_bytes_per_launch": (fetch_kb * 2 + write_kb) * 1024 / launches,
+    "hbm_bytes_per_product": (fetch_kb * 2 + write_kb) * 1024,
+    "algorithmic_bytes_per_product": bench["config"]["algorithmic_bytes_per_step"],
+    "note": "fabric-side (L2-miss) bytes: Infinity-Cache hits are included in FETCH_SIZE",
+}
+rec_path.write_text(json.dumps(rec, indent=1))
+print(json.dumps(rec[workload], indent=1))

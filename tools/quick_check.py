@@ -49,7 +49,7 @@ def main():
         B = torch.rand(K, N, generator=gen)
         exp = a @ B
         Bd = B.to(dev)
-        for variant in range(0, 7):
+        for variant in range(0, 14):
             C = torch.full((M, N), float("nan"), device=dev)
             try:
                 spmm(variant, rp, ci, v, M, K, Bd, C)
@@ -67,7 +67,7 @@ def main():
         sys.exit(1)
 
     if "--big" in sys.argv:
-        for (M, K, N, deg) in [(1 << 20, 1 << 20, 256, 105), (1 << 16, 1 << 16, 128, 66)]:
+        for (M, K, N, deg) in [(1 << 20, 1 << 20, 256, 105), (1 << 16, 1 << 16, 128, 66), (1 << 18, 1 << 16, 64, 64), (1 << 17, 1 << 19, 512, 64)]:
             col = torch.randint(0, K, (M, deg), device=dev, dtype=torch.int32).sort(dim=1).values.reshape(-1).contiguous()
             val = torch.rand(M * deg, device=dev)
             rowptr = (torch.arange(M + 1, device=dev, dtype=torch.int64) * deg).to(torch.int32)
@@ -76,7 +76,7 @@ def main():
             nnz = M * deg
             bytes_alg = nnz * (4 * N + 8) + 4 * (M + 1) + 4 * M * N
             ref = None
-            for variant in range(0, 7):
+            for variant in range(0, 14):
                 try:
                     spmm(variant, rowptr, col, val, M, K, B, C)
                 except RuntimeError as e:
