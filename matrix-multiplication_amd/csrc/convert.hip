@@ -144,8 +144,12 @@ int launch_scan_rowptr(const int* counts, long n, int rows, int* out, int* block
 }
 
 // --------------------------------------------------------------------------
-// Dense → CSR: one wave per dense row.
+// Dense → CSR: one wave per dense row.  VEC = 4: a lane reads 16 B (4 columns),
+// the row is swept 256 columns per wave-instruction; VEC = 1 for rows that are
+// not 16-B aligned.  Ranks come from four ballots (one per lane component) so
+// columns stay ascending.
 // --------------------------------------------------------------------------
+template <int VEC>
 __global__ __launch_bounds__(256) void count_nonzeros_kernel(const float* __restrict__ dense,
                                                              long total_rows, int rows, int cols,
                                                              long ld, long stride,
@@ -156,14 +160,36 @@ __global__ __launch_bounds__(256) void count_nonzeros_kernel(const float* __rest
   const long b = id / rows;
   const float* src = dense + b * stride + (id - b * rows) * ld;
   int cnt = 0;
-  for (int c0 = 0; c0 < cols; c0 += 64) {
-    const int c = c0 + lane;
-    const bool nz = c < cols && src[c] != 0.0f;
-    cnt += __builtin_popcountll(__ballot(nz));
+  if (VEC == 4) {
+    for (int c0 = 0; c0 < cols; c0 += 256) {
+      const int c = c0 + lane * 4;
+      mi::f32x4 x = mi::f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c + 3 < cols) {
+        x = __builtin_nontemporal_load(reinterpret_cast<const mi::f32x4*>(src + c));
+      } else {
+        if (c + 0 < cols) x.x = src[c + 0];
+        if (c + 1 < cols) x.y = src[c + 1];
+        if (c + 2 < cols) x.z = src[c + 2];
+      }
+      cnt += (x.x != 0.0f) + (x.y != 0.0f) + (x.z != 0.0f) + (x.w != 0.0f);
+    }
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) cnt += __shfl_xor(cnt, w, 64);
+  } else {
+    for (int c0 = 0; c0 < cols; c0 += 64) {
+      const int c = c0 + lane;
+      const bool nz = c < cols && src[c] != 0.0f;
+      cnt += __builtin_popcountll(__ballot(nz));
+    }
   }
   if (lane == 0) counts[id] = cnt;
 }
 
+__device__ __forceinline__ int lanes_below(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+
+template <int VEC>
 __global__ __launch_bounds__(256) void fill_csr_kernel(const float* __restrict__ dense,
                                                        long total_rows, int rows, int cols, long ld,
                                                        long stride, const int* __restrict__ rowptr,
@@ -176,18 +202,39 @@ __global__ __launch_bounds__(256) void fill_csr_kernel(const float* __restrict__
   const int r = (int)(id - b * rows);
   const float* src = dense + b * stride + (long)r * ld;
   long out = rowptr[b * ((long)rows + 1) + r];
-  for (int c0 = 0; c0 < cols; c0 += 64) {
-    const int c = c0 + lane;
-    const float x = c < cols ? src[c] : 0.0f;
-    const bool nz = c < cols && x != 0.0f;
-    const unsigned long long mask = __ballot(nz);
-    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                               __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-    if (nz) {
-      col[out + rank] = c;
-      val[out + rank] = x;
+  if (VEC == 4) {
+    for (int c0 = 0; c0 < cols; c0 += 256) {
+      const int c = c0 + lane * 4;
+      mi::f32x4 x = mi::f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c + 3 < cols) {
+        x = __builtin_nontemporal_load(reinterpret_cast<const mi::f32x4*>(src + c));
+      } else {
+        if (c + 0 < cols) x.x = src[c + 0];
+        if (c + 1 < cols) x.y = src[c + 1];
+        if (c + 2 < cols) x.z = src[c + 2];
+      }
+      const bool n0 = x.x != 0.0f, n1 = x.y != 0.0f, n2 = x.z != 0.0f, n3 = x.w != 0.0f;
+      const unsigned long long m0 = __ballot(n0), m1 = __ballot(n1), m2 = __ballot(n2), m3 = __ballot(n3);
+      long o = out + lanes_below(m0) + lanes_below(m1) + lanes_below(m2) + lanes_below(m3);
+      if (n0) { col[o] = c;     val[o] = x.x; ++o; }
+      if (n1) { col[o] = c + 1; val[o] = x.y; ++o; }
+      if (n2) { col[o] = c + 2; val[o] = x.z; ++o; }
+      if (n3) { col[o] = c + 3; val[o] = x.w; }
+      out += __builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) +
+             __builtin_popcountll(m3);
     }
-    out += __builtin_popcountll(mask);
+  } else {
+    for (int c0 = 0; c0 < cols; c0 += 64) {
+      const int c = c0 + lane;
+      const float x = c < cols ? src[c] : 0.0f;
+      const bool nz = c < cols && x != 0.0f;
+      const unsigned long long mask = __ballot(nz);
+      if (nz) {
+        col[out + lanes_below(mask)] = c;
+        val[out + lanes_below(mask)] = x;
+      }
+      out += __builtin_popcountll(mask);
+    }
   }
 }
 
@@ -324,8 +371,12 @@ int mi_dense_to_csr_count(const float* dense, int32_t batch, int32_t rows, int32
   int* block_sums = reinterpret_cast<int*>(static_cast<char*>(workspace) + align_up((size_t)n * 4));
   const long blocks = (n + 3) / 4;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
-  hipLaunchKernelGGL(count_nonzeros_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dense, n, rows,
-                     cols, ld, stride, counts);
+  if (ld % 4 == 0 && stride % 4 == 0 && mi::aligned16(dense))
+    hipLaunchKernelGGL(count_nonzeros_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, dense, n, rows,
+                       cols, ld, stride, counts);
+  else
+    hipLaunchKernelGGL(count_nonzeros_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, dense, n, rows,
+                       cols, ld, stride, counts);
   int st = mi::check_launch();
   if (st != MI_OK) return st;
   return launch_scan_rowptr(counts, n, rows, rowptr, block_sums, s);
@@ -342,8 +393,12 @@ int mi_dense_to_csr_fill(const float* dense, int32_t batch, int32_t rows, int32_
   if (!dense || !rowptr || !col || !val || ld < cols || stride < 0) return MI_EINVAL;
   const long blocks = (n + 3) / 4;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
-  hipLaunchKernelGGL(fill_csr_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dense, n, rows, cols,
-                     ld, stride, rowptr, col, val);
+  if (ld % 4 == 0 && stride % 4 == 0 && mi::aligned16(dense))
+    hipLaunchKernelGGL(fill_csr_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, dense, n, rows, cols,
+                       ld, stride, rowptr, col, val);
+  else
+    hipLaunchKernelGGL(fill_csr_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, dense, n, rows, cols,
+                       ld, stride, rowptr, col, val);
   return mi::check_launch();
 }
 

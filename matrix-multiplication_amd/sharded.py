@@ -80,9 +80,11 @@ class ShardedSpMM:
     def alloc_output(self, N: int) -> torch.Tensor:
         return torch.empty((self.padded_rows, N), device=self.device, dtype=torch.float32)
 
-    def forward(self, B: torch.Tensor, out: torch.Tensor = None, gather: bool = True) -> torch.Tensor:
+    def forward(self, B: torch.Tensor, out: torch.Tensor = None, gather: bool = True,
+                force_collective: bool = False) -> torch.Tensor:
         '''Returns C [M, N] (a view of the padded buffer), complete on every rank
-        when `gather` is true; with gather=False only this rank's blocks are valid.'''
+        when `gather` is true; with gather=False only this rank's blocks are valid.
+        `force_collective` issues the all-gather even in a one-rank group (tests).'''
         N = B.shape[1]
         if out is None:
             out = self.alloc_output(N)
@@ -92,7 +94,7 @@ class ShardedSpMM:
         for j, (blk, rp, ci, v, nnz) in enumerate(self.blocks):
             mine = out[blk * br:(blk + 1) * br]
             self.mm_op(v, ci, rp, nnz, br, self.K, B, mine)
-            if gather and self.world > 1:
+            if gather and (self.world > 1 or force_collective):
                 span = out[j * self.world * br:(j + 1) * self.world * br]
                 # in place: `mine` is span[rank*br : (rank+1)*br]; the collective is
                 # ordered after the kernel above and runs beside the next step's kernel

@@ -470,3 +470,49 @@ def test_sharded_layout_on_one_gpu(cmm, dev, oracle_mod):
     single = torch.empty(M, N, device=dev)
     cmm.naive_spmm(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, B, single)
     assert C.shape == (M, N) and torch.equal(C, single)
+
+
+def test_spmm_addresses_beyond_2_31_elements(cmm, dev, oracle_mod):
+    """B with more than 2^31 elements (K·N = 2.36e9): row offsets need 64-bit arithmetic
+    (the reference multiplies `int` indices, src/naive_sparse_mm.cu:32-42,86)."""
+    K, N, M = 2_300_000, 1024, 300
+    g = torch.Generator(device=dev).manual_seed(5)
+    B = torch.rand(K, N, device=dev, generator=g)
+    rng = np.random.Generator(np.random.PCG64(5))
+    rows = []
+    for r in range(M):
+        c = np.unique(rng.integers(0, K, size=40))
+        c[-1] = K - 1 - r           # make sure the far end of B is touched
+        rows.append(np.unique(c))
+    col = np.concatenate(rows).astype(np.int32)
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    val = rng.random(len(col), dtype=np.float32)
+    C = torch.empty(M, N, device=dev)
+    cmm.naive_spmm(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, B, C)
+    # oracle on the compacted problem: only the referenced rows of B travel to the host
+    used, inv = np.unique(col, return_inverse=True)
+    Bsmall = B[torch.from_numpy(used.astype(np.int64)).to(dev)].cpu().numpy()
+    expect = oracle_mod.spmm_csr(rowptr, inv.astype(np.int32), val, M, len(used), Bsmall)
+    assert np.array_equal(C.cpu().numpy(), expect)
+
+
+def test_sharded_collective_on_a_one_rank_rccl_group(cmm, dev, oracle_mod):
+    """The RCCL leg of sharded.ShardedSpMM (in-place all_gather_into_tensor on RCCL's stream beside
+    the next chunk's kernel) under a real NCCL(=RCCL) process group of one rank."""
+    import os
+    import torch.distributed as dist
+    import sharded
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        M, K, N = 4099, 3000, 256
+        rowptr, col, val = oracle_mod.make_csr(M, K, 0.01, seed=6)
+        B = t(np.random.Generator(np.random.PCG64(6)).random((K, N), dtype=np.float32), dev)
+        op = sharded.ShardedSpMM(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), M, K, dev,
+                                 chunks=3)
+        C = op.forward(B, force_collective=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr(rowptr, col, val, M, K, B.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
