@@ -142,6 +142,22 @@ int mi_gemm_f32(int transa, int transb, int32_t m, int32_t n, int32_t k,
                 int64_t strideC, int32_t batch, mi_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
+ * Fused FC-layer epilogues:  C = (product) + bias, bias[N] (resp. bias[n]) added
+ * to every row AFTER the accumulation chain (one extra rounding, exactly what
+ * `output = t.clone(); output += self.bias` computes).  bias may be NULL.
+ * Replace the separate clone + add of cublasLinear / cusparseLinear.forward
+ * (reference benchmarks/cublas_fc_layer.py:41-45, cusparse_fc_layer.py:41-45).
+ * ------------------------------------------------------------------------ */
+int mi_spmm_csr_bias_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                         int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
+                         int64_t ldb, const float* bias, float* C, int64_t ldc,
+                         mi_stream_t stream);
+int mi_gemm_bias_f32(int transa, int transb, int32_t m, int32_t n, int32_t k,
+                     const float* A, int64_t lda, int64_t strideA, const float* B,
+                     int64_t ldb, int64_t strideB, const float* bias, float* C,
+                     int64_t ldc, int64_t strideC, int32_t batch, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
  * Dense → CSR on the device (exact-zero test, columns ascending within a row),
  * batched: `batch` matrices of rows×cols (leading dimension ld, item stride
  * `stride`).  Two steps so the caller can size col/val without a host sync

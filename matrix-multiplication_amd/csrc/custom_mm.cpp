@@ -133,7 +133,8 @@ int64_t batch_count(const torch::Tensor& t, int nbatch_dims) {
 
 // C = op(A)·op(B) for `nbatch_dims` leading batch dims.
 torch::Tensor gemm_impl(const torch::Tensor& A, const torch::Tensor& B, torch::Tensor C,
-                        int nbatch_dims, bool transa, bool transb, const char* what) {
+                        int nbatch_dims, bool transa, bool transb, const char* what,
+                        const torch::Tensor* bias = nullptr) {
   check_device_f32(A, "A");
   check_device_f32(B, "B");
   check_device_f32(C, "C");
@@ -153,11 +154,20 @@ torch::Tensor gemm_impl(const torch::Tensor& A, const torch::Tensor& B, torch::T
               C.size(-2), "x", C.size(-1));
   TORCH_CHECK(m <= INT32_MAX && n <= INT32_MAX && ka <= INT32_MAX, what, ": dimension too large");
   const int64_t batch = batch_count(C, nbatch_dims);
+  const float* bias_ptr = nullptr;
+  torch::Tensor bias_keep;
+  if (bias != nullptr && bias->defined()) {
+    check_device_f32(*bias, "bias");
+    check_same_device(*bias, C, what);
+    TORCH_CHECK(bias->dim() == 1 && bias->size(0) == n, what, ": bias must have ", n, " entries");
+    bias_keep = bias->contiguous();
+    bias_ptr = bias_keep.data_ptr<float>();
+  }
   c10::hip::HIPGuard guard(C.device().index());
-  const int st = mi_gemm_f32(transa != a.stored_transposed, transb != b.stored_transposed, (int32_t)m,
-                             (int32_t)n, (int32_t)ka, a.ptr, a.ld, a.batch_stride, b.ptr, b.ld,
-                             b.batch_stride, C.data_ptr<float>(), std::max<int64_t>(n, 1), m * n,
-                             (int32_t)batch, stream_of(C));
+  const int st = mi_gemm_bias_f32(transa != a.stored_transposed, transb != b.stored_transposed,
+                                  (int32_t)m, (int32_t)n, (int32_t)ka, a.ptr, a.ld, a.batch_stride,
+                                  b.ptr, b.ld, b.batch_stride, bias_ptr, C.data_ptr<float>(),
+                                  std::max<int64_t>(n, 1), m * n, (int32_t)batch, stream_of(C));
   check_status(st, what);
   return C;
 }
@@ -181,7 +191,8 @@ torch::Tensor cublas_bmm(torch::Tensor A, torch::Tensor B, torch::Tensor C, int 
 
 torch::Tensor spmm_impl(const torch::Tensor& A_values, const torch::Tensor& A_columns,
                         const torch::Tensor& A_offsets, int64_t nnzA, int64_t A_rows,
-                        int64_t A_cols, const torch::Tensor& B, torch::Tensor C, const char* what) {
+                        int64_t A_cols, const torch::Tensor& B, torch::Tensor C, const char* what,
+                        const torch::Tensor* bias = nullptr) {
   check_device_f32(A_values, "A_values");
   check_device_i32(A_columns, "A_columns");
   check_device_i32(A_offsets, "A_offsets");
@@ -208,11 +219,20 @@ torch::Tensor spmm_impl(const torch::Tensor& A_values, const torch::Tensor& A_co
                          : B.contiguous();
   const int64_t N = B.size(1);
   const int64_t ldb = Bc.size(0) > 1 ? Bc.stride(0) : std::max<int64_t>(N, 1);
+  const float* bias_ptr = nullptr;
+  torch::Tensor bias_keep;
+  if (bias != nullptr && bias->defined()) {
+    check_device_f32(*bias, "bias");
+    check_same_device(*bias, C, what);
+    TORCH_CHECK(bias->dim() == 1 && bias->size(0) == N, what, ": bias must have ", N, " entries");
+    bias_keep = bias->contiguous();
+    bias_ptr = bias_keep.data_ptr<float>();
+  }
   c10::hip::HIPGuard guard(C.device().index());
-  const int st = mi_spmm_csr_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
-                                 A_values.data_ptr<float>(), nnzA, (int32_t)A_rows, (int32_t)A_cols,
-                                 (int32_t)N, Bc.data_ptr<float>(), ldb, C.data_ptr<float>(),
-                                 std::max<int64_t>(N, 1), stream_of(C));
+  const int st = mi_spmm_csr_bias_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
+                                      A_values.data_ptr<float>(), nnzA, (int32_t)A_rows,
+                                      (int32_t)A_cols, (int32_t)N, Bc.data_ptr<float>(), ldb, bias_ptr,
+                                      C.data_ptr<float>(), std::max<int64_t>(N, 1), stream_of(C));
   check_status(st, what);
   return C;
 }
@@ -225,6 +245,20 @@ torch::Tensor naive_spmm(torch::Tensor A_values, torch::Tensor A_columns, torch:
 torch::Tensor cusparse_mmul(torch::Tensor A_values, torch::Tensor A_columns, torch::Tensor A_offsets,
                             int nnzA, int A_rows, int A_cols, torch::Tensor B, torch::Tensor C) {
   return spmm_impl(A_values, A_columns, A_offsets, nnzA, A_rows, A_cols, B, C, "cusparse_mmul");
+}
+
+// Fused FC-layer forms (additions): C = op(A)·op(B) + bias and C = A_csr·B + bias, bias[n]
+// added to every row in the kernel epilogue — what cublasLinear / cusparseLinear.forward
+// compute with a clone and an in-place add (reference benchmarks/cublas_fc_layer.py:41-45).
+torch::Tensor cublas_mmul_bias(torch::Tensor A, torch::Tensor B, torch::Tensor bias, torch::Tensor C,
+                               bool transa, bool transb) {
+  return gemm_impl(A, B, C, 0, transa, transb, "cublas_mmul_bias", &bias);
+}
+
+torch::Tensor naive_spmm_bias(torch::Tensor A_values, torch::Tensor A_columns, torch::Tensor A_offsets,
+                              int64_t nnzA, int64_t A_rows, int64_t A_cols, torch::Tensor B,
+                              torch::Tensor bias, torch::Tensor C) {
+  return spmm_impl(A_values, A_columns, A_offsets, nnzA, A_rows, A_cols, B, C, "naive_spmm_bias", &bias);
 }
 
 // ---- additions to the reference surface (used by matmuls.py) -----------------
@@ -592,4 +626,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("naive_spmm_batched", &naive_spmm_batched, "Batched CSR x dense in one launch");
   m.def("csr_transpose", &csr_transpose, "Device CSR transpose (values, columns, offsets)");
   m.def("sddmm", &sddmm, "Sampled dense-dense product on a CSR pattern");
+  m.def("cublas_mmul_bias", &cublas_mmul_bias, "op(A) op(B) + bias, fused epilogue");
+  m.def("naive_spmm_bias", &naive_spmm_bias, "CSR x dense + bias, fused epilogue");
 }

@@ -114,7 +114,7 @@ template <int BM, int BN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int m, int n,
     int k, long lda, long ldb, long ldc, long strideA, long strideB, long strideC, int tiles_n,
-    bool vecA, bool vecB) {
+    bool vecA, bool vecB, const float* __restrict__ bias) {
   constexpr int TM = BM / 64;  // 32×32 tiles per wave along m (2×2 waves)
   constexpr int TN = BN / 64;
   typedef TileLoader<BM, !TA> LA;  // A not transposed → contiguous along k
@@ -180,10 +180,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
       const int col = n0 + wn * (BN / 2) + j * 32 + l31;
       const int row_base = m0 + wm * (BM / 2) + i * 32 + 4 * lhi;
       if (col < n) {
+        const float bj = bias ? bias[col] : 0.f;  // fused epilogue: + bias[col] after the k chain
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = row_base + (r & 3) + 8 * (r >> 2);
-          if (row < m) __builtin_nontemporal_store(acc[i][j][r], C + (long)row * ldc + col);
+          if (row < m)
+            __builtin_nontemporal_store(bias ? acc[i][j][r] + bj : acc[i][j][r], C + (long)row * ldc + col);
         }
       }
     }
@@ -191,42 +193,44 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
 
 template <int BM, int BN, bool TA, bool TB>
 int launch(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb,
-           long ldc, long sA, long sB, long sC, int batch, bool vecA, bool vecB, hipStream_t s) {
+           long ldc, long sA, long sB, long sC, int batch, bool vecA, bool vecB, const float* bias,
+           hipStream_t s) {
   const long tiles_m = (m + BM - 1) / BM, tiles_n = (n + BN - 1) / BN;
   const long blocks = tiles_m * tiles_n;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB>), dim3((unsigned)blocks, (unsigned)batch),
                      dim3(256), 0, s, A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, (int)tiles_n,
-                     vecA, vecB);
+                     vecA, vecB, bias);
   return mi::check_launch();
 }
 
 template <bool TA, bool TB>
 int pick_tile(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb,
-              long ldc, long sA, long sB, long sC, int batch, bool vecA, bool vecB, hipStream_t s) {
+              long ldc, long sA, long sB, long sC, int batch, bool vecA, bool vecB, const float* bias,
+              hipStream_t s) {
   // Wide tiles when both extents fill them; the 64-wide n tile covers BERT's
   // head dim (probs·V, n = 64) without wasting half the MFMAs.
   if (n > 64 && m > 64)
-    return launch<128, 128, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, s);
+    return launch<128, 128, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, bias, s);
   if (m > 64)
-    return launch<128, 64, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, s);
+    return launch<128, 64, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, bias, s);
   if (n > 64)
-    return launch<64, 128, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, s);
-  return launch<64, 64, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, s);
+    return launch<64, 128, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, bias, s);
+  return launch<64, 64, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, bias, s);
 }
 
-// k == 0: C = 0 (beta = 0 semantics).
-__global__ void zero_rows_kernel(float* C, int m, int n, long ldc, long strideC) {
+// k == 0: C = 0 (beta = 0 semantics), or the bias row.
+__global__ void zero_rows_kernel(float* C, int m, int n, long ldc, long strideC, const float* bias) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < (long)m * n) C[blockIdx.y * strideC + (idx / n) * ldc + (idx % n)] = 0.f;
+  if (idx < (long)m * n) C[blockIdx.y * strideC + (idx / n) * ldc + (idx % n)] = bias ? bias[idx % n] : 0.f;
 }
 
 }  // namespace
 
-extern "C" int mi_gemm_f32(int transa, int transb, int32_t m, int32_t n, int32_t k, const float* A,
-                           int64_t lda, int64_t strideA, const float* B, int64_t ldb,
-                           int64_t strideB, float* C, int64_t ldc, int64_t strideC, int32_t batch,
-                           mi_stream_t stream) {
+extern "C" int mi_gemm_bias_f32(int transa, int transb, int32_t m, int32_t n, int32_t k,
+                                const float* A, int64_t lda, int64_t strideA, const float* B,
+                                int64_t ldb, int64_t strideB, const float* bias, float* C,
+                                int64_t ldc, int64_t strideC, int32_t batch, mi_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (m < 0 || n < 0 || k < 0 || batch < 0) return MI_EINVAL;
   if (batch > 65535) return MI_ERANGE;
@@ -235,7 +239,7 @@ extern "C" int mi_gemm_f32(int transa, int transb, int32_t m, int32_t n, int32_t
   if (k == 0) {
     const long total = (long)m * n;
     hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)batch),
-                       dim3(256), 0, s, C, m, n, ldc, strideC);
+                       dim3(256), 0, s, C, m, n, ldc, strideC, bias);
     return mi::check_launch();
   }
   if (!A || !B) return MI_EINVAL;
@@ -245,10 +249,18 @@ extern "C" int mi_gemm_f32(int transa, int transb, int32_t m, int32_t n, int32_t
   const bool vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && mi::aligned16(B);
 #define MI_GEMM(TA_, TB_)                                                                       \
   return pick_tile<TA_, TB_>(A, B, C, m, n, k, lda, ldb, ldc, strideA, strideB, strideC, batch, \
-                             vecA, vecB, s)
+                             vecA, vecB, bias, s)
   if (!transa && !transb) MI_GEMM(false, false);
   if (!transa && transb) MI_GEMM(false, true);
   if (transa && !transb) MI_GEMM(true, false);
   MI_GEMM(true, true);
 #undef MI_GEMM
+}
+
+extern "C" int mi_gemm_f32(int transa, int transb, int32_t m, int32_t n, int32_t k, const float* A,
+                           int64_t lda, int64_t strideA, const float* B, int64_t ldb,
+                           int64_t strideB, float* C, int64_t ldc, int64_t strideC, int32_t batch,
+                           mi_stream_t stream) {
+  return mi_gemm_bias_f32(transa, transb, m, n, k, A, lda, strideA, B, ldb, strideB, nullptr, C, ldc,
+                          strideC, batch, stream);
 }

@@ -45,7 +45,7 @@ template <int T, int U>
 __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
-    int M, long ldb, long ldc, long strideB, long strideC) {
+    int M, long ldb, long ldc, long strideB, long strideC, const float* __restrict__ bias) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long row = (long)blockIdx.x * 4 + wave;
@@ -91,6 +91,10 @@ __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
     for (int t = 0; t < T; ++t)
       acc[t] = fma4(v, *reinterpret_cast<const f32x4*>(src + t * 256), acc[t]);
   }
+  if (bias) {  // fused epilogue: + bias[j] after the chain (one extra rounding, like `out += bias`)
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] += *reinterpret_cast<const f32x4*>(bias + lane * 4 + t * 256);
+  }
 #pragma unroll
   for (int t = 0; t < T; ++t)
     __builtin_nontemporal_store(acc[t], reinterpret_cast<f32x4*>(Cl + t * 256));
@@ -104,7 +108,7 @@ template <int U>
 __global__ __launch_bounds__(256) void spmm_wave_row_vl_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
-    int M, long ldb, long ldc, long strideB, long strideC) {
+    int M, long ldb, long ldc, long strideB, long strideC, const float* __restrict__ bias) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long row = (long)blockIdx.x * 4 + wave;
@@ -142,6 +146,7 @@ __global__ __launch_bounds__(256) void spmm_wave_row_vl_kernel(
       acc = fma4(v, *reinterpret_cast<const f32x4*>(Bl + (long)c * ldb), acc);
     }
   }
+  if (bias) acc += *reinterpret_cast<const f32x4*>(bias + lane * 4);
   __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(Cl));
 }
 
@@ -161,7 +166,7 @@ template <bool FIRST, int T, int U>
 __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
-    int M, long ldb, long ldc, int c_lo, int c_hi) {
+    int M, long ldb, long ldc, int c_lo, int c_hi, const float* __restrict__ bias) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long row = (long)blockIdx.x * 4 + wave;
@@ -212,6 +217,10 @@ __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
         acc[t] = fma4(v, *reinterpret_cast<const f32x4*>(src + t * 256), acc[t]);
     }
   }
+  if (bias) {  // only the last pass is given the bias
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] += *reinterpret_cast<const f32x4*>(bias + lane * 4 + t * 256);
+  }
 #pragma unroll
   for (int t = 0; t < T; ++t)
     __builtin_nontemporal_store(acc[t], reinterpret_cast<f32x4*>(Cl + t * 256));
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
 
 template <int T, int U>
 int launch_panels_t(int panels, const int* rowptr, const int* col, const float* val, const float* B,
-                    float* C, int M, int K, long ldb, long ldc, hipStream_t s) {
+                    float* C, int M, int K, long ldb, long ldc, const float* bias, hipStream_t s) {
   const long blocks = ((long)M + 3) / 4;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   const long kp = ((long)K + panels - 1) / panels;
@@ -228,19 +237,21 @@ int launch_panels_t(int panels, const int* rowptr, const int* col, const float* 
     const int hi = (int)((q + 1) * kp < K ? (q + 1) * kp : K);
     if (q == 0)
       hipLaunchKernelGGL((spmm_wave_row_panel_kernel<true, T, U>), dim3((unsigned)blocks), dim3(256), 0,
-                         s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi);
+                         s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi,
+                         q == panels - 1 ? bias : (const float*)nullptr);
     else
       hipLaunchKernelGGL((spmm_wave_row_panel_kernel<false, T, U>), dim3((unsigned)blocks), dim3(256), 0,
-                         s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi);
+                         s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi,
+                         q == panels - 1 ? bias : (const float*)nullptr);
   }
   return mi::check_launch();
 }
 
 int launch_panels(int panels, const int* rowptr, const int* col, const float* val, const float* B,
-                  float* C, int M, int K, int N, long ldb, long ldc, hipStream_t s) {
-  if (N == 256) return launch_panels_t<1, 8>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, s);
-  if (N == 512) return launch_panels_t<2, 4>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, s);
-  return launch_panels_t<4, 2>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, s);
+                  float* C, int M, int K, int N, long ldb, long ldc, const float* bias, hipStream_t s) {
+  if (N == 256) return launch_panels_t<1, 8>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, s);
+  if (N == 512) return launch_panels_t<2, 4>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, s);
+  return launch_panels_t<4, 2>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -288,7 +299,7 @@ template <int G, int VEC, int T>
 __global__ __launch_bounds__(256) void spmm_group_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
-    int M, int N, long ldb, long ldc, long strideB, long strideC) {
+    int M, int N, long ldb, long ldc, long strideB, long strideC, const float* __restrict__ bias) {
   typedef Vec<VEC> V;
   typedef typename V::type vec_t;
   constexpr int RPW = 64 / G;  // rows per wave
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
       float* dst = Ci + row * ldc;
 #pragma unroll
       for (int t = 0; t < T; ++t)
-        if (on[t]) V::store(dst + coff[t], acc[t]);
+        if (on[t]) V::store(dst + coff[t], bias ? acc[t] + V::load(bias + coff[t]) : acc[t]);
     }
   }
 }
@@ -363,23 +374,23 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
 template <int G, int VEC, int T>
 int launch_group(const int* rowptr, const int* col, const float* val, const float* B,
                  float* C, int M, int N, long ldb, long ldc, long strideB, long strideC,
-                 int batch, hipStream_t s) {
+                 int batch, const float* bias, hipStream_t s) {
   constexpr int rows_per_block = 4 * (64 / G);
   const long blocks = ((long)M + rows_per_block - 1) / rows_per_block;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   hipLaunchKernelGGL((spmm_group_kernel<G, VEC, T>), dim3((unsigned)blocks, (unsigned)batch),
-                     dim3(256), 0, s, rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC);
+                     dim3(256), 0, s, rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, bias);
   return mi::check_launch();
 }
 
 template <int VEC>
 int dispatch_group(const int* rowptr, const int* col, const float* val, const float* B,
                    float* C, int M, int N, long ldb, long ldc, long strideB, long strideC,
-                   int batch, hipStream_t s) {
+                   int batch, const float* bias, hipStream_t s) {
   const int nv = (N + VEC - 1) / VEC;  // vector columns
   const int G = nv >= 64 ? 64 : mi::pow2_ceil(nv);
 #define MI_GROUP(G_, T_) \
-  return launch_group<G_, VEC, T_>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, s)
+  return launch_group<G_, VEC, T_>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, s)
   switch (G) {
     case 1: MI_GROUP(1, 1);
     case 2: MI_GROUP(2, 1);
@@ -399,22 +410,22 @@ int dispatch_group(const int* rowptr, const int* col, const float* val, const fl
 template <int T, int U>
 int launch_wave_row(const int* rowptr, const int* col, const float* val, const float* B,
                     float* C, int M, long ldb, long ldc, long strideB, long strideC,
-                    int batch, hipStream_t s) {
+                    int batch, const float* bias, hipStream_t s) {
   const long blocks = ((long)M + 3) / 4;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   hipLaunchKernelGGL((spmm_wave_row_kernel<T, U>), dim3((unsigned)blocks, (unsigned)batch),
-                     dim3(256), 0, s, rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC);
+                     dim3(256), 0, s, rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, bias);
   return mi::check_launch();
 }
 
 template <int U>
 int launch_wave_row_vl(const int* rowptr, const int* col, const float* val, const float* B,
                        float* C, int M, long ldb, long ldc, long strideB, long strideC,
-                       int batch, hipStream_t s) {
+                       int batch, const float* bias, hipStream_t s) {
   const long blocks = ((long)M + 3) / 4;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   hipLaunchKernelGGL((spmm_wave_row_vl_kernel<U>), dim3((unsigned)blocks, (unsigned)batch),
-                     dim3(256), 0, s, rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC);
+                     dim3(256), 0, s, rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, bias);
   return mi::check_launch();
 }
 
@@ -454,7 +465,7 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
 int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const float* val,
                   int64_t nnz, int32_t batch, int32_t M, int32_t K, int32_t N, const float* B,
                   int64_t ldb, int64_t strideB, float* C, int64_t ldc, int64_t strideC,
-                  hipStream_t s) {
+                  const float* bias, hipStream_t s) {
   if (M < 0 || K < 0 || N < 0 || nnz < 0 || batch < 0) return MI_EINVAL;
   if (variant < 0 || variant >= MI_SPMM_VARIANT_COUNT) return MI_EINVAL;
   if (nnz > 0x7fffffffLL) return MI_ERANGE;  // int32 rowptr entries
@@ -464,12 +475,14 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
   if (nnz > 0 && (!col || !val || !B)) return MI_EINVAL;
   if (ldb < N || ldc < N) return MI_EINVAL;
 
-  const Shape sh = classify(N, ldb, ldc, strideB, strideC, B, C);
+  Shape sh = classify(N, ldb, ldc, strideB, strideC, B, C);
+  if (bias && !mi::aligned16(bias)) sh.vec4_ok = sh.wave_ok = false;
+  if (bias && (reinterpret_cast<uintptr_t>(bias) & 7u)) sh.vec2_ok = false;
   const bool vec4_ok = sh.vec4_ok, vec2_ok = sh.vec2_ok, wave_ok = sh.wave_ok;
   if (variant == MI_SPMM_AUTO) variant = choose_variant(sh, nnz, batch, M, K, N, ldb);
 
 #define MI_WAVE(T_, U_) \
-  return launch_wave_row<T_, U_>(rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, batch, s)
+  return launch_wave_row<T_, U_>(rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, batch, bias, s)
   switch (variant) {
     case MI_SPMM_WAVE_ROW_U4:
       if (!wave_ok) return MI_EINVAL;
@@ -488,21 +501,21 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
       MI_WAVE(4, 4);
     case MI_SPMM_WAVE_ROW_VL:
       if (!(vec4_ok && N == 256)) return MI_EINVAL;
-      return launch_wave_row_vl<8>(rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, batch, s);
+      return launch_wave_row_vl<8>(rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, batch, bias, s);
     case MI_SPMM_PANELS_2: case MI_SPMM_PANELS_3: case MI_SPMM_PANELS_4: case MI_SPMM_PANELS_5:
     case MI_SPMM_PANELS_6: case MI_SPMM_PANELS_8: {
       if (!(wave_ok && batch == 1)) return MI_EINVAL;
       static const int kPanels[] = {2, 3, 4, 5, 6, 8};
-      return launch_panels(kPanels[variant - MI_SPMM_PANELS_2], rowptr, col, val, B, C, M, K, N, ldb, ldc, s);
+      return launch_panels(kPanels[variant - MI_SPMM_PANELS_2], rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, s);
     }
     case MI_SPMM_GROUP_VEC4:
       if (!vec4_ok) return MI_EINVAL;
-      return dispatch_group<4>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, s);
+      return dispatch_group<4>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, s);
     case MI_SPMM_GROUP_VEC2:
       if (!vec2_ok) return MI_EINVAL;
-      return dispatch_group<2>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, s);
+      return dispatch_group<2>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, s);
     case MI_SPMM_GROUP_SCALAR:
-      return dispatch_group<1>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, s);
+      return dispatch_group<1>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, s);
     default:
       return MI_EINVAL;
   }
@@ -516,7 +529,14 @@ extern "C" {
 int mi_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
                     int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb, float* C,
                     int64_t ldc, mi_stream_t stream) {
-  return spmm_dispatch(MI_SPMM_AUTO, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0,
+  return spmm_dispatch(MI_SPMM_AUTO, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0, nullptr,
+                       static_cast<hipStream_t>(stream));
+}
+
+int mi_spmm_csr_bias_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
+                         int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,
+                         const float* bias, float* C, int64_t ldc, mi_stream_t stream) {
+  return spmm_dispatch(MI_SPMM_AUTO, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0, bias,
                        static_cast<hipStream_t>(stream));
 }
 
@@ -524,7 +544,7 @@ int mi_spmm_csr_f32_variant(int variant, const int32_t* rowptr, const int32_t* c
                             const float* val, int64_t nnz, int32_t M, int32_t K, int32_t N,
                             const float* B, int64_t ldb, float* C, int64_t ldc,
                             mi_stream_t stream) {
-  return spmm_dispatch(variant, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0,
+  return spmm_dispatch(variant, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0, nullptr,
                        static_cast<hipStream_t>(stream));
 }
 
@@ -534,7 +554,7 @@ int mi_spmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col, const flo
                             int64_t strideC, mi_stream_t stream) {
   if (strideB < 0 || strideC < 0) return MI_EINVAL;
   return spmm_dispatch(MI_SPMM_AUTO, rowptr, col, val, nnz_total, batch, M, K, N, B, ldb, strideB,
-                       C, ldc, strideC, static_cast<hipStream_t>(stream));
+                       C, ldc, strideC, nullptr, static_cast<hipStream_t>(stream));
 }
 
 int mi_spmm_csr_f32_plan(int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,

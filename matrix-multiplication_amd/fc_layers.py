@@ -1,0 +1,144 @@
+'''
+fc_layers — the reference's fully-connected call-site modules on the MI355X kernels.
+
+`cublasLinear` and `cusparseLinear` keep the constructor, parameters, initialisation and
+`forward(inp)` contract of the reference's modules (benchmarks/cublas_fc_layer.py:12-51,
+benchmarks/cusparse_fc_layer.py:12-51): `y = inp @ weight.t() + bias` with `weight`
+`[out_features, in_features]`, any number of leading dims on `inp`.
+
+The reference computes `t = cublasMM.apply(inp, self.weight.t()); output = t.clone();
+output += self.bias` — a product, a copy and an add, i.e. two extra passes over the output.
+Here the bias is added in the kernel epilogue (`custom_mm.cublas_mmul_bias` /
+`custom_mm.naive_spmm_bias`) and the backward runs on the same
+kernels: grad_inp = dY·W, grad_W = dYᵀ·inp, grad_bias = 1ᵀ·dY.
+
+`cusparseLinear` treats the *activations* as the sparse operand, exactly like the reference
+(`cusparseMM.apply(inp, weight.t())`: exact zeros of `inp` are dropped, e.g. after a ReLU).
+'''
+
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd.function import InplaceFunction
+
+import custom_mm
+from matmuls import custom_matmul
+
+
+def _column_sums(g2d):
+    '''1ᵀ·g as a product on the dense kernel (keeps the path on the hand-written kernels).'''
+    ones = torch.ones((1, g2d.shape[0]), device=g2d.device, dtype=torch.float32)
+    return custom_matmul(ones, g2d).reshape(-1)
+
+
+class _LinearBias(InplaceFunction):
+    '''y = x·Wᵀ (+ bias) with the dense kernel; x [..., in], W [out, in].'''
+
+    @staticmethod
+    def forward(ctx, inp, weight, bias):
+        ctx.save_for_backward(inp, weight)
+        ctx.has_bias = bias is not None
+        x2 = inp.reshape(-1, inp.shape[-1])
+        out = torch.empty((x2.shape[0], weight.shape[0]), device=inp.device, dtype=torch.float32)
+        if bias is not None:
+            custom_mm.cublas_mmul_bias(x2, weight, bias, out, False, True)
+        else:
+            custom_mm.cublas_mmul(x2, weight, out, False, True)
+        return out.view(tuple(inp.shape[:-1]) + (weight.shape[0],))
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        inp, weight = ctx.saved_tensors
+        g2 = grad_output.reshape(-1, grad_output.shape[-1])
+        x2 = inp.reshape(-1, inp.shape[-1])
+        grad_inp = grad_w = grad_b = None
+        if ctx.needs_input_grad[0]:
+            grad_inp = custom_matmul(g2, weight).view(inp.shape)       # dY·W
+        if ctx.needs_input_grad[1]:
+            grad_w = custom_matmul(g2, x2, transa=True)                 # dYᵀ·x
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_b = _column_sums(g2)
+        return grad_inp, grad_w, grad_b
+
+
+class _SparseLinearBias(InplaceFunction):
+    '''y = sparse(x)·Wᵀ (+ bias): the activations' exact zeros are skipped (CSR on the device).'''
+
+    @staticmethod
+    def forward(ctx, inp, weight, bias):
+        ctx.save_for_backward(inp, weight)
+        ctx.has_bias = bias is not None
+        x2 = inp.reshape(-1, inp.shape[-1])
+        values, columns, offsets = custom_mm.dense_to_csr(x2)
+        wt = weight.t().contiguous()                                     # [in, out] row-major B operand
+        out = torch.empty((x2.shape[0], weight.shape[0]), device=inp.device, dtype=torch.float32)
+        if bias is not None:
+            custom_mm.naive_spmm_bias(values, columns, offsets.view(-1), values.numel(), x2.shape[0], x2.shape[1],
+                                      wt, bias, out)
+        else:
+            custom_mm.naive_spmm(values, columns, offsets.view(-1), values.numel(), x2.shape[0], x2.shape[1], wt, out)
+        return out.view(tuple(inp.shape[:-1]) + (weight.shape[0],))
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        inp, weight = ctx.saved_tensors
+        g2 = grad_output.reshape(-1, grad_output.shape[-1])
+        x2 = inp.reshape(-1, inp.shape[-1])
+        grad_inp = grad_w = grad_b = None
+        if ctx.needs_input_grad[0]:
+            grad_inp = custom_matmul(g2, weight).view(inp.shape)       # dense gradient, as torch autograd gives
+        if ctx.needs_input_grad[1]:
+            # dYᵀ·x = (xᵀ·dY)ᵀ with x sparse: CSR transpose, then the row-split kernel
+            values, columns, offsets = custom_mm.dense_to_csr(x2)
+            t_val, t_col, t_off = custom_mm.csr_transpose(values, columns, offsets.view(-1), values.numel(),
+                                                          x2.shape[0], x2.shape[1])
+            gwt = torch.empty((x2.shape[1], g2.shape[1]), device=g2.device, dtype=torch.float32)
+            custom_mm.naive_spmm(t_val, t_col, t_off, values.numel(), x2.shape[1], x2.shape[0], g2, gwt)
+            grad_w = gwt.t()
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_b = _column_sums(g2)
+        return grad_inp, grad_w, grad_b
+
+
+class _LinearBase(nn.Module):
+    _fn = None
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        torch.manual_seed(0)  # the reference seeds here (cublas_fc_layer.py:15)
+
+        self.in_features = in_features
+        self.out_features = out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_features))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, inp):
+        if inp.shape[-1] != self.in_features:
+            print('Invalid dimensions')  # reference behaviour (cublas_fc_layer.py:37-40)
+            return 0
+        return type(self)._fn.apply(inp, self.weight, self.bias)
+
+    def extra_repr(self):
+        return 'in_features={}, out_features={}, bias={}'.format(
+            self.in_features, self.out_features, self.bias is not None
+        )
+
+
+class cublasLinear(_LinearBase):
+    _fn = _LinearBias
+
+
+class cusparseLinear(_LinearBase):
+    _fn = _SparseLinearBias

@@ -74,6 +74,16 @@ def sddmm(cols, offs, nnz, rows, kcols, dC, B):
     return torch.from_numpy(oracle.sddmm(_np(offs), _np(cols)[:nnz], rows, _np(dC), _np(B)).copy())
 
 
+def cublas_mmul_bias(A, B, bias, C, transa, transb):
+    calls.append(("cublas_mmul_bias", (transa, transb)))
+    return _write(C, oracle.gemm(_np(A), _np(B), transa, transb) + _np(bias)[None, :])
+
+
+def naive_spmm_bias(vals, cols, offs, nnz, rows, kcols, B, bias, C):
+    calls.append(("naive_spmm_bias", (rows, kcols)))
+    return _write(C, oracle.spmm_csr(_np(offs), _np(cols)[:nnz], _np(vals)[:nnz], rows, kcols, _np(B)) + _np(bias)[None, :])
+
+
 def init_cublas():
     pass
 

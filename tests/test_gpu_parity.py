@@ -516,3 +516,69 @@ def test_sharded_collective_on_a_one_rank_rccl_group(cmm, dev, oracle_mod):
         assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr(rowptr, col, val, M, K, B.cpu().numpy()))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N", [256, 512, 100, 64, 7])
+def test_fused_bias_epilogues_bit_exact(cmm, dev, oracle_mod, N):
+    """C = A·B + bias and C = op(A)·op(B) + bias: bias added once, after the accumulation chain."""
+    M, K = 130, 200
+    rowptr, col, val = oracle_mod.make_csr(M, K, 0.1, seed=N)
+    g = np.random.Generator(np.random.PCG64(N))
+    B, bias = g.random((K, N), dtype=np.float32), g.random(N, dtype=np.float32)
+    C = torch.empty(M, N, device=dev)
+    cmm.naive_spmm_bias(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, t(B, dev), t(bias, dev), C)
+    assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr(rowptr, col, val, M, K, B) + bias[None, :])
+    a, w = g.random((M, K), dtype=np.float32), g.random((N, K), dtype=np.float32)
+    cmm.cublas_mmul_bias(t(a, dev), t(w, dev), t(bias, dev), C, False, True)
+    assert np.array_equal(C.cpu().numpy(), oracle_mod.gemm(a, w, False, True) + bias[None, :])
+
+
+def test_fused_bias_on_the_panel_path(capi, dev, oracle_mod):
+    """The two-panel large-B path adds the bias in its LAST pass only (forced through the variant id)."""
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    M, K, N = 700, 900, 256
+    rowptr, col, val = oracle_mod.make_csr(M, K, 0.05, seed=2)
+    g = np.random.Generator(np.random.PCG64(2))
+    B = g.random((K, N), dtype=np.float32)
+    d = [t(x, dev) for x in (rowptr, col, val, B)]
+    expect = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    for variant in (7, 8, 12):  # 2, 3 and 8 panels
+        C = torch.full((M, N), float("nan"), device=dev)
+        assert capi.mi_spmm_csr_f32_variant(variant, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(val), M,
+                                            K, N, d[3].data_ptr(), N, C.data_ptr(), N,
+                                            torch.cuda.current_stream().cuda_stream) == 0
+        assert np.array_equal(C.cpu().numpy(), expect)
+    # unsorted columns inside a row: the panel path still gives the right product (order of the
+    # fmaf chain then follows (panel, CSR position), so compare at the reference tolerance)
+    perm = np.concatenate([np.random.Generator(np.random.PCG64(r)).permutation(np.arange(rowptr[r], rowptr[r + 1]))
+                           for r in range(M)])
+    colp, valp = col[perm], val[perm]
+    C = torch.empty(M, N, device=dev)
+    assert capi.mi_spmm_csr_f32_variant(7, d[0].data_ptr(), t(colp, dev).data_ptr(), t(valp, dev).data_ptr(), len(val),
+                                        M, K, N, d[3].data_ptr(), N, C.data_ptr(), N,
+                                        torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert np.allclose(C.cpu().numpy(), expect, rtol=RTOL, atol=ATOL)
+
+
+def test_fc_layer_modules_on_device(mm, dev):
+    """reference benchmarks/cublas_fc_layer.py / cusparse_fc_layer.py call sites vs nn.Linear."""
+    sys.modules.pop("fc_layers", None)
+    import fc_layers
+    g = torch.Generator().manual_seed(41)
+    for cls in (fc_layers.cublasLinear, fc_layers.cusparseLinear):
+        for bias in (True, False):
+            layer = cls(768, 256, bias=bias).to(dev)
+            ref = torch.nn.Linear(768, 256, bias=bias)
+            ref.load_state_dict({k: v.cpu() for k, v in layer.state_dict().items()})
+            x = torch.relu(torch.rand(4, 32, 768, generator=g) - 0.5)   # half the activations are exact zeros
+            x1, x2 = x.to(dev).requires_grad_(True), x.clone().requires_grad_(True)
+            y, yr = layer(x1), ref(x2)
+            assert y.is_cuda and torch.allclose(yr, y.cpu(), rtol=RTOL, atol=1e-6)
+            dy = torch.rand(yr.shape, generator=g)
+            y.backward(dy.to(dev))
+            yr.backward(dy)
+            assert torch.allclose(x2.grad, x1.grad.cpu(), rtol=RTOL, atol=1e-6)
+            assert torch.allclose(ref.weight.grad, layer.weight.grad.cpu(), rtol=1e-4, atol=1e-5)
+            if bias:
+                assert torch.allclose(ref.bias.grad, layer.bias.grad.cpu(), rtol=RTOL, atol=1e-5)

@@ -208,3 +208,32 @@ def test_golden_through_wrappers(mm, golden):
     out.backward(torch.from_numpy(c["dc"]))
     assert np.allclose(a.grad.numpy(), c["grad_a"], rtol=RTOL, atol=ATOL)
     assert np.allclose(b.grad.numpy(), c["grad_b"], rtol=RTOL, atol=ATOL)
+
+
+def test_fc_layer_modules_host_logic(mm):
+    """cublasLinear / cusparseLinear (reference benchmarks/*_fc_layer.py) against nn.Linear with the
+    same parameters: forward with the fused bias epilogue, backward for input, weight and bias."""
+    matmuls, fake = mm
+    sys.modules.pop("fc_layers", None)
+    import fc_layers
+    g = torch.Generator().manual_seed(31)
+    for cls in (fc_layers.cublasLinear, fc_layers.cusparseLinear):
+        for bias in (True, False):
+            layer = cls(12, 7, bias=bias)
+            ref = torch.nn.Linear(12, 7, bias=bias)
+            ref.load_state_dict(layer.state_dict())
+            x = torch.rand(3, 5, 12, generator=g) * (torch.rand(3, 5, 12, generator=g) < 0.6)
+            x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+            y, yr = layer(x1), ref(x2)
+            assert y.shape == yr.shape and torch.allclose(yr, y, rtol=RTOL, atol=1e-6)
+            dy = torch.rand(yr.shape, generator=g)
+            y.backward(dy)
+            yr.backward(dy)
+            assert torch.allclose(x2.grad, x1.grad, rtol=RTOL, atol=1e-6)
+            assert torch.allclose(ref.weight.grad, layer.weight.grad, rtol=RTOL, atol=1e-6)
+            if bias:
+                assert torch.allclose(ref.bias.grad, layer.bias.grad, rtol=RTOL, atol=1e-6)
+        assert "in_features=12, out_features=7" in repr(layer)
+        assert layer(torch.rand(2, 5)) == 0  # wrong width: prints and returns 0, like the reference
+    names = [c[0] for c in fake.calls]
+    assert "cublas_mmul_bias" in names and "naive_spmm_bias" in names
