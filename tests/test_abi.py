@@ -66,7 +66,8 @@ def test_argument_validation_needs_no_gpu(lib):
                                 i32, vp]
     assert lib.mi_gemm_f32(0, 0, -1, 2, 2, None, 2, 0, None, 2, 0, None, 2, 0, 1, None) == -1
     assert lib.mi_gemm_f32(0, 0, 0, 2, 2, None, 2, 0, None, 2, 0, None, 2, 0, 1, None) == 0
-    assert lib.mi_gemm_f32(0, 0, 2, 2, 2, None, 2, 0, None, 2, 0, None, 2, 0, 70000, None) == -2
+    assert lib.mi_gemm_f32(0, 0, 2, 2, 0, None, 2, 0, None, 2, 0, None, 2, 0, 70000, None) == -1  # null C
+    assert lib.mi_gemm_f32(1, 1, 2, 2, 2, None, 2, 0, None, 2, 0, None, 1, 0, 1, None) == -1       # ldc < n
     lib.mi_spmm_colmajor_workspace_bytes.restype = ctypes.c_size_t
     lib.mi_spmm_colmajor_workspace_bytes.argtypes = [i32, i32, i32]
     assert lib.mi_spmm_colmajor_workspace_bytes(10, 20, 5) >= 4 * (20 * 5 + 10 * 5)
