@@ -96,7 +96,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
-    ap.add_argument("--chunks", type=int, default=4, help="block-cyclic chunks per rank for N > 1")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="block-cyclic chunks per rank for N > 1 (0 = 4 up to 4 GPUs, 8 beyond: the gather is the "
+                         "longer leg at 8 GPUs, so finer chunks expose less of the first chunk's compute)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -121,6 +123,8 @@ def main():
     import oracle  # only make_csr (the pinned generator) and the cpu_baseline leg
     import sharded
 
+    if args.chunks <= 0:
+        args.chunks = 4 if world <= 4 else 8
     M, K, density, N, desc = WORKLOADS[args.workload]
     t0 = time.perf_counter()
     rowptr, col, val = oracle.make_csr(M, K, density, seed=0)

@@ -142,6 +142,24 @@ int mi_gemm_f32(int transa, int transb, int32_t m, int32_t n, int32_t k,
                 int64_t strideC, int32_t batch, mi_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
+ * Fused "sparsify on the fly" form: A is given DENSE (batch × M×K, leading
+ * dimension lda, item stride strideA) and its exact zeros are skipped inside the
+ * kernel, in ascending column order — bit-identical to mi_dense_to_csr_* followed
+ * by mi_spmm_csr_batched_f32, without materialising a CSR.  B[b] is K×N
+ * (strideB = 0 shares one B); bias (N entries) may be NULL.
+ * Replaces `a.to_sparse_csr()` + get_sparse_tensor_properties + spmm_kernel per
+ * call / per slice (reference matmuls.py:289-297, :178-187).
+ * Supported when mi_spmm_dense_skip_supported(...) != 0 (N ≤ 1024, N % 4 == 0,
+ * 16-byte aligned B and C rows); otherwise MI_EINVAL — use the CSR entry points.
+ * ------------------------------------------------------------------------ */
+int mi_spmm_dense_skip_supported(int32_t N, int64_t lda, int64_t ldb, int64_t ldc,
+                                 const float* A, const float* B, const float* C);
+int mi_spmm_dense_skip_f32(const float* A, int64_t lda, int64_t strideA, int32_t batch,
+                           int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,
+                           int64_t strideB, const float* bias, float* C, int64_t ldc,
+                           int64_t strideC, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
  * Fused FC-layer epilogues:  C = (product) + bias, bias[N] (resp. bias[n]) added
  * to every row AFTER the accumulation chain (one extra rounding, exactly what
  * `output = t.clone(); output += self.bias` computes).  bias may be NULL.

@@ -346,6 +346,63 @@ torch::Tensor naive_spmm_batched(torch::Tensor A_values, torch::Tensor A_columns
   return C;
 }
 
+// C[b] = A[b]·B[b] (+ bias) with A DENSE [batch…, M, K]: exact zeros are skipped inside the
+// kernel (no CSR is built).  B is [batch…, K, N] or [K, N] (shared), C [batch…, M, N].
+// Returns false (and does nothing) when the fused kernel does not cover the shape, so the
+// caller can take the dense_to_csr + naive_spmm_batched route instead.
+bool spmm_dense_impl(const torch::Tensor& A, const torch::Tensor& B, const torch::Tensor* bias, torch::Tensor C,
+                     const char* what) {
+  check_device_f32(A, "A");
+  check_device_f32(B, "B");
+  check_device_f32(C, "C");
+  check_same_device(A, C, what);
+  check_same_device(B, C, what);
+  TORCH_CHECK(A.dim() >= 2 && C.dim() == A.dim(), what, ": A and C must have the same rank (>= 2)");
+  TORCH_CHECK(C.is_contiguous(), what, ": C must be contiguous");
+  torch::Tensor Ac = A.contiguous(), Bc = B.contiguous();
+  const int64_t M = Ac.size(-2), K = Ac.size(-1), N = C.size(-1);
+  const int64_t batch = M * K > 0 ? Ac.numel() / (M * K) : (C.numel() / std::max<int64_t>(C.size(-2) * N, 1));
+  TORCH_CHECK(C.size(-2) == M, what, ": C must have ", M, " rows");
+  int64_t strideB = 0;
+  if (Bc.dim() == 2) {
+    TORCH_CHECK(Bc.size(0) == K && Bc.size(1) == N, what, ": B must be [", K, ", ", N, "]");
+  } else {
+    TORCH_CHECK(Bc.dim() == Ac.dim() && Bc.size(-2) == K && Bc.size(-1) == N && Bc.numel() == batch * K * N, what,
+                ": B must be [batch…, ", K, ", ", N, "] with A's batch dims");
+    strideB = K * N;
+  }
+  TORCH_CHECK(C.numel() == batch * M * N, what, ": C must be [batch…, ", M, ", ", N, "]");
+  TORCH_CHECK(M <= INT32_MAX && K <= INT32_MAX && N <= INT32_MAX, what, ": dimension too large");
+  if (batch > 65535) return false;
+  const float* bias_ptr = nullptr;
+  torch::Tensor bias_keep;
+  if (bias != nullptr && bias->defined()) {
+    check_device_f32(*bias, "bias");
+    TORCH_CHECK(bias->dim() == 1 && bias->size(0) == N, what, ": bias must have ", N, " entries");
+    bias_keep = bias->contiguous();
+    bias_ptr = bias_keep.data_ptr<float>();
+  }
+  if (batch == 0 || M == 0 || N == 0) return true;
+  if (!mi_spmm_dense_skip_supported((int32_t)N, K, N, N, Ac.data_ptr<float>(), Bc.data_ptr<float>(),
+                                    C.data_ptr<float>()) ||
+      (M * N) % 4 != 0 || (bias_ptr && (reinterpret_cast<uintptr_t>(bias_ptr) & 15u)))
+    return false;
+  c10::hip::HIPGuard guard(C.device().index());
+  check_status(mi_spmm_dense_skip_f32(Ac.data_ptr<float>(), std::max<int64_t>(K, 1), M * K, (int32_t)batch,
+                                      (int32_t)M, (int32_t)K, (int32_t)N, Bc.data_ptr<float>(), N, strideB, bias_ptr,
+                                      C.data_ptr<float>(), N, M * N, stream_of(C)),
+               what);
+  return true;
+}
+
+bool naive_spmm_dense(torch::Tensor A, torch::Tensor B, torch::Tensor C) {
+  return spmm_dense_impl(A, B, nullptr, C, "naive_spmm_dense");
+}
+
+bool naive_spmm_dense_bias(torch::Tensor A, torch::Tensor B, torch::Tensor bias, torch::Tensor C) {
+  return spmm_dense_impl(A, B, &bias, C, "naive_spmm_dense_bias");
+}
+
 // CSR of A (A_rows×A_cols) → CSR of Aᵀ: (values, columns, offsets[A_cols+1]).
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> csr_transpose(torch::Tensor A_values,
                                                                       torch::Tensor A_columns,
@@ -626,6 +683,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("naive_spmm_batched", &naive_spmm_batched, "Batched CSR x dense in one launch");
   m.def("csr_transpose", &csr_transpose, "Device CSR transpose (values, columns, offsets)");
   m.def("sddmm", &sddmm, "Sampled dense-dense product on a CSR pattern");
+  m.def("naive_spmm_dense", &naive_spmm_dense,
+        "A·B with A dense, zeros skipped in the kernel; False if the shape is not covered");
+  m.def("naive_spmm_dense_bias", &naive_spmm_dense_bias, "as naive_spmm_dense, + bias in the epilogue");
   m.def("cublas_mmul_bias", &cublas_mmul_bias, "op(A) op(B) + bias, fused epilogue");
   m.def("naive_spmm_bias", &naive_spmm_bias, "CSR x dense + bias, fused epilogue");
 }

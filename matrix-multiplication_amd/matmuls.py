@@ -268,8 +268,12 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch
         raise RuntimeError(f'sparse matmul: inner dimensions differ ({a_shape[-1]} vs {b_shape[-2]})')
     dev = b.device if b.is_cuda else a.device
 
+    fused = mm_op is default_op and not a.is_sparse_csr  # dense A + stock kernel: skip zeros in the kernel
+
     if a.dim() == 2 and b.dim() == 2:
         c = torch.empty((c_rows, c_cols), device=dev, dtype=torch.float32)
+        if fused and custom_mm.naive_spmm_dense(a, b, c):
+            return c
         return mm_op(*_csr_of(a), b, c)
 
     if a.dim() == 2:
@@ -287,7 +291,8 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch
         # batch of A × one B (the FC-layer call shape): flatten A's rows
         _a = a.reshape(-1, a_shape[-1])
         c = torch.empty((_a.shape[0], c_cols), device=dev, dtype=torch.float32)
-        c = mm_op(*_csr_of(_a), b, c)
+        if not (fused and custom_mm.naive_spmm_dense(_a, b, c)):
+            c = mm_op(*_csr_of(_a), b, c)
         return c.view(tuple(a_shape[:-1]) + (c_cols,))
 
     # batch × batch
@@ -296,7 +301,9 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch
     _b = b.expand(batch + tuple(b_shape[-2:])).reshape((-1,) + tuple(b_shape[-2:]))
     nb = _a.shape[0]
     c = torch.empty((nb, c_rows, c_cols), device=dev, dtype=torch.float32)
-    if mm_op is default_op:
+    if fused and custom_mm.naive_spmm_dense(_a, _b, c):
+        pass  # one launch, A read once, no CSR materialised
+    elif mm_op is default_op:
         # one dense→CSR conversion and one launch for the whole batch
         for lo in range(0, nb, 65535):
             hi = min(nb, lo + 65535)

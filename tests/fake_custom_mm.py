@@ -74,6 +74,21 @@ def sddmm(cols, offs, nnz, rows, kcols, dC, B):
     return torch.from_numpy(oracle.sddmm(_np(offs), _np(cols)[:nnz], rows, _np(dC), _np(B)).copy())
 
 
+fused_dense = True  # tests flip this to exercise the CSR route as well
+
+
+def naive_spmm_dense(A, B, C):
+    calls.append(("naive_spmm_dense", tuple(A.shape)))
+    if not fused_dense or C.shape[-1] % 4 != 0:
+        return False
+    a = _np(A)
+    rows, kcols = a.shape[-2:]
+    batch = int(np.prod(a.shape[:-2])) if a.ndim > 2 else 1
+    rp, c, v = oracle.dense_to_csr(a)
+    _write(C, oracle.spmm_csr_batched(rp, c, v, batch, rows, kcols, np.ascontiguousarray(_np(B))))
+    return True
+
+
 def cublas_mmul_bias(A, B, bias, C, transa, transb):
     calls.append(("cublas_mmul_bias", (transa, transb)))
     return _write(C, oracle.gemm(_np(A), _np(B), transa, transb) + _np(bias)[None, :])

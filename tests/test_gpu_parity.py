@@ -582,3 +582,30 @@ def test_fc_layer_modules_on_device(mm, dev):
             assert torch.allclose(ref.weight.grad, layer.weight.grad.cpu(), rtol=1e-4, atol=1e-5)
             if bias:
                 assert torch.allclose(ref.bias.grad, layer.bias.grad.cpu(), rtol=RTOL, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape_a,shape_b,density", [
+    ((37, 29), (29, 64), 0.3), ((130, 257), (257, 256), 0.2), ((65, 300), (300, 128), 0.1), ((9, 70), (70, 4), 0.5),
+    ((70, 1000), (1000, 100), 0.05), ((300, 64), (64, 36), 0.6),
+    ((6, 512, 512), (6, 512, 64), 0.1),      # BERT-shaped: B[item] = 128 KiB → staged in LDS
+    ((3, 100, 96), (96, 128), 0.2),          # one B shared by every item, LDS-staged
+    ((2, 3, 64, 200), (2, 3, 200, 256), 1.0), ((4, 64, 0), (4, 0, 8), 0.5), ((1, 1), (1, 4), 1.0),
+])
+def test_fused_dense_skip_is_bit_identical_to_the_csr_route(cmm, dev, oracle_mod, shape_a, shape_b, density):
+    g = np.random.Generator(np.random.PCG64(sum(shape_a) + sum(shape_b)))
+    a = (g.random(shape_a, dtype=np.float32) * (g.random(shape_a) < density)).astype(np.float32)
+    if a.size > 3:
+        a.flat[1] = -0.0
+    b = g.random(shape_b, dtype=np.float32)
+    M, K, N = shape_a[-2], shape_a[-1], shape_b[-1]
+    batch = int(np.prod(shape_a[:-2])) if len(shape_a) > 2 else 1
+    C = torch.full(tuple(shape_a[:-1]) + (N,), float("nan"), device=dev)
+    assert cmm.naive_spmm_dense(t(a, dev), t(b, dev), C) is True
+    rp, col, val = oracle_mod.dense_to_csr(a)
+    bb = b if b.ndim == 2 else b.reshape(batch, K, N)
+    expect = oracle_mod.spmm_csr_batched(rp, col, val, batch, M, K, bb).reshape(C.shape)
+    assert np.array_equal(C.cpu().numpy(), expect)
+    # widths the fused kernel does not cover are declined, not mis-computed
+    for n_bad in (7, 512):
+        C2 = torch.empty(tuple(shape_a[:-1]) + (n_bad,), device=dev)
+        assert cmm.naive_spmm_dense(t(a, dev), t(g.random(shape_b[:-1] + (n_bad,), dtype=np.float32), dev), C2) is False

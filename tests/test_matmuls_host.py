@@ -66,7 +66,15 @@ def test_c1_plumbing_config(mm):
     check_fwd_bwd(matmuls.naiveSpMM.apply, torch.mm, a, b)
     check_fwd_bwd(matmuls.cusparseMM.apply, torch.mm, a, b)
     names = [c[0] for c in fake.calls]
-    assert "cublas_mmul" in names and "naive_spmm" in names and "cusparse_mmul" in names
+    assert "cublas_mmul" in names and "naive_spmm_dense" in names
+    fake.fused_dense = False  # and through the CSR kernels proper
+    try:
+        check_fwd_bwd(matmuls.naiveSpMM.apply, torch.mm, a, b)
+        check_fwd_bwd(matmuls.cusparseMM.apply, torch.mm, a, b)
+    finally:
+        fake.fused_dense = True
+    names = [c[0] for c in fake.calls]
+    assert "naive_spmm" in names and "cusparse_mmul" in names
 
 
 @pytest.mark.parametrize("cls,ta,tb", [("cublasMM", False, False), ("cublasTransaMM", True, False),
@@ -116,9 +124,14 @@ def sparsify(g, *shape, density=0.3):
     return torch.rand(*shape, generator=g) * (torch.rand(*shape, generator=g) < density)
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("cls", ["naiveSpMM", "cusparseMM"])
-def test_sparse_classes_all_ranks(mm, cls):
+def test_sparse_classes_all_ranks(mm, cls, fused, monkeypatch):
+    """Dense inputs take the fused skip-zeros kernel when it covers the shape (fused=True) and the
+    dense→CSR + batched-CSR route otherwise (fused=False: the stand-in declines, as the real module
+    does for unsupported widths)."""
     matmuls, fake = mm
+    monkeypatch.setattr(fake, "fused_dense", fused)
     g = torch.Generator().manual_seed(14)
     apply = getattr(matmuls, cls).apply
     check_fwd_bwd(apply, torch.matmul, sparsify(g, 7, 9), rand(g, 9, 5))                    # 2-d × 2-d
@@ -126,8 +139,11 @@ def test_sparse_classes_all_ranks(mm, cls):
     check_fwd_bwd(apply, torch.matmul, sparsify(g, 2, 4, 9), rand(g, 9, 5))                 # 3-d × 2-d (FC layer)
     fake.calls.clear()
     check_fwd_bwd(apply, torch.matmul, sparsify(g, 2, 3, 8, 8), rand(g, 2, 3, 8, 4))        # BERT-shaped batch
-    assert [c for c in fake.calls if c[0] == "naive_spmm_batched"] == [("naive_spmm_batched", (6, 8, 8))]
-    assert len([c for c in fake.calls if c[0] == "dense_to_csr"]) == 1                       # one conversion
+    if fused:
+        assert [c[0] for c in fake.calls if c[0].startswith("naive_spmm") or c[0] == "dense_to_csr"] == ["naive_spmm_dense"]
+    else:
+        assert [c for c in fake.calls if c[0] == "naive_spmm_batched"] == [("naive_spmm_batched", (6, 8, 8))]
+        assert len([c for c in fake.calls if c[0] == "dense_to_csr"]) == 1                   # one conversion
     check_fwd_bwd(apply, torch.matmul, sparsify(g, 3, 8, 8), rand(g, 1, 8, 4))              # broadcast batch
     check_fwd_bwd(apply, torch.matmul, sparsify(g, 9), rand(g, 9, 5))                       # vector × matrix
     check_fwd_bwd(apply, torch.matmul, sparsify(g, 7, 9), rand(g, 9))                       # matrix × vector

@@ -79,8 +79,10 @@ def main():
         v3 = v.reshape(-1, S, D)
         t = timeit(lambda: custom_mm.naive_spmm_batched(vals, cols, offs, vals.numel(), Bz * H, S, S, v3, c3))
         print(f"batched spmm keep={keep}: {t:8.3f} ms  {2.0 * vals.numel() * D / t / 1e9:8.1f} TFLOP/s")
+        t = timeit(lambda: custom_mm.naive_spmm_dense(pp, v, c3.view(Bz, H, S, D)))
+        print(f"fused dense-skip keep={keep}: {t:8.3f} ms  (A read {pp.numel() * 4 / t / 1e6:7.0f} GB/s)")
         t = timeit(lambda: matmuls.naiveSpMM.apply(pp, v), iters=5)
-        print(f"naiveSpMM.apply keep={keep}: {t:8.3f} ms (conversion + launch)")
+        print(f"naiveSpMM.apply keep={keep}: {t:8.3f} ms (whole call)")
 
     # column-major executor (FC layer: y[N,M] = x[N,K] · Wᵀ, sparse W M×K)
     M, K, N = 4096, 4096, 512
