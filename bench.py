@@ -90,17 +90,75 @@ def cpu_baseline(rowptr, col, val, K, B, N, sample_rows):
                       f"SpMM, best of 2, {best:.2f} s"}
 
 
+def bench_c5(args):
+    """BASELINE.json configs[4]: BERT-base attention (B 32, H 12, S 512, D 64) through the drop-in
+    wrappers, forward + backward: scores = cublasTransbMM.apply(q, k); ctx = cublasMM.apply(probs, v).
+    One step = both products forward and backward (6 dense fp32 products, 12.9 GFLOP each)."""
+    import torch
+    import custom_mm
+    import matmuls
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(0)
+    Bz, H, S, D = 32, 12, 512, 64
+    q, k, v = (torch.rand(Bz, H, S, D, device=dev, generator=g).requires_grad_(True) for _ in range(3))
+    probs = torch.softmax(torch.rand(Bz, H, S, S, device=dev, generator=g), dim=-1).requires_grad_(True)
+    d_scores = torch.rand(Bz, H, S, S, device=dev, generator=g)
+    d_ctx = torch.rand(Bz, H, S, D, device=dev, generator=g)
+    custom_mm.init_cublas()
+
+    def step():
+        for t in (q, k, v, probs):
+            t.grad = None
+        matmuls.cublasTransbMM.apply(q, k).backward(d_scores)
+        matmuls.cublasMM.apply(probs, v).backward(d_ctx)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    flops = 6 * 2.0 * Bz * H * S * S * D
+    kern_ms = e0.elapsed_time(e1) / args.steps
+    # light parity check against torch autograd of matmul on one head
+    qq, kk2 = q.detach()[:1, :1].clone().requires_grad_(True), k.detach()[:1, :1].clone().requires_grad_(True)
+    torch.matmul(qq, kk2.transpose(-1, -2)).backward(d_scores[:1, :1])
+    assert torch.allclose(qq.grad, q.grad[:1, :1], rtol=1e-5, atol=1e-6)
+    print(json.dumps({
+        "metric": "BERT-base attention matmuls fwd+bwd (q.kT and probs.v), dense fp32", "value": round(flops * args.steps / elapsed / 1e12, 2),
+        "unit": "TFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BERT-base attention B=32 H=12 S=512 D=64 via cublasTransbMM / cublasMM .apply, fwd+bwd "
+                               "(BASELINE.json configs[4])", "flops_per_step": flops},
+        "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (6 launches per step)", "achieved": round(flops / kern_ms / 1e9, 2),
+                     "peak": 157.3, "unit": "TFLOP/s", "frac": round(flops / kern_ms / 1e9 / 157.3, 4), "traffic": None,
+                     "note": "fp32-input MFMA peak (MI355X_MICROARCH.md); the q.kT product is also bound by writing "
+                             "403 MB of scores"},
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["c5"], default="c3")
     ap.add_argument("--chunks", type=int, default=0,
                     help="block-cyclic chunks per rank for N > 1 (0 = 4 up to 4 GPUs, 8 beyond: the gather is the "
                          "longer leg at 8 GPUs, so finer chunks expose less of the first chunk's compute)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.workload == "c5":
+        if args.gpus != 1:
+            raise SystemExit("--workload c5 is a single-GPU measurement")
+        return bench_c5(args)
 
     import torch
     import torch.distributed as dist

@@ -609,3 +609,44 @@ def test_fused_dense_skip_is_bit_identical_to_the_csr_route(cmm, dev, oracle_mod
     for n_bad in (7, 512):
         C2 = torch.empty(tuple(shape_a[:-1]) + (n_bad,), device=dev)
         assert cmm.naive_spmm_dense(t(a, dev), t(g.random(shape_b[:-1] + (n_bad,), dtype=np.float32), dev), C2) is False
+
+
+def test_entry_points_are_graph_capturable(cmm, dev, oracle_mod):
+    """The C-ABI launches neither allocate nor synchronise, so a hipGraph can capture them
+    (`custom_mm.naive_spmm`, `cublas_bmm`, the fused dense-input product) and replay on new data."""
+    M, K, N = 3000, 2000, 256
+    rowptr, col, val = oracle_mod.make_csr(M, K, 0.01, seed=12)
+    d_rp, d_col, d_val = t(rowptr, dev), t(col, dev), t(val, dev)
+    B = torch.zeros(K, N, device=dev)
+    C = torch.empty(M, N, device=dev)
+    q = torch.zeros(3, 2, 96, 64, device=dev)
+    kk = torch.zeros(3, 2, 96, 64, device=dev)
+    S = torch.empty(3, 2, 96, 96, device=dev)
+    P = torch.empty(3, 2, 96, 64, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # warm-up outside capture
+        cmm.naive_spmm(d_val, d_col, d_rp, len(val), M, K, B, C)
+        cmm.cublas_bmm(q, kk, S, 4, False, True)
+        cmm.naive_spmm_dense(S, kk, P)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        cmm.naive_spmm(d_val, d_col, d_rp, len(val), M, K, B, C)
+        cmm.cublas_bmm(q, kk, S, 4, False, True)
+        assert cmm.naive_spmm_dense(S, kk, P) is True
+    g = np.random.Generator(np.random.PCG64(12))
+    for _ in range(2):  # replay on fresh contents of the same buffers
+        Bh = g.random((K, N), dtype=np.float32)
+        qh, kh = g.random(q.shape, dtype=np.float32), g.random(kk.shape, dtype=np.float32)
+        B.copy_(torch.from_numpy(Bh))
+        q.copy_(torch.from_numpy(qh))
+        kk.copy_(torch.from_numpy(kh))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr(rowptr, col, val, M, K, Bh))
+        s_exp = oracle_mod.gemm(qh, kh, False, True)
+        assert np.array_equal(S.cpu().numpy(), s_exp)
+        rp2, c2, v2 = oracle_mod.dense_to_csr(s_exp)
+        assert np.array_equal(P.cpu().numpy().reshape(6, 96, 64),
+                              oracle_mod.spmm_csr_batched(rp2, c2, v2, 6, 96, 96, kh.reshape(6, 96, 64)))
