@@ -346,7 +346,7 @@ def naive_matmul(a: torch.Tensor,
     return _spmm_dispatch(a, b, mm_op, custom_mm.naive_spmm)
 
 
-def _sparse_backward(ctx, grad_output, matmul):
+def _sparse_backward(ctx, grad_output):
     '''Gradients of C = m1 @ m2 with m1 taken as sparse.
 
     grad_m2 = m1ᵀ·dC.  grad_m1 = dC·m2ᵀ: dense when m1 is a dense tensor (what
@@ -399,7 +399,7 @@ class cusparseMM(InplaceFunction):
 
     @staticmethod
     def backward(ctx, grad_output):
-        return _sparse_backward(ctx, grad_output, sparse_matmul)
+        return _sparse_backward(ctx, grad_output)
 
 
 class naiveSpMM(InplaceFunction):
@@ -410,4 +410,4 @@ class naiveSpMM(InplaceFunction):
 
     @staticmethod
     def backward(ctx, grad_output):
-        return _sparse_backward(ctx, grad_output, naive_matmul)
+        return _sparse_backward(ctx, grad_output)

@@ -175,7 +175,8 @@ def sddmm(rowptr, col, M, dC, B):
 
 def make_csr(M, K, density, seed):
     """The pinned synthetic generator of SURVEY.md §8(d): numpy PCG64, unique uniform
-    keys in [0, M*K), values U[0,1) float32.  Returns (rowptr i32, col i32, val f32)."""
+    keys in [0, M*K), values U[0,1) float32.  Returns (rowptr i32, col i32, val f32).
+    (Test-side twin of matrix-multiplication_amd/synthetic.py: tests/test_oracle.py checks the two agree.)"""
     rng = np.random.Generator(np.random.PCG64(seed))
     keys = np.unique(rng.integers(0, M * K, size=round(M * K * density), dtype=np.int64))
     row = keys // K

@@ -157,6 +157,11 @@ def test_pinned_generator_is_stable(oracle_mod):
     assert all(np.all(np.diff(col[rp[r]:rp[r + 1]]) > 0) for r in range(0, 1024, 37))  # sorted, unique
     digest = hashlib.sha256(rp.tobytes() + col.tobytes() + val.tobytes()).hexdigest()
     assert digest == PINNED_DIGEST, digest
+    # bench.py's generator (product side, no oracle import) is the same function
+    import synthetic
+    rp2, col2, val2 = synthetic.make_csr(1024, 1024, 1e-2, 0)
+    assert np.array_equal(rp, rp2) and np.array_equal(col, col2) and np.array_equal(val, val2)
+    assert np.array_equal(synthetic.make_dense(7, 5, 1), np.random.Generator(np.random.PCG64(1)).random((7, 5), dtype=np.float32))
 
 
 PINNED_DIGEST = "79ff35ca20d2cd54c4a2c59f975a106bd2463ffeb37eb5cbc058671113352e84"
