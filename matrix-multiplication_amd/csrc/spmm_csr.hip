@@ -299,18 +299,36 @@ template <int G, int VEC, int T>
 __global__ __launch_bounds__(256) void spmm_group_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
-    int M, int N, long ldb, long ldc, long strideB, long strideC, const float* __restrict__ bias) {
+    int M, int N, long ldb, long ldc, long strideB, long strideC, const float* __restrict__ bias,
+    int ctiles, int tile_cols, unsigned row_blocks) {
   typedef Vec<VEC> V;
   typedef typename V::type vec_t;
   constexpr int RPW = 64 / G;  // rows per wave
   constexpr int UI = G < 4 ? G : 4;  // B-row loads in flight per group
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);
-  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + (lane / G);
   const long item = blockIdx.y;
   const int* rp = rowptr + item * ((long)M + 1);
   const float* Bi = B + item * strideB;
   float* Ci = C + item * strideC;
+  unsigned rb = blockIdx.x;
+  if (ctiles > 1) {
+    // XCD-aware column tiling (wide N): workgroup b runs on XCD b % 8, whose private 4 MiB L2
+    // should hold the K × tile_cols slice of B it gathers from.  XCD x takes column tiles
+    // x, x+8, x+16, … one after the other, all row blocks of a tile before the next tile, so the
+    // CUs of an XCD share one slice at a time.  Per-element arithmetic is unchanged (each output
+    // element still sees its row's non-zeros in CSR order); placement affects speed only.
+    const unsigned xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+    const int tile = (int)(xcd + 8 * (idx / row_blocks));
+    if (tile >= ctiles) return;
+    rb = idx % row_blocks;
+    const int c0 = tile * tile_cols;
+    Bi += c0;
+    Ci += c0;
+    if (bias) bias += c0;
+    N = N - c0 < tile_cols ? N - c0 : tile_cols;
+  }
+  const long row = ((long)rb * 4 + (threadIdx.x >> 6)) * RPW + (lane / G);
 
   int start = 0, end = 0;
   if (row < M) {
@@ -379,8 +397,40 @@ int launch_group(const int* rowptr, const int* col, const float* val, const floa
   const long blocks = ((long)M + rows_per_block - 1) / rows_per_block;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   hipLaunchKernelGGL((spmm_group_kernel<G, VEC, T>), dim3((unsigned)blocks, (unsigned)batch),
-                     dim3(256), 0, s, rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, bias);
+                     dim3(256), 0, s, rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, bias, 1, N,
+                     (unsigned)blocks);
   return mi::check_launch();
+}
+
+// Column-tiled launch of the float4 group kernel: tile_cols = 4·G columns per tile.
+template <int G>
+int launch_coltile(const int* rowptr, const int* col, const float* val, const float* B, float* C, int M,
+                   int N, long ldb, long ldc, const float* bias, hipStream_t s) {
+  constexpr int rows_per_block = 4 * (64 / G);
+  constexpr int tile_cols = 4 * G;
+  const long row_blocks = ((long)M + rows_per_block - 1) / rows_per_block;
+  const int ctiles = (N + tile_cols - 1) / tile_cols;
+  const long blocks = 8L * ((ctiles + 7) / 8) * row_blocks;  // every XCD gets the same count; extras exit
+  if (blocks > 0x7fffffffL) return MI_ERANGE;
+  hipLaunchKernelGGL((spmm_group_kernel<G, 4, 1>), dim3((unsigned)blocks, 1u), dim3(256), 0, s, rowptr, col, val,
+                     B, C, M, N, ldb, ldc, 0L, 0L, bias, ctiles, tile_cols, (unsigned)row_blocks);
+  return mi::check_launch();
+}
+
+// Tile width (columns) for the XCD-aware column-tiled launch, or 0 when it does not apply.
+// The K-row slice of B an XCD gathers from should fit its 4 MiB L2; the tiles must spread evenly
+// over the 8 XCDs and each tile needs enough row blocks to occupy an XCD's 32 CUs.  Measured on
+// MI355X (tools/bench_wide.py): 4096² 1 % 0.344 → 0.129 ms (21 TB/s of gathers served by L2),
+// 65536×8192 × 1024 0.5 % 1.33 → 0.51 ms, 8192² 1 % 2.96 → 2.13 ms, 16384² 1 % 24.2 → 20.7 ms.
+int coltile_width(int32_t M, int32_t K, int32_t N, int64_t ldb) {
+  const long slice_budget = 4L << 20;
+  if (N < 512 || M < 2048 || (long)K * ldb * 4 <= (8L << 20)) return 0;  // narrow, short, or B small as it is
+  for (int w : {256, 128, 64}) {
+    if ((long)K * w * 4 > slice_budget || N < 8 * w) continue;
+    const int tiles = (N + w - 1) / w, rounds = (tiles + 7) / 8;
+    if (tiles * 5 >= rounds * 8 * 4) return w;  // at least 80 % of the XCD × round slots used
+  }
+  return 0;
 }
 
 template <int VEC>
@@ -458,6 +508,7 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
   if (sh.wave_ok && batch == 1 && b_elems * 4 >= (768L << 20) && nnz >= 32L * M &&
       nnz * (long)N >= 8 * b_elems)
     return MI_SPMM_PANELS_2;
+  if (sh.vec4_ok && batch == 1 && coltile_width(M, K, N, ldb) > 0) return MI_SPMM_COLTILE;
   if (sh.wave_ok) return MI_SPMM_WAVE_ROW_U8;
   return sh.vec4_ok ? MI_SPMM_GROUP_VEC4 : MI_SPMM_GROUP_SCALAR;
 }
@@ -507,6 +558,14 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
       if (!(wave_ok && batch == 1)) return MI_EINVAL;
       static const int kPanels[] = {2, 3, 4, 5, 6, 8};
       return launch_panels(kPanels[variant - MI_SPMM_PANELS_2], rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, s);
+    }
+    case MI_SPMM_COLTILE: {
+      if (!(vec4_ok && batch == 1)) return MI_EINVAL;
+      int w = coltile_width(M, K, N, ldb);
+      if (w == 0) w = N >= 256 ? 256 : (N >= 128 ? 128 : 64);  // forced by the caller: any width works
+      if (w == 256) return launch_coltile<64>(rowptr, col, val, B, C, M, N, ldb, ldc, bias, s);
+      if (w == 128) return launch_coltile<32>(rowptr, col, val, B, C, M, N, ldb, ldc, bias, s);
+      return launch_coltile<16>(rowptr, col, val, B, C, M, N, ldb, ldc, bias, s);
     }
     case MI_SPMM_GROUP_VEC4:
       if (!vec4_ok) return MI_EINVAL;
@@ -574,7 +633,8 @@ const char* mi_spmm_variant_name(int variant) {
     case MI_SPMM_AUTO: return "auto";
     case MI_SPMM_WAVE_ROW_U4: case MI_SPMM_WAVE_ROW_U8: case MI_SPMM_WAVE_ROW_U16: return "spmm_wave_row_kernel";
     case MI_SPMM_WAVE_ROW_VL: return "spmm_wave_row_vl_kernel";
-    case MI_SPMM_GROUP_VEC4: case MI_SPMM_GROUP_VEC2: case MI_SPMM_GROUP_SCALAR: return "spmm_group_kernel";
+    case MI_SPMM_GROUP_VEC4: case MI_SPMM_GROUP_VEC2: case MI_SPMM_GROUP_SCALAR: case MI_SPMM_COLTILE:
+      return "spmm_group_kernel";
     case MI_SPMM_PANELS_2: case MI_SPMM_PANELS_3: case MI_SPMM_PANELS_4: case MI_SPMM_PANELS_5:
     case MI_SPMM_PANELS_6: case MI_SPMM_PANELS_8: return "spmm_wave_row_panel_kernel";
     default: return "unknown";

@@ -87,7 +87,7 @@ def test_spmm_every_variant_is_bit_identical(capi, dev, oracle_mod, M, K, N, den
     expect = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
     d = [t(x, dev) for x in (rowptr, col, val, B)]
     ran = 0
-    for variant in range(14):
+    for variant in range(15):
         C = torch.full((M, N), float("nan"), device=dev)
         st = capi.mi_spmm_csr_f32_variant(variant, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(val), M, K,
                                           N, d[3].data_ptr(), N, C.data_ptr(), N,
@@ -650,3 +650,18 @@ def test_entry_points_are_graph_capturable(cmm, dev, oracle_mod):
         rp2, c2, v2 = oracle_mod.dense_to_csr(s_exp)
         assert np.array_equal(P.cpu().numpy().reshape(6, 96, 64),
                               oracle_mod.spmm_csr_batched(rp2, c2, v2, 6, 96, 96, kh.reshape(6, 96, 64)))
+
+
+def test_wide_n_column_tiled_launch_is_bit_exact(capi, cmm, dev, oracle_mod):
+    """Wide N with a B that fits neither one L2 nor 8 MiB: AUTO takes the XCD-aware column-tiled launch
+    (variant 14); every output element still sees its row's non-zeros in CSR order."""
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_spmm_csr_f32_plan.argtypes = [i64, i32, i32, i32, vp, i64, vp, i64]
+    for (M, K, N) in [(2048, 2048, 2048), (2100, 1500, 2560), (4096, 3000, 1024)]:
+        rowptr, col, val = oracle_mod.make_csr(M, K, 0.02, seed=N)
+        B = np.random.Generator(np.random.PCG64(N)).random((K, N), dtype=np.float32)
+        d_B = t(B, dev)
+        C = torch.full((M, N), float("nan"), device=dev)
+        assert capi.mi_spmm_csr_f32_plan(len(val), M, K, N, d_B.data_ptr(), N, C.data_ptr(), N) == 14
+        cmm.naive_spmm(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, d_B, C)
+        assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr_omp(rowptr, col, val, M, K, B))
