@@ -373,7 +373,6 @@ bool spmm_dense_impl(const torch::Tensor& A, const torch::Tensor& B, const torch
   }
   TORCH_CHECK(C.numel() == batch * M * N, what, ": C must be [batch…, ", M, ", ", N, "]");
   TORCH_CHECK(M <= INT32_MAX && K <= INT32_MAX && N <= INT32_MAX, what, ": dimension too large");
-  if (batch > 65535) return false;
   const float* bias_ptr = nullptr;
   torch::Tensor bias_keep;
   if (bias != nullptr && bias->defined()) {

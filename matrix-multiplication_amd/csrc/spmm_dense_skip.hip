@@ -46,13 +46,13 @@ struct Pair {
   float v;
 };
 
-// grid = (row_blocks, batch); block = WAVES*64 threads.
+// grid = 1-D over (item, row block), XCD-aware (below); block = WAVES*64 threads.
 // G lanes per row (N ≤ 4·G), R = 64/G rows per wave, chunk = 4·G columns of A per row.
 template <int G, bool VECA, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void spmm_dense_skip_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int K,
     int N, long lda, long ldb, long ldc, long strideA, long strideB, long strideC,
-    int rows_per_block, const float* __restrict__ bias) {
+    int rows_per_block, const float* __restrict__ bias, int batch, unsigned row_blocks) {
   constexpr int R = 64 / G;
   constexpr int CH = 4 * G;
   constexpr int LIST_STRIDE = CH + 1;  // pairs; +1 keeps the R broadcast reads on different banks
@@ -61,7 +61,13 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_dense_skip_kernel(
   const int wave = threadIdx.x >> 6;
   const int gl = lane & (G - 1);
   const int g = lane / G;
-  const long item = blockIdx.y;
+  // 1-D grid, XCD-aware: workgroup b runs on XCD b % 8, so give every XCD whole items
+  // (item = xcd + 8·n): all row blocks of an item then share one L2 copy of that item's B
+  // instead of pulling it into up to 8 L2s.  Placement affects speed only.
+  const unsigned xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+  const long item = xcd + 8L * (idx / row_blocks);
+  if (item >= batch) return;
+  const unsigned rb = idx % row_blocks;
   const float* Ai = A + item * strideA;
   const float* Bi = B + item * strideB;
   float* Ci = C + item * strideC;
@@ -71,9 +77,9 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_dense_skip_kernel(
   const bool on = gl * 4 < N;
   // this lane's group as a lane mask
   const unsigned long long gm = G == 64 ? ~0ull : (((1ull << G) - 1ull) << (g * G));
-  const int row_end = min(M, (int)(blockIdx.x + 1) * rows_per_block);
+  const int row_end = min(M, (int)(rb + 1) * rows_per_block);
 
-  for (int row0 = blockIdx.x * rows_per_block + wave * R; row0 < row_end; row0 += WAVES * R) {
+  for (int row0 = rb * rows_per_block + wave * R; row0 < row_end; row0 += WAVES * R) {
     const int row = row0 + g;
     const bool valid = row < row_end;
     const float* arow = Ai + (long)(valid ? row : row0) * lda;
@@ -152,14 +158,17 @@ int launch_for_width(bool veca, const float* A, const float* B, float* C, int ba
   constexpr int R = 64 / G;
   constexpr size_t lds_bytes = (size_t)WAVES * R * (4 * G + 1) * sizeof(Pair);
   const int rows_per_block = WAVES * R;
-  const long blocks = ((long)M + rows_per_block - 1) / rows_per_block;
+  const long row_blocks = ((long)M + rows_per_block - 1) / rows_per_block;
+  const long blocks = 8L * ((batch + 7) / 8) * row_blocks;  // every XCD gets the same count; extras exit
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   if (veca)
-    hipLaunchKernelGGL((spmm_dense_skip_kernel<G, true, WAVES>), dim3((unsigned)blocks, (unsigned)batch),
-                       dim3(WAVES * 64), lds_bytes, s, A, B, C, M, K, N, lda, ldb, ldc, sA, sB, sC, rows_per_block, bias);
+    hipLaunchKernelGGL((spmm_dense_skip_kernel<G, true, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), lds_bytes,
+                       s, A, B, C, M, K, N, lda, ldb, ldc, sA, sB, sC, rows_per_block, bias, batch,
+                       (unsigned)row_blocks);
   else
-    hipLaunchKernelGGL((spmm_dense_skip_kernel<G, false, WAVES>), dim3((unsigned)blocks, (unsigned)batch),
-                       dim3(WAVES * 64), lds_bytes, s, A, B, C, M, K, N, lda, ldb, ldc, sA, sB, sC, rows_per_block, bias);
+    hipLaunchKernelGGL((spmm_dense_skip_kernel<G, false, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), lds_bytes,
+                       s, A, B, C, M, K, N, lda, ldb, ldc, sA, sB, sC, rows_per_block, bias, batch,
+                       (unsigned)row_blocks);
   return mi::check_launch();
 }
 
@@ -180,7 +189,6 @@ int mi_spmm_dense_skip_f32(const float* A, int64_t lda, int64_t strideA, int32_t
                            mi_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (batch < 0 || M < 0 || K < 0 || N < 0 || strideA < 0 || strideB < 0 || strideC < 0) return MI_EINVAL;
-  if (batch > 65535) return MI_ERANGE;
   if (batch == 0 || M == 0 || N == 0) return MI_OK;
   if (!C || ldc < N) return MI_EINVAL;
   if (K > 0 && (!A || !B || lda < K || ldb < N)) return MI_EINVAL;
