@@ -75,7 +75,8 @@ enum {
   MI_SPMM_PANELS_8 = 12,
   MI_SPMM_GROUP_VEC2 = 13,  /* G = N/2 lanes per row, 8 B per lane                    */
   MI_SPMM_COLTILE = 14,     /* wide N: XCD-aware column tiles so each XCD's L2 holds its B slice */
-  MI_SPMM_VARIANT_COUNT = 15
+  MI_SPMM_COLTILE_PANELS = 15, /* wide N and tall K: column tiles × row panels of B, one launch per panel */
+  MI_SPMM_VARIANT_COUNT = 16
 };
 int mi_spmm_csr_f32_variant(int variant, const int32_t* rowptr, const int32_t* col,
                             const float* val, int64_t nnz, int32_t M, int32_t K,

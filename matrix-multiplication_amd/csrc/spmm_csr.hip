@@ -166,10 +166,23 @@ template <bool FIRST, int T, int U>
 __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
-    int M, long ldb, long ldc, int c_lo, int c_hi, const float* __restrict__ bias) {
+    int M, long ldb, long ldc, int c_lo, int c_hi, const float* __restrict__ bias, int ctiles,
+    unsigned row_blocks) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long row = (long)blockIdx.x * 4 + wave;
+  unsigned rb = blockIdx.x;
+  if (ctiles > 1) {
+    // wide N: column tiles of 256·T columns dealt XCD-aware exactly as in spmm_group_kernel, so the
+    // (row panel × column tile) slice of B this pass gathers from stays in the XCD's L2
+    const unsigned xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+    const int tile = (int)(xcd + 8 * (idx / row_blocks));
+    if (tile >= ctiles) return;
+    rb = idx % row_blocks;
+    B += (long)tile * (256 * T);
+    C += (long)tile * (256 * T);
+    if (bias) bias += (long)tile * (256 * T);
+  }
+  const long row = (long)rb * 4 + wave;
   if (row >= M) return;
   const float* Bl = B + lane * 4;
   float* Cl = C + row * ldc + lane * 4;
@@ -228,8 +241,10 @@ __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
 
 template <int T, int U>
 int launch_panels_t(int panels, const int* rowptr, const int* col, const float* val, const float* B,
-                    float* C, int M, int K, long ldb, long ldc, const float* bias, hipStream_t s) {
-  const long blocks = ((long)M + 3) / 4;
+                    float* C, int M, int K, long ldb, long ldc, const float* bias, hipStream_t s,
+                    int ctiles = 1) {
+  const long row_blocks = ((long)M + 3) / 4;
+  const long blocks = ctiles > 1 ? 8L * ((ctiles + 7) / 8) * row_blocks : row_blocks;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   const long kp = ((long)K + panels - 1) / panels;
   for (int q = 0; q < panels; ++q) {
@@ -238,11 +253,11 @@ int launch_panels_t(int panels, const int* rowptr, const int* col, const float* 
     if (q == 0)
       hipLaunchKernelGGL((spmm_wave_row_panel_kernel<true, T, U>), dim3((unsigned)blocks), dim3(256), 0,
                          s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi,
-                         q == panels - 1 ? bias : (const float*)nullptr);
+                         q == panels - 1 ? bias : (const float*)nullptr, ctiles, (unsigned)row_blocks);
     else
       hipLaunchKernelGGL((spmm_wave_row_panel_kernel<false, T, U>), dim3((unsigned)blocks), dim3(256), 0,
                          s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi,
-                         q == panels - 1 ? bias : (const float*)nullptr);
+                         q == panels - 1 ? bias : (const float*)nullptr, ctiles, (unsigned)row_blocks);
   }
   return mi::check_launch();
 }
@@ -479,6 +494,19 @@ int launch_wave_row_vl(const int* rowptr, const int* col, const float* val, cons
   return mi::check_launch();
 }
 
+// Wide N with K too tall for a K × 256 slice to fit an L2: block BOTH ways — 256-column tiles
+// dealt XCD-aware and K cut into row panels of B (one launch per panel, C carried through memory
+// like the two-panel path), so each XCD gathers from a (K/P) × 256 slice of ≈3 MiB.
+// Returns the number of panels, or 0 when the plan does not apply.
+int coltile_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
+  if (N % 256 != 0 || N < 2048 || M < 2048 || ldb != N) return 0;
+  if ((long)K * 1024 <= (4L << 20)) return 0;              // plain column tiling already fits
+  const int panels = (int)(((long)K * 1024 + (3L << 20) - 1) / (3L << 20));
+  if (panels > 16 || nnz < 8L * panels * M) return 0;       // too many C round trips for the work per pass
+  const int tiles = N / 256, rounds = (tiles + 7) / 8;
+  return tiles * 5 >= rounds * 8 * 4 ? panels : 0;
+}
+
 struct Shape {
   bool vec4_ok, vec2_ok, wave_ok;
 };
@@ -508,6 +536,7 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
   if (sh.wave_ok && batch == 1 && b_elems * 4 >= (768L << 20) && nnz >= 32L * M &&
       nnz * (long)N >= 8 * b_elems)
     return MI_SPMM_PANELS_2;
+  if (sh.vec4_ok && batch == 1 && coltile_panels(M, K, N, ldb, nnz) > 0) return MI_SPMM_COLTILE_PANELS;
   if (sh.vec4_ok && batch == 1 && coltile_width(M, K, N, ldb) > 0) return MI_SPMM_COLTILE;
   if (sh.wave_ok) return MI_SPMM_WAVE_ROW_U8;
   return sh.vec4_ok ? MI_SPMM_GROUP_VEC4 : MI_SPMM_GROUP_SCALAR;
@@ -558,6 +587,12 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
       if (!(wave_ok && batch == 1)) return MI_EINVAL;
       static const int kPanels[] = {2, 3, 4, 5, 6, 8};
       return launch_panels(kPanels[variant - MI_SPMM_PANELS_2], rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, s);
+    }
+    case MI_SPMM_COLTILE_PANELS: {
+      if (!(vec4_ok && batch == 1 && N % 256 == 0 && N >= 256)) return MI_EINVAL;
+      int panels = coltile_panels(M, K, N, ldb, nnz);
+      if (panels == 0) panels = 3;  // forced by the caller
+      return launch_panels_t<1, 8>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, s, N / 256);
     }
     case MI_SPMM_COLTILE: {
       if (!(vec4_ok && batch == 1)) return MI_EINVAL;
@@ -625,6 +660,7 @@ int mi_spmm_csr_f32_plan(int64_t nnz, int32_t M, int32_t K, int32_t N, const flo
 int mi_spmm_variant_launches(int variant) {
   static const int kPanels[] = {2, 3, 4, 5, 6, 8};
   if (variant >= MI_SPMM_PANELS_2 && variant <= MI_SPMM_PANELS_8) return kPanels[variant - MI_SPMM_PANELS_2];
+  if (variant == MI_SPMM_COLTILE_PANELS) return 0;  // one per row panel of B: depends on K
   return (variant > MI_SPMM_AUTO && variant < MI_SPMM_VARIANT_COUNT) ? 1 : MI_EINVAL;
 }
 
@@ -636,7 +672,8 @@ const char* mi_spmm_variant_name(int variant) {
     case MI_SPMM_GROUP_VEC4: case MI_SPMM_GROUP_VEC2: case MI_SPMM_GROUP_SCALAR: case MI_SPMM_COLTILE:
       return "spmm_group_kernel";
     case MI_SPMM_PANELS_2: case MI_SPMM_PANELS_3: case MI_SPMM_PANELS_4: case MI_SPMM_PANELS_5:
-    case MI_SPMM_PANELS_6: case MI_SPMM_PANELS_8: return "spmm_wave_row_panel_kernel";
+    case MI_SPMM_PANELS_6: case MI_SPMM_PANELS_8: case MI_SPMM_COLTILE_PANELS:
+      return "spmm_wave_row_panel_kernel";
     default: return "unknown";
   }
 }

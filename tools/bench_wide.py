@@ -46,9 +46,12 @@ for (M, K, N, dens) in [(4096, 4096, 4096, 0.01), (4096, 4096, 4096, 0.1), (8192
     ref = torch.empty(M, N, device=dev)
     run(5, rp, ci, v, M, K, B, ref)  # scalar group kernel as the reference result
     line = f"M={M} K={K} N={N} dens={dens} nnz={v.numel()}:"
-    for variant, name in [(0, "auto"), (4, "group"), (14, "coltile")]:
+    for variant, name in [(0, "auto"), (4, "group"), (14, "coltile"), (15, "coltile+panels")]:
         C = torch.empty(M, N, device=dev)
-        run(variant, rp, ci, v, M, K, B, C)
+        try:
+            run(variant, rp, ci, v, M, K, B, C)
+        except AssertionError:
+            continue
         same = torch.equal(C, ref)
         t = timeit(lambda: run(variant, rp, ci, v, M, K, B, C))
         line += f"  {name} {t:.3f} ms ({v.numel() * 4.0 * N / t / 1e9:.1f} TB/s gather){'' if same else ' MISMATCH'}"
