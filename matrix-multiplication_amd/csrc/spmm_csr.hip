@@ -45,7 +45,8 @@ template <int T, int U>
 __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
-    int M, long ldb, long ldc, long strideB, long strideC, const float* __restrict__ bias) {
+    int M, long ldb, long ldc, long strideB, long strideC, const float* __restrict__ bias,
+    int long_thresh) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long row = (long)blockIdx.x * 4 + wave;
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
 
   int p = rp[row];
   const int end = rp[row + 1];
+  if (end - p > long_thresh) return;  // left to spmm_long_rows_kernel
 
   f32x4 acc[T];
 #pragma unroll
@@ -108,7 +110,8 @@ template <int U>
 __global__ __launch_bounds__(256) void spmm_wave_row_vl_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
-    int M, long ldb, long ldc, long strideB, long strideC, const float* __restrict__ bias) {
+    int M, long ldb, long ldc, long strideB, long strideC, const float* __restrict__ bias,
+    int long_thresh) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long row = (long)blockIdx.x * 4 + wave;
@@ -120,6 +123,7 @@ __global__ __launch_bounds__(256) void spmm_wave_row_vl_kernel(
 
   const int start = rp[row];
   const int end = rp[row + 1];
+  if (end - start > long_thresh) return;  // left to spmm_long_rows_kernel
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int p = start; p < end; p += 64) {
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
     int M, long ldb, long ldc, int c_lo, int c_hi, const float* __restrict__ bias, int ctiles,
-    unsigned row_blocks) {
+    unsigned row_blocks, int long_thresh) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned rb = blockIdx.x;
@@ -188,6 +192,7 @@ __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
   float* Cl = C + row * ldc + lane * 4;
   const int start = rowptr[row];
   const int end = rowptr[row + 1];
+  if (end - start > long_thresh) return;  // left to spmm_long_rows_kernel (in every pass)
   f32x4 acc[T];
 #pragma unroll
   for (int t = 0; t < T; ++t)
@@ -241,8 +246,8 @@ __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
 
 template <int T, int U>
 int launch_panels_t(int panels, const int* rowptr, const int* col, const float* val, const float* B,
-                    float* C, int M, int K, long ldb, long ldc, const float* bias, hipStream_t s,
-                    int ctiles = 1) {
+                    float* C, int M, int K, long ldb, long ldc, const float* bias, int long_thresh,
+                    hipStream_t s, int ctiles = 1) {
   const long row_blocks = ((long)M + 3) / 4;
   const long blocks = ctiles > 1 ? 8L * ((ctiles + 7) / 8) * row_blocks : row_blocks;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
@@ -253,20 +258,23 @@ int launch_panels_t(int panels, const int* rowptr, const int* col, const float* 
     if (q == 0)
       hipLaunchKernelGGL((spmm_wave_row_panel_kernel<true, T, U>), dim3((unsigned)blocks), dim3(256), 0,
                          s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi,
-                         q == panels - 1 ? bias : (const float*)nullptr, ctiles, (unsigned)row_blocks);
+                         q == panels - 1 ? bias : (const float*)nullptr, ctiles, (unsigned)row_blocks,
+                         long_thresh);
     else
       hipLaunchKernelGGL((spmm_wave_row_panel_kernel<false, T, U>), dim3((unsigned)blocks), dim3(256), 0,
                          s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi,
-                         q == panels - 1 ? bias : (const float*)nullptr, ctiles, (unsigned)row_blocks);
+                         q == panels - 1 ? bias : (const float*)nullptr, ctiles, (unsigned)row_blocks,
+                         long_thresh);
   }
   return mi::check_launch();
 }
 
 int launch_panels(int panels, const int* rowptr, const int* col, const float* val, const float* B,
-                  float* C, int M, int K, int N, long ldb, long ldc, const float* bias, hipStream_t s) {
-  if (N == 256) return launch_panels_t<1, 8>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, s);
-  if (N == 512) return launch_panels_t<2, 4>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, s);
-  return launch_panels_t<4, 2>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, s);
+                  float* C, int M, int K, int N, long ldb, long ldc, const float* bias, int long_thresh,
+                  hipStream_t s) {
+  if (N == 256) return launch_panels_t<1, 8>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, long_thresh, s);
+  if (N == 512) return launch_panels_t<2, 4>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, long_thresh, s);
+  return launch_panels_t<4, 2>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, long_thresh, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
     int M, int N, long ldb, long ldc, long strideB, long strideC, const float* __restrict__ bias,
-    int ctiles, int tile_cols, unsigned row_blocks) {
+    int ctiles, int tile_cols, unsigned row_blocks, int long_thresh) {
   typedef Vec<VEC> V;
   typedef typename V::type vec_t;
   constexpr int RPW = 64 / G;  // rows per wave
@@ -350,6 +358,8 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
     start = rp[row];
     end = rp[row + 1];
   }
+  const bool skipped = end - start > long_thresh;  // left to spmm_long_rows_kernel
+  if (skipped) end = start;
 
   for (int n0 = 0; n0 < N; n0 += G * VEC * T) {  // wave-uniform pass loop
     vec_t acc[T];
@@ -395,7 +405,7 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
           if (on[t]) acc[t] = V::fma(v, V::load(src + coff[t]), acc[t]);
       }
     }
-    if (row < M) {
+    if (row < M && !skipped) {
       float* dst = Ci + row * ldc;
 #pragma unroll
       for (int t = 0; t < T; ++t)
@@ -407,20 +417,20 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
 template <int G, int VEC, int T>
 int launch_group(const int* rowptr, const int* col, const float* val, const float* B,
                  float* C, int M, int N, long ldb, long ldc, long strideB, long strideC,
-                 int batch, const float* bias, hipStream_t s) {
+                 int batch, const float* bias, int long_thresh, hipStream_t s) {
   constexpr int rows_per_block = 4 * (64 / G);
   const long blocks = ((long)M + rows_per_block - 1) / rows_per_block;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   hipLaunchKernelGGL((spmm_group_kernel<G, VEC, T>), dim3((unsigned)blocks, (unsigned)batch),
                      dim3(256), 0, s, rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, bias, 1, N,
-                     (unsigned)blocks);
+                     (unsigned)blocks, long_thresh);
   return mi::check_launch();
 }
 
 // Column-tiled launch of the float4 group kernel: tile_cols = 4·G columns per tile.
 template <int G>
 int launch_coltile(const int* rowptr, const int* col, const float* val, const float* B, float* C, int M,
-                   int N, long ldb, long ldc, const float* bias, hipStream_t s) {
+                   int N, long ldb, long ldc, const float* bias, int long_thresh, hipStream_t s) {
   constexpr int rows_per_block = 4 * (64 / G);
   constexpr int tile_cols = 4 * G;
   const long row_blocks = ((long)M + rows_per_block - 1) / rows_per_block;
@@ -428,7 +438,7 @@ int launch_coltile(const int* rowptr, const int* col, const float* val, const fl
   const long blocks = 8L * ((ctiles + 7) / 8) * row_blocks;  // every XCD gets the same count; extras exit
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   hipLaunchKernelGGL((spmm_group_kernel<G, 4, 1>), dim3((unsigned)blocks, 1u), dim3(256), 0, s, rowptr, col, val,
-                     B, C, M, N, ldb, ldc, 0L, 0L, bias, ctiles, tile_cols, (unsigned)row_blocks);
+                     B, C, M, N, ldb, ldc, 0L, 0L, bias, ctiles, tile_cols, (unsigned)row_blocks, long_thresh);
   return mi::check_launch();
 }
 
@@ -451,11 +461,12 @@ int coltile_width(int32_t M, int32_t K, int32_t N, int64_t ldb) {
 template <int VEC>
 int dispatch_group(const int* rowptr, const int* col, const float* val, const float* B,
                    float* C, int M, int N, long ldb, long ldc, long strideB, long strideC,
-                   int batch, const float* bias, hipStream_t s) {
+                   int batch, const float* bias, int long_thresh, hipStream_t s) {
   const int nv = (N + VEC - 1) / VEC;  // vector columns
   const int G = nv >= 64 ? 64 : mi::pow2_ceil(nv);
 #define MI_GROUP(G_, T_) \
-  return launch_group<G_, VEC, T_>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, s)
+  return launch_group<G_, VEC, T_>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, \
+                                   long_thresh, s)
   switch (G) {
     case 1: MI_GROUP(1, 1);
     case 2: MI_GROUP(2, 1);
@@ -475,23 +486,105 @@ int dispatch_group(const int* rowptr, const int* col, const float* val, const fl
 template <int T, int U>
 int launch_wave_row(const int* rowptr, const int* col, const float* val, const float* B,
                     float* C, int M, long ldb, long ldc, long strideB, long strideC,
-                    int batch, const float* bias, hipStream_t s) {
+                    int batch, const float* bias, int long_thresh, hipStream_t s) {
   const long blocks = ((long)M + 3) / 4;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   hipLaunchKernelGGL((spmm_wave_row_kernel<T, U>), dim3((unsigned)blocks, (unsigned)batch),
-                     dim3(256), 0, s, rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, bias);
+                     dim3(256), 0, s, rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, bias, long_thresh);
   return mi::check_launch();
 }
 
 template <int U>
 int launch_wave_row_vl(const int* rowptr, const int* col, const float* val, const float* B,
                        float* C, int M, long ldb, long ldc, long strideB, long strideC,
-                       int batch, const float* bias, hipStream_t s) {
+                       int batch, const float* bias, int long_thresh, hipStream_t s) {
   const long blocks = ((long)M + 3) / 4;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   hipLaunchKernelGGL((spmm_wave_row_vl_kernel<U>), dim3((unsigned)blocks, (unsigned)batch),
-                     dim3(256), 0, s, rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, bias);
+                     dim3(256), 0, s, rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, bias, long_thresh);
   return mi::check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// Skewed matrices.  A row is owned by one wave, which sustains only a few GB/s of gathers, so
+// a row with 10⁵–10⁶ non-zeros would be a serial tail of tens of milliseconds.  When the caller
+// supplies a workspace (custom_mm always does), rows with more than kLongRow non-zeros are
+// skipped by the kernels above (`long_thresh`), collected by find_long_rows_kernel, and summed
+// here by a whole 16-wave workgroup: wave w runs the fmaf chain over the row's 1024-non-zero
+// chunks w, w+16, w+32, … (in increasing position), and the 16 partial results are added in wave
+// order.  That is a different — fixed, launch-independent — summation order for those rows only;
+// oracle_spmm_csr_f32 restates it, so results stay bit-identical to the oracle.
+// ---------------------------------------------------------------------------
+constexpr int kLongRow = 8192;
+constexpr int kLongChunk = 1024;
+constexpr int kLongWaves = 16;
+
+__global__ void find_long_rows_kernel(const int* __restrict__ rowptr, int M, int* __restrict__ ws, int cap) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < M && rowptr[r + 1] - rowptr[r] > kLongRow) {
+    const int slot = atomicAdd(&ws[0], 1);  // order of the list does not matter
+    if (slot < cap) ws[1 + slot] = (int)r;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kLongWaves * 64) void spmm_long_rows_kernel(
+    const int* __restrict__ ws, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C, int N, long ldb,
+    long ldc, const float* __restrict__ bias) {
+  typedef Vec<VEC> V;
+  typedef typename V::type vec_t;
+  __shared__ vec_t part[kLongWaves][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int count = ws[0];
+  for (int e = blockIdx.x; e < count; e += gridDim.x) {
+    const int row = ws[1 + e];
+    const int start = rowptr[row], end = rowptr[row + 1];
+    for (int n0 = 0; n0 < N; n0 += 64 * VEC) {  // 64·VEC output columns per pass
+      const int c0 = n0 + lane * VEC;
+      const bool on = c0 < N;
+      vec_t acc = V::zero();
+      for (int cb = start + wave * kLongChunk; cb < end; cb += kLongWaves * kLongChunk) {
+        const int ce = cb + kLongChunk < end ? cb + kLongChunk : end;
+        for (int p = cb; p < ce; p += 64) {
+          const int idx = p + lane;
+          const int myc = idx < ce ? col[idx] : 0;
+          const float myv = idx < ce ? val[idx] : 0.f;
+          const int cnt = ce - p < 64 ? ce - p : 64;
+          int i = 0;
+          for (; i + 8 <= cnt; i += 8) {
+            vec_t x[8];
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int c = __builtin_amdgcn_readlane(myc, i + u);
+              v[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), i + u));
+              if (on) x[u] = V::load(B + (long)c * ldb + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (on) acc = V::fma(v[u], x[u], acc);
+          }
+          for (; i < cnt; ++i) {
+            const int c = __builtin_amdgcn_readlane(myc, i);
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), i));
+            if (on) acc = V::fma(v, V::load(B + (long)c * ldb + c0), acc);
+          }
+        }
+      }
+      part[wave][lane] = acc;
+      __syncthreads();
+      if (wave == 0 && on) {
+        vec_t tot = part[0][lane];
+#pragma unroll
+        for (int w = 1; w < kLongWaves; ++w) tot += part[w][lane];
+        if (bias) tot += V::load(bias + c0);
+        V::store(C + (long)row * ldc + c0, tot);
+      }
+      __syncthreads();
+    }
+  }
 }
 
 // Wide N with K too tall for a K × 256 slice to fit an L2: block BOTH ways — 256-column tiles
@@ -542,27 +635,16 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
   return sh.vec4_ok ? MI_SPMM_GROUP_VEC4 : MI_SPMM_GROUP_SCALAR;
 }
 
-int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const float* val,
-                  int64_t nnz, int32_t batch, int32_t M, int32_t K, int32_t N, const float* B,
-                  int64_t ldb, int64_t strideB, float* C, int64_t ldc, int64_t strideC,
-                  const float* bias, hipStream_t s) {
-  if (M < 0 || K < 0 || N < 0 || nnz < 0 || batch < 0) return MI_EINVAL;
-  if (variant < 0 || variant >= MI_SPMM_VARIANT_COUNT) return MI_EINVAL;
-  if (nnz > 0x7fffffffLL) return MI_ERANGE;  // int32 rowptr entries
-  if (batch > 65535) return MI_ERANGE;       // grid.y
-  if (M == 0 || N == 0 || batch == 0) return MI_OK;
-  if (!rowptr || !C) return MI_EINVAL;
-  if (nnz > 0 && (!col || !val || !B)) return MI_EINVAL;
-  if (ldb < N || ldc < N) return MI_EINVAL;
+size_t long_rows_workspace_bytes(int64_t nnz) { return ((size_t)(nnz / kLongRow) + 2) * sizeof(int); }
 
-  Shape sh = classify(N, ldb, ldc, strideB, strideC, B, C);
-  if (bias && !mi::aligned16(bias)) sh.vec4_ok = sh.wave_ok = false;
-  if (bias && (reinterpret_cast<uintptr_t>(bias) & 7u)) sh.vec2_ok = false;
+int launch_variant(int variant, const Shape& sh, const int32_t* rowptr, const int32_t* col, const float* val,
+                   int64_t nnz, int32_t batch, int32_t M, int32_t K, int32_t N, const float* B,
+                   int64_t ldb, int64_t strideB, float* C, int64_t ldc, int64_t strideC,
+                   const float* bias, int long_thresh, hipStream_t s) {
   const bool vec4_ok = sh.vec4_ok, vec2_ok = sh.vec2_ok, wave_ok = sh.wave_ok;
-  if (variant == MI_SPMM_AUTO) variant = choose_variant(sh, nnz, batch, M, K, N, ldb);
 
 #define MI_WAVE(T_, U_) \
-  return launch_wave_row<T_, U_>(rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, batch, bias, s)
+  return launch_wave_row<T_, U_>(rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, batch, bias, long_thresh, s)
   switch (variant) {
     case MI_SPMM_WAVE_ROW_U4:
       if (!wave_ok) return MI_EINVAL;
@@ -581,39 +663,81 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
       MI_WAVE(4, 4);
     case MI_SPMM_WAVE_ROW_VL:
       if (!(vec4_ok && N == 256)) return MI_EINVAL;
-      return launch_wave_row_vl<8>(rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, batch, bias, s);
+      return launch_wave_row_vl<8>(rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, batch, bias, long_thresh, s);
     case MI_SPMM_PANELS_2: case MI_SPMM_PANELS_3: case MI_SPMM_PANELS_4: case MI_SPMM_PANELS_5:
     case MI_SPMM_PANELS_6: case MI_SPMM_PANELS_8: {
       if (!(wave_ok && batch == 1)) return MI_EINVAL;
       static const int kPanels[] = {2, 3, 4, 5, 6, 8};
-      return launch_panels(kPanels[variant - MI_SPMM_PANELS_2], rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, s);
+      return launch_panels(kPanels[variant - MI_SPMM_PANELS_2], rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, long_thresh, s);
     }
     case MI_SPMM_COLTILE_PANELS: {
       if (!(vec4_ok && batch == 1 && N % 256 == 0 && N >= 256)) return MI_EINVAL;
       int panels = coltile_panels(M, K, N, ldb, nnz);
       if (panels == 0) panels = 3;  // forced by the caller
-      return launch_panels_t<1, 8>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, s, N / 256);
+      return launch_panels_t<1, 8>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, long_thresh, s, N / 256);
     }
     case MI_SPMM_COLTILE: {
       if (!(vec4_ok && batch == 1)) return MI_EINVAL;
       int w = coltile_width(M, K, N, ldb);
       if (w == 0) w = N >= 256 ? 256 : (N >= 128 ? 128 : 64);  // forced by the caller: any width works
-      if (w == 256) return launch_coltile<64>(rowptr, col, val, B, C, M, N, ldb, ldc, bias, s);
-      if (w == 128) return launch_coltile<32>(rowptr, col, val, B, C, M, N, ldb, ldc, bias, s);
-      return launch_coltile<16>(rowptr, col, val, B, C, M, N, ldb, ldc, bias, s);
+      if (w == 256) return launch_coltile<64>(rowptr, col, val, B, C, M, N, ldb, ldc, bias, long_thresh, s);
+      if (w == 128) return launch_coltile<32>(rowptr, col, val, B, C, M, N, ldb, ldc, bias, long_thresh, s);
+      return launch_coltile<16>(rowptr, col, val, B, C, M, N, ldb, ldc, bias, long_thresh, s);
     }
     case MI_SPMM_GROUP_VEC4:
       if (!vec4_ok) return MI_EINVAL;
-      return dispatch_group<4>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, s);
+      return dispatch_group<4>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, long_thresh, s);
     case MI_SPMM_GROUP_VEC2:
       if (!vec2_ok) return MI_EINVAL;
-      return dispatch_group<2>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, s);
+      return dispatch_group<2>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, long_thresh, s);
     case MI_SPMM_GROUP_SCALAR:
-      return dispatch_group<1>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, s);
+      return dispatch_group<1>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, long_thresh, s);
     default:
       return MI_EINVAL;
   }
 #undef MI_WAVE
+}
+
+int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const float* val,
+                  int64_t nnz, int32_t batch, int32_t M, int32_t K, int32_t N, const float* B,
+                  int64_t ldb, int64_t strideB, float* C, int64_t ldc, int64_t strideC,
+                  const float* bias, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  if (M < 0 || K < 0 || N < 0 || nnz < 0 || batch < 0) return MI_EINVAL;
+  if (variant < 0 || variant >= MI_SPMM_VARIANT_COUNT) return MI_EINVAL;
+  if (nnz > 0x7fffffffLL) return MI_ERANGE;  // int32 rowptr entries
+  if (batch > 65535) return MI_ERANGE;       // grid.y
+  if (M == 0 || N == 0 || batch == 0) return MI_OK;
+  if (!rowptr || !C) return MI_EINVAL;
+  if (nnz > 0 && (!col || !val || !B)) return MI_EINVAL;
+  if (ldb < N || ldc < N) return MI_EINVAL;
+
+  Shape sh = classify(N, ldb, ldc, strideB, strideC, B, C);
+  if (bias && !mi::aligned16(bias)) sh.vec4_ok = sh.wave_ok = false;
+  if (bias && (reinterpret_cast<uintptr_t>(bias) & 7u)) sh.vec2_ok = false;
+  if (variant == MI_SPMM_AUTO) variant = choose_variant(sh, nnz, batch, M, K, N, ldb);
+
+  // long rows get their own kernel when a workspace is there to list them (no row can be long
+  // unless the matrix has more than kLongRow non-zeros)
+  const bool split = workspace != nullptr && batch == 1 && nnz > kLongRow;
+  int* ws = static_cast<int*>(workspace);
+  if (split) {
+    if (workspace_bytes < long_rows_workspace_bytes(nnz)) return MI_ENOMEM;
+    MI_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(int), s));
+    hipLaunchKernelGGL(find_long_rows_kernel, dim3((unsigned)(((long)M + 255) / 256)), dim3(256), 0, s, rowptr, M,
+                       ws, (int)(nnz / kLongRow) + 1);
+  }
+  int st = launch_variant(variant, sh, rowptr, col, val, nnz, batch, M, K, N, B, ldb, strideB, C, ldc, strideC,
+                          bias, split ? kLongRow : 0x7fffffff, s);
+  if (st != MI_OK || !split) return st;
+  const unsigned cap = (unsigned)(nnz / kLongRow) + 1;
+  const unsigned grid = cap < 1024u ? cap : 1024u;
+  if (sh.vec4_ok)
+    hipLaunchKernelGGL(spmm_long_rows_kernel<4>, dim3(grid), dim3(kLongWaves * 64), 0, s, ws, rowptr, col, val, B,
+                       C, N, ldb, ldc, bias);
+  else
+    hipLaunchKernelGGL(spmm_long_rows_kernel<1>, dim3(grid), dim3(kLongWaves * 64), 0, s, ws, rowptr, col, val, B,
+                       C, N, ldb, ldc, bias);
+  return mi::check_launch();
 }
 
 }  // namespace
@@ -623,14 +747,24 @@ extern "C" {
 int mi_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
                     int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb, float* C,
                     int64_t ldc, mi_stream_t stream) {
-  return spmm_dispatch(MI_SPMM_AUTO, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0, nullptr,
+  return spmm_dispatch(MI_SPMM_AUTO, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0, nullptr, nullptr, 0,
                        static_cast<hipStream_t>(stream));
+}
+
+size_t mi_spmm_csr_workspace_bytes(int64_t nnz) { return nnz > 0 ? long_rows_workspace_bytes(nnz) : 0; }
+
+int mi_spmm_csr_ws_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
+                       int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb, const float* bias,
+                       float* C, int64_t ldc, void* workspace, size_t workspace_bytes,
+                       mi_stream_t stream) {
+  return spmm_dispatch(MI_SPMM_AUTO, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0, bias, workspace,
+                       workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int mi_spmm_csr_bias_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
                          int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,
                          const float* bias, float* C, int64_t ldc, mi_stream_t stream) {
-  return spmm_dispatch(MI_SPMM_AUTO, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0, bias,
+  return spmm_dispatch(MI_SPMM_AUTO, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0, bias, nullptr, 0,
                        static_cast<hipStream_t>(stream));
 }
 
@@ -638,7 +772,7 @@ int mi_spmm_csr_f32_variant(int variant, const int32_t* rowptr, const int32_t* c
                             const float* val, int64_t nnz, int32_t M, int32_t K, int32_t N,
                             const float* B, int64_t ldb, float* C, int64_t ldc,
                             mi_stream_t stream) {
-  return spmm_dispatch(variant, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0, nullptr,
+  return spmm_dispatch(variant, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0, nullptr, nullptr, 0,
                        static_cast<hipStream_t>(stream));
 }
 
@@ -648,7 +782,7 @@ int mi_spmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col, const flo
                             int64_t strideC, mi_stream_t stream) {
   if (strideB < 0 || strideC < 0) return MI_EINVAL;
   return spmm_dispatch(MI_SPMM_AUTO, rowptr, col, val, nnz_total, batch, M, K, N, B, ldb, strideB,
-                       C, ldc, strideC, nullptr, static_cast<hipStream_t>(stream));
+                       C, ldc, strideC, nullptr, nullptr, 0, static_cast<hipStream_t>(stream));
 }
 
 int mi_spmm_csr_f32_plan(int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,

@@ -33,7 +33,7 @@ def lib(built):
 
 def test_header_declares_the_expected_entry_points():
     names = declared_functions()
-    assert len(names) == 26, names
+    assert len(names) == 28, names
     for must in ("mi_spmm_csr_f32", "mi_spmm_csr_batched_f32", "mi_spmm_csr_colmajor_f32", "mi_gemm_f32",
                  "mi_dense_to_csr_count", "mi_dense_to_csr_fill", "mi_csr_transpose_f32", "mi_sddmm_csr_f32",
                  "mi_coo_to_csr_host", "mi_dummy_kernel"):

@@ -665,3 +665,30 @@ def test_wide_n_column_tiled_launch_is_bit_exact(capi, cmm, dev, oracle_mod):
         assert capi.mi_spmm_csr_f32_plan(len(val), M, K, N, d_B.data_ptr(), N, C.data_ptr(), N) == 14
         cmm.naive_spmm(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, d_B, C)
         assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr_omp(rowptr, col, val, M, K, B))
+
+
+@pytest.mark.parametrize("N", [256, 100, 64, 1024, 7])
+def test_skewed_rows_long_row_kernel(cmm, dev, oracle_mod, N):
+    """Rows far longer than the rest (one fully dense, some just over / at the 8192 threshold): the
+    custom_mm path hands them to the 16-wave long-row kernel; result bit-identical to the oracle's
+    statement of that order, and equal to torch's product at the reference tolerance."""
+    M, K = 301, 30000
+    g = np.random.Generator(np.random.PCG64(N))
+    lens = g.integers(0, 200, size=M)
+    lens[5], lens[17], lens[18], lens[150], lens[300] = K, 8193, 8192, 20011, 9000
+    cols = [np.sort(g.choice(K, size=int(n), replace=False)).astype(np.int32) for n in lens]
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate(cols)
+    val = g.random(len(col), dtype=np.float32)
+    B = g.random((K, N), dtype=np.float32)
+    for op in ("naive_spmm", "cusparse_mmul"):
+        got = run_spmm(cmm, dev, rowptr, col, val, M, K, B, op)
+        assert np.array_equal(got, oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B)), op
+    A = torch.sparse_csr_tensor(torch.from_numpy(rowptr.astype(np.int64)), torch.from_numpy(col.astype(np.int64)),
+                                torch.from_numpy(val), (M, K))
+    assert np.allclose((A @ torch.from_numpy(B)).numpy(), got, rtol=RTOL, atol=ATOL)
+    # with a bias, through the fused epilogue of the long-row kernel as well
+    bias = g.random(N, dtype=np.float32)
+    C = torch.empty(M, N, device=dev)
+    cmm.naive_spmm_bias(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, t(B, dev), t(bias, dev), C)
+    assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B) + bias[None, :])

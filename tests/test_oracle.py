@@ -165,3 +165,24 @@ def test_pinned_generator_is_stable(oracle_mod):
 
 
 PINNED_DIGEST = "79ff35ca20d2cd54c4a2c59f975a106bd2463ffeb37eb5cbc058671113352e84"
+
+
+def test_long_row_rule_is_a_reassociation_only(oracle_mod):
+    """Rows of more than 8192 non-zeros (mi_spmm_csr_ws_f32's 16-chain order): same product within
+    the reference tolerance, identical bits for every shorter row."""
+    M, K, N = 6, 20000, 24
+    g = np.random.Generator(np.random.PCG64(3))
+    lens = [20000, 8193, 8192, 0, 17, 12000]
+    cols = [np.sort(g.choice(K, size=n, replace=False)).astype(np.int32) for n in lens]
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate(cols)
+    val = g.random(len(col), dtype=np.float32)
+    B = g.random((K, N), dtype=np.float32)
+    plain = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    long_ = oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B)
+    assert np.array_equal(plain[[2, 3, 4]], long_[[2, 3, 4]])
+    assert not np.array_equal(plain[0], long_[0])  # really a different order …
+    assert np.allclose(plain, long_, rtol=1e-5, atol=1e-8)  # … of the same sum
+    A = torch.sparse_csr_tensor(torch.from_numpy(rowptr.astype(np.int64)), torch.from_numpy(col.astype(np.int64)),
+                                torch.from_numpy(val), (M, K))
+    assert np.allclose((A @ torch.from_numpy(B)).numpy(), long_, rtol=1e-5, atol=1e-8)
