@@ -692,3 +692,28 @@ def test_skewed_rows_long_row_kernel(cmm, dev, oracle_mod, N):
     C = torch.empty(M, N, device=dev)
     cmm.naive_spmm_bias(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, t(B, dev), t(bias, dev), C)
     assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B) + bias[None, :])
+
+
+def test_spmm_shape_fuzz_against_oracle(cmm, capi, dev, oracle_mod):
+    """Seeded random shapes through custom_mm.naive_spmm (AUTO dispatch incl. the column-tiled and
+    panel plans, partial last tiles, odd widths) — every one bit-identical to the oracle."""
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_spmm_csr_f32_plan.argtypes = [i64, i32, i32, i32, vp, i64, vp, i64]
+    rng = np.random.Generator(np.random.PCG64(2026))
+    seen = set()
+    cases = [(2100, 1100, 2100, 0.02), (2048, 9000, 2048, 0.02), (2300, 5000, 2304, 0.01), (2048, 1030, 4100, 0.002),
+             (3000, 2500, 1028, 0.02)]
+    for _ in range(40):
+        cases.append((int(rng.integers(1, 600)), int(rng.integers(1, 900)), int(rng.choice([1, 2, 3, 4, 5, 8, 12, 31, 32, 33, 64,
+                     96, 100, 128, 192, 255, 256, 257, 260, 384, 512, 516, 640, 1000, 1024, 1028, 2048])),
+                      float(rng.choice([0.0, 0.002, 0.02, 0.2]))))
+    for (M, K, N, density) in cases:
+        rowptr, col, val = oracle_mod.make_csr(M, K, density, seed=M * 7 + N) if density > 0 else \
+            (np.zeros(M + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
+        B = rng.random((K, N), dtype=np.float32)
+        d_B = t(B, dev)
+        C = torch.full((M, N), float("nan"), device=dev)
+        seen.add(capi.mi_spmm_csr_f32_plan(len(val), M, K, N, d_B.data_ptr(), N, C.data_ptr(), N))
+        cmm.naive_spmm(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, d_B, C)
+        assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr_omp(rowptr, col, val, M, K, B)), (M, K, N, density)
+    assert {2, 4, 5, 14, 15} <= seen, seen  # wave-row, group vec4 / scalar, column-tiled, tiles × panels all exercised
