@@ -90,6 +90,19 @@ def cpu_baseline(rowptr, col, val, K, B, N, sample_rows, gpu_rows=None):
     rec = {"value": round(2.0 * nnz * N / best / 1e9, 3), "unit": "GFLOP/s", "cores": threads, "kind": "port",
            "sample": f"first {sample_rows} rows of the same A ({nnz} nnz) x the same B, oracle OpenMP row-split "
                      f"SpMM, best of 2, {best:.2f} s"}
+    # the reference's own CPU expression for this product is `a @ b` with a CSR `a`
+    # (matmuls.py:41,71,210,234,279,302): torch-CPU (MKL) on the same sample, same thread count
+    import torch
+    torch.set_num_threads(threads)
+    a_csr = torch.sparse_csr_tensor(torch.from_numpy(rp.astype(np.int64)), torch.from_numpy(col[:nnz].astype(np.int64)),
+                                    torch.from_numpy(val[:nnz]), (sample_rows, K))
+    b_t = torch.from_numpy(B)
+    t_best = float("inf")
+    for _ in range(2):
+        t0 = time.perf_counter()
+        a_csr @ b_t
+        t_best = min(t_best, time.perf_counter() - t0)
+    rec["torch_cpu_csr_matmul_gflops"] = round(2.0 * nnz * N / t_best / 1e9, 3)
     if gpu_rows is not None:
         rec["gpu_matches_oracle_on_sample"] = "bit-exact" if np.array_equal(gpu_rows, out) else "MISMATCH"
         assert rec["gpu_matches_oracle_on_sample"] == "bit-exact", "GPU result differs from the oracle on the sample rows"
