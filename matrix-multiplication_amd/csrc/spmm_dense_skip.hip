@@ -55,7 +55,8 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_dense_skip_kernel(
     int rows_per_block, const float* __restrict__ bias, int batch, unsigned row_blocks) {
   constexpr int R = 64 / G;
   constexpr int CH = 4 * G;
-  constexpr int LIST_STRIDE = CH + 1;  // pairs; +1 keeps the R broadcast reads on different banks
+  constexpr int CAP = 3 * CH;            // list entries per row group: several sparse chunks share one walk
+  constexpr int LIST_STRIDE = CAP + 1;  // pairs; +1 keeps the R broadcast reads on different banks
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -102,44 +103,47 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_dense_skip_kernel(
       return a;
     };
     f32x4 a_next = load_chunk(0);
+    int fill = 0;  // entries waiting in this group's list (group-uniform)
     for (int k0 = 0; k0 < K; k0 += CH) {
       const int kc = k0 + gl * 4;
       const f32x4 a = a_next;
-      a_next = load_chunk(k0 + CH);  // in flight while this chunk is compacted and consumed
+      a_next = load_chunk(k0 + CH);  // in flight while this chunk is compacted
       // NaN counts as non-zero, -0.0 as zero (same test as to_sparse_csr / mi_dense_to_csr)
       const bool n0 = a.x != 0.0f, n1 = a.y != 0.0f, n2 = a.z != 0.0f, n3 = a.w != 0.0f;
       const unsigned long long m0 = __ballot(n0) & gm, m1 = __ballot(n1) & gm, m2 = __ballot(n2) & gm,
                                m3 = __ballot(n3) & gm;
       // rank in ascending column order: everything held by lower lanes of the group, then own
-      int rank = lanes_below(m0) + lanes_below(m1) + lanes_below(m2) + lanes_below(m3);
-      const int cnt = __builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) +
-                      __builtin_popcountll(m3);  // group-uniform
+      int rank = fill + lanes_below(m0) + lanes_below(m1) + lanes_below(m2) + lanes_below(m3);
       if (n0) list[rank++] = Pair{kc + 0, a.x};
       if (n1) list[rank++] = Pair{kc + 1, a.y};
       if (n2) list[rank++] = Pair{kc + 2, a.z};
       if (n3) list[rank] = Pair{kc + 3, a.w};
+      fill += __builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) +
+              __builtin_popcountll(m3);
+      // walk the list once it could not take another chunk, or at the end of the row
+      if (!__any(fill > CAP - CH) && k0 + CH < K) continue;
       // same-wave LDS traffic is executed in order; only the compiler must not reorder
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-
-      for (int i = 0; __any(i < cnt); i += 4) {
+      for (int i = 0; __any(i < fill); i += 4) {
         Pair p[4];
         f32x4 x[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int idx = i + u < cnt ? i + u : 0;  // entry 0 is always readable; unused when masked
+          const int idx = i + u < fill ? i + u : 0;  // entry 0 is always readable; unused when masked
           p[u] = list[idx];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const bool take = on && i + u < cnt;
+          const bool take = on && i + u < fill;
           x[u] = take ? *reinterpret_cast<const f32x4*>(Bi + (long)p[u].k * ldb + gl * 4)
                       : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (on && i + u < cnt) acc = fma4(p[u].v, x[u], acc);
+          if (on && i + u < fill) acc = fma4(p[u].v, x[u], acc);
       }
+      fill = 0;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
     }
@@ -156,7 +160,7 @@ int launch_for_width(bool veca, const float* A, const float* B, float* C, int ba
                      long ldb, long ldc, long sA, long sB, long sC, const float* bias, hipStream_t s) {
   constexpr int WAVES = 4;
   constexpr int R = 64 / G;
-  constexpr size_t lds_bytes = (size_t)WAVES * R * (4 * G + 1) * sizeof(Pair);
+  constexpr size_t lds_bytes = (size_t)WAVES * R * (3 * 4 * G + 1) * sizeof(Pair);
   const int rows_per_block = WAVES * R;
   const long row_blocks = ((long)M + rows_per_block - 1) / rows_per_block;
   const long blocks = 8L * ((batch + 7) / 8) * row_blocks;  // every XCD gets the same count; extras exit
