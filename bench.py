@@ -252,6 +252,20 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
+    compute_only_ms = None
+    if world > 1:
+        # the same steps without the all-gather: what the row shards alone cost (reported beside the
+        # end-to-end figure; `value` stays end-to-end)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            op.forward(B, out=C, gather=False)
+        barrier()
+        tc = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+        compute_only_ms = float(tc) / args.steps * 1e3
+        op.forward(B, out=C)  # leave the gathered result in C
+        barrier()
     step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     # the step's launches run back to back on this stream: their durations sum to the step's event time
     kernels_ms_per_step = float(np.mean(step_ms))
@@ -279,6 +293,7 @@ def main():
                 "flops_per_step": flops, "algorithmic_bytes_per_step": bytes_alg,
                 "effective_GBps_whole_job": round(bytes_alg * args.steps / elapsed / 1e9, 1),
                 "input_generation_s": round(gen_s, 1),
+                "compute_only_ms_per_step": None if compute_only_ms is None else round(compute_only_ms, 4),
             },
             "roofline": {
                 "bound": "hbm", "kernel": kernel_name, "launches_per_step": launches_per_step,
