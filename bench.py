@@ -190,11 +190,19 @@ def main():
                          f"--nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # MI_BENCH_REHEARSE=1: run the N > 1 path with every rank on GPU 0 over gloo — a functional rehearsal of
+    # the sharded driver on a one-GPU box (RCCL refuses two ranks on one device); never a measurement.
+    rehearse = os.environ.get("MI_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
 
     import custom_mm
     import sharded
@@ -266,11 +274,25 @@ def main():
         compute_only_ms = float(tc) / args.steps * 1e3
         op.forward(B, out=C)  # leave the gathered result in C
         barrier()
+        # placement self-check of the all-gather (no oracle involved): recompute a block that ANOTHER rank
+        # owns with the same kernel and compare it bit-for-bit with what arrived in its slot of C
+        peer = (rank + 1) % world
+        r0 = peer * op.block_rows
+        r1 = min(r0 + op.block_rows, M)
+        if r1 > r0:
+            rp_t = torch.from_numpy(rowptr)
+            p0, p1 = int(rowptr[r0]), int(rowptr[r1])
+            chk = torch.empty(r1 - r0, N, device=dev)
+            custom_mm.naive_spmm(torch.from_numpy(val[p0:p1]).to(dev), torch.from_numpy(col[p0:p1]).to(dev),
+                                 (rp_t[r0:r1 + 1] - rp_t[r0]).to(torch.int32).to(dev), p1 - p0, r1 - r0, K, B, chk)
+            assert torch.equal(chk, C[r0:r1]), f"rank {rank}: gathered block of rank {peer} differs from a local recompute"
     step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     # the step's launches run back to back on this stream: their durations sum to the step's event time
     kernels_ms_per_step = float(np.mean(step_ms))
 
     if rank == 0:
+        if compute_only_ms is not None:  # N > 1: the event interval also spans the gather wait; use the compute-only loop
+            kernels_ms_per_step = compute_only_ms
         achieved = local_bytes_alg / (kernels_ms_per_step * 1e-3) / 1e9
         rec = {
             "metric": "SpMM GFLOP/s, CSR(1M,0.01%) x dense(256)" if args.workload == "c3"
@@ -283,7 +305,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks on one GPU over gloo, not a measurement)",
             "config": {
                 "workload": desc, "M": M, "K": K, "N": N, "nnz": nnz,
                 "generator": "numpy PCG64 seedA=0 seedB=1 (SURVEY.md 8d)",
