@@ -233,6 +233,14 @@ int mi_sddmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz,
                      const float* B, int64_t ldb, float* out_val,
                      mi_stream_t stream);
 
+/* Column sums dst[j] = Σ_r src[r, j] (src rows×n, leading dimension ld): the bias gradient of
+ * the FC layers (autograd of `output += self.bias`, reference benchmarks/cublas_fc_layer.py:44-45).
+ * Fixed summation order (4 interleaved chains per 1024-row chunk, chunks in order), no atomics.
+ * workspace ≥ mi_colsum_workspace_bytes(rows, n). */
+size_t mi_colsum_workspace_bytes(int32_t rows, int32_t n);
+int mi_colsum_f32(const float* src, int32_t rows, int32_t n, int64_t ld, float* dst,
+                  void* workspace, size_t workspace_bytes, mi_stream_t stream);
+
 /* Dense 2-D transpose  dst[cols, rows] = src[rows, cols]ᵀ (row-major, ld's). */
 int mi_transpose_f32(const float* src, int32_t rows, int32_t cols, int64_t ld_src,
                      float* dst, int64_t ld_dst, mi_stream_t stream);

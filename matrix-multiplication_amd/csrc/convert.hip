@@ -273,6 +273,38 @@ __global__ void gather_transposed_kernel(const int* __restrict__ perm, long nnz,
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // --------------------------------------------------------------------------
+// Column sums  dst[j] = Σ_r src[r, j]  (bias gradient of the FC layers).  Block (ct, rc):
+// 64 columns × one chunk of rows; lane ↔ column (256-B coalesced row segments), the 4 waves take
+// rows rc0 + w, rc0 + w + 4, …; their partial sums are added in wave order, the row chunks in
+// chunk order by a second launch.  Fixed order, no atomics.
+// --------------------------------------------------------------------------
+constexpr int kColsumChunkRows = 1024;
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ src, int rows, int n,
+                                                             long ld, float* __restrict__ partial) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int colj = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * kColsumChunkRows;
+  const int r1 = r0 + kColsumChunkRows < rows ? r0 + kColsumChunkRows : rows;
+  float acc = 0.f;
+  if (colj < n)
+    for (int r = r0 + wave; r < r1; r += 4) acc += src[(long)r * ld + colj];
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && colj < n)
+    partial[(long)blockIdx.y * n + colj] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int chunks, int n, float* __restrict__ dst) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  float acc = 0.f;
+  for (int c = 0; c < chunks; ++c) acc += partial[(long)c * n + j];
+  dst[j] = acc;
+}
+
+// --------------------------------------------------------------------------
 // SDDMM: one wave per row of A; lane l sums j ≡ l (mod 64) ascending, then a
 // xor-butterfly (32,16,…,1) combines the 64 partial sums.
 // --------------------------------------------------------------------------
@@ -461,6 +493,33 @@ int mi_csr_transpose_f32(const int32_t* rowptr, const int32_t* col, const float*
                                        end_bit, s));
   hipLaunchKernelGGL(gather_transposed_kernel, dim3(nb), dim3(256), 0, s, perm, nnz, rowptr, M, val,
                      t_col, t_val);
+  return mi::check_launch();
+}
+
+size_t mi_colsum_workspace_bytes(int32_t rows, int32_t n) {
+  if (rows < 0 || n < 0) return 0;
+  const size_t chunks = ((size_t)rows + kColsumChunkRows - 1) / kColsumChunkRows;
+  return align_up((chunks ? chunks : 1) * (size_t)n * sizeof(float));
+}
+
+int mi_colsum_f32(const float* src, int32_t rows, int32_t n, int64_t ld, float* dst, void* workspace,
+                  size_t workspace_bytes, mi_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (rows < 0 || n < 0) return MI_EINVAL;
+  if (n == 0) return MI_OK;
+  if (!dst) return MI_EINVAL;
+  if (rows == 0) {
+    MI_HIP_TRY(hipMemsetAsync(dst, 0, sizeof(float) * (size_t)n, s));
+    return MI_OK;
+  }
+  if (!src || ld < n || !workspace) return MI_EINVAL;
+  if (workspace_bytes < mi_colsum_workspace_bytes(rows, n)) return MI_ENOMEM;
+  const int chunks = (rows + kColsumChunkRows - 1) / kColsumChunkRows;
+  if (chunks > 65535) return MI_ERANGE;
+  float* partial = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)chunks), dim3(256), 0, s, src,
+                     rows, n, ld, partial);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, partial, chunks, n, dst);
   return mi::check_launch();
 }
 

@@ -264,6 +264,23 @@ torch::Tensor naive_spmm_bias(torch::Tensor A_values, torch::Tensor A_columns, t
   return spmm_impl(A_values, A_columns, A_offsets, nnzA, A_rows, A_cols, B, C, "naive_spmm_bias", &bias);
 }
 
+// Column sums of a 2-d tensor (bias gradient of the FC layers): returns a [n] tensor.
+torch::Tensor column_sums(torch::Tensor src) {
+  check_device_f32(src, "src");
+  TORCH_CHECK(src.dim() == 2, "column_sums: expected a 2-d tensor");
+  torch::Tensor x = src.stride(1) == 1 && src.stride(0) >= src.size(1) ? src : src.contiguous();
+  const int64_t rows = x.size(0), n = x.size(1);
+  TORCH_CHECK(rows <= INT32_MAX && n <= INT32_MAX, "column_sums: dimension too large");
+  c10::hip::HIPGuard guard(x.device().index());
+  torch::Tensor out = torch::empty({n}, x.options());
+  const size_t ws_bytes = mi_colsum_workspace_bytes((int32_t)rows, (int32_t)n);
+  torch::Tensor ws = torch::empty({(int64_t)std::max<size_t>(ws_bytes, 4)}, torch::dtype(torch::kUInt8).device(x.device()));
+  check_status(mi_colsum_f32(x.data_ptr<float>(), (int32_t)rows, (int32_t)n, rows > 1 ? x.stride(0) : std::max<int64_t>(n, 1),
+                             out.data_ptr<float>(), ws.data_ptr(), ws_bytes, stream_of(x)),
+               "column_sums");
+  return out;
+}
+
 // ---- additions to the reference surface (used by matmuls.py) -----------------
 // The reference batches by Python recursion + torch.stack with one
 // to_sparse_csr() per slice (matmuls.py:289-297) and has no working backward
@@ -689,5 +706,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         "A·B with A dense, zeros skipped in the kernel; False if the shape is not covered");
   m.def("naive_spmm_dense_bias", &naive_spmm_dense_bias, "as naive_spmm_dense, + bias in the epilogue");
   m.def("cublas_mmul_bias", &cublas_mmul_bias, "op(A) op(B) + bias, fused epilogue");
+  m.def("column_sums", &column_sums, "sum over rows of a 2-d tensor (bias gradient)");
   m.def("naive_spmm_bias", &naive_spmm_bias, "CSR x dense + bias, fused epilogue");
 }

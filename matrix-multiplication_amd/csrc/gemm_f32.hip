@@ -259,18 +259,22 @@ template <bool TA, bool TB>
 int pick_tile(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb,
               long ldc, long sA, long sB, long sC, int batch, bool vecA, bool vecB, bool vecC,
               const float* bias, hipStream_t s) {
-  // Wide tiles when both extents fill them; the 64-wide n tile covers BERT's
-  // head dim (probs·V, n = 64) without wasting half the MFMAs.
-  const long wide_blocks = (long)((m + 127) / 128) * ((n + 63) / 64) * batch;
-  if (n <= 64 && m > 64 && wide_blocks < 2048)  // too few 128-row tiles to fill 256 CUs: halve them
-    return launch<64, 64, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, vecC, bias, s);
-  if (n > 64 && m > 64)
-    return launch<128, 128, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, vecC, bias, s);
-  if (m > 64)
-    return launch<128, 64, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, vecC, bias, s);
-  if (n > 64)
-    return launch<64, 128, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, vecC, bias, s);
-  return launch<64, 64, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, vecC, bias, s);
+  // Largest tile that still gives the chip ≥ 2 workgroups per CU; the 64-wide n tile covers
+  // BERT's head dim (probs·V, n = 64) without wasting half the MFMAs, and long-k products with
+  // few output tiles (weight gradients: m = 3072, n = 768, k = 16384) drop to 64×64 tiles rather
+  // than leave CUs idle — the k order per element is the same for every tile shape.
+  auto blocks_for = [&](int bm, int bn) { return (long)((m + bm - 1) / bm) * ((n + bn - 1) / bn) * batch; };
+  const long want = 2L * 256;
+#define MI_TILE(BM_, BN_) \
+  return launch<BM_, BN_, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, vecC, bias, s)
+  if (m > 64 && n > 64 && blocks_for(128, 128) >= want) MI_TILE(128, 128);
+  if (m > 64 && blocks_for(128, 64) >= want) MI_TILE(128, 64);
+  if (n > 64 && blocks_for(64, 128) >= want) MI_TILE(64, 128);
+  if (blocks_for(64, 64) >= want || (m <= 64 && n <= 64)) MI_TILE(64, 64);
+  // small problems: the widest tile the shape fills
+  if (m > 64 && n > 64 && blocks_for(64, 64) < 64) MI_TILE(128, 128);
+  MI_TILE(64, 64);
+#undef MI_TILE
 }
 
 // k == 0: C = 0 (beta = 0 semantics), or the bias row.

@@ -33,7 +33,7 @@ def lib(built):
 
 def test_header_declares_the_expected_entry_points():
     names = declared_functions()
-    assert len(names) == 28, names
+    assert len(names) == 30, names
     for must in ("mi_spmm_csr_f32", "mi_spmm_csr_batched_f32", "mi_spmm_csr_colmajor_f32", "mi_gemm_f32",
                  "mi_dense_to_csr_count", "mi_dense_to_csr_fill", "mi_csr_transpose_f32", "mi_sddmm_csr_f32",
                  "mi_coo_to_csr_host", "mi_dummy_kernel"):
@@ -106,7 +106,7 @@ def test_custom_mm_surface(custom_mm):
     for name in REFERENCE_NAMES:
         assert callable(getattr(custom_mm, name)), name
     for extra in ("dense_to_csr", "naive_spmm_batched", "csr_transpose", "sddmm", "naive_spmm_dense",
-                  "naive_spmm_dense_bias", "cublas_mmul_bias", "naive_spmm_bias"):
+                  "naive_spmm_dense_bias", "cublas_mmul_bias", "naive_spmm_bias", "column_sums"):
         assert callable(getattr(custom_mm, extra)), extra
     # positional-only, like the reference's m.def without py::arg
     with pytest.raises(TypeError):

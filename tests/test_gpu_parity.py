@@ -717,3 +717,13 @@ def test_spmm_shape_fuzz_against_oracle(cmm, capi, dev, oracle_mod):
         cmm.naive_spmm(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, d_B, C)
         assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr_omp(rowptr, col, val, M, K, B)), (M, K, N, density)
     assert {2, 4, 5, 14, 15} <= seen, seen  # wave-row, group vec4 / scalar, column-tiled, tiles × panels all exercised
+
+
+@pytest.mark.parametrize("rows,n", [(1, 1), (5, 7), (1024, 64), (1025, 65), (16384, 3072), (3, 1000)])
+def test_column_sums(cmm, dev, rows, n):
+    g = np.random.Generator(np.random.PCG64(rows + n))
+    x = g.random((rows, n), dtype=np.float32)
+    got = cmm.column_sums(t(x, dev)).cpu().numpy()
+    assert got.shape == (n,) and np.allclose(got, x.astype(np.float64).sum(0), rtol=1e-5, atol=1e-6)
+    wide = torch.rand(rows, 2 * n + 3, device=dev)
+    assert torch.allclose(cmm.column_sums(wide[:, 1:n + 1]), wide[:, 1:n + 1].double().sum(0).float(), rtol=1e-5, atol=1e-6)
