@@ -50,6 +50,9 @@ const char* mi_last_hip_error_string(void);
  * Per output element the products are accumulated with fused multiply-add in
  * CSR order (p = rowptr[r] … rowptr[r+1]-1), so the result does not depend on
  * the launch geometry.  Every element of C is written (zeros for empty rows).
+ * Exception, N < 4 (SpMV-like): 64 lane-strided chains (lane l takes the row's
+ * non-zeros l, l+64, …) combined by a xor-butterfly (32, 16, …, 1) — also a fixed,
+ * launch-independent order, restated by the oracle.
  * ------------------------------------------------------------------------ */
 int mi_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                     int64_t nnz, int32_t M, int32_t K, int32_t N,
@@ -88,7 +91,8 @@ enum {
   MI_SPMM_GROUP_VEC2 = 13,  /* G = N/2 lanes per row, 8 B per lane                    */
   MI_SPMM_COLTILE = 14,     /* wide N: XCD-aware column tiles so each XCD's L2 holds its B slice */
   MI_SPMM_COLTILE_PANELS = 15, /* wide N and tall K: column tiles × row panels of B, one launch per panel */
-  MI_SPMM_VARIANT_COUNT = 16
+  MI_SPMM_NARROW = 16,      /* N < 4: wave per row, lanes over non-zeros, shuffle reduction (own order) */
+  MI_SPMM_VARIANT_COUNT = 17
 };
 int mi_spmm_csr_f32_variant(int variant, const int32_t* rowptr, const int32_t* col,
                             const float* val, int64_t nnz, int32_t M, int32_t K,

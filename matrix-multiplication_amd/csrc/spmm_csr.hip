@@ -371,6 +371,39 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
       coff[t] = n0 + (t * G + gl) * VEC;
       on[t] = coff[t] < N;
     }
+    if constexpr (G < 4) {
+      // 1- or 2-lane groups: a chunk of G entries would leave only G gathers in flight, so take
+      // 4 entries (4/G chunks) per round; entry e of the round sits in chunk e/G, lane e%G.
+      constexpr int CHK = 4 / G;
+      for (int p = start; p < end; p += 4) {  // trip count differs between groups
+        int myc[CHK];
+        float myv[CHK];
+#pragma unroll
+        for (int u = 0; u < CHK; ++u) {
+          const int idx = p + u * G + gl;
+          myc[u] = idx < end ? col[idx] : 0;
+          myv[u] = idx < end ? val[idx] : 0.f;
+        }
+        const int cnt = end - p;  // entries of this round that exist (≥ 4 except in the last round)
+        vec_t x[4][T];
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = __shfl(myc[e / G], e % G, G);
+          v[e] = __shfl(myv[e / G], e % G, G);
+          const float* src = Bi + (long)c * ldb;
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+            if (on[t] && e < cnt) x[e][t] = V::load(src + coff[t]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int t = 0; t < T; ++t)
+            if (on[t] && e < cnt) acc[t] = V::fma(v[e], x[e][t], acc[t]);
+        }
+      }
+    } else {
     for (int p = start; p < end; p += G) {  // trip count differs between groups
       const int idx = p + gl;
       const int myc = idx < end ? col[idx] : 0;
@@ -404,6 +437,7 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
         for (int t = 0; t < T; ++t)
           if (on[t]) acc[t] = V::fma(v, V::load(src + coff[t]), acc[t]);
       }
+    }
     }
     if (row < M && !skipped) {
       float* dst = Ci + row * ldc;
@@ -503,6 +537,45 @@ int launch_wave_row_vl(const int* rowptr, const int* col, const float* val, cons
   hipLaunchKernelGGL((spmm_wave_row_vl_kernel<U>), dim3((unsigned)blocks, (unsigned)batch),
                      dim3(256), 0, s, rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, bias, long_thresh);
   return mi::check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// Narrow outputs, N < 4 (SpMV-like; matmuls promotes `A @ vector` to N = 1).  Lanes-over-columns
+// leaves a row to a single lane there, so this kernel turns the wave around: one wave per row,
+// lane l walks the row's non-zeros l, l+64, l+128, … (coalesced col/val loads, one 4-byte gather
+// of B per non-zero and column) keeping N partial sums, and a xor-butterfly (32, 16, …, 1) adds the
+// 64 partial rows.  This is the classic wavefront shuffle reduction; its summation order (64
+// lane-strided chains, then the butterfly) is fixed and stated in oracle_spmm_csr_f32, so results
+// stay bit-identical to the oracle.  grid = (⌈M/4⌉, batch).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spmm_narrow_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+    const float* __restrict__ B, float* __restrict__ C, int M, int N, long ldb, long ldc, long strideB,
+    long strideC, const float* __restrict__ bias) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const long item = blockIdx.y;
+  const int* rp = rowptr + item * ((long)M + 1);
+  const float* Bi = B + item * strideB;
+  const int start = rp[row], end = rp[row + 1];
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int p = start + lane; p < end; p += 64) {
+    const float v = val[p];
+    const float* brow = Bi + (long)col[p] * ldb;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      if (j < N) acc[j] = __builtin_fmaf(v, brow[j], acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (j < N) {
+      float s = acc[j];
+#pragma unroll
+      for (int w = 32; w >= 1; w >>= 1) s += __shfl_xor(s, w, 64);
+      if (lane == 0) C[item * strideC + row * ldc + j] = bias ? s + bias[j] : s;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -629,6 +702,7 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
   if (sh.wave_ok && batch == 1 && b_elems * 4 >= (768L << 20) && nnz >= 32L * M &&
       nnz * (long)N >= 8 * b_elems)
     return MI_SPMM_PANELS_2;
+  if (N < 4) return MI_SPMM_NARROW;
   if (sh.vec4_ok && batch == 1 && coltile_panels(M, K, N, ldb, nnz) > 0) return MI_SPMM_COLTILE_PANELS;
   if (sh.vec4_ok && batch == 1 && coltile_width(M, K, N, ldb) > 0) return MI_SPMM_COLTILE;
   if (sh.wave_ok) return MI_SPMM_WAVE_ROW_U8;
@@ -692,6 +766,14 @@ int launch_variant(int variant, const Shape& sh, const int32_t* rowptr, const in
       return dispatch_group<2>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, long_thresh, s);
     case MI_SPMM_GROUP_SCALAR:
       return dispatch_group<1>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, long_thresh, s);
+    case MI_SPMM_NARROW: {
+      if (N >= 4) return MI_EINVAL;
+      const long blocks = ((long)M + 3) / 4;
+      if (blocks > 0x7fffffffL) return MI_ERANGE;
+      hipLaunchKernelGGL(spmm_narrow_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(256), 0, s, rowptr, col,
+                         val, B, C, M, N, ldb, ldc, strideB, strideC, bias);
+      return mi::check_launch();
+    }
     default:
       return MI_EINVAL;
   }
@@ -718,7 +800,7 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
 
   // long rows get their own kernel when a workspace is there to list them (no row can be long
   // unless the matrix has more than kLongRow non-zeros)
-  const bool split = workspace != nullptr && batch == 1 && nnz > kLongRow;
+  const bool split = workspace != nullptr && batch == 1 && nnz > kLongRow && variant != MI_SPMM_NARROW;
   int* ws = static_cast<int*>(workspace);
   if (split) {
     if (workspace_bytes < long_rows_workspace_bytes(nnz)) return MI_ENOMEM;
@@ -805,6 +887,7 @@ const char* mi_spmm_variant_name(int variant) {
     case MI_SPMM_WAVE_ROW_VL: return "spmm_wave_row_vl_kernel";
     case MI_SPMM_GROUP_VEC4: case MI_SPMM_GROUP_VEC2: case MI_SPMM_GROUP_SCALAR: case MI_SPMM_COLTILE:
       return "spmm_group_kernel";
+    case MI_SPMM_NARROW: return "spmm_narrow_kernel";
     case MI_SPMM_PANELS_2: case MI_SPMM_PANELS_3: case MI_SPMM_PANELS_4: case MI_SPMM_PANELS_5:
     case MI_SPMM_PANELS_6: case MI_SPMM_PANELS_8: case MI_SPMM_COLTILE_PANELS:
       return "spmm_wave_row_panel_kernel";

@@ -11,7 +11,7 @@ from pathlib import Path
 
 import numpy as np
 
-__all__ = ["build", "lib", "spmm_csr", "spmm_csr_omp", "spmm_csr_long", "spmm_csr_batched", "spmm_csr_colmajor", "gemm",
+__all__ = ["build", "lib", "spmm_csr", "spmm_csr_omp", "spmm_csr_long", "spmm_csr_chain", "spmm_csr_batched", "spmm_csr_colmajor", "gemm",
            "coo_to_csr", "dense_to_csr", "csr_transpose", "sddmm", "make_csr"]
 
 _DIR = Path(__file__).resolve().parent
@@ -37,7 +37,7 @@ def lib():
         L = ctypes.CDLL(str(_SO))
         spmm_args = [_i32, _i32, _f32, _c32, _c32, _c32, _f32, _c64, _f32, _c64]
         for name in ("oracle_spmm_csr_f32", "oracle_spmm_csr_f32_omp", "oracle_spmm_csr_colmajor_f32",
-                     "oracle_spmm_csr_long_f32"):
+                     "oracle_spmm_csr_long_f32", "oracle_spmm_csr_chain_f32"):
             getattr(L, name).argtypes = spmm_args
             getattr(L, name).restype = None
         L.oracle_spmm_csr_batched_f32.argtypes = [_i32, _i32, _f32, _c32, _c32, _c32, _c32, _f32, _c64, _c64,
@@ -85,6 +85,17 @@ def spmm_csr(rowptr, col, val, M, K, B, omp=False):
 
 def spmm_csr_omp(rowptr, col, val, M, K, B):
     return spmm_csr(rowptr, col, val, M, K, B, omp=True)
+
+
+def spmm_csr_chain(rowptr, col, val, M, K, B):
+    """The pure CSR-order fmaf chain for every N (no narrow-N rule): what the explicit group-kernel
+    variants compute when forced onto N < 4."""
+    B = _f(B)
+    N = B.shape[1]
+    C = np.empty((M, N), dtype=np.float32)
+    lib().oracle_spmm_csr_chain_f32(_i(rowptr), _pad1(col, np.int32), _pad1(val, np.float32), M, K, N,
+                                    _pad1(B, np.float32), max(N, 1), C if C.size else np.zeros(1, np.float32), max(N, 1))
+    return C
 
 
 def spmm_csr_long(rowptr, col, val, M, K, B):

@@ -87,7 +87,8 @@ def test_spmm_every_variant_is_bit_identical(capi, dev, oracle_mod, M, K, N, den
     expect = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
     d = [t(x, dev) for x in (rowptr, col, val, B)]
     ran = 0
-    for variant in range(16):
+    chain = oracle_mod.spmm_csr_chain(rowptr, col, val, M, K, B)  # explicit group variants ignore the N < 4 rule
+    for variant in range(17):
         C = torch.full((M, N), float("nan"), device=dev)
         st = capi.mi_spmm_csr_f32_variant(variant, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(val), M, K,
                                           N, d[3].data_ptr(), N, C.data_ptr(), N,
@@ -96,7 +97,7 @@ def test_spmm_every_variant_is_bit_identical(capi, dev, oracle_mod, M, K, N, den
             continue
         assert st == 0
         ran += 1
-        assert np.array_equal(C.cpu().numpy(), expect), f"variant {variant}"
+        assert np.array_equal(C.cpu().numpy(), chain if variant in (4, 5, 13) else expect), f"variant {variant}"
     assert ran >= 2  # AUTO plus the generic kernel at least
 
 

@@ -49,7 +49,7 @@ def main():
         B = torch.rand(K, N, generator=gen)
         exp = a @ B
         Bd = B.to(dev)
-        for variant in range(0, 16):
+        for variant in range(0, 17):
             C = torch.full((M, N), float("nan"), device=dev)
             try:
                 spmm(variant, rp, ci, v, M, K, Bd, C)
@@ -76,7 +76,7 @@ def main():
             nnz = M * deg
             bytes_alg = nnz * (4 * N + 8) + 4 * (M + 1) + 4 * M * N
             ref = None
-            for variant in range(0, 16):
+            for variant in range(0, 17):
                 try:
                     spmm(variant, rowptr, col, val, M, K, B, C)
                 except RuntimeError as e:
