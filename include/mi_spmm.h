@@ -59,13 +59,16 @@ int mi_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                     const float* B, int64_t ldb, float* C, int64_t ldc,
                     mi_stream_t stream);
 
-/* Skew-robust form.  With a workspace of mi_spmm_csr_workspace_bytes(nnz) bytes, rows with
- * more than 8192 non-zeros are not left to a single wave: a 16-wave workgroup per such row runs
- * 16 interleaved fmaf chains (wave w takes the row's 1024-non-zero chunks w, w+16, …, in
- * increasing position) and adds the 16 partial rows in wave order (then + bias).  Rows up to
- * 8192 non-zeros keep the plain CSR-order chain, so results equal mi_spmm_csr_f32 for them.
- * bias (N entries) may be NULL.  This is what custom_mm.naive_spmm / cusparse_mmul call. */
-size_t mi_spmm_csr_workspace_bytes(int64_t nnz);
+/* Skew-robust form.  With a workspace of mi_spmm_csr_workspace_bytes(nnz, N) bytes (16-byte
+ * aligned; ≈ nnz·N/8192 + nnz/400 bytes), rows with more than 8192 non-zeros are not left to a
+ * single wave.  Such a row of `len` non-zeros is summed by S = clamp(len/32768, 1, 128) 16-wave
+ * workgroups: its 1024-non-zero chunks are dealt round-robin to 16·S fmaf chains (chain q takes
+ * chunks q, q+16S, …, in increasing position), workgroup g adds chains 16g … 16g+15 in that
+ * order, and the S workgroup sums are added in order g = 0 … S-1 (then + bias).  The order
+ * depends on the row length only.  Rows up to 8192 non-zeros keep the plain CSR-order chain, so
+ * results equal mi_spmm_csr_f32 for them.  bias (N entries) may be NULL.  This is what
+ * custom_mm.naive_spmm / cusparse_mmul call. */
+size_t mi_spmm_csr_workspace_bytes(int64_t nnz, int32_t N);
 int mi_spmm_csr_ws_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                        int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
                        int64_t ldb, const float* bias, float* C, int64_t ldc,

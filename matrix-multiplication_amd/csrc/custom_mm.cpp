@@ -229,8 +229,8 @@ torch::Tensor spmm_impl(const torch::Tensor& A_values, const torch::Tensor& A_co
     bias_ptr = bias_keep.data_ptr<float>();
   }
   c10::hip::HIPGuard guard(C.device().index());
-  // workspace for the list of over-long rows (a few bytes per 8192 non-zeros; caching allocator)
-  const size_t ws_bytes = mi_spmm_csr_workspace_bytes(nnzA);
+  // workspace for the over-long rows (list + partial rows of the split ones; caching allocator)
+  const size_t ws_bytes = mi_spmm_csr_workspace_bytes(nnzA, (int32_t)N);
   torch::Tensor ws = torch::empty({(int64_t)std::max<size_t>(ws_bytes, 4)}, torch::dtype(torch::kUInt8).device(C.device()));
   const int st = mi_spmm_csr_ws_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
                                     A_values.data_ptr<float>(), nnzA, (int32_t)A_rows, (int32_t)A_cols,

@@ -583,48 +583,96 @@ __global__ __launch_bounds__(256) void spmm_narrow_kernel(
 // a row with 10⁵–10⁶ non-zeros would be a serial tail of tens of milliseconds.  When the caller
 // supplies a workspace (custom_mm always does), rows with more than kLongRow non-zeros are
 // skipped by the kernels above (`long_thresh`), collected by find_long_rows_kernel, and summed
-// here by a whole 16-wave workgroup: wave w runs the fmaf chain over the row's 1024-non-zero
-// chunks w, w+16, w+32, … (in increasing position), and the 16 partial results are added in wave
-// order.  That is a different — fixed, launch-independent — summation order for those rows only;
-// oracle_spmm_csr_f32 restates it, so results stay bit-identical to the oracle.
+// here by S = clamp(len / 32768, 1, 128) 16-wave workgroups: the row's 1024-non-zero chunks are
+// dealt round-robin to 16·S chains (chain q runs the fmaf chain over chunks q, q+16S, q+32S, …
+// in increasing position), workgroup g owns chains 16g … 16g+15 and adds them in that order,
+// and the S workgroup sums are added in order g = 0 … S-1 (by the same workgroup when S = 1,
+// else through the workspace by combine_long_rows_kernel).  That is a different — fixed,
+// launch-independent, a function of the row length only — summation order for those rows;
+// oracle_spmm_csr_long_f32 restates it, so results stay bit-identical to the oracle.
+//
+// Workspace (ints): [0] rows listed, [1] workgroup slots handed out, [2] partial-row slots
+// handed out, then cap_e entries {row, slot base, S, partial base}, then cap_s slot → entry
+// indices, then (16-B aligned) cap_p × N floats of partial rows.
 // ---------------------------------------------------------------------------
 constexpr int kLongRow = 8192;
 constexpr int kLongChunk = 1024;
 constexpr int kLongWaves = 16;
+constexpr int kLongSplitShift = 15;  // one workgroup per 32768 non-zeros of a row …
+constexpr int kLongSplitMax = 128;   // … up to 128 workgroups
 
-__global__ void find_long_rows_kernel(const int* __restrict__ rowptr, int M, int* __restrict__ ws, int cap) {
+struct LongWs {
+  long cap_e, cap_s, cap_p;
+  size_t owner_off, partial_off, bytes;  // offsets in ints / bytes
+};
+
+LongWs long_ws_layout(int64_t nnz, int32_t N) {
+  LongWs w;
+  w.cap_e = nnz / kLongRow + 1;
+  w.cap_p = nnz >> kLongSplitShift;
+  w.cap_s = w.cap_e + w.cap_p;
+  w.owner_off = 4 + 4 * (size_t)w.cap_e;
+  const size_t ints = w.owner_off + (size_t)w.cap_s;
+  w.partial_off = (ints * sizeof(int) + 15) / 16 * 16;
+  w.bytes = w.partial_off + (size_t)w.cap_p * (size_t)N * sizeof(float);
+  return w;
+}
+
+__global__ void find_long_rows_kernel(const int* __restrict__ rowptr, int M, int* __restrict__ ws, int cap_e,
+                                      int cap_s, int cap_p) {
   const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < M && rowptr[r + 1] - rowptr[r] > kLongRow) {
-    const int slot = atomicAdd(&ws[0], 1);  // order of the list does not matter
-    if (slot < cap) ws[1 + slot] = (int)r;
-  }
+  if (r >= M) return;
+  const int len = rowptr[r + 1] - rowptr[r];
+  if (len <= kLongRow) return;
+  int S = len >> kLongSplitShift;
+  S = S < 1 ? 1 : (S > kLongSplitMax ? kLongSplitMax : S);
+  // the order of the lists does not matter: every slot is a fixed function of (row, g)
+  const int e = atomicAdd(&ws[0], 1);
+  const int sb = atomicAdd(&ws[1], S);
+  const int pb = S > 1 ? atomicAdd(&ws[2], S) : 0;
+  // the caps hold for any rowptr consistent with nnz; a lying rowptr must not write out of bounds
+  if (e >= cap_e || sb + S > cap_s || (S > 1 && pb + S > cap_p)) return;
+  int* ent = ws + 4 + 4 * e;
+  ent[0] = (int)r;
+  ent[1] = sb;
+  ent[2] = S;
+  ent[3] = pb;
+  int* owner = ws + 4 + 4 * (long)cap_e;
+  for (int g = 0; g < S; ++g) owner[sb + g] = e;
 }
 
 template <int VEC>
 __global__ __launch_bounds__(kLongWaves * 64) void spmm_long_rows_kernel(
-    const int* __restrict__ ws, const int* __restrict__ rowptr, const int* __restrict__ col,
-    const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C, int N, long ldb,
-    long ldc, const float* __restrict__ bias) {
+    const int* __restrict__ ws, int cap_e, int cap_s, float* __restrict__ partial, const int* __restrict__ rowptr,
+    const int* __restrict__ col, const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
+    int N, long ldb, long ldc, const float* __restrict__ bias) {
   typedef Vec<VEC> V;
   typedef typename V::type vec_t;
   __shared__ vec_t part[kLongWaves][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int count = ws[0];
-  for (int e = blockIdx.x; e < count; e += gridDim.x) {
-    const int row = ws[1 + e];
-    const int start = rowptr[row], end = rowptr[row + 1];
+  const int slots = ws[1] < cap_s ? ws[1] : cap_s;
+  const int* owner = ws + 4 + 4 * (long)cap_e;
+  for (int t = blockIdx.x; t < slots; t += gridDim.x) {
+    const int e = owner[t];
+    if ((unsigned)e >= (unsigned)cap_e) continue;
+    const int* ent = ws + 4 + 4 * e;
+    const int row = ent[0], S = ent[2], pb = ent[3];
+    const int g = t - ent[1];
+    if ((unsigned)g >= (unsigned)S) continue;  // slot of a dropped entry
+    const long start = rowptr[row], end = rowptr[row + 1];
+    const long stride = (long)kLongWaves * S * kLongChunk;
     for (int n0 = 0; n0 < N; n0 += 64 * VEC) {  // 64·VEC output columns per pass
       const int c0 = n0 + lane * VEC;
       const bool on = c0 < N;
       vec_t acc = V::zero();
-      for (int cb = start + wave * kLongChunk; cb < end; cb += kLongWaves * kLongChunk) {
-        const int ce = cb + kLongChunk < end ? cb + kLongChunk : end;
-        for (int p = cb; p < ce; p += 64) {
-          const int idx = p + lane;
+      for (long cb = start + ((long)g * kLongWaves + wave) * kLongChunk; cb < end; cb += stride) {
+        const long ce = cb + kLongChunk < end ? cb + kLongChunk : end;
+        for (long p = cb; p < ce; p += 64) {
+          const long idx = p + lane;
           const int myc = idx < ce ? col[idx] : 0;
           const float myv = idx < ce ? val[idx] : 0.f;
-          const int cnt = ce - p < 64 ? ce - p : 64;
+          const int cnt = ce - p < 64 ? (int)(ce - p) : 64;
           int i = 0;
           for (; i + 8 <= cnt; i += 8) {
             vec_t x[8];
@@ -652,10 +700,33 @@ __global__ __launch_bounds__(kLongWaves * 64) void spmm_long_rows_kernel(
         vec_t tot = part[0][lane];
 #pragma unroll
         for (int w = 1; w < kLongWaves; ++w) tot += part[w][lane];
-        if (bias) tot += V::load(bias + c0);
-        V::store(C + (long)row * ldc + c0, tot);
+        if (S == 1) {
+          if (bias) tot += V::load(bias + c0);
+          V::store(C + (long)row * ldc + c0, tot);
+        } else {
+          V::store(partial + (long)(pb + g) * N + c0, tot);  // N % VEC == 0 and 16-B base when VEC = 4
+        }
       }
       __syncthreads();
+    }
+  }
+}
+
+// Rows summed by S > 1 workgroups: add the S partial rows in order g = 0 … S-1, then the bias.
+__global__ __launch_bounds__(256) void combine_long_rows_kernel(const int* __restrict__ ws, int cap_e,
+                                                               const float* __restrict__ partial,
+                                                               float* __restrict__ C, int N, long ldc,
+                                                               const float* __restrict__ bias) {
+  const int count = ws[0] < cap_e ? ws[0] : cap_e;
+  for (int e = blockIdx.x; e < count; e += gridDim.x) {
+    const int* ent = ws + 4 + 4 * e;
+    const int row = ent[0], S = ent[2], pb = ent[3];
+    if (S <= 1) continue;
+    for (int c = threadIdx.x; c < N; c += blockDim.x) {
+      float tot = partial[(long)pb * N + c];
+      for (int g = 1; g < S; ++g) tot += partial[(long)(pb + g) * N + c];
+      if (bias) tot += bias[c];
+      C[(long)row * ldc + c] = tot;
     }
   }
 }
@@ -709,7 +780,7 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
   return sh.vec4_ok ? MI_SPMM_GROUP_VEC4 : MI_SPMM_GROUP_SCALAR;
 }
 
-size_t long_rows_workspace_bytes(int64_t nnz) { return ((size_t)(nnz / kLongRow) + 2) * sizeof(int); }
+size_t long_rows_workspace_bytes(int64_t nnz, int32_t N) { return long_ws_layout(nnz, N).bytes; }
 
 int launch_variant(int variant, const Shape& sh, const int32_t* rowptr, const int32_t* col, const float* val,
                    int64_t nnz, int32_t batch, int32_t M, int32_t K, int32_t N, const float* B,
@@ -802,23 +873,31 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
   // unless the matrix has more than kLongRow non-zeros)
   const bool split = workspace != nullptr && batch == 1 && nnz > kLongRow && variant != MI_SPMM_NARROW;
   int* ws = static_cast<int*>(workspace);
+  const LongWs lw = long_ws_layout(nnz, N);
   if (split) {
-    if (workspace_bytes < long_rows_workspace_bytes(nnz)) return MI_ENOMEM;
-    MI_HIP_TRY(hipMemsetAsync(ws, 0, sizeof(int), s));
+    if (workspace_bytes < lw.bytes) return MI_ENOMEM;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return MI_EINVAL;
+    // counters, entries and the slot → entry map (a few KB per 10⁶ non-zeros)
+    MI_HIP_TRY(hipMemsetAsync(ws, 0, lw.partial_off, s));
     hipLaunchKernelGGL(find_long_rows_kernel, dim3((unsigned)(((long)M + 255) / 256)), dim3(256), 0, s, rowptr, M,
-                       ws, (int)(nnz / kLongRow) + 1);
+                       ws, (int)lw.cap_e, (int)lw.cap_s, (int)lw.cap_p);
   }
   int st = launch_variant(variant, sh, rowptr, col, val, nnz, batch, M, K, N, B, ldb, strideB, C, ldc, strideC,
                           bias, split ? kLongRow : 0x7fffffff, s);
   if (st != MI_OK || !split) return st;
-  const unsigned cap = (unsigned)(nnz / kLongRow) + 1;
-  const unsigned grid = cap < 1024u ? cap : 1024u;
+  float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + lw.partial_off);
+  const unsigned grid = lw.cap_s < 2048 ? (unsigned)lw.cap_s : 2048u;
   if (sh.vec4_ok)
-    hipLaunchKernelGGL(spmm_long_rows_kernel<4>, dim3(grid), dim3(kLongWaves * 64), 0, s, ws, rowptr, col, val, B,
-                       C, N, ldb, ldc, bias);
+    hipLaunchKernelGGL(spmm_long_rows_kernel<4>, dim3(grid), dim3(kLongWaves * 64), 0, s, ws, (int)lw.cap_e,
+                       (int)lw.cap_s, partial, rowptr, col, val, B, C, N, ldb, ldc, bias);
   else
-    hipLaunchKernelGGL(spmm_long_rows_kernel<1>, dim3(grid), dim3(kLongWaves * 64), 0, s, ws, rowptr, col, val, B,
-                       C, N, ldb, ldc, bias);
+    hipLaunchKernelGGL(spmm_long_rows_kernel<1>, dim3(grid), dim3(kLongWaves * 64), 0, s, ws, (int)lw.cap_e,
+                       (int)lw.cap_s, partial, rowptr, col, val, B, C, N, ldb, ldc, bias);
+  if (lw.cap_p >= 2) {  // a row can be split only when the matrix has ≥ 65536 non-zeros
+    const unsigned cgrid = lw.cap_e < 1024 ? (unsigned)lw.cap_e : 1024u;
+    hipLaunchKernelGGL(combine_long_rows_kernel, dim3(cgrid), dim3(256), 0, s, ws, (int)lw.cap_e, partial, C, N, ldc,
+                       bias);
+  }
   return mi::check_launch();
 }
 
@@ -833,7 +912,9 @@ int mi_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                        static_cast<hipStream_t>(stream));
 }
 
-size_t mi_spmm_csr_workspace_bytes(int64_t nnz) { return nnz > 0 ? long_rows_workspace_bytes(nnz) : 0; }
+size_t mi_spmm_csr_workspace_bytes(int64_t nnz, int32_t N) {
+  return nnz > 0 && N > 0 ? long_rows_workspace_bytes(nnz, N) : 0;
+}
 
 int mi_spmm_csr_ws_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
                        int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb, const float* bias,

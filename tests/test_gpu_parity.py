@@ -695,6 +695,34 @@ def test_skewed_rows_long_row_kernel(cmm, dev, oracle_mod, N):
     assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B) + bias[None, :])
 
 
+@pytest.mark.parametrize("N", [64, 256, 30])
+def test_hub_rows_split_over_workgroups(cmm, dev, oracle_mod, N):
+    """Rows of ≥ 65536 non-zeros are summed by S = len/32768 workgroups through partial rows in the
+    workspace (S = 2, 3, 9 here, beside S = 1 long rows and ordinary ones); bit-identical to the
+    oracle's statement of that order, with and without the fused bias."""
+    M, K = 40, 300000
+    g = np.random.Generator(np.random.PCG64(N + 1))
+    lens = g.integers(0, 300, size=M)
+    lens[0], lens[7], lens[8], lens[20], lens[39] = 65536, 65535, 100000, K, 9000
+    cols = [np.sort(g.choice(K, size=int(n), replace=False)).astype(np.int32) for n in lens]
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate(cols)
+    val = (g.random(len(col), dtype=np.float32) - 0.5)
+    B = g.random((K, N), dtype=np.float32)
+    want = oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B)
+    got = run_spmm(cmm, dev, rowptr, col, val, M, K, B, "naive_spmm")
+    assert np.array_equal(got, want)
+    ref = np.zeros((M, N), dtype=np.float64)
+    for r in (0, 8, 20):
+        sl = slice(rowptr[r], rowptr[r + 1])
+        ref[r] = val[sl].astype(np.float64) @ B[col[sl]].astype(np.float64)
+        assert np.allclose(got[r], ref[r], rtol=1e-4, atol=1e-2)
+    bias = g.random(N, dtype=np.float32)
+    C = torch.full((M, N), float("nan"), device=dev)
+    cmm.naive_spmm_bias(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, t(B, dev), t(bias, dev), C)
+    assert np.array_equal(C.cpu().numpy(), want + bias[None, :])
+
+
 def test_spmm_shape_fuzz_against_oracle(cmm, capi, dev, oracle_mod):
     """Seeded random shapes through custom_mm.naive_spmm (AUTO dispatch incl. the column-tiled and
     panel plans, partial last tiles, odd widths) — every one bit-identical to the oracle."""

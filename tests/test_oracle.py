@@ -186,3 +186,39 @@ def test_long_row_rule_is_a_reassociation_only(oracle_mod):
     A = torch.sparse_csr_tensor(torch.from_numpy(rowptr.astype(np.int64)), torch.from_numpy(col.astype(np.int64)),
                                 torch.from_numpy(val), (M, K))
     assert np.allclose((A @ torch.from_numpy(B)).numpy(), long_, rtol=1e-5, atol=1e-8)
+
+
+def test_long_row_rule_split_rows(oracle_mod):
+    """Rows of ≥ 65536 non-zeros use S = len/32768 groups of 16 chains (mi_spmm_csr_ws_f32): still
+    only a reassociation, and restated here chunk by chunk in numpy for one column."""
+    M, K, N = 3, 140000, 5  # N >= 4: below that the narrow-N rule applies instead
+    g = np.random.Generator(np.random.PCG64(5))
+    lens = [131072, 65535, 70000]
+    cols = [np.sort(g.choice(K, size=n, replace=False)).astype(np.int32) for n in lens]
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate(cols)
+    val = g.random(len(col), dtype=np.float32) - 0.5
+    B = g.random((K, N), dtype=np.float32)
+    long_ = oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B)
+    exact = np.stack([val[rowptr[r]:rowptr[r + 1]].astype(np.float64) @ B[col[rowptr[r]:rowptr[r + 1]]].astype(np.float64)
+                      for r in range(M)])
+    assert np.allclose(long_, exact, rtol=1e-4, atol=1e-3)
+    # independent restatement of the rule for row 0 (S = 4), column 1
+    s, e = int(rowptr[0]), int(rowptr[1])
+    S = min(128, max(1, (e - s) >> 15))
+    assert S == 4
+    prods_v, prods_b = val[s:e], B[col[s:e], 1]
+    chains = []
+    for q in range(16 * S):
+        acc = np.float32(0)
+        for cb in range(q * 1024, e - s, 16 * S * 1024):
+            for p in range(cb, min(cb + 1024, e - s)):
+                acc = np.float32(np.float64(prods_v[p]) * np.float64(prods_b[p]) + np.float64(acc))  # fma: one rounding
+        chains.append(acc)
+    tot = None
+    for gi in range(S):
+        grp = chains[16 * gi]
+        for w in range(1, 16):
+            grp = np.float32(grp + chains[16 * gi + w])
+        tot = grp if tot is None else np.float32(tot + grp)
+    assert tot == long_[0, 1]

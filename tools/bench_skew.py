@@ -45,4 +45,4 @@ for r in (7, 5000, 99_999, 3):
     ref = (val[s:e].double()[:, None] * B[col[s:e].long()].double()).sum(0)
     e1 = ((C1[r].double() - ref).abs() / ref.abs()).max().item()
     e2 = ((C2[r].double() - ref).abs() / ref.abs()).max().item()
-    print(f"row {r} ({e - s} nnz): max rel err vs fp64 — single chain {e1:.2e}, 16 chains {e2:.2e}")
+    print(f"row {r} ({e - s} nnz): max rel err vs fp64 — single chain {e1:.2e}, 16·S chains {e2:.2e}")
