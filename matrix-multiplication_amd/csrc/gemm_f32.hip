@@ -15,17 +15,28 @@
 // operand's contiguous dimension) and the MFMA operand read (32 lanes on 32
 // consecutive m or n at one k) bank-conflict free:
 //    source contiguous along k  → Xs[mn][BK+1]   (A not transposed, B transposed)
-//    source contiguous along mn → Xs[BK][BMN+4]  (A transposed, B not transposed)
-// The next k-tile's global loads are issued before the MFMAs of the current
-// one (register staging).  The MFMA operands are swapped so the accumulators hold
-// Cᵀ tiles (lane ↔ row, registers ↔ 4-column groups): the epilogue stages each
-// 32×32 tile through LDS with b128 writes and stores whole 128-B row segments
-// with non-temporal 16-B stores.  Work ids are dealt XCD-contiguously so tiles
-// sharing an operand panel share an L2.
-// Measured at BERT-base attention shapes (B 32, H 12, S 512, D 64): q·kᵀ 0.156 ms
-// (82.6 TFLOP/s; torch/rocBLAS 0.181 ms), probs·v 0.158 ms (rocBLAS 0.133 ms);
-// ablation shows load, MFMA and store phases of co-resident workgroups still run
-// mostly in sequence — a multi-stage LDS pipeline is the next step.
+//    source contiguous along mn → Xs[BK][BMN]    (A transposed, B not transposed)
+// The MFMA operands are swapped so the accumulators hold Cᵀ tiles (lane ↔ row, registers ↔
+// 4-column groups): the epilogue stages each 32×32 tile through LDS with b128 writes and stores
+// whole 128-B row segments with non-temporal 16-B stores.  Work ids are dealt XCD-contiguously and
+// in 8-tile column groups, so the workgroups an XCD runs together share operand panels in its L2.
+//
+// Two kernels share loader, layouts and epilogue (same k order per element → same bits):
+//  * gemm_f32_kernel (k < 256): one LDS buffer, two barriers per k-tile, the next tile's global
+//    loads issued before the MFMAs; 3–4 workgroups per CU overlap each other's phases.  BERT's
+//    q·kᵀ (k = 64) is bound by writing the 403 MB of scores and runs here.
+//  * gemm_f32_pipe_kernel (k ≥ 256): two LDS buffers, ONE barrier per k-tile.  While the MFMAs
+//    of tile t run, the registers holding tile t+1 go to the other buffer (dealt 2 LDS writes per
+//    MFMA) and the loads of tile t+2 are issued (1 per MFMA); operand reads run one 8-MFMA batch
+//    ahead.  The issue order is pinned with sched_group_barrier/sched_barrier: left alone, hipcc
+//    sinks the loads to the end of the tile, directly in front of the waits on them.
+// Measured (MI355X, fp32 MFMA peak 157 TFLOP/s; tools/gemm_square_probe.py, tools/bench_misc.py):
+// 8192³ A·Bᵀ 7.80 ms = 141 TFLOP/s (single-buffer kernel 8.37, rocBLAS 7.15), A·B 8.16,
+// Aᵀ·B 8.31; 4096³ 0.985–1.06 ms (rocBLAS 0.91); 1024³ 0.026 ms (was 0.034; rocBLAS 0.022);
+// BERT-base attention (B 32, H 12, S 512, D 64): q·kᵀ 0.164 ms (rocBLAS 0.184), probs·v
+// 0.144 ms (was 0.156; rocBLAS 0.131).  Ablation of the pipelined kernel at 8192³: MFMAs alone
+// 7.13 ms; + operand reads 7.34; + LDS writes 7.52; + global loads 7.80 (half of that is issue
+// cost, half L2-miss latency beyond the one-tile prefetch distance).
 #include "mi_common.h"
 
 namespace {
@@ -40,8 +51,13 @@ constexpr int BK = 32;
 template <int EXT, bool KCONTIG>
 struct TileLoader {
   static constexpr int VECS = EXT * BK / 4 / 256;  // float4 per thread
-  static constexpr int LDS_LD = KCONTIG ? (BK + 1) : (EXT + 4);
-  static constexpr int LDS_FLOATS = KCONTIG ? EXT * (BK + 1) : BK * (EXT + 4);
+  static constexpr int LDS_LD = KCONTIG ? (BK + 1) : EXT;
+  static constexpr int LDS_FLOATS = KCONTIG ? EXT * (BK + 1) : BK * EXT;
+  // instruction counts as hipcc emits them (for the issue-order hints of the pipelined kernel):
+  // LDS writes per k-tile (ds_write2_b32 pairs / ds_write_b128), LDS reads per 32-row operand
+  // block and two k-steps (hipcc pairs them into one ds_read2_b32 in both layouts)
+  static constexpr int WRITES = KCONTIG ? 2 * VECS : VECS;
+  static constexpr int READS_PER_BATCH = 1;
 
   // (e, k) of the first element of this thread's v-th float4.
   static __device__ __forceinline__ void coords(int v, int tid, int& e, int& k) {
@@ -94,6 +110,18 @@ struct TileLoader {
     }
   }
 
+  // Interior tile (every element in range, 16-B aligned rows): unconditional vector loads.
+  static __device__ __forceinline__ void load_fast(f32x4 (&r)[VECS], const float* src, long ld, int e0, int k0,
+                                                   int tid) {
+#pragma unroll
+    for (int v = 0; v < VECS; ++v) {
+      int e, k;
+      coords(v, tid, e, k);
+      const float* p = KCONTIG ? src + (long)(e0 + e) * ld + (k0 + k) : src + (long)(k0 + k) * ld + (e0 + e);
+      r[v] = *reinterpret_cast<const f32x4*>(p);
+    }
+  }
+
   // Registers → LDS.
   static __device__ __forceinline__ void store(const f32x4 (&r)[VECS], float* lds, int tid) {
 #pragma unroll
@@ -118,80 +146,25 @@ struct TileLoader {
   }
 };
 
-template <int BM, int BN, bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(
-    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int m, int n,
-    int k, long lda, long ldb, long ldc, long strideA, long strideB, long strideC, int tiles_n,
-    int tiles_per_item, bool vecA, bool vecB, bool vecC, const float* __restrict__ bias) {
-  constexpr int TM = BM / 64;  // 32×32 tiles per wave along m (2×2 waves)
-  constexpr int TN = BN / 64;
-  typedef TileLoader<BM, !TA> LA;  // A not transposed → contiguous along k
-  typedef TileLoader<BN, TB> LB;   // B transposed     → contiguous along k
-  constexpr int kOperandFloats = LA::LDS_FLOATS + LB::LDS_FLOATS;
-  constexpr int kEpilogueFloats = 4 * 32 * 36;  // one [32][36] staging patch per wave
-  __shared__ __attribute__((aligned(16))) float lds[kOperandFloats > kEpilogueFloats ? kOperandFloats : kEpilogueFloats];
-  float* As = lds;
-  float* Bs = lds + LA::LDS_FLOATS;
+// Tile order inside one product: column groups of 8 tiles, walked row by row, so the ≈64
+// workgroups an XCD runs at a time form an 8×8 patch (8 A panels + 8 B panels stream through its
+// L2) instead of one tile row (1 A panel + every B panel).  Bijective; speed only.
+__device__ __forceinline__ void tile_coords(int tile, int tiles_n, int tiles_m, int& tile_m, int& tile_n) {
+  constexpr int G = 8;
+  const int per_group = G * tiles_m;
+  const int g = tile / per_group, r = tile % per_group;
+  const int width = tiles_n - g * G < G ? tiles_n - g * G : G;
+  tile_m = r / width;
+  tile_n = g * G + r % width;
+}
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware work order: workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD
-  // b % 8, each with a private L2), so give every XCD a CONTIGUOUS range of work ids: the tiles
-  // that share an A panel (same item, same tile_m) or a B panel then hit in one L2 instead of
-  // being fetched by up to 8 of them.  Bijective for any grid size; speed only.
-  const unsigned total = gridDim.x, bid = blockIdx.x;
-  const unsigned q = total / 8, rem = total % 8, xcd = bid % 8, pos = bid / 8;
-  const unsigned work = xcd * q + (xcd < rem ? xcd : rem) + pos;
-  const long item = work / tiles_per_item;
-  const int tile = work % tiles_per_item;
-  const int tile_m = tile / tiles_n;
-  const int tile_n = tile % tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  A += item * strideA;
-  B += item * strideB;
-  C += item * strideC;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  f32x4 ra[LA::VECS], rb[LB::VECS];
-  LA::load(ra, A, lda, m0, 0, m, k, vecA, tid);
-  LB::load(rb, B, ldb, n0, 0, n, k, vecB, tid);
-
+// Epilogue shared by both kernels.  D' = Cᵀ tile: lane&31 = row m inside the tile, register r
+// holds column n = (r&3) + 8·(r>>2) + 4·(lane>>5).
+template <int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds, float* __restrict__ C, int m, int n,
+                                              long ldc, int m0, int n0, int wm, int wn, int wave, int lane, bool vecC,
+                                              const float* __restrict__ bias) {
   const int l31 = lane & 31, lhi = lane >> 5;
-  for (int k0 = 0; k0 < k; k0 += BK) {
-    LA::store(ra, As, tid);
-    LB::store(rb, Bs, tid);
-    __syncthreads();
-    if (k0 + BK < k) {
-      LA::load(ra, A, lda, m0, k0 + BK, m, k, vecA, tid);
-      LB::load(rb, B, ldb, n0, k0 + BK, n, k, vecB, tid);
-    }
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = LA::at(As, wm * (BM / 2) + i * 32 + l31, kk + lhi);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = LB::at(Bs, wn * (BN / 2) + j * 32 + l31, kk + lhi);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          // operands swapped: the accumulator tile is Cᵀ (lane ↔ row m of C, registers ↔ 4-column
-          // groups of n), so the epilogue can move 16 B per lane; a·b = b·a keeps every bit.
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-
   // Epilogue.  D' = Cᵀ tile: lane&31 = row m inside the tile, register r holds column
   // n = (r&3) + 8·(r>>2) + 4·(lane>>5).  Each wave stages one 32×32 tile at a time in its own
   // LDS patch ([32][36] floats, conflict-free b128 writes), reads it back row-major and stores
@@ -242,16 +215,251 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
 }
 
 template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int m, int n,
+    int k, long lda, long ldb, long ldc, long strideA, long strideB, long strideC, int tiles_n,
+    int tiles_per_item, bool vecA, bool vecB, bool vecC, const float* __restrict__ bias) {
+  constexpr int TM = BM / 64;  // 32×32 tiles per wave along m (2×2 waves)
+  constexpr int TN = BN / 64;
+  typedef TileLoader<BM, !TA> LA;  // A not transposed → contiguous along k
+  typedef TileLoader<BN, TB> LB;   // B transposed     → contiguous along k
+  constexpr int kOperandFloats = LA::LDS_FLOATS + LB::LDS_FLOATS;
+  constexpr int kEpilogueFloats = 4 * 32 * 36;  // one [32][36] staging patch per wave
+  __shared__ __attribute__((aligned(16))) float lds[kOperandFloats > kEpilogueFloats ? kOperandFloats : kEpilogueFloats];
+  float* As = lds;
+  float* Bs = lds + LA::LDS_FLOATS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware work order: workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD
+  // b % 8, each with a private L2), so give every XCD a CONTIGUOUS range of work ids: the tiles
+  // that share an A panel (same item, same tile_m) or a B panel then hit in one L2 instead of
+  // being fetched by up to 8 of them.  Bijective for any grid size; speed only.
+  const unsigned total = gridDim.x, bid = blockIdx.x;
+  const unsigned q = total / 8, rem = total % 8, xcd = bid % 8, pos = bid / 8;
+  const unsigned work = xcd * q + (xcd < rem ? xcd : rem) + pos;
+  const long item = work / tiles_per_item;
+  const int tile = work % tiles_per_item;
+  int tile_m, tile_n;
+  tile_coords(tile, tiles_n, tiles_per_item / tiles_n, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  A += item * strideA;
+  B += item * strideB;
+  C += item * strideC;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[LA::VECS], rb[LB::VECS];
+  LA::load(ra, A, lda, m0, 0, m, k, vecA, tid);
+  LB::load(rb, B, ldb, n0, 0, n, k, vecB, tid);
+
+  const int l31 = lane & 31, lhi = lane >> 5;
+  for (int k0 = 0; k0 < k; k0 += BK) {
+    LA::store(ra, As, tid);
+    LB::store(rb, Bs, tid);
+    __syncthreads();
+    if (k0 + BK < k) {
+      LA::load(ra, A, lda, m0, k0 + BK, m, k, vecA, tid);
+      LB::load(rb, B, ldb, n0, k0 + BK, n, k, vecB, tid);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = LA::at(As, wm * (BM / 2) + i * 32 + l31, kk + lhi);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = LB::at(Bs, wn * (BN / 2) + j * 32 + l31, kk + lhi);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          // operands swapped: the accumulator tile is Cᵀ (lane ↔ row m of C, registers ↔ 4-column
+          // groups of n), so the epilogue can move 16 B per lane; a·b = b·a keeps every bit.
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  gemm_epilogue<BM, BN, TM, TN>(acc, lds, C, m, n, ldc, m0, n0, wm, wn, wave, lane, vecC, bias);
+}
+
+// Pipelined form: two LDS buffers, ONE barrier per k-tile.  While the MFMAs of tile t run out of
+// buffer t&1, the registers holding tile t+1 (loaded during tile t-1) are written to the other
+// buffer and the loads of tile t+2 are issued, so a global load has a whole MFMA phase to land and
+// a wave that is alone on its SIMD keeps the matrix pipe busy.
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int m, int n,
+    int k, long lda, long ldb, long ldc, long strideA, long strideB, long strideC, int tiles_n,
+    int tiles_per_item, bool vecA, bool vecB, bool vecC, const float* __restrict__ bias) {
+  constexpr int TM = BM / 64;
+  constexpr int TN = BN / 64;
+  typedef TileLoader<BM, !TA> LA;
+  typedef TileLoader<BN, TB> LB;
+  constexpr int kStage = LA::LDS_FLOATS + LB::LDS_FLOATS;
+  constexpr int kEpilogueFloats = 4 * 32 * 36;
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStage > kEpilogueFloats ? 2 * kStage : kEpilogueFloats];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned total = gridDim.x, bid = blockIdx.x;
+  const unsigned q = total / 8, rem = total % 8, xcd = bid % 8, pos = bid / 8;
+  const unsigned work = xcd * q + (xcd < rem ? xcd : rem) + pos;
+  const long item = work / tiles_per_item;
+  const int tile = work % tiles_per_item;
+  int tile_m, tile_n;
+  tile_coords(tile, tiles_n, tiles_per_item / tiles_n, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  A += item * strideA;
+  B += item * strideB;
+  C += item * strideC;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lhi = lane >> 5;
+  // block-uniform: whole tiles only (inside C, k a multiple of BK, 16-B loads) take the
+  // straight-line loop below; everything else the simple one with the bounds-checked loader
+  const bool interior = vecA && vecB && m0 + BM <= m && n0 + BN <= n && k % BK == 0;
+  if (interior) {
+    f32x4 ra[LA::VECS], rb[LB::VECS];
+    LA::load_fast(ra, A, lda, m0, 0, tid);
+    LB::load_fast(rb, B, ldb, n0, 0, tid);
+    LA::store(ra, lds, tid);
+    LB::store(rb, lds + LA::LDS_FLOATS, tid);
+    const int k_last = k - BK;  // start of the last tile: later "prefetches" re-read it (never used)
+    {
+      const int k1 = BK < k_last ? BK : k_last;
+      LA::load_fast(ra, A, lda, m0, k1, tid);
+      LB::load_fast(rb, B, ldb, n0, k1, tid);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < k; k0 += BK, buf ^= 1) {
+      const float* As = lds + buf * kStage;
+      const float* Bs = As + LA::LDS_FLOATS;
+      float* An = lds + (buf ^ 1) * kStage;
+      float* Bn = An + LA::LDS_FLOATS;
+      // operand registers for two k-steps (one "batch" = 2·TM·TN MFMAs), double-buffered: the
+      // reads of batch s+1 are issued before the MFMAs of batch s
+      float a[2][2][TM], b[2][2][TN];
+      auto read_batch = [&](int s, int slot) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[slot][h][i] = LA::at(As, wm * (BM / 2) + i * 32 + l31, 4 * s + 2 * h + lhi);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[slot][h][j] = LB::at(Bs, wn * (BN / 2) + j * 32 + l31, 4 * s + 2 * h + lhi);
+        }
+      };
+      read_batch(0, 0);
+#pragma unroll
+      for (int s = 0; s < BK / 4; ++s) {
+        if (s + 1 < BK / 4) read_batch(s + 1, (s + 1) & 1);
+        if (s == 0) {
+          // tile t+1 (loaded during tile t-1): registers → the other buffer, whose last readers
+          // passed the previous barrier.  After the last tile this writes a buffer nobody reads.
+          LA::store(ra, An, tid);
+          LB::store(rb, Bn, tid);
+        }
+        if (s == 1) {
+          const int k2 = k0 + 2 * BK < k_last ? k0 + 2 * BK : k_last;
+          LA::load_fast(ra, A, lda, m0, k2, tid);
+          LB::load_fast(rb, B, ldb, n0, k2, tid);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s & 1][h][j], a[s & 1][h][i], acc[i][j], 0, 0, 0);
+        // Fence the scheduler per batch: hipcc otherwise sinks the operand reads next to their
+        // use and the global loads to the end of the tile (right in front of the waits on them).
+        if (s == 0) {
+          __builtin_amdgcn_sched_group_barrier(0x100, LA::READS_PER_BATCH * TM + LB::READS_PER_BATCH * TN, 0);
+#pragma unroll
+          for (int q = 0; q < 2 * TM * TN; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, (LA::WRITES + LB::WRITES + 2 * TM * TN - 1) / (2 * TM * TN), 0);
+          }
+        }
+        if (s == 1) {
+          __builtin_amdgcn_sched_group_barrier(0x100, LA::READS_PER_BATCH * TM + LB::READS_PER_BATCH * TN, 0);
+#pragma unroll
+          for (int q = 0; q < 2 * TM * TN; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x20, (LA::VECS + LB::VECS + 2 * TM * TN - 1) / (2 * TM * TN), 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
+  } else {
+    f32x4 ra[LA::VECS], rb[LB::VECS];
+    LA::load(ra, A, lda, m0, 0, m, k, vecA, tid);
+    LB::load(rb, B, ldb, n0, 0, n, k, vecB, tid);
+    for (int k0 = 0; k0 < k; k0 += BK) {
+      float* As = lds;
+      float* Bs = lds + LA::LDS_FLOATS;
+      LA::store(ra, As, tid);
+      LB::store(rb, Bs, tid);
+      __syncthreads();
+      if (k0 + BK < k) {
+        LA::load(ra, A, lda, m0, k0 + BK, m, k, vecA, tid);
+        LB::load(rb, B, ldb, n0, k0 + BK, n, k, vecB, tid);
+      }
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = LA::at(As, wm * (BM / 2) + i * 32 + l31, kk + lhi);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = LB::at(Bs, wn * (BN / 2) + j * 32 + l31, kk + lhi);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+  gemm_epilogue<BM, BN, TM, TN>(acc, lds, C, m, n, ldc, m0, n0, wm, wn, wave, lane, vecC, bias);
+}
+
+template <int BM, int BN, bool TA, bool TB>
 int launch(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb,
            long ldc, long sA, long sB, long sC, int batch, bool vecA, bool vecB, bool vecC,
            const float* bias, hipStream_t s) {
   const long tiles_m = (m + BM - 1) / BM, tiles_n = (n + BN - 1) / BN;
   const long blocks = tiles_m * tiles_n * batch;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
-  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB>), dim3((unsigned)blocks),
-                     dim3(256), 0, s, A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, (int)tiles_n,
-                     (int)(tiles_m * tiles_n),
-                     vecA, vecB, vecC, bias);
+  // long k: the pipelined kernel (its prologue and double LDS buffer pay off from ≈8 k-tiles);
+  // short k (BERT q·kᵀ, k = 64): the single-buffer kernel, which keeps 3–4 workgroups per CU
+  if (k >= 8 * BK)
+    hipLaunchKernelGGL((gemm_f32_pipe_kernel<BM, BN, TA, TB>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m,
+                       n, k, lda, ldb, ldc, sA, sB, sC, (int)tiles_n, (int)(tiles_m * tiles_n), vecA, vecB, vecC,
+                       bias);
+  else
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m, n, k,
+                       lda, ldb, ldc, sA, sB, sC, (int)tiles_n, (int)(tiles_m * tiles_n), vecA, vecB, vecC, bias);
   return mi::check_launch();
 }
 
