@@ -95,7 +95,9 @@ enum {
   MI_SPMM_COLTILE = 14,     /* wide N: XCD-aware column tiles so each XCD's L2 holds its B slice */
   MI_SPMM_COLTILE_PANELS = 15, /* wide N and tall K: column tiles × row panels of B, one launch per panel */
   MI_SPMM_NARROW = 16,      /* N < 4: wave per row, lanes over non-zeros, shuffle reduction (own order) */
-  MI_SPMM_VARIANT_COUNT = 17
+  MI_SPMM_SLAB = 17,        /* moderate density, N ≥ 128: 128 rows × 256 columns per workgroup, B staged
+                               through LDS in 32-row slabs, one ds_read_b128 per non-zero           */
+  MI_SPMM_VARIANT_COUNT = 18
 };
 int mi_spmm_csr_f32_variant(int variant, const int32_t* rowptr, const int32_t* col,
                             const float* val, int64_t nnz, int32_t M, int32_t K,

@@ -29,6 +29,11 @@ inline int pow2_ceil(int x) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// spmm_slab.hip — the LDS-slab kernel for moderate density (caller checks the vec4 requirements).
+int launch_spmm_slab(const int32_t* rowptr, const int32_t* col, const float* val, const float* B, float* C,
+                     int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t ldc, const float* bias,
+                     int long_thresh, hipStream_t s);
+
 }  // namespace mi
 
 #define MI_HIP_TRY(expr)                                  \

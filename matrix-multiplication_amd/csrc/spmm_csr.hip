@@ -774,6 +774,16 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
       nnz * (long)N >= 8 * b_elems)
     return MI_SPMM_PANELS_2;
   if (N < 4) return MI_SPMM_NARROW;
+  // Moderate density on a problem with enough 128 × 256 output blocks to fill the chip: stage B
+  // through LDS (spmm_slab.hip).  Measured (tools/bench_density.py, square A): 8192² × 8192 at
+  // 50 / 25 / 10 / 5 % non-zeros 19.9 / 11.2 / 5.9 / 4.1 ms vs 41.8 / 22.4 / 9.4 / 4.9 ms row-split;
+  // 4096² × 4096 at 25 / 10 % 1.41 / 0.75 vs 2.52 / 0.98 ms; it loses below ≈512 workgroups
+  // (8192² × 1024: 1.48 vs 1.12 ms at 10 %) and below ≈4–7 % density.
+  if (sh.vec4_ok && batch == 1 && K >= 64) {
+    const long wgs = (((long)M + 127) / 128) * (((long)N + 255) / 256);
+    const double density = (double)nnz / ((double)M * (double)K);
+    if ((wgs >= 2048 && density >= 0.04) || (wgs >= 512 && density >= 0.07)) return MI_SPMM_SLAB;
+  }
   if (sh.vec4_ok && batch == 1 && coltile_panels(M, K, N, ldb, nnz) > 0) return MI_SPMM_COLTILE_PANELS;
   if (sh.vec4_ok && batch == 1 && coltile_width(M, K, N, ldb) > 0) return MI_SPMM_COLTILE;
   if (sh.wave_ok) return MI_SPMM_WAVE_ROW_U8;
@@ -837,6 +847,9 @@ int launch_variant(int variant, const Shape& sh, const int32_t* rowptr, const in
       return dispatch_group<2>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, long_thresh, s);
     case MI_SPMM_GROUP_SCALAR:
       return dispatch_group<1>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, long_thresh, s);
+    case MI_SPMM_SLAB:
+      if (!(vec4_ok && batch == 1 && K > 0)) return MI_EINVAL;
+      return mi::launch_spmm_slab(rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, long_thresh, s);
     case MI_SPMM_NARROW: {
       if (N >= 4) return MI_EINVAL;
       const long blocks = ((long)M + 3) / 4;
@@ -969,6 +982,7 @@ const char* mi_spmm_variant_name(int variant) {
     case MI_SPMM_GROUP_VEC4: case MI_SPMM_GROUP_VEC2: case MI_SPMM_GROUP_SCALAR: case MI_SPMM_COLTILE:
       return "spmm_group_kernel";
     case MI_SPMM_NARROW: return "spmm_narrow_kernel";
+    case MI_SPMM_SLAB: return "spmm_slab_kernel";
     case MI_SPMM_PANELS_2: case MI_SPMM_PANELS_3: case MI_SPMM_PANELS_4: case MI_SPMM_PANELS_5:
     case MI_SPMM_PANELS_6: case MI_SPMM_PANELS_8: case MI_SPMM_COLTILE_PANELS:
       return "spmm_wave_row_panel_kernel";

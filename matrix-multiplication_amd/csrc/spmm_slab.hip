@@ -1,0 +1,270 @@
+// Moderate-density CSR × dense for gfx950:  C = A·B with B staged through LDS in k-slabs.
+//
+// The row-split kernels (spmm_csr.hip) gather one 1-KB piece of a B row per non-zero and 256
+// columns through the texture path, ≈16 cycles of a CU's 64 B/clk load pipe each; at the
+// densities of pruned network weights (3–30 % non-zeros; the regime of the reference's
+// dense-vs-sparse sweep, benchmarks/random_tensor_benchmark.py:70-73) every B row is wanted by
+// many rows of A at once, so it pays to bring it on chip ONCE per 128 rows:
+//
+//  * a workgroup (16 waves) owns 128 rows of A × one 256-column tile of C; wave w keeps the
+//    accumulators of its 8 rows in registers for the whole k loop (lane l ↔ columns 4l…4l+3);
+//  * B is walked in slabs of 64 k-rows: the slab's 64 × 1 KB go global → registers → LDS (two
+//    LDS buffers, one barrier per slab, two register sets so a slab's loads are issued two
+//    iterations before they are needed);
+//  * each row keeps a 64-entry window of its (column, value) pairs in two VGPRs (lane j ↔ entry
+//    base+j).  Columns inside a row ascend, so the entries that fall into the current slab are a
+//    run starting at the row's cursor: one ballot counts them, v_readlane broadcasts each
+//    (column, value), and the B row comes from LDS with one ds_read_b128 per lane (256 B/clk
+//    instead of 64) feeding the fmaf chain;
+//  * non-zeros are consumed in CSR order (slabs ascend, entries inside a slab ascend), so the
+//    result is bit-identical to the row-split kernels and the oracle.
+//
+// CSR rows whose columns do NOT ascend are legal input (the reference's COO→CSR keeps the input
+// order inside a row, src/sparse_mm.cu:110-134): every window load checks the order, and a row
+// that breaks it is recomputed after the slab loop by the plain CSR-order gather chain from
+// global memory — same bits, just not fast.
+#include <limits.h>
+
+#include "mi_common.h"
+
+namespace {
+
+using mi::f32x4;
+
+constexpr int kSlab = 64;         // k rows of B per slab
+constexpr int kWaves = 16;        // waves per workgroup
+constexpr int kRows = 8;          // rows of A per wave
+constexpr int kStage = kSlab / kWaves;  // float4 per thread and slab
+constexpr int kTileCols = 256;    // columns of C per workgroup
+// LDS: two slabs of kSlab × 1 KB and one all-zero row (the target of padding slots, below)
+constexpr int kLdsVec = 2 * kSlab * 64 + 64;
+constexpr size_t kLdsBytes = (size_t)kLdsVec * sizeof(f32x4);
+
+__device__ __forceinline__ f32x4 fma4(float a, f32x4 x, f32x4 acc) {
+  acc.x = __builtin_fmaf(a, x.x, acc.x);
+  acc.y = __builtin_fmaf(a, x.y, acc.y);
+  acc.z = __builtin_fmaf(a, x.z, acc.z);
+  acc.w = __builtin_fmaf(a, x.w, acc.w);
+  return acc;
+}
+
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// grid: 1-D, XCD-aware over (column tile, row block) as launch_coltile in spmm_csr.hip: workgroup b
+// runs on XCD b % 8; XCD x takes column tiles x, x+8, … one after the other, all row blocks of a
+// tile before the next, so the workgroups streaming one K × 256 slice of B share an L2.
+__global__ __launch_bounds__(kWaves * 64) void spmm_slab_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+    const float* __restrict__ B, float* __restrict__ C, int M, int K, int N, long ldb, long ldc,
+    const float* __restrict__ bias, int ctiles, unsigned row_blocks, int long_thresh) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 lds[];  // [2][kSlab][64] + zero row [64]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+  const int tile = (int)(xcd + 8 * (idx / row_blocks));
+  if (tile >= ctiles) return;
+  const unsigned rb = idx % row_blocks;
+  const int c0 = tile * kTileCols;
+  const int ncols = N - c0 < kTileCols ? N - c0 : kTileCols;
+  const bool on = lane * 4 < ncols;  // N % 4 == 0: a lane's four columns are all in or all out
+  const int row0 = (int)rb * (kWaves * kRows) + wave * kRows;
+  constexpr int kZeroRow = 2 * kSlab;  // row index (in 64-float4 rows) of the zero row
+  if (wave == 0) lds[kZeroRow * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- per-row state: window of 64 entries, cursor, accumulators
+  int base[kRows], endp[kRows], pos[kRows], next[kRows];
+  int wcol[kRows];
+  float wval[kRows];
+  f32x4 acc[kRows];
+  unsigned unsorted = 0;  // bit i: row i's columns do not ascend → recomputed at the end
+  unsigned skip = 0;      // bit i: row beyond M, or left to the long-row kernel
+  auto load_window = [&](int i, int prev_last) {
+    const int e = base[i] + lane;
+    const bool v = e < endp[i];
+    wcol[i] = v ? col[e] : INT_MAX;
+    wval[i] = v ? val[e] : 0.f;
+    // ascending inside the window and across the window boundary?
+    int before = __shfl_up(wcol[i], 1, 64);
+    if (lane == 0) before = prev_last;
+    if (__any(v && wcol[i] < before)) unsorted |= 1u << i;
+  };
+#pragma unroll
+  for (int i = 0; i < kRows; ++i) {
+    const int r = row0 + i;
+    acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int s = 0, e = 0;
+    if (r < M) {
+      s = rowptr[r];
+      e = rowptr[r + 1];
+      if (e - s > long_thresh) {
+        e = s;
+        skip |= 1u << i;
+      }
+    } else {
+      skip |= 1u << i;
+    }
+    base[i] = s;
+    endp[i] = e;
+    pos[i] = 0;
+    load_window(i, INT_MIN);
+    next[i] = ((unsorted >> i) & 1u) ? INT_MAX : __builtin_amdgcn_readlane(wcol[i], 0);
+  }
+
+  // ---- slab staging: kSlab rows × 64 float4 = kStage float4 per thread (slab row = wave + 16·v),
+  // two register sets so a slab's loads have two whole iterations to land
+  const int nslab = (K + kSlab - 1) / kSlab;
+  const float* bcol = B + c0 + (on ? lane * 4 : 0);
+  auto load_slab = [&](f32x4 (&st)[kStage], int s) {
+#pragma unroll
+    for (int v = 0; v < kStage; ++v) {
+      int kr = s * kSlab + wave + kWaves * v;
+      kr = kr < K ? kr : K - 1;  // rows past K are never referenced: any valid address will do
+      st[v] = *reinterpret_cast<const f32x4*>(bcol + (long)kr * ldb);
+    }
+  };
+  auto store_slab = [&](const f32x4 (&st)[kStage], int buf) {
+#pragma unroll
+    for (int v = 0; v < kStage; ++v) lds[(buf * kSlab + wave + kWaves * v) * 64 + lane] = st[v];
+  };
+
+  // One slab: every row consumes its entries with column < slab_end from LDS buffer `cur`, then
+  // the registers holding slab s+1 go to the other buffer and are refilled with slab s+3.
+  auto do_slab = [&](int s, int cur, f32x4 (&st)[kStage]) {
+    const int k0 = s * kSlab;
+    const int slab_end = k0 + kSlab;
+    const int rowbase = cur * kSlab - k0;  // LDS row of column c: rowbase + c
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) {
+      // next[i] = column at the row's cursor (INT_MAX when the row is used up or set aside): a
+      // scalar compare decides whether the row has anything in this slab
+      while (next[i] < slab_end) {
+        // entries of this row inside the slab: a run of lanes starting at the cursor
+        const bool in = lane >= pos[i] && wcol[i] < slab_end;
+        const int n = __popcll(__ballot(in));
+        int j = 0;
+        for (; j + 4 <= n; j += 4) {  // four B rows in flight
+          int r[4];
+          float v[4];
+          f32x4 x[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            r[u] = rowbase + __builtin_amdgcn_readlane(wcol[i], pos[i] + j + u);
+            v[u] = readlane_f(wval[i], pos[i] + j + u);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) x[u] = lds[r[u] * 64 + lane];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[i] = fma4(v[u], x[u], acc[i]);
+        }
+        // the last 1–3, two at a time; an odd count is padded with the product (-0.0)·(+0.0) from
+        // the zero row, which leaves every bit of the accumulator as it is (x + (-0) = x, also ±0)
+        for (; j < n; j += 2) {
+          const int p0 = pos[i] + j, p1 = p0 + 1 < 63 ? p0 + 1 : 63;
+          const bool two = j + 1 < n;
+          const int r0 = rowbase + __builtin_amdgcn_readlane(wcol[i], p0);
+          const int c1 = __builtin_amdgcn_readlane(wcol[i], p1);
+          const int r1 = two ? rowbase + c1 : kZeroRow;
+          const float v0 = readlane_f(wval[i], p0);
+          const float v1r = readlane_f(wval[i], p1);
+          const float v1 = two ? v1r : -0.0f;
+          const f32x4 x0 = lds[r0 * 64 + lane];
+          const f32x4 x1 = lds[r1 * 64 + lane];
+          acc[i] = fma4(v0, x0, acc[i]);
+          acc[i] = fma4(v1, x1, acc[i]);
+        }
+        pos[i] += n;
+        if (pos[i] < 64) {
+          next[i] = __builtin_amdgcn_readlane(wcol[i], pos[i]);  // INT_MAX beyond the row's end
+          break;
+        }
+        if (base[i] + 64 >= endp[i]) {
+          next[i] = INT_MAX;
+          break;
+        }
+        // window used up and the row goes on: next 64 entries (may continue in this slab)
+        const int last = __builtin_amdgcn_readlane(wcol[i], 63);
+        base[i] += 64;
+        pos[i] = 0;
+        load_window(i, last);
+        next[i] = ((unsorted >> i) & 1u) ? INT_MAX : __builtin_amdgcn_readlane(wcol[i], 0);
+      }
+    }
+    if (s + 1 < nslab) {
+      store_slab(st, cur ^ 1);  // its last readers passed the previous barrier
+      if (s + 3 < nslab) load_slab(st, s + 3);
+    }
+    __syncthreads();
+  };
+
+  f32x4 sta[kStage], stb[kStage];
+  load_slab(sta, 0);
+  store_slab(sta, 0);
+  if (nslab > 2) load_slab(sta, 2);  // slab t travels in sta for even t, stb for odd t
+  if (nslab > 1) load_slab(stb, 1);
+  __syncthreads();
+  for (int s = 0; s < nslab; s += 2) {
+    do_slab(s, 0, stb);
+    if (s + 1 < nslab) do_slab(s + 1, 1, sta);
+  }
+
+  // ---- rows whose columns do not ascend: the plain CSR-order chain from global memory
+  if (unsorted) {
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) {
+      if (!((unsorted >> i) & 1u)) continue;
+      const int r = row0 + i;
+      f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int s = rowptr[r], e = rowptr[r + 1];
+      for (int p = s; p < e; p += 64) {
+        const int q = p + lane;
+        const int myc = q < e ? col[q] : 0;
+        const float myv = q < e ? val[q] : 0.f;
+        const int cnt = e - p < 64 ? e - p : 64;
+        for (int j = 0; j < cnt; ++j) {
+          const int cc = __builtin_amdgcn_readlane(myc, j);
+          const float vv = readlane_f(myv, j);
+          if (on) a = fma4(vv, *reinterpret_cast<const f32x4*>(bcol + (long)cc * ldb), a);
+        }
+      }
+      acc[i] = a;
+    }
+  }
+
+  // ---- epilogue
+  f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (bias && on) bv = *reinterpret_cast<const f32x4*>(bias + c0 + lane * 4);
+#pragma unroll
+  for (int i = 0; i < kRows; ++i) {
+    if ((skip >> i) & 1u) continue;
+    if (on) {
+      f32x4 o = acc[i];
+      if (bias) o += bv;
+      __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(C + (long)(row0 + i) * ldc + c0 + lane * 4));
+    }
+  }
+}
+
+}  // namespace
+
+namespace mi {
+
+// Requirements (checked by the caller, spmm_csr.hip): N % 4 == 0, ldb % 4 == 0, ldc % 4 == 0,
+// B / C / bias 16-byte aligned, K > 0.
+int launch_spmm_slab(const int32_t* rowptr, const int32_t* col, const float* val, const float* B, float* C,
+                     int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t ldc, const float* bias,
+                     int long_thresh, hipStream_t s) {
+  const long row_blocks = ((long)M + kWaves * kRows - 1) / (kWaves * kRows);
+  const int ctiles = (N + kTileCols - 1) / kTileCols;
+  const long blocks = 8L * ((ctiles + 7) / 8) * row_blocks;
+  if (blocks > 0x7fffffffL) return MI_ERANGE;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_slab_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+  if (attr != hipSuccess) return record_hip_error(attr);
+  hipLaunchKernelGGL(spmm_slab_kernel, dim3((unsigned)blocks), dim3(kWaves * 64), kLdsBytes, s, rowptr, col, val, B, C, M,
+                     K, N, (long)ldb, (long)ldc, bias, ctiles, (unsigned)row_blocks, long_thresh);
+  return check_launch();
+}
+
+}  // namespace mi

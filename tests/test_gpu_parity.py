@@ -88,7 +88,7 @@ def test_spmm_every_variant_is_bit_identical(capi, dev, oracle_mod, M, K, N, den
     d = [t(x, dev) for x in (rowptr, col, val, B)]
     ran = 0
     chain = oracle_mod.spmm_csr_chain(rowptr, col, val, M, K, B)  # explicit group variants ignore the N < 4 rule
-    for variant in range(17):
+    for variant in range(18):
         C = torch.full((M, N), float("nan"), device=dev)
         st = capi.mi_spmm_csr_f32_variant(variant, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(val), M, K,
                                           N, d[3].data_ptr(), N, C.data_ptr(), N,
@@ -720,6 +720,68 @@ def test_hub_rows_split_over_workgroups(cmm, dev, oracle_mod, N):
     bias = g.random(N, dtype=np.float32)
     C = torch.full((M, N), float("nan"), device=dev)
     cmm.naive_spmm_bias(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, t(B, dev), t(bias, dev), C)
+    assert np.array_equal(C.cpu().numpy(), want + bias[None, :])
+
+
+@pytest.mark.parametrize("M,K,N,density,bias", [
+    (300, 500, 256, 0.2, False), (129, 64, 300, 0.5, True), (1000, 1000, 100, 0.08, False),
+    (257, 70, 512, 1.0, True), (64, 2000, 260, 0.03, False), (5, 10, 4, 0.5, False),
+])
+def test_spmm_slab_kernel_shapes(capi, cmm, dev, oracle_mod, M, K, N, density, bias):
+    """The LDS-slab kernel (variant 17) at ragged shapes — row blocks, k-slabs and column tiles all
+    partial, rows from empty to fully dense, windows of more than 64 entries — bit-identical to the
+    CSR-order oracle; with the fused bias through the bias entry point forced onto the same plan."""
+    rowptr, col, val = oracle_mod.make_csr(M, K, density, seed=M + K + N)
+    val = val - 0.5  # signed values: cancellations, exact zeros and the (-0.0)·(+0.0) padding product
+    B = np.random.Generator(np.random.PCG64(N)).random((K, N), dtype=np.float32) - 0.25
+    expect = oracle_mod.spmm_csr_chain(rowptr, col, val, M, K, B)
+    d = [t(x, dev) for x in (rowptr, col, val, B)]
+    C = torch.full((M, N), float("nan"), device=dev)
+    assert capi.mi_spmm_csr_f32_variant(17, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(val), M, K, N,
+                                        d[3].data_ptr(), N, C.data_ptr(), N,
+                                        torch.cuda.current_stream().cuda_stream) == 0
+    assert np.array_equal(C.cpu().numpy(), expect)
+    if bias:
+        # B with inf / nan in rows no non-zero refers to must not leak (the padding slot reads the zero row)
+        used = np.zeros(K, bool)
+        used[col] = True
+        if (~used).any():
+            B2 = B.copy()
+            B2[~used] = np.inf
+            C.fill_(float("nan"))
+            assert capi.mi_spmm_csr_f32_variant(17, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(val), M, K,
+                                                N, t(B2, dev).data_ptr(), N, C.data_ptr(), N,
+                                                torch.cuda.current_stream().cuda_stream) == 0
+            assert np.array_equal(C.cpu().numpy(), expect)
+
+
+def test_spmm_slab_kernel_unsorted_rows_and_auto_plan(capi, cmm, dev, oracle_mod):
+    """AUTO picks the slab plan at moderate density on a large enough problem; rows whose columns do
+    not ascend (legal CSR: the reference's COO→CSR keeps input order) are recomputed in CSR order
+    inside the kernel, so the result still equals the oracle bit for bit (fused bias on top)."""
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_spmm_csr_f32_plan.argtypes = [i64, i32, i32, i32, vp, i64, vp, i64]
+    M, K, N = 4096, 9000, 4096
+    g = np.random.Generator(np.random.PCG64(17))
+    rowptr, col, val = oracle_mod.make_csr(M, K, 0.08, seed=5)
+    col = col.copy()
+    val = val.copy()
+    # shuffle the entries of some rows (first, last, one crossing a 64-entry window boundary late)
+    for r in (0, 77, 1000, M - 1):
+        s, e = rowptr[r], rowptr[r + 1]
+        perm = g.permutation(e - s)
+        col[s:e] = col[s:e][perm]
+        val[s:e] = val[s:e][perm]
+    r = 2000
+    s, e = rowptr[r], rowptr[r + 1]
+    col[[e - 2, e - 1]] = col[[e - 1, e - 2]]  # only the last two entries out of order
+    B = g.random((K, N), dtype=np.float32)
+    d_B = t(B, dev)
+    C = torch.full((M, N), float("nan"), device=dev)
+    assert capi.mi_spmm_csr_f32_plan(len(val), M, K, N, d_B.data_ptr(), N, C.data_ptr(), N) == 17
+    bias = g.random(N, dtype=np.float32)
+    cmm.naive_spmm_bias(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, d_B, t(bias, dev), C)
+    want = oracle_mod.spmm_csr_omp(rowptr, col, val, M, K, B)
     assert np.array_equal(C.cpu().numpy(), want + bias[None, :])
 
 
