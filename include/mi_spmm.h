@@ -66,8 +66,9 @@ int mi_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
  * chunks q, q+16S, …, in increasing position), workgroup g adds chains 16g … 16g+15 in that
  * order, and the S workgroup sums are added in order g = 0 … S-1 (then + bias).  The order
  * depends on the row length only.  Rows up to 8192 non-zeros keep the plain CSR-order chain, so
- * results equal mi_spmm_csr_f32 for them.  bias (N entries) may be NULL.  This is what
- * custom_mm.naive_spmm / cusparse_mmul call. */
+ * results equal mi_spmm_csr_f32 for them.  When the plan (mi_spmm_csr_f32_plan) is MI_SPMM_SLAB
+ * or MI_SPMM_NARROW no row is split: every row keeps that plan's own order.  bias (N entries)
+ * may be NULL.  This is what custom_mm.naive_spmm / cusparse_mmul call. */
 size_t mi_spmm_csr_workspace_bytes(int64_t nnz, int32_t N);
 int mi_spmm_csr_ws_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                        int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,

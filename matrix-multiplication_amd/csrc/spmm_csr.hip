@@ -884,7 +884,11 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
 
   // long rows get their own kernel when a workspace is there to list them (no row can be long
   // unless the matrix has more than kLongRow non-zeros)
-  const bool split = workspace != nullptr && batch == 1 && nnz > kLongRow && variant != MI_SPMM_NARROW;
+  // (the slab plan needs no split: a long row there is 8 rows' worth of ordinary work for its wave,
+  // not a serial tail — and a matrix dense enough to have thousands of long rows would drown the
+  // one-workgroup-per-row kernel; its rows all keep the plain CSR order)
+  const bool split = workspace != nullptr && batch == 1 && nnz > kLongRow && variant != MI_SPMM_NARROW &&
+                     variant != MI_SPMM_SLAB;
   int* ws = static_cast<int*>(workspace);
   const LongWs lw = long_ws_layout(nnz, N);
   if (split) {

@@ -785,6 +785,28 @@ def test_spmm_slab_kernel_unsorted_rows_and_auto_plan(capi, cmm, dev, oracle_mod
     assert np.array_equal(C.cpu().numpy(), want + bias[None, :])
 
 
+def test_spmm_slab_plan_keeps_csr_order_for_long_rows(capi, cmm, dev, oracle_mod):
+    """Under the slab plan rows of more than 8192 non-zeros are NOT handed to the long-row kernel
+    (mi_spmm.h: no split under MI_SPMM_SLAB): custom_mm.naive_spmm equals the plain CSR-order chain."""
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_spmm_csr_f32_plan.argtypes = [i64, i32, i32, i32, vp, i64, vp, i64]
+    M, K, N = 4096, 12000, 4096
+    g = np.random.Generator(np.random.PCG64(23))
+    mask = g.random((M, K), dtype=np.float32) < 0.08
+    mask[[3, 2500, M - 1]] = True       # three fully dense rows (12000 non-zeros each)
+    mask[7] = False                      # and an empty one
+    rows, col = np.nonzero(mask)
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=M))]).astype(np.int32)
+    col = col.astype(np.int32)
+    val = g.random(len(col), dtype=np.float32)
+    B = g.random((K, N), dtype=np.float32)
+    d_B = t(B, dev)
+    C = torch.full((M, N), float("nan"), device=dev)
+    assert capi.mi_spmm_csr_f32_plan(len(val), M, K, N, d_B.data_ptr(), N, C.data_ptr(), N) == 17
+    cmm.naive_spmm(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, d_B, C)
+    assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr_omp(rowptr, col, val, M, K, B))
+
+
 def test_spmm_shape_fuzz_against_oracle(cmm, capi, dev, oracle_mod):
     """Seeded random shapes through custom_mm.naive_spmm (AUTO dispatch incl. the column-tiled and
     panel plans, partial last tiles, odd widths) — every one bit-identical to the oracle."""
