@@ -155,7 +155,7 @@ def bench_c5(args):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BERT-base attention B=32 H=12 S=512 D=64 via cublasTransbMM / cublasMM .apply, fwd+bwd "
                                "(BASELINE.json configs[4])", "flops_per_step": flops},
-        "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (6 launches per step)", "achieved": round(flops / kern_ms / 1e9, 2),
+        "roofline": {"bound": "mfma", "kernel": "gemm_f32_pipe_kernel ×4 (k = 512) + gemm_f32_kernel ×2 (k = 64) per step", "achieved": round(flops / kern_ms / 1e9, 2),
                      "peak": 157.3, "unit": "TFLOP/s", "frac": round(flops / kern_ms / 1e9 / 157.3, 4), "traffic": None,
                      "note": "fp32-input MFMA peak (MI355X_MICROARCH.md); the q.kT product is also bound by writing "
                              "403 MB of scores"},
