@@ -1,5 +1,5 @@
 """Developer probe: square A (dim×dim) at several densities × dense B (dim×N): the row-split AUTO plan, the LDS-slab
-kernel (variant 17) and the dense MFMA product.   python tools/bench_density.py [dim] [N]"""
+kernel (variant 17) and the dense MFMA product.   python tools/bench_density.py [dim] [N] [densities…]"""
 import ctypes
 import sys
 from pathlib import Path
@@ -29,7 +29,8 @@ def timeit(fn, iters=5):
 
 B = torch.rand(dim, N, device=dev, generator=g)
 C0, C1 = torch.empty(dim, N, device=dev), torch.empty(dim, N, device=dev)
-for density in (0.5, 0.25, 0.1, 0.05, 0.03, 0.02, 0.01, 0.003):
+DENS = [float(x) for x in sys.argv[3:]] or [0.5, 0.25, 0.1, 0.05, 0.03, 0.02, 0.01, 0.003]
+for density in DENS:
     a = torch.rand(dim, dim, device=dev, generator=g)
     a = a * (torch.rand(dim, dim, device=dev, generator=g) < density)
     val, col, rp = custom_mm.dense_to_csr(a)
