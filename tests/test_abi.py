@@ -76,6 +76,29 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.mi_dense_to_csr_workspace_bytes(3, 7) >= 4 * 21
 
 
+def test_every_variant_id_has_a_kernel_name_and_the_plan_query_needs_no_gpu(lib):
+    """The MI_SPMM_* enum of mi_spmm.h, the name table and the AUTO planner agree (host-only calls)."""
+    import re
+    hdr = (Path(__file__).resolve().parent.parent / "include" / "mi_spmm.h").read_text()
+    count = int(re.search(r"MI_SPMM_VARIANT_COUNT\s*=\s*(\d+)", hdr).group(1))
+    ids = {int(v) for v in re.findall(r"MI_SPMM_[A-Z0-9_]+\s*=\s*(\d+)", hdr)} - {count}
+    assert ids == set(range(count))
+    lib.mi_spmm_variant_name.restype = ctypes.c_char_p
+    for v in range(1, count):
+        assert lib.mi_spmm_variant_name(v) != b"unknown", v
+    assert lib.mi_spmm_variant_name(count) == b"unknown"
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    lib.mi_spmm_csr_f32_plan.argtypes = [i64, i32, i32, i32, vp, i64, vp, i64]
+    al = 4096  # an aligned fake address: the planner only looks at alignment
+    plan = lambda nnz, M, K, N: lib.mi_spmm_csr_f32_plan(nnz, M, K, N, al, N, al, N)  # noqa: E731
+    assert plan(109945643, 1 << 20, 1 << 20, 256) == 7      # C3: two Infinity-Cache panels
+    assert plan(4292815, 65536, 65536, 128) == 4            # C2: group kernel, 16 B per lane
+    assert plan(100, 64, 64, 1) == 16                       # SpMV-like: narrow kernel
+    assert plan(int(0.1 * 8192 * 8192), 8192, 8192, 8192) == 17   # pruned-weight density: LDS slabs
+    assert plan(int(0.01 * 8192 * 8192), 8192, 8192, 8192) == 15  # 1 %: column tiles x row panels
+    assert plan(int(0.1 * 8192 * 8192), 8192, 8192, 256) == 2     # too few 128 x 256 blocks for the slab kernel
+
+
 def test_host_inspector_coo_to_csr(lib, golden, oracle_mod):
     c = golden.case("coo")
     M, nnz = c["a"].shape[0], len(c["val"])
