@@ -304,15 +304,114 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, int chunk
   dst[j] = acc;
 }
 
-// --------------------------------------------------------------------------
-// SDDMM: one wave per row of A; lane l sums j ≡ l (mod 64) ascending, then a
-// xor-butterfly (32,16,…,1) combines the 64 partial sums.
-// --------------------------------------------------------------------------
+// SDDMM on A's pattern (the gradient of C = A·B with respect to A's stored values):
+//   out[p] = Σ_j dC[row(p), j] · B[col[p], j]
+// Summation order (restated by oracle_sddmm_csr_f32): lane l of a 64-lane wave chains the products
+// of columns j = 256t + 4l + c (t ascending, c = 0…3, j < N) with fmaf, and the 64 lane sums are
+// combined by the xor tree 32, 16, 8, 4, 2, 1.
+//
+// One wave per row of A; the row of dC stays in registers (16 B per lane and 256 columns).  The
+// row's non-zeros are taken 64 at a time: eight 1-KB rows of B are gathered per step (the same
+// pipeline as the forward kernel), each leaving one partial sum per lane, and the 64 × 64 partial
+// sums of a batch are reduced TOGETHER: at xor distance w the two halves of the remaining values
+// are exchanged between the lanes with bit w clear and set, so every level halves the number of
+// live registers and after six levels lane i holds the finished out[p0 + i] — 63 exchanges for 64
+// results instead of 6 × 64, and one coalesced 256-B store.  The pairing is exactly the butterfly's,
+// so the bits are the same as a per-non-zero butterfly would give.
+template <int T, bool VEC>
 __global__ __launch_bounds__(256) void sddmm_kernel(const int* __restrict__ rowptr,
                                                     const int* __restrict__ col, int M, int N,
                                                     const float* __restrict__ dC, long lddc,
                                                     const float* __restrict__ B, long ldb,
                                                     float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (row >= M) return;
+  const int start = rowptr[row], end = rowptr[row + 1];
+  if (start == end) return;
+
+  // 4 consecutive columns per lane and pass; zero beyond N (0·y adds +0 to a sum that starts at +0)
+  auto load4 = [&](const float* src, int t) {
+    const int j = 256 * t + 4 * lane;
+    mi::f32x4 v = mi::f32x4{0.f, 0.f, 0.f, 0.f};
+    if (VEC) {
+      if (j < N) v = *reinterpret_cast<const mi::f32x4*>(src + j);
+    } else {
+      if (j + 0 < N) v.x = src[j + 0];
+      if (j + 1 < N) v.y = src[j + 1];
+      if (j + 2 < N) v.z = src[j + 2];
+      if (j + 3 < N) v.w = src[j + 3];
+    }
+    return v;
+  };
+  mi::f32x4 x[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) x[t] = load4(dC + row * lddc, t);
+
+  constexpr int U = 8;
+  for (int p0 = start; p0 < end; p0 += 64) {
+    const int cnt = end - p0 < 64 ? end - p0 : 64;
+    const int mycol = lane < cnt ? col[p0 + lane] : 0;
+    float s[64];
+#pragma unroll
+    for (int i = 0; i < 64; i += U) {
+      if (i < cnt) {
+        mi::f32x4 y[U][T];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float* brow = B + (long)__builtin_amdgcn_readlane(mycol, i + u) * ldb;  // row 0 when past cnt
+#pragma unroll
+          for (int t = 0; t < T; ++t) y[u][t] = load4(brow, t);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float acc = 0.f;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            // columns at or beyond N are not part of the chain (adding their +0 would turn a -0 sum into +0)
+            const int j = 256 * t + 4 * lane;
+            if (VEC) {
+              if (j < N) {  // N % 4 == 0: all four or none
+                acc = __builtin_fmaf(x[t].x, y[u][t].x, acc);
+                acc = __builtin_fmaf(x[t].y, y[u][t].y, acc);
+                acc = __builtin_fmaf(x[t].z, y[u][t].z, acc);
+                acc = __builtin_fmaf(x[t].w, y[u][t].w, acc);
+              }
+            } else {
+              if (j + 0 < N) acc = __builtin_fmaf(x[t].x, y[u][t].x, acc);
+              if (j + 1 < N) acc = __builtin_fmaf(x[t].y, y[u][t].y, acc);
+              if (j + 2 < N) acc = __builtin_fmaf(x[t].z, y[u][t].z, acc);
+              if (j + 3 < N) acc = __builtin_fmaf(x[t].w, y[u][t].w, acc);
+            }
+          }
+          s[i + u] = acc;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) s[i + u] = 0.f;
+      }
+    }
+    // joint xor tree: level w pairs value k with value k + w; lanes with bit w set keep the upper one
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+      const bool hi = (lane & w) != 0;
+#pragma unroll
+      for (int k = 0; k < w; ++k) {
+        const float keep = hi ? s[k + w] : s[k];
+        const float send = hi ? s[k] : s[k + w];
+        s[k] = keep + __shfl_xor(send, w, 64);
+      }
+    }
+    if (lane < cnt) out[p0 + lane] = s[0];
+  }
+}
+
+// Any N (used beyond 1024 columns): same order, one butterfly per non-zero.
+__global__ __launch_bounds__(256) void sddmm_generic_kernel(const int* __restrict__ rowptr,
+                                                            const int* __restrict__ col, int M, int N,
+                                                            const float* __restrict__ dC, long lddc,
+                                                            const float* __restrict__ B, long ldb,
+                                                            float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -321,7 +420,9 @@ __global__ __launch_bounds__(256) void sddmm_kernel(const int* __restrict__ rowp
   for (int p = start; p < end; ++p) {
     const float* y = B + (long)col[p] * ldb;
     float s = 0.f;
-    for (int j = lane; j < N; j += 64) s = __builtin_fmaf(x[j], y[j], s);
+    for (int j0 = 4 * lane; j0 < N; j0 += 256)
+      for (int c = 0; c < 4; ++c)
+        if (j0 + c < N) s = __builtin_fmaf(x[j0 + c], y[j0 + c], s);
 #pragma unroll
     for (int w = 32; w >= 1; w >>= 1) s += __shfl_xor(s, w, 64);
     if (lane == 0) out[p] = s;
@@ -532,8 +633,28 @@ int mi_sddmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz, int
   if (!rowptr || !col || !out_val) return MI_EINVAL;
   if (N > 0 && (!dC || !B || lddc < N || ldb < N)) return MI_EINVAL;
   const long blocks = ((long)M + 3) / 4;
-  hipLaunchKernelGGL(sddmm_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), rowptr, col, M, N, dC, lddc, B, ldb, out_val);
+  if (blocks > 0x7fffffffL) return MI_ERANGE;
+  if (N > 1024) {  // beyond four register passes of the dC row
+    hipLaunchKernelGGL(sddmm_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       rowptr, col, M, N, dC, (long)lddc, B, (long)ldb, out_val);
+    return mi::check_launch();
+  }
+  const bool vec = N % 4 == 0 && lddc % 4 == 0 && ldb % 4 == 0 && mi::aligned16(dC) && mi::aligned16(B);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int T = N <= 256 ? 1 : (N <= 512 ? 2 : 4);
+#define MI_SDDMM(T_, V_)                                                                                    \
+  hipLaunchKernelGGL((sddmm_kernel<T_, V_>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, M, N, dC, \
+                     (long)lddc, B, (long)ldb, out_val)
+  if (vec) {
+    if (T == 1) MI_SDDMM(1, true);
+    else if (T == 2) MI_SDDMM(2, true);
+    else MI_SDDMM(4, true);
+  } else {
+    if (T == 1) MI_SDDMM(1, false);
+    else if (T == 2) MI_SDDMM(2, false);
+    else MI_SDDMM(4, false);
+  }
+#undef MI_SDDMM
   return mi::check_launch();
 }
 

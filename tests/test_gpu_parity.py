@@ -228,14 +228,22 @@ def test_csr_transpose_bit_exact(cmm, dev, oracle_mod, M, K, density):
     assert np.array_equal(t_val.cpu().numpy(), e_val)
 
 
-@pytest.mark.parametrize("N", [1, 8, 64, 100, 256, 300])
+@pytest.mark.parametrize("N", [1, 8, 64, 100, 256, 300, 512, 777, 1024, 1500])
 def test_sddmm_bit_exact(cmm, dev, oracle_mod, N):
-    M, K = 120, 90
-    rowptr, col, val = oracle_mod.make_csr(M, K, 0.1, seed=N)
+    """Rows of 0 … 400 pattern entries (batches of 64 with a ragged tail), every register-pass count
+    of the dC row, odd widths (scalar loads) and the generic kernel beyond 1024 columns; signed data."""
+    M, K = 120, 400
+    rowptr, col, val = oracle_mod.make_csr(M, K, 0.3, seed=N)
     g = np.random.Generator(np.random.PCG64(N))
-    dC, B = g.random((M, N), dtype=np.float32), g.random((K, N), dtype=np.float32)
+    dC, B = g.random((M, N), dtype=np.float32) - 0.5, g.random((K, N), dtype=np.float32) - 0.5
     got = cmm.sddmm(t(col, dev), t(rowptr, dev), len(val), M, K, t(dC, dev), t(B, dev))
     assert np.array_equal(got.cpu().numpy(), oracle_mod.sddmm(rowptr, col, M, dC, B))
+    # strided operands (column slices of wider tensors) go through lddc / ldb
+    if N % 4 == 0 and N <= 512:
+        dCw, Bw = torch.rand(M, N + 8, device=dev) - 0.5, torch.rand(K, 2 * N, device=dev) - 0.5
+        got = cmm.sddmm(t(col, dev), t(rowptr, dev), len(val), M, K, dCw[:, 4:4 + N], Bw[:, N:])
+        assert np.array_equal(got.cpu().numpy(), oracle_mod.sddmm(rowptr, col, M, dCw[:, 4:4 + N].cpu().numpy(),
+                                                                   Bw[:, N:].cpu().numpy()))
 
 
 # ------------------------------------------------------------------ GEMM ----
