@@ -241,33 +241,36 @@ __global__ __launch_bounds__(256) void fill_csr_kernel(const float* __restrict__
 // --------------------------------------------------------------------------
 // CSR transpose helpers.
 // --------------------------------------------------------------------------
-__global__ void iota_kernel(int* out, long n) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (int)i;
+// CSR transpose helpers.  Every entry travels through the sort as an 8-byte payload
+// {row of A, value bits}, so the result needs no gather afterwards.
+__global__ __launch_bounds__(256) void pack_row_val_kernel(const int* __restrict__ rowptr, int M,
+                                                          const float* __restrict__ val,
+                                                          unsigned long long* __restrict__ payload) {
+  const int lane = threadIdx.x & 63;
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += (long)gridDim.x * 4) {
+    const int start = rowptr[row], end = rowptr[row + 1];
+    for (int p = start + lane; p < end; p += 64)
+      payload[p] = (unsigned long long)(unsigned)row |
+                   ((unsigned long long)__builtin_bit_cast(unsigned, val[p]) << 32);
+  }
 }
 
-__global__ void histogram_kernel(const int* __restrict__ col, long nnz, int* __restrict__ counts) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nnz) atomicAdd(&counts[col[i]], 1);
-}
-
-// q-th entry of Aᵀ comes from original entry p = perm[q]: its row in A (found
-// by binary search in rowptr) becomes the column index.
-__global__ void gather_transposed_kernel(const int* __restrict__ perm, long nnz,
-                                         const int* __restrict__ rowptr, int M,
-                                         const float* __restrict__ val, int* __restrict__ t_col,
-                                         float* __restrict__ t_val) {
+// After the stable sort by column: split the payload, and write the row offsets of Aᵀ from the
+// run boundaries of the sorted keys (t_rowptr[c] = first position whose key is ≥ c).
+__global__ __launch_bounds__(256) void unpack_transposed_kernel(const int* __restrict__ keys,
+                                                               const unsigned long long* __restrict__ payload,
+                                                               long nnz, int K, int* __restrict__ t_rowptr,
+                                                               int* __restrict__ t_col, float* __restrict__ t_val) {
   const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nnz) return;
-  const int p = perm[q];
-  int lo = 0, hi = M;  // largest r with rowptr[r] <= p
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (rowptr[mid] <= p) lo = mid;
-    else hi = mid;
-  }
-  t_col[q] = lo;
-  t_val[q] = val[p];
+  const unsigned long long w = payload[q];
+  t_col[q] = (int)(unsigned)w;
+  t_val[q] = __builtin_bit_cast(float, (unsigned)(w >> 32));
+  const int key = keys[q];
+  const int prev = q > 0 ? keys[q - 1] : -1;
+  for (int c = prev + 1; c <= key && c <= K; ++c) t_rowptr[c] = (int)q;  // empty columns in between start here too
+  if (q == nnz - 1)
+    for (int c = key + 1; c <= K; ++c) t_rowptr[c] = (int)nnz;
 }
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -535,21 +538,20 @@ int mi_dense_to_csr_fill(const float* dense, int32_t batch, int32_t rows, int32_
   return mi::check_launch();
 }
 
-// Workspace: sorted keys | iota | permutation | column counts | scan sums | rocPRIM temp.
+// Workspace: sorted keys | payload in | payload out | rocPRIM temp.
 static size_t transpose_sort_temp_bytes(int64_t nnz) {
   size_t bytes = 0;
   if (nnz > 0 &&
       rocprim::radix_sort_pairs(nullptr, bytes, (const int*)nullptr, (int*)nullptr,
-                                (const int*)nullptr, (int*)nullptr, (size_t)nnz, 0, 32,
-                                (hipStream_t)0) != hipSuccess)
+                                (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)nnz, 0,
+                                32, (hipStream_t)0) != hipSuccess)
     return 0;
   return bytes;
 }
 
 size_t mi_csr_transpose_workspace_bytes(int32_t M, int32_t K, int64_t nnz) {
   if (M < 0 || K < 0 || nnz < 0) return 0;
-  return 3 * align_up((size_t)nnz * 4) + align_up(((size_t)K + 1) * 4) +
-         align_up(scan_workspace_ints(K) * 4) + align_up(transpose_sort_temp_bytes(nnz));
+  return align_up((size_t)nnz * 4) + 2 * align_up((size_t)nnz * 8) + align_up(transpose_sort_temp_bytes(nnz));
 }
 
 int mi_csr_transpose_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
@@ -565,34 +567,27 @@ int mi_csr_transpose_f32(const int32_t* rowptr, const int32_t* col, const float*
   }
   if (!rowptr || !col || !val || !t_col || !t_val) return MI_EINVAL;
   if (workspace_bytes < mi_csr_transpose_workspace_bytes(M, K, nnz)) return MI_ENOMEM;
-  if (!workspace) return MI_EINVAL;
+  if (!workspace || !mi::aligned16(workspace)) return MI_EINVAL;
   char* w = static_cast<char*>(workspace);
   int* keys_out = reinterpret_cast<int*>(w);
   w += align_up((size_t)nnz * 4);
-  int* iota = reinterpret_cast<int*>(w);
-  w += align_up((size_t)nnz * 4);
-  int* perm = reinterpret_cast<int*>(w);
-  w += align_up((size_t)nnz * 4);
-  int* counts = reinterpret_cast<int*>(w);
-  w += align_up(((size_t)K + 1) * 4);
-  int* block_sums = reinterpret_cast<int*>(w);
-  w += align_up(scan_workspace_ints(K) * 4);
+  unsigned long long* pay_in = reinterpret_cast<unsigned long long*>(w);
+  w += align_up((size_t)nnz * 8);
+  unsigned long long* pay_out = reinterpret_cast<unsigned long long*>(w);
+  w += align_up((size_t)nnz * 8);
   size_t temp_bytes = transpose_sort_temp_bytes(nnz);
 
-  const unsigned nb = (unsigned)((nnz + 255) / 256);
-  // rows of Aᵀ: histogram of columns → exclusive scan (rows = K, one "item").
-  MI_HIP_TRY(hipMemsetAsync(counts, 0, sizeof(int) * ((size_t)K + 1), s));
-  hipLaunchKernelGGL(histogram_kernel, dim3(nb), dim3(256), 0, s, col, nnz, counts);
-  int st = launch_scan_rowptr(counts, K, K, t_rowptr, block_sums, s);
-  if (st != MI_OK) return st;
-  // stable sort of entry ids by column: inside a row of Aᵀ entries keep
-  // ascending original order (= ascending row of A).
-  hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, s, iota, nnz);
+  // {row, value} per entry, written coalesced by one wave per row of A
+  const long row_blocks = ((long)M + 3) / 4;
+  hipLaunchKernelGGL(pack_row_val_kernel, dim3((unsigned)(row_blocks < 65536 * 16 ? row_blocks : 65536 * 16)),
+                     dim3(256), 0, s, rowptr, M, val, pay_in);
+  // stable sort by column: inside a row of Aᵀ the entries keep ascending original order
+  // (= ascending row of A); only the bits a column index can have take part
   int end_bit = 1;
   while (end_bit < 32 && (1LL << end_bit) < (long long)K) ++end_bit;
-  MI_HIP_TRY(rocprim::radix_sort_pairs(w, temp_bytes, col, keys_out, iota, perm, (size_t)nnz, 0,
-                                       end_bit, s));
-  hipLaunchKernelGGL(gather_transposed_kernel, dim3(nb), dim3(256), 0, s, perm, nnz, rowptr, M, val,
+  MI_HIP_TRY(rocprim::radix_sort_pairs(w, temp_bytes, col, keys_out, pay_in, pay_out, (size_t)nnz, 0, end_bit, s));
+  const unsigned nb = (unsigned)((nnz + 255) / 256);
+  hipLaunchKernelGGL(unpack_transposed_kernel, dim3(nb), dim3(256), 0, s, keys_out, pay_out, (long)nnz, K, t_rowptr,
                      t_col, t_val);
   return mi::check_launch();
 }

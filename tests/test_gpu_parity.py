@@ -218,7 +218,8 @@ def test_dense_to_csr_bit_exact(cmm, dev, oracle_mod, shape, density):
     assert np.array_equal(cols.cpu().numpy(), col) and np.array_equal(vals.cpu().numpy(), val)
 
 
-@pytest.mark.parametrize("M,K,density", [(300, 170, 0.05), (50, 4000, 0.01), (4000, 50, 0.3), (1, 1, 1.0), (64, 64, 0.0)])
+@pytest.mark.parametrize("M,K,density", [(300, 170, 0.05), (50, 4000, 0.01), (4000, 50, 0.3), (1, 1, 1.0), (64, 64, 0.0),
+                                          (7, 100000, 0.00002), (3000, 3000, 0.02)])
 def test_csr_transpose_bit_exact(cmm, dev, oracle_mod, M, K, density):
     rowptr, col, val = oracle_mod.make_csr(M, K, density, seed=3) if density > 0 else \
         (np.zeros(M + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32))
