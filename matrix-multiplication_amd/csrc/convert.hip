@@ -313,7 +313,8 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, int chunk
 // of columns j = 256t + 4l + c (t ascending, c = 0…3, j < N) with fmaf, and the 64 lane sums are
 // combined by the xor tree 32, 16, 8, 4, 2, 1.
 //
-// One wave per row of A; the row of dC stays in registers (16 B per lane and 256 columns).  The
+// One wave per row of A; 256·T columns of the dC row sit in registers at a time (16 B per lane and
+// 256 columns; wider rows are walked in chunks, each lane's chain simply continuing).  The
 // row's non-zeros are taken 64 at a time: eight 1-KB rows of B are gathered per step (the same
 // pipeline as the forward kernel), each leaving one partial sum per lane, and the 64 × 64 partial
 // sums of a batch are reduced TOGETHER: at xor distance w the two halves of the remaining values
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256) void sddmm_kernel(const int* __restrict__ rowp
   const int start = rowptr[row], end = rowptr[row + 1];
   if (start == end) return;
 
-  // 4 consecutive columns per lane and pass; zero beyond N (0·y adds +0 to a sum that starts at +0)
+  // 4 consecutive columns per lane and pass (zeros beyond N, which the chain below never uses)
   auto load4 = [&](const float* src, int t) {
     const int j = 256 * t + 4 * lane;
     mi::f32x4 v = mi::f32x4{0.f, 0.f, 0.f, 0.f};
@@ -347,51 +348,53 @@ __global__ __launch_bounds__(256) void sddmm_kernel(const int* __restrict__ rowp
     }
     return v;
   };
-  mi::f32x4 x[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) x[t] = load4(dC + row * lddc, t);
-
   constexpr int U = 8;
+  const float* xrow = dC + row * lddc;
   for (int p0 = start; p0 < end; p0 += 64) {
     const int cnt = end - p0 < 64 ? end - p0 : 64;
     const int mycol = lane < cnt ? col[p0 + lane] : 0;
     float s[64];
 #pragma unroll
-    for (int i = 0; i < 64; i += U) {
-      if (i < cnt) {
-        mi::f32x4 y[U][T];
+    for (int i = 0; i < 64; ++i) s[i] = 0.f;
+    // columns in chunks of 256·T (one chunk when N ≤ 256·T): each lane's chain simply continues
+    for (int t0 = 0; 256 * t0 < N; t0 += T) {
+      mi::f32x4 x[T];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const float* brow = B + (long)__builtin_amdgcn_readlane(mycol, i + u) * ldb;  // row 0 when past cnt
+      for (int t = 0; t < T; ++t) x[t] = load4(xrow, t0 + t);
 #pragma unroll
-          for (int t = 0; t < T; ++t) y[u][t] = load4(brow, t);
-        }
+      for (int i = 0; i < 64; i += U) {
+        if (i < cnt) {
+          mi::f32x4 y[U][T];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          float acc = 0.f;
+          for (int u = 0; u < U; ++u) {
+            const float* brow = B + (long)__builtin_amdgcn_readlane(mycol, i + u) * ldb;  // row 0 when past cnt
 #pragma unroll
-          for (int t = 0; t < T; ++t) {
-            // columns at or beyond N are not part of the chain (adding their +0 would turn a -0 sum into +0)
-            const int j = 256 * t + 4 * lane;
-            if (VEC) {
-              if (j < N) {  // N % 4 == 0: all four or none
-                acc = __builtin_fmaf(x[t].x, y[u][t].x, acc);
-                acc = __builtin_fmaf(x[t].y, y[u][t].y, acc);
-                acc = __builtin_fmaf(x[t].z, y[u][t].z, acc);
-                acc = __builtin_fmaf(x[t].w, y[u][t].w, acc);
-              }
-            } else {
-              if (j + 0 < N) acc = __builtin_fmaf(x[t].x, y[u][t].x, acc);
-              if (j + 1 < N) acc = __builtin_fmaf(x[t].y, y[u][t].y, acc);
-              if (j + 2 < N) acc = __builtin_fmaf(x[t].z, y[u][t].z, acc);
-              if (j + 3 < N) acc = __builtin_fmaf(x[t].w, y[u][t].w, acc);
-            }
+            for (int t = 0; t < T; ++t) y[u][t] = load4(brow, t0 + t);
           }
-          s[i + u] = acc;
-        }
-      } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u) s[i + u] = 0.f;
+          for (int u = 0; u < U; ++u) {
+            float acc = s[i + u];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              // columns at or beyond N are not part of the chain (adding their +0 would turn a -0 sum into +0)
+              const int j = 256 * (t0 + t) + 4 * lane;
+              if (VEC) {
+                if (j < N) {  // N % 4 == 0: all four or none
+                  acc = __builtin_fmaf(x[t].x, y[u][t].x, acc);
+                  acc = __builtin_fmaf(x[t].y, y[u][t].y, acc);
+                  acc = __builtin_fmaf(x[t].z, y[u][t].z, acc);
+                  acc = __builtin_fmaf(x[t].w, y[u][t].w, acc);
+                }
+              } else {
+                if (j + 0 < N) acc = __builtin_fmaf(x[t].x, y[u][t].x, acc);
+                if (j + 1 < N) acc = __builtin_fmaf(x[t].y, y[u][t].y, acc);
+                if (j + 2 < N) acc = __builtin_fmaf(x[t].z, y[u][t].z, acc);
+                if (j + 3 < N) acc = __builtin_fmaf(x[t].w, y[u][t].w, acc);
+              }
+            }
+            s[i + u] = acc;
+          }
+        }
       }
     }
     // joint xor tree: level w pairs value k with value k + w; lanes with bit w set keep the upper one
@@ -406,29 +409,6 @@ __global__ __launch_bounds__(256) void sddmm_kernel(const int* __restrict__ rowp
       }
     }
     if (lane < cnt) out[p0 + lane] = s[0];
-  }
-}
-
-// Any N (used beyond 1024 columns): same order, one butterfly per non-zero.
-__global__ __launch_bounds__(256) void sddmm_generic_kernel(const int* __restrict__ rowptr,
-                                                            const int* __restrict__ col, int M, int N,
-                                                            const float* __restrict__ dC, long lddc,
-                                                            const float* __restrict__ B, long ldb,
-                                                            float* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const float* x = dC + row * lddc;
-  const int start = rowptr[row], end = rowptr[row + 1];
-  for (int p = start; p < end; ++p) {
-    const float* y = B + (long)col[p] * ldb;
-    float s = 0.f;
-    for (int j0 = 4 * lane; j0 < N; j0 += 256)
-      for (int c = 0; c < 4; ++c)
-        if (j0 + c < N) s = __builtin_fmaf(x[j0 + c], y[j0 + c], s);
-#pragma unroll
-    for (int w = 32; w >= 1; w >>= 1) s += __shfl_xor(s, w, 64);
-    if (lane == 0) out[p] = s;
   }
 }
 
@@ -629,25 +609,18 @@ int mi_sddmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz, int
   if (N > 0 && (!dC || !B || lddc < N || ldb < N)) return MI_EINVAL;
   const long blocks = ((long)M + 3) / 4;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
-  if (N > 1024) {  // beyond four register passes of the dC row
-    hipLaunchKernelGGL(sddmm_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       rowptr, col, M, N, dC, (long)lddc, B, (long)ldb, out_val);
-    return mi::check_launch();
-  }
   const bool vec = N % 4 == 0 && lddc % 4 == 0 && ldb % 4 == 0 && mi::aligned16(dC) && mi::aligned16(B);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int T = N <= 256 ? 1 : (N <= 512 ? 2 : 4);
+  const int T = N <= 256 ? 1 : 2;  // wider rows: chunks of 512 columns
 #define MI_SDDMM(T_, V_)                                                                                    \
   hipLaunchKernelGGL((sddmm_kernel<T_, V_>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, M, N, dC, \
                      (long)lddc, B, (long)ldb, out_val)
   if (vec) {
     if (T == 1) MI_SDDMM(1, true);
-    else if (T == 2) MI_SDDMM(2, true);
-    else MI_SDDMM(4, true);
+    else MI_SDDMM(2, true);
   } else {
     if (T == 1) MI_SDDMM(1, false);
-    else if (T == 2) MI_SDDMM(2, false);
-    else MI_SDDMM(4, false);
+    else MI_SDDMM(2, false);
   }
 #undef MI_SDDMM
   return mi::check_launch();

@@ -229,10 +229,10 @@ def test_csr_transpose_bit_exact(cmm, dev, oracle_mod, M, K, density):
     assert np.array_equal(t_val.cpu().numpy(), e_val)
 
 
-@pytest.mark.parametrize("N", [1, 8, 64, 100, 256, 300, 512, 777, 1024, 1500])
+@pytest.mark.parametrize("N", [1, 8, 64, 100, 256, 300, 512, 777, 1024, 1500, 4100])
 def test_sddmm_bit_exact(cmm, dev, oracle_mod, N):
     """Rows of 0 … 400 pattern entries (batches of 64 with a ragged tail), every register-pass count
-    of the dC row, odd widths (scalar loads) and the generic kernel beyond 1024 columns; signed data."""
+    of the dC row, odd widths (scalar loads) and rows wider than one register chunk; signed data."""
     M, K = 120, 400
     rowptr, col, val = oracle_mod.make_csr(M, K, 0.3, seed=N)
     g = np.random.Generator(np.random.PCG64(N))
