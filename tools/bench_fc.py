@@ -56,4 +56,5 @@ gb = torch.empty(1, fout, device=dev)
 print(f"fwd x.WT        {timeit(lambda: custom_mm.cublas_mmul(x, w, y, False, True)):.3f} ms (torch {timeit(lambda: torch.matmul(x, w.t(), out=y)):.3f})")
 print(f"grad_inp dY.W   {timeit(lambda: custom_mm.cublas_mmul(dy, w, gi, False, False)):.3f} ms (torch {timeit(lambda: torch.matmul(dy, w, out=gi)):.3f})")
 print(f"grad_w dYT.x    {timeit(lambda: custom_mm.cublas_mmul(dy, x, gw, True, False)):.3f} ms (torch {timeit(lambda: torch.matmul(dy.t(), x, out=gw)):.3f})")
-print(f"grad_b 1T.dY    {timeit(lambda: custom_mm.cublas_mmul(ones, dy, gb, False, False)):.3f} ms (torch sum {timeit(lambda: dy.sum(0)):.3f})")
+print(f"grad_b colsums  {timeit(lambda: custom_mm.column_sums(dy)):.3f} ms (torch sum {timeit(lambda: dy.sum(0)):.3f}; as a 1 x tokens GEMM "
+      f"{timeit(lambda: custom_mm.cublas_mmul(ones, dy, gb, False, False)):.3f})")
