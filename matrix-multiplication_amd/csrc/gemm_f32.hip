@@ -27,12 +27,12 @@
 //    q·kᵀ (k = 64) is bound by writing the 403 MB of scores and runs here.
 //  * gemm_f32_pipe_kernel (k ≥ 256): two LDS buffers, ONE barrier per k-tile.  While the MFMAs
 //    of tile t run, the registers holding tile t+1 go to the other buffer (dealt 2 LDS writes per
-//    MFMA) and the loads of tile t+2 are issued (1 per MFMA); operand reads run one 8-MFMA batch
-//    ahead.  The issue order is pinned with sched_group_barrier/sched_barrier: left alone, hipcc
+//    MFMA) and the loads of tile t+3 are issued (1 per MFMA; two register sets, so a load has
+//    almost two k-tiles to land); operand reads run one 8-MFMA batch ahead.  The issue order is pinned with sched_group_barrier/sched_barrier: left alone, hipcc
 //    sinks the loads to the end of the tile, directly in front of the waits on them.
 // Measured (MI355X, fp32 MFMA peak 157 TFLOP/s; tools/gemm_square_probe.py, tools/bench_misc.py):
-// 8192³ A·Bᵀ 7.80 ms = 141 TFLOP/s (single-buffer kernel 8.37, rocBLAS 7.15), A·B 8.16,
-// Aᵀ·B 8.31; 4096³ 0.985–1.06 ms (rocBLAS 0.91); 1024³ 0.026 ms (was 0.034; rocBLAS 0.022);
+// 8192³ A·Bᵀ 7.64 ms = 144 TFLOP/s (single-buffer kernel 8.37, rocBLAS 7.15), A·B 7.90,
+// Aᵀ·B 8.10; 4096³ 0.97–1.02 ms (rocBLAS 0.91); 1024³ 0.026 ms (was 0.034; rocBLAS 0.022);
 // BERT-base attention (B 32, H 12, S 512, D 64): q·kᵀ 0.164 ms (rocBLAS 0.184), probs·v
 // 0.144 ms (was 0.156; rocBLAS 0.131).  Ablation of the pipelined kernel at 8192³: MFMAs alone
 // 7.13 ms; + operand reads 7.34; + LDS writes 7.52; + global loads 7.80 (half of that is issue
@@ -337,20 +337,26 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
   // straight-line loop below; everything else the simple one with the bounds-checked loader
   const bool interior = vecA && vecB && m0 + BM <= m && n0 + BN <= n && k % BK == 0;
   if (interior) {
-    f32x4 ra[LA::VECS], rb[LB::VECS];
-    LA::load_fast(ra, A, lda, m0, 0, tid);
-    LB::load_fast(rb, B, ldb, n0, 0, tid);
-    LA::store(ra, lds, tid);
-    LB::store(rb, lds + LA::LDS_FLOATS, tid);
+    // Two register sets: tile t+1 and tile t+3 travel in one, tile t+2 in the other, so a tile's
+    // global loads are issued almost two k-tiles (not one) before they are written to LDS — the
+    // MFMA phase of a 128×64 tile is only ≈0.85 µs, shorter than an HBM round trip.
+    f32x4 ra0[LA::VECS], rb0[LB::VECS], ra1[LA::VECS], rb1[LB::VECS];
     const int k_last = k - BK;  // start of the last tile: later "prefetches" re-read it (never used)
-    {
-      const int k1 = BK < k_last ? BK : k_last;
-      LA::load_fast(ra, A, lda, m0, k1, tid);
-      LB::load_fast(rb, B, ldb, n0, k1, tid);
-    }
+    auto load_tile = [&](f32x4 (&ra)[LA::VECS], f32x4 (&rb)[LB::VECS], int k0) {
+      const int kk = k0 < k_last ? k0 : k_last;
+      LA::load_fast(ra, A, lda, m0, kk, tid);
+      LB::load_fast(rb, B, ldb, n0, kk, tid);
+    };
+    load_tile(ra0, rb0, 0);
+    LA::store(ra0, lds, tid);
+    LB::store(rb0, lds + LA::LDS_FLOATS, tid);
+    load_tile(ra1, rb1, BK);       // odd tiles travel in set 1
+    load_tile(ra0, rb0, 2 * BK);   // even tiles in set 0
     __syncthreads();
-    int buf = 0;
-    for (int k0 = 0; k0 < k; k0 += BK, buf ^= 1) {
+
+    // One k-tile: MFMAs out of LDS buffer `buf`; the set holding tile t+1 goes to the other buffer
+    // and is refilled with tile t+3.
+    auto k_tile = [&](int k0, int buf, f32x4 (&ra)[LA::VECS], f32x4 (&rb)[LB::VECS]) {
       const float* As = lds + buf * kStage;
       const float* Bs = As + LA::LDS_FLOATS;
       float* An = lds + (buf ^ 1) * kStage;
@@ -372,16 +378,12 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
       for (int s = 0; s < BK / 4; ++s) {
         if (s + 1 < BK / 4) read_batch(s + 1, (s + 1) & 1);
         if (s == 0) {
-          // tile t+1 (loaded during tile t-1): registers → the other buffer, whose last readers
-          // passed the previous barrier.  After the last tile this writes a buffer nobody reads.
+          // tile t+1: registers → the other buffer, whose last readers passed the previous
+          // barrier.  After the last tile this writes a buffer nobody reads.
           LA::store(ra, An, tid);
           LB::store(rb, Bn, tid);
         }
-        if (s == 1) {
-          const int k2 = k0 + 2 * BK < k_last ? k0 + 2 * BK : k_last;
-          LA::load_fast(ra, A, lda, m0, k2, tid);
-          LB::load_fast(rb, B, ldb, n0, k2, tid);
-        }
+        if (s == 1) load_tile(ra, rb, k0 + 3 * BK);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -410,6 +412,10 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
+    };
+    for (int k0 = 0; k0 < k; k0 += 2 * BK) {
+      k_tile(k0, 0, ra1, rb1);                        // even tile: tile t+1 is odd → set 1
+      if (k0 + BK < k) k_tile(k0 + BK, 1, ra0, rb0);  // odd tile: tile t+1 is even → set 0
     }
   } else {
     f32x4 ra[LA::VECS], rb[LB::VECS];
