@@ -483,7 +483,7 @@ int launch_coltile(const int* rowptr, const int* col, const float* val, const fl
 // 65536×8192 × 1024 0.5 % 1.33 → 0.51 ms, 8192² 1 % 2.96 → 2.13 ms, 16384² 1 % 24.2 → 20.7 ms.
 int coltile_width(int32_t M, int32_t K, int32_t N, int64_t ldb) {
   const long slice_budget = 4L << 20;
-  if (N < 512 || M < 2048 || (long)K * ldb * 4 <= (8L << 20)) return 0;  // narrow, short, or B small as it is
+  if (N < 512 || M < 512 || (long)K * ldb * 4 <= (8L << 20)) return 0;  // narrow, short, or B small as it is
   for (int w : {256, 128, 64}) {
     if ((long)K * w * 4 > slice_budget || N < 8 * w) continue;
     const int tiles = (N + w - 1) / w, rounds = (tiles + 7) / 8;
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256) void combine_long_rows_kernel(const int* __res
 // like the two-panel path), so each XCD gathers from a (K/P) × 256 slice of ≈3 MiB.
 // Returns the number of panels, or 0 when the plan does not apply.
 int coltile_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
-  if (N % 256 != 0 || N < 2048 || M < 2048 || ldb != N) return 0;
+  if (N % 256 != 0 || N < 2048 || M < 512 || ldb != N) return 0;
   if ((long)K * 1024 <= (4L << 20)) return 0;              // plain column tiling already fits
   const int panels = (int)(((long)K * 1024 + (3L << 20) - 1) / (3L << 20));
   if (panels > 16 || nnz < 8L * panels * M) return 0;       // too many C round trips for the work per pass
@@ -774,15 +774,20 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
       nnz * (long)N >= 8 * b_elems)
     return MI_SPMM_PANELS_2;
   if (N < 4) return MI_SPMM_NARROW;
-  // Moderate density on a problem with enough 128 × 256 output blocks to fill the chip: stage B
-  // through LDS (spmm_slab.hip).  Measured (tools/bench_density.py, square A): 8192² × 8192 at
-  // 50 / 25 / 10 / 5 % non-zeros 19.9 / 11.2 / 5.9 / 4.1 ms vs 41.8 / 22.4 / 9.4 / 4.9 ms row-split;
-  // 4096² × 4096 at 25 / 10 % 1.41 / 0.75 vs 2.52 / 0.98 ms; it loses below ≈512 workgroups
-  // (8192² × 1024: 1.48 vs 1.12 ms at 10 %) and below ≈4–7 % density.
-  if (sh.vec4_ok && batch == 1 && K >= 64) {
-    const long wgs = (((long)M + 127) / 128) * (((long)N + 255) / 256);
+  // Moderate density: stage B through LDS (spmm_slab.hip) when its cost model beats the L2-blocked
+  // row-split plans.  Fitted on MI355X (tools/bench_density.py, tools/bench_plans.py): a slab
+  // workgroup (128 rows × 256 columns) spends ≈2.35 µs + 34 µs × density per 64-row slab of B, one
+  // workgroup per CU at a time; the row-split plans sustain ≈13 TFLOP/s with L2 blocking (N ≥ 512)
+  // and ≈5 without.  E.g. 8192² × 8192 at 10 %: 5.9 ms slab vs 9.4 ms; 4096² × 2048 at 20 %: 0.60 vs
+  // 0.96 ms; 8192² × 8192 at 3 %: 3.3 vs 3.0 ms (row-split kept).
+  if (sh.vec4_ok && batch == 1 && K >= 64 && N >= 128 && nnz > 0) {
+    const double wgs = (double)(((long)M + 127) / 128) * (double)(((long)N + 255) / 256);
     const double density = (double)nnz / ((double)M * (double)K);
-    if ((wgs >= 2048 && density >= 0.04) || (wgs >= 512 && density >= 0.07)) return MI_SPMM_SLAB;
+    const double rounds = wgs <= 256.0 ? 1.0 : wgs / 256.0;  // beyond one wave of workgroups the tail averages out
+    const double t_slab = rounds * (double)(((long)K + 63) / 64) * (2.35e-6 + 34e-6 * density);
+    const double t_rows = 2.0 * (double)nnz * (double)N / (N >= 512 ? 13e12 : 5e12);
+    // below ≈100 workgroups too few CUs have work for the model to hold
+    if (wgs >= 96.0 && t_slab < t_rows) return MI_SPMM_SLAB;
   }
   if (sh.vec4_ok && batch == 1 && coltile_panels(M, K, N, ldb, nnz) > 0) return MI_SPMM_COLTILE_PANELS;
   if (sh.vec4_ok && batch == 1 && coltile_width(M, K, N, ldb) > 0) return MI_SPMM_COLTILE;

@@ -52,9 +52,7 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
-// grid: 1-D, XCD-aware over (column tile, row block) as launch_coltile in spmm_csr.hip: workgroup b
-// runs on XCD b % 8; XCD x takes column tiles x, x+8, … one after the other, all row blocks of a
-// tile before the next, so the workgroups streaming one K × 256 slice of B share an L2.
+// grid: 1-D over (column tile, row block), dealt XCD-contiguously (below).
 __global__ __launch_bounds__(kWaves * 64) void spmm_slab_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ B, float* __restrict__ C, int M, int K, int N, long ldb, long ldc,
@@ -62,10 +60,14 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_slab_kernel(
   extern __shared__ __attribute__((aligned(16))) f32x4 lds[];  // [2][kSlab][64] + zero row [64]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const unsigned xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
-  const int tile = (int)(xcd + 8 * (idx / row_blocks));
-  if (tile >= ctiles) return;
-  const unsigned rb = idx % row_blocks;
+  // XCD-contiguous work order (workgroup b runs on XCD b % 8): XCD x takes a contiguous eighth of
+  // the (column tile, row block) list, tile-major, so the workgroups streaming one K × 256 slice of
+  // B share an L2 — and every XCD gets the same amount of work whatever the number of column
+  // tiles.  Bijective for any grid size; speed only.
+  const unsigned total = gridDim.x, q8 = total / 8, rem = total % 8, xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+  const unsigned work = xcd * q8 + (xcd < rem ? xcd : rem) + slot;
+  const int tile = (int)(work / row_blocks);
+  const unsigned rb = work % row_blocks;
   const int c0 = tile * kTileCols;
   const int ncols = N - c0 < kTileCols ? N - c0 : kTileCols;
   const bool on = lane * 4 < ncols;  // N % 4 == 0: a lane's four columns are all in or all out
@@ -257,7 +259,7 @@ int launch_spmm_slab(const int32_t* rowptr, const int32_t* col, const float* val
                      int long_thresh, hipStream_t s) {
   const long row_blocks = ((long)M + kWaves * kRows - 1) / (kWaves * kRows);
   const int ctiles = (N + kTileCols - 1) / kTileCols;
-  const long blocks = 8L * ((ctiles + 7) / 8) * row_blocks;
+  const long blocks = (long)ctiles * row_blocks;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_slab_kernel),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
