@@ -764,6 +764,37 @@ def test_spmm_slab_kernel_shapes(capi, cmm, dev, oracle_mod, M, K, N, density, b
             assert np.array_equal(C.cpu().numpy(), expect)
 
 
+def test_spmm_slab_kernel_fuzz(capi, dev, oracle_mod):
+    """Seeded random shapes / densities through the LDS-slab kernel (variant 17), a fraction of the
+    rows shuffled out of column order, duplicate columns allowed — always the CSR-order chain."""
+    rng = np.random.Generator(np.random.PCG64(4242))
+    for case in range(30):
+        M = int(rng.integers(1, 400))
+        K = int(rng.integers(1, 700))
+        N = 4 * int(rng.integers(1, 160))
+        density = float(rng.choice([0.0, 0.01, 0.1, 0.5, 1.0]))
+        lens = rng.binomial(K, density, size=M) if density < 1.0 else np.full(M, K)
+        if case % 5 == 0:
+            lens = (lens * rng.integers(0, 3, size=M)).clip(0, 3 * K)  # rows longer than K: duplicate columns
+        cols = []
+        for n in lens:
+            c = rng.integers(0, K, size=int(n)) if n > K else rng.choice(K, size=int(n), replace=False)
+            c = np.sort(c)
+            if rng.random() < 0.2:
+                c = rng.permutation(c)  # an unsorted row
+            cols.append(c.astype(np.int32))
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        col = np.concatenate(cols) if len(cols) else np.zeros(0, np.int32)
+        val = (rng.random(len(col), dtype=np.float32) - 0.5)
+        B = rng.random((K, N), dtype=np.float32) - 0.5
+        d = [t(x, dev) for x in (rowptr, col, val, B)]
+        C = torch.full((M, N), float("nan"), device=dev)
+        st = capi.mi_spmm_csr_f32_variant(17, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(val), M, K, N,
+                                          d[3].data_ptr(), N, C.data_ptr(), N, torch.cuda.current_stream().cuda_stream)
+        assert st == 0, (case, st)
+        assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr_chain(rowptr, col, val, M, K, B)), (case, M, K, N, density)
+
+
 def test_spmm_slab_kernel_unsorted_rows_and_auto_plan(capi, cmm, dev, oracle_mod):
     """AUTO picks the slab plan at moderate density on a large enough problem; rows whose columns do
     not ascend (legal CSR: the reference's COO→CSR keeps input order) are recomputed in CSR order
