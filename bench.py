@@ -87,7 +87,14 @@ def cpu_baseline(rowptr, col, val, K, B, N, sample_rows, gpu_rows=None):
         t0 = time.perf_counter()
         out = oracle.spmm_csr_omp(rp, col[:nnz], val[:nnz], sample_rows, K, B)
         best = min(best, time.perf_counter() - t0)
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
     rec = {"value": round(2.0 * nnz * N / best / 1e9, 3), "unit": "GFLOP/s", "cores": threads, "kind": "port",
+           "host_cpu": model, "host_logical_cpus": os.cpu_count(),
            "sample": f"first {sample_rows} rows of the same A ({nnz} nnz) x the same B, oracle OpenMP row-split "
                      f"SpMM, best of 2, {best:.2f} s"}
     # the reference's own CPU expression for this product is `a @ b` with a CSR `a`
