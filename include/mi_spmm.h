@@ -97,7 +97,7 @@ enum {
   MI_SPMM_COLTILE_PANELS = 15, /* wide N and tall K: column tiles × row panels of B, one launch per panel */
   MI_SPMM_NARROW = 16,      /* N < 4: wave per row, lanes over non-zeros, shuffle reduction (own order) */
   MI_SPMM_SLAB = 17,        /* moderate density, N ≥ 128: 128 rows × 256 columns per workgroup, B staged
-                               through LDS in 32-row slabs, one ds_read_b128 per non-zero           */
+                               through LDS in 64-row slabs, one ds_read_b128 per non-zero           */
   MI_SPMM_VARIANT_COUNT = 18
 };
 int mi_spmm_csr_f32_variant(int variant, const int32_t* rowptr, const int32_t* col,
@@ -224,8 +224,8 @@ int mi_dense_to_csr_fill(const float* dense, int32_t batch, int32_t rows,
 /* ------------------------------------------------------------------------ *
  * Device CSR transpose (A M×K → Aᵀ K×M, columns ascending within each row of
  * Aᵀ, stable): used by the backward pass  grad_B = Aᵀ · dC.
- * `workspace` ≥ mi_csr_transpose_workspace_bytes(M, K, nnz).
- * No counterpart in the reference (its backward re-sparsifies a strided view,
+ * `workspace` ≥ mi_csr_transpose_workspace_bytes(M, K, nnz) (≈ 20 bytes per non-zero plus the
+ * sort's scratch), 16-byte aligned.  No counterpart in the reference (its backward re-sparsifies a strided view,
  * matmuls.py:319-325, SURVEY.md §8a defect 1).
  * ------------------------------------------------------------------------ */
 size_t mi_csr_transpose_workspace_bytes(int32_t M, int32_t K, int64_t nnz);
@@ -236,7 +236,8 @@ int mi_csr_transpose_f32(const int32_t* rowptr, const int32_t* col, const float*
 
 /* ------------------------------------------------------------------------ *
  * SDDMM on A's pattern:  out[p] = Σ_j dC[row(p), j] · B[col[p], j]
- * = the gradient of C = A·B with respect to A's stored values.
+ * = the gradient of C = A·B with respect to A's stored values.  Any N; fixed summation order
+ * (lane l of 64 chains columns 256t + 4l + c, then a xor tree), restated by the oracle.
  * ------------------------------------------------------------------------ */
 int mi_sddmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz,
                      int32_t M, int32_t K, int32_t N, const float* dC, int64_t lddc,
@@ -245,7 +246,8 @@ int mi_sddmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz,
 
 /* Column sums dst[j] = Σ_r src[r, j] (src rows×n, leading dimension ld): the bias gradient of
  * the FC layers (autograd of `output += self.bias`, reference benchmarks/cublas_fc_layer.py:44-45).
- * Fixed summation order (4 interleaved chains per 1024-row chunk, chunks in order), no atomics.
+ * Fixed summation order (per row chunk: 4 waves × 4 interleaved row chains, added in a fixed
+ * order; chunks — 64 rows up to 64 Ki rows, larger beyond — added in order), no atomics.
  * workspace ≥ mi_colsum_workspace_bytes(rows, n). */
 size_t mi_colsum_workspace_bytes(int32_t rows, int32_t n);
 int mi_colsum_f32(const float* src, int32_t rows, int32_t n, int64_t ld, float* dst,
