@@ -75,6 +75,27 @@ int mi_spmm_csr_ws_f32(const int32_t* rowptr, const int32_t* col, const float* v
                        int64_t ldb, const float* bias, float* C, int64_t ldc,
                        void* workspace, size_t workspace_bytes, mi_stream_t stream);
 
+/* The same product with the long-row rule pinned by the caller instead of following the plan:
+ *   MI_LONG_ROWS_AUTO   what mi_spmm_csr_ws_f32 does (split unless the plan is SLAB / NARROW);
+ *   MI_LONG_ROWS_NONE   every row keeps the plain CSR-order chain; workspace may be NULL — also the
+ *                       cheap call when the caller knows no row exceeds mi_spmm_long_row_threshold()
+ *                       non-zeros (one launch, no list building);
+ *   MI_LONG_ROWS_SPLIT  rows beyond the threshold are always summed in the split order above, also
+ *                       under the SLAB plan (workspace required).
+ * A row shard of a larger matrix uses this to sum its rows exactly as the whole matrix would
+ * (mi_spmm_auto_splits_long_rows on the WHOLE problem gives the rule), which keeps the
+ * row-sharded multi-GPU result bit-identical to the single-GPU one (sharded.py).
+ * No counterpart in the reference (single device, one wave per row: src/naive_sparse_mm.cu:24-101). */
+enum { MI_LONG_ROWS_AUTO = -1, MI_LONG_ROWS_NONE = 0, MI_LONG_ROWS_SPLIT = 1 };
+int mi_spmm_csr_ex_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                       int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
+                       int64_t ldb, const float* bias, float* C, int64_t ldc, int long_rows,
+                       void* workspace, size_t workspace_bytes, mi_stream_t stream);
+/* 1 when mi_spmm_csr_ws_f32 would split long rows for this problem, 0 when not (no GPU work). */
+int mi_spmm_auto_splits_long_rows(int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
+                                  int64_t ldb, const float* C, int64_t ldc);
+int mi_spmm_long_row_threshold(void);
+
 /* As above with a kernel-variant override, for benchmarks and tests.
  * variant: MI_SPMM_AUTO or one of the MI_SPMM_* ids below; an id that cannot
  * handle the shape returns MI_EINVAL. */
@@ -87,7 +108,10 @@ enum {
   MI_SPMM_GROUP_SCALAR = 5, /* any N / alignment: one float per lane                */
   MI_SPMM_WAVE_ROW_VL = 6,  /* wave per row, col/val via vector load + readlane     */
   MI_SPMM_PANELS_2 = 7,     /* N = 256: K cut into 2 column panels, one launch per   */
-  MI_SPMM_PANELS_3 = 8,     /*   panel (Infinity-Cache blocking of B); … 3 panels    */
+  MI_SPMM_PANELS_3 = 8,     /*   panel (Infinity-Cache blocking of B); … 3 panels.   */
+                            /*   Rows whose columns descend somewhere are detected   */
+                            /*   and summed in plain CSR order, so the result equals */
+                            /*   the one-pass kernels' for every legal CSR input     */
   MI_SPMM_PANELS_4 = 9,
   MI_SPMM_PANELS_5 = 10,
   MI_SPMM_PANELS_6 = 11,
@@ -173,7 +197,7 @@ int mi_gemm_f32(int transa, int transb, int32_t m, int32_t n, int32_t k,
  * (strideB = 0 shares one B); bias (N entries) may be NULL.
  * Replaces `a.to_sparse_csr()` + get_sparse_tensor_properties + spmm_kernel per
  * call / per slice (reference matmuls.py:289-297, :178-187).
- * Supported when mi_spmm_dense_skip_supported(...) != 0 (N ≤ 1024, N % 4 == 0,
+ * Supported when mi_spmm_dense_skip_supported(...) != 0 (N ≤ 256, N % 4 == 0,
  * 16-byte aligned B and C rows); otherwise MI_EINVAL — use the CSR entry points.
  * ------------------------------------------------------------------------ */
 int mi_spmm_dense_skip_supported(int32_t N, int64_t lda, int64_t ldb, int64_t ldc,

@@ -192,7 +192,7 @@ torch::Tensor cublas_bmm(torch::Tensor A, torch::Tensor B, torch::Tensor C, int 
 torch::Tensor spmm_impl(const torch::Tensor& A_values, const torch::Tensor& A_columns,
                         const torch::Tensor& A_offsets, int64_t nnzA, int64_t A_rows,
                         int64_t A_cols, const torch::Tensor& B, torch::Tensor C, const char* what,
-                        const torch::Tensor* bias = nullptr) {
+                        const torch::Tensor* bias = nullptr, int long_rows = MI_LONG_ROWS_AUTO) {
   check_device_f32(A_values, "A_values");
   check_device_i32(A_columns, "A_columns");
   check_device_i32(A_offsets, "A_offsets");
@@ -229,13 +229,16 @@ torch::Tensor spmm_impl(const torch::Tensor& A_values, const torch::Tensor& A_co
     bias_ptr = bias_keep.data_ptr<float>();
   }
   c10::hip::HIPGuard guard(C.device().index());
-  // workspace for the over-long rows (list + partial rows of the split ones; caching allocator)
-  const size_t ws_bytes = mi_spmm_csr_workspace_bytes(nnzA, (int32_t)N);
-  torch::Tensor ws = torch::empty({(int64_t)std::max<size_t>(ws_bytes, 4)}, torch::dtype(torch::kUInt8).device(C.device()));
-  const int st = mi_spmm_csr_ws_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
+  // workspace for the over-long rows (list + partial rows of the split ones; caching allocator);
+  // none when the caller pins "no row is split" (MI_LONG_ROWS_NONE: one launch, nothing else)
+  const size_t ws_bytes = long_rows == MI_LONG_ROWS_NONE ? 0 : mi_spmm_csr_workspace_bytes(nnzA, (int32_t)N);
+  torch::Tensor ws;
+  if (ws_bytes > 0) ws = torch::empty({(int64_t)ws_bytes}, torch::dtype(torch::kUInt8).device(C.device()));
+  const int st = mi_spmm_csr_ex_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
                                     A_values.data_ptr<float>(), nnzA, (int32_t)A_rows, (int32_t)A_cols,
                                     (int32_t)N, Bc.data_ptr<float>(), ldb, bias_ptr, C.data_ptr<float>(),
-                                    std::max<int64_t>(N, 1), ws.data_ptr(), ws_bytes, stream_of(C));
+                                    std::max<int64_t>(N, 1), long_rows, ws_bytes > 0 ? ws.data_ptr() : nullptr,
+                                    ws_bytes, stream_of(C));
   check_status(st, what);
   return C;
 }
@@ -263,6 +266,38 @@ torch::Tensor naive_spmm_bias(torch::Tensor A_values, torch::Tensor A_columns, t
                               torch::Tensor bias, torch::Tensor C) {
   return spmm_impl(A_values, A_columns, A_offsets, nnzA, A_rows, A_cols, B, C, "naive_spmm_bias", &bias);
 }
+
+// naive_spmm with the long-row rule pinned (include/mi_spmm.h, MI_LONG_ROWS_*): -1 = as naive_spmm,
+// 0 = plain CSR-order chain for every row, ONE launch and no workspace (also right when the caller
+// knows no row exceeds long_row_threshold() non-zeros), 1 = always split the long rows.  Used by
+// sharded.py so a row shard sums exactly as the whole matrix would.
+torch::Tensor naive_spmm_ex(torch::Tensor A_values, torch::Tensor A_columns, torch::Tensor A_offsets,
+                            int64_t nnzA, int64_t A_rows, int64_t A_cols, torch::Tensor B, torch::Tensor C,
+                            int long_rows) {
+  if (long_rows < MI_LONG_ROWS_AUTO || long_rows > MI_LONG_ROWS_SPLIT)
+    throw std::invalid_argument("naive_spmm_ex: long_rows must be -1, 0 or 1");
+  return spmm_impl(A_values, A_columns, A_offsets, nnzA, A_rows, A_cols, B, C, "naive_spmm_ex", nullptr, long_rows);
+}
+
+// (variant id, kernel name, launches per product, splits_long_rows) of the AUTO plan for
+// C[M,N] = A[M,K]·B with nnz non-zeros and these operand buffers — no GPU work.
+std::tuple<int, std::string, int, bool> spmm_plan(int64_t nnz, int64_t M, int64_t K, torch::Tensor B, torch::Tensor C) {
+  check_device_f32(B, "B");
+  check_device_f32(C, "C");
+  TORCH_CHECK(B.dim() == 2 && C.dim() == 2 && B.size(1) == C.size(1), "spmm_plan: B [K,N] and C [M,N] expected");
+  TORCH_CHECK(M <= INT32_MAX && K <= INT32_MAX, "spmm_plan: dimension too large");
+  const int64_t N = B.size(1);
+  const int64_t ldb = B.size(0) > 1 ? B.stride(0) : std::max<int64_t>(N, 1);
+  const int64_t ldc = C.size(0) > 1 ? C.stride(0) : std::max<int64_t>(N, 1);
+  const int v = mi_spmm_csr_f32_plan(nnz, (int32_t)M, (int32_t)K, (int32_t)N, B.data_ptr<float>(), ldb,
+                                     C.data_ptr<float>(), ldc);
+  check_status(v < 0 ? v : MI_OK, "spmm_plan");
+  const int sp = mi_spmm_auto_splits_long_rows(nnz, (int32_t)M, (int32_t)K, (int32_t)N, B.data_ptr<float>(), ldb,
+                                               C.data_ptr<float>(), ldc);
+  return std::make_tuple(v, std::string(mi_spmm_variant_name(v)), mi_spmm_variant_launches(v), sp == 1);
+}
+
+int long_row_threshold() { return mi_spmm_long_row_threshold(); }
 
 // Column sums of a 2-d tensor (bias gradient of the FC layers): returns a [n] tensor.
 torch::Tensor column_sums(torch::Tensor src) {
@@ -708,4 +743,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("cublas_mmul_bias", &cublas_mmul_bias, "op(A) op(B) + bias, fused epilogue");
   m.def("column_sums", &column_sums, "sum over rows of a 2-d tensor (bias gradient)");
   m.def("naive_spmm_bias", &naive_spmm_bias, "CSR x dense + bias, fused epilogue");
+  m.def("naive_spmm_ex", &naive_spmm_ex, "naive_spmm with the long-row rule pinned (-1 auto, 0 none, 1 split)");
+  m.def("spmm_plan", &spmm_plan, "(variant, kernel name, launches, splits_long_rows) of the AUTO plan");
+  m.def("long_row_threshold", &long_row_threshold, "rows with more non-zeros are 'long' (split rule)");
 }

@@ -162,15 +162,22 @@ __global__ __launch_bounds__(256) void spmm_wave_row_vl_kernel(
 // the gathers into cache hits; the price is that C is carried through memory
 // between passes ((2P-1) row passes instead of 1) and col is scanned P times.
 // A pass handles the nonzeros with c_lo <= col < c_hi in CSR order on top of the
-// previous pass's C, so for column-sorted rows (torch CSR, the pinned generator)
-// the per-element fmaf chain is exactly the CSR-order chain of the one-pass
+// previous pass's C, so for rows whose columns do not descend (torch CSR, the pinned
+// generator) the per-element fmaf chain is exactly the CSR-order chain of the one-pass
 // kernel: bit-identical results.
+// Rows whose columns DO descend somewhere (legal CSR: the reference's COO→CSR keeps the
+// input order inside a row, src/sparse_mm.cu:110-134) would be summed panel by panel, i.e.
+// in another order.  Every pass therefore checks, on the col entries it scans anyway
+// (one ds_bpermute + compare + ballot per 64 entries), whether the row's columns ascend; the
+// verdict is a function of the row alone, so all passes agree without any flag in memory:
+// the FIRST pass recomputes such a row from scratch over all its non-zeros in plain CSR order
+// (+ bias) and the later passes leave it untouched.
 // ---------------------------------------------------------------------------
 template <bool FIRST, int T, int U>
 __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
-    int M, long ldb, long ldc, int c_lo, int c_hi, const float* __restrict__ bias, int ctiles,
+    int M, long ldb, long ldc, int c_lo, int c_hi, const float* __restrict__ bias, int last_pass, int ctiles,
     unsigned row_blocks, int long_thresh) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -199,10 +206,16 @@ __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
     acc[t] = FIRST ? f32x4{0.f, 0.f, 0.f, 0.f}
                    : __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Cl + t * 256));
   const unsigned width = (unsigned)(c_hi - c_lo);
+  bool descends = false;   // wave-uniform: some column of the row is smaller than its predecessor
+  int prev_last = -1;      // last column of the previous chunk
 
   for (int p = start; p < end; p += 64) {
     const int idx = p + lane;
-    const int myc = idx < end ? col[idx] : -1;
+    const int myc = idx < end ? col[idx] : 0x7fffffff;
+    int before = __shfl_up(myc, 1, 64);
+    if (lane == 0) before = prev_last;
+    descends |= __ballot(myc < before) != 0ull;
+    prev_last = __builtin_amdgcn_readlane(myc, 63);  // 0x7fffffff past the end: only the last chunk has such lanes
     const bool in = (unsigned)(myc - c_lo) < width && idx < end;
     const float myv = in ? val[idx] : 0.f;
     unsigned long long mask = __ballot(in);  // this chunk's nonzeros that fall in the panel
@@ -235,7 +248,46 @@ __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
         acc[t] = fma4(v, *reinterpret_cast<const f32x4*>(src + t * 256), acc[t]);
     }
   }
-  if (bias) {  // only the last pass is given the bias
+  bool add_bias = bias != nullptr && last_pass != 0;
+  if (descends) {
+    if (!FIRST) return;  // the first pass wrote the whole row
+    // plain CSR-order chain over every non-zero of the row, whatever its panel
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = start; p < end; p += 64) {
+      const int idx = p + lane;
+      const int myc = idx < end ? col[idx] : 0;
+      const float myv = idx < end ? val[idx] : 0.f;
+      const int cnt = (end - p) < 64 ? (end - p) : 64;
+      int i = 0;
+      for (; i + 4 <= cnt; i += 4) {
+        f32x4 x[4][T];
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = __builtin_amdgcn_readlane(myc, i + u);
+          v[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), i + u));
+          const float* src = Bl + (long)c * ldb;
+#pragma unroll
+          for (int t = 0; t < T; ++t) x[u][t] = *reinterpret_cast<const f32x4*>(src + t * 256);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int t = 0; t < T; ++t) acc[t] = fma4(v[u], x[u][t], acc[t]);
+      }
+      for (; i < cnt; ++i) {
+        const int c = __builtin_amdgcn_readlane(myc, i);
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), i));
+        const float* src = Bl + (long)c * ldb;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+          acc[t] = fma4(v, *reinterpret_cast<const f32x4*>(src + t * 256), acc[t]);
+      }
+    }
+    add_bias = bias != nullptr;
+  }
+  if (add_bias) {
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] += *reinterpret_cast<const f32x4*>(bias + lane * 4 + t * 256);
   }
@@ -257,14 +309,12 @@ int launch_panels_t(int panels, const int* rowptr, const int* col, const float* 
     const int hi = (int)((q + 1) * kp < K ? (q + 1) * kp : K);
     if (q == 0)
       hipLaunchKernelGGL((spmm_wave_row_panel_kernel<true, T, U>), dim3((unsigned)blocks), dim3(256), 0,
-                         s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi,
-                         q == panels - 1 ? bias : (const float*)nullptr, ctiles, (unsigned)row_blocks,
-                         long_thresh);
+                         s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi, bias, q == panels - 1 ? 1 : 0, ctiles,
+                         (unsigned)row_blocks, long_thresh);
     else
       hipLaunchKernelGGL((spmm_wave_row_panel_kernel<false, T, U>), dim3((unsigned)blocks), dim3(256), 0,
-                         s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi,
-                         q == panels - 1 ? bias : (const float*)nullptr, ctiles, (unsigned)row_blocks,
-                         long_thresh);
+                         s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi, bias, q == panels - 1 ? 1 : 0, ctiles,
+                         (unsigned)row_blocks, long_thresh);
   }
   return mi::check_launch();
 }
@@ -872,9 +922,11 @@ int launch_variant(int variant, const Shape& sh, const int32_t* rowptr, const in
 int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const float* val,
                   int64_t nnz, int32_t batch, int32_t M, int32_t K, int32_t N, const float* B,
                   int64_t ldb, int64_t strideB, float* C, int64_t ldc, int64_t strideC,
-                  const float* bias, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                  const float* bias, void* workspace, size_t workspace_bytes, hipStream_t s,
+                  int long_mode = MI_LONG_ROWS_AUTO) {
   if (M < 0 || K < 0 || N < 0 || nnz < 0 || batch < 0) return MI_EINVAL;
   if (variant < 0 || variant >= MI_SPMM_VARIANT_COUNT) return MI_EINVAL;
+  if (long_mode < MI_LONG_ROWS_AUTO || long_mode > MI_LONG_ROWS_SPLIT) return MI_EINVAL;
   if (nnz > 0x7fffffffLL) return MI_ERANGE;  // int32 rowptr entries
   if (batch > 65535) return MI_ERANGE;       // grid.y
   if (M == 0 || N == 0 || batch == 0) return MI_OK;
@@ -892,8 +944,10 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
   // (the slab plan needs no split: a long row there is 8 rows' worth of ordinary work for its wave,
   // not a serial tail — and a matrix dense enough to have thousands of long rows would drown the
   // one-workgroup-per-row kernel; its rows all keep the plain CSR order)
+  // MI_LONG_ROWS_SPLIT / _NONE pin the rule whatever the plan (a row shard must sum its rows the way
+  // the whole matrix would: sharded.py); N < 4 keeps the narrow kernel's own order in every mode.
   const bool split = workspace != nullptr && batch == 1 && nnz > kLongRow && variant != MI_SPMM_NARROW &&
-                     variant != MI_SPMM_SLAB;
+                     long_mode != MI_LONG_ROWS_NONE && (variant != MI_SPMM_SLAB || long_mode == MI_LONG_ROWS_SPLIT);
   int* ws = static_cast<int*>(workspace);
   const LongWs lw = long_ws_layout(nnz, N);
   if (split) {
@@ -945,6 +999,24 @@ int mi_spmm_csr_ws_f32(const int32_t* rowptr, const int32_t* col, const float* v
   return spmm_dispatch(MI_SPMM_AUTO, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0, bias, workspace,
                        workspace_bytes, static_cast<hipStream_t>(stream));
 }
+
+int mi_spmm_csr_ex_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
+                       int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb, const float* bias,
+                       float* C, int64_t ldc, int long_rows, void* workspace, size_t workspace_bytes,
+                       mi_stream_t stream) {
+  if (long_rows == MI_LONG_ROWS_SPLIT && workspace == nullptr && nnz > kLongRow) return MI_EINVAL;
+  return spmm_dispatch(MI_SPMM_AUTO, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0, bias, workspace,
+                       workspace_bytes, static_cast<hipStream_t>(stream), long_rows);
+}
+
+int mi_spmm_auto_splits_long_rows(int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,
+                                  const float* C, int64_t ldc) {
+  const int v = mi_spmm_csr_f32_plan(nnz, M, K, N, B, ldb, C, ldc);
+  if (v < 0) return v;
+  return (nnz > kLongRow && v != MI_SPMM_NARROW && v != MI_SPMM_SLAB) ? 1 : 0;
+}
+
+int mi_spmm_long_row_threshold(void) { return kLongRow; }
 
 int mi_spmm_csr_bias_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
                          int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,

@@ -8,25 +8,38 @@ and C assembled on every rank with an RCCL all-gather over xGMI
 (`torch.distributed`, backend "nccl" = RCCL on ROCm).
 
 Rows of C depend only on the same rows of A, so the shards are independent and
-each rank runs the same row-split kernel on its rows; per-row arithmetic is
-identical to the single-GPU run, so the gathered C is bit-identical to it.
+each rank runs the same row-split kernel on its rows.  Per-row arithmetic is made
+identical to the single-GPU run by pinning the one thing that depends on the
+launch shape — whether rows beyond `custom_mm.long_row_threshold()` non-zeros are
+summed in the split order — to what the WHOLE problem's plan does
+(`custom_mm.spmm_plan`), not to what a shard's own plan would do; so the gathered
+C is bit-identical to the single-GPU result, hub rows included.
 
 Layout (block-cyclic, so the gather overlaps the compute): the M rows are cut
-into `chunks * world` blocks of `block_rows` rows (the tail is padded with empty
-rows); rank r owns blocks j*world + r for j = 0 … chunks-1.  Step j computes the
-rank's block straight into its final position inside the full C buffer and then
-all-gathers blocks [j*world, (j+1)*world) IN PLACE (each rank's input is already
-the right slice of the output), on RCCL's stream, while step j+1 computes.
-xGMI is point-to-point (7 links per GPU): one shard per peer link per step, no
-repacking, `chunks` collectives of M*N*4/chunks bytes each.
+into `chunks * world` blocks; rank r owns blocks j*world + r for
+j = 0 … chunks-1.  Step j computes the rank's block straight into its final
+position inside the full C buffer and then gathers blocks
+[j*world, (j+1)*world) IN PLACE (each rank's input is already the right slice of
+the output) on RCCL's stream, while step j+1 computes.  xGMI is point-to-point
+(7 links per GPU): one shard per peer link per step, no repacking, `chunks`
+collectives of M*N*4/chunks bytes each.
+
+Two ways to cut the rows:
+  * split="rows": equal row counts (the tail padded with empty rows) — right for
+    uniform patterns; one `all_gather_into_tensor` per step.
+  * split="nnz": nnz-balanced split points, block i = rows
+    [lower_bound(rowptr, i*nnz/nblocks), lower_bound(rowptr, (i+1)*nnz/nblocks)) —
+    for skewed matrices; blocks have different heights, so a step's exchange is one
+    in-place broadcast per owner (RCCL runs them back to back on its stream).
 '''
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
 
 def block_layout(M: int, world: int, chunks: int):
-    '''(block_rows, padded_rows) of the block-cyclic row layout.'''
+    '''(block_rows, padded_rows) of the equal-rows block-cyclic layout.'''
     nblocks = world * chunks
     block_rows = max(1, -(-M // nblocks))
     return block_rows, block_rows * nblocks
@@ -34,6 +47,20 @@ def block_layout(M: int, world: int, chunks: int):
 
 def owned_blocks(rank: int, world: int, chunks: int):
     return [j * world + rank for j in range(chunks)]
+
+
+def balanced_boundaries(rowptr, nblocks: int):
+    '''nnz-balanced split points (exact integer arithmetic): boundary i is the first row r
+    with rowptr[r] >= i*nnz // nblocks (lower_bound), boundary nblocks is M.  Returns int64[nblocks+1],
+    non-decreasing, block i = rows [b[i], b[i+1]).'''
+    rp = np.asarray(rowptr.cpu() if isinstance(rowptr, torch.Tensor) else rowptr).astype(np.int64)
+    M = len(rp) - 1
+    nnz = int(rp[-1])
+    targets = (np.arange(nblocks + 1, dtype=np.int64) * nnz) // nblocks
+    b = np.searchsorted(rp, targets, side="left").astype(np.int64)
+    b[0] = 0
+    b[-1] = M
+    return np.minimum(np.maximum.accumulate(b), M)
 
 
 def shard_rowptr(rowptr: torch.Tensor, r0: int, r1: int, M: int) -> torch.Tensor:
@@ -49,56 +76,106 @@ class ShardedSpMM:
 
     :param rowptr, col, val: the FULL CSR of A (int32 / int32 / float32) on any
         device; only this rank's row blocks are kept (on `device`).
-    :param mm_op: 2-d kernel, signature of ``custom_mm.naive_spmm``.
+    :param split: "rows" (equal row counts) or "nnz" (nnz-balanced split points).
+    :param mm_op: 2-d kernel with the signature of ``custom_mm.naive_spmm`` (tests);
+        default: ``custom_mm.naive_spmm_ex`` with the long-row rule of the whole problem.
     '''
 
-    def __init__(self, rowptr, col, val, M, K, device, group=None, chunks=4, mm_op=None):
+    def __init__(self, rowptr, col, val, M, K, device, group=None, chunks=4, mm_op=None, split="rows"):
+        if split not in ("rows", "nnz"):
+            raise ValueError("split must be 'rows' or 'nnz'")
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.M, self.K = int(M), int(K)
         self.chunks = max(1, int(chunks))
         self.device = torch.device(device)
+        self.split = split
+        self.mm_op = mm_op
+        self.long_threshold = 8192
         if mm_op is None:
             import custom_mm
-            mm_op = custom_mm.naive_spmm
-        self.mm_op = mm_op
-        self.block_rows, self.padded_rows = block_layout(self.M, self.world, self.chunks)
-        self.blocks = []  # per owned block: (block id, rowptr_local, col, val, nnz)
-        rowptr = rowptr.to(torch.int32)
+            self.long_threshold = custom_mm.long_row_threshold()
+        rowptr = rowptr.to(torch.int32).cpu()
+        self.nnz = int(rowptr[-1])
+        nblocks = self.world * self.chunks
+        if split == "rows":
+            self.block_rows, self.padded_rows = block_layout(self.M, self.world, self.chunks)
+            self.bounds = np.minimum(np.arange(nblocks + 1, dtype=np.int64) * self.block_rows, self.padded_rows)
+        else:
+            self.bounds = balanced_boundaries(rowptr, nblocks)
+            self.block_rows, self.padded_rows = None, self.M
+        lens = (rowptr[1:] - rowptr[:-1]) if self.M > 0 else rowptr[:0]
+        self.blocks = []  # per owned block: (block id, rowptr_local, col, val, nnz, rows, has_long_rows)
         for blk in owned_blocks(self.rank, self.world, self.chunks):
-            r0, r1 = blk * self.block_rows, (blk + 1) * self.block_rows
-            p0 = int(rowptr[min(r0, self.M)])
-            p1 = int(rowptr[min(r1, self.M)])
+            r0, r1 = int(self.bounds[blk]), int(self.bounds[blk + 1])
+            c0, c1 = min(r0, self.M), min(r1, self.M)
+            p0, p1 = int(rowptr[c0]), int(rowptr[c1])
+            has_long = bool(c1 > c0 and int(lens[c0:c1].max()) > self.long_threshold)
             self.blocks.append((blk,
                                 shard_rowptr(rowptr, r0, r1, self.M).to(self.device),
                                 col[p0:p1].to(torch.int32).to(self.device).contiguous(),
                                 val[p0:p1].to(torch.float32).to(self.device).contiguous(),
-                                p1 - p0))
+                                p1 - p0, r1 - r0, has_long))
         self.local_nnz = sum(b[4] for b in self.blocks)
+        self.local_rows = sum(b[5] for b in self.blocks)
+        self._rule = {}  # N -> does the whole problem split long rows
 
     def alloc_output(self, N: int) -> torch.Tensor:
         return torch.empty((self.padded_rows, N), device=self.device, dtype=torch.float32)
+
+    def _global_rule(self, B, out):
+        '''Whether the single-GPU product of the WHOLE matrix with this B would sum rows beyond the
+        threshold in the split order (host-side plan query; cached per N).'''
+        N = B.shape[1]
+        if N not in self._rule:
+            import custom_mm
+            self._rule[N] = bool(custom_mm.spmm_plan(self.nnz, self.M, self.K, B, out[:self.M])[3])
+        return self._rule[N]
+
+    def _multiply(self, blk, B, mine, out):
+        _, rp, ci, v, nnz, rows, has_long = blk
+        if rows == 0:
+            return
+        if self.mm_op is not None:
+            self.mm_op(v, ci, rp, nnz, rows, self.K, B, mine)
+            return
+        import custom_mm
+        # no long row in the block → both rules give the same bits: take the one-launch call
+        mode = 1 if (has_long and self._global_rule(B, out)) else 0
+        custom_mm.naive_spmm_ex(v, ci, rp, nnz, rows, self.K, B, mine, mode)
+
+    def _src(self, r):
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
 
     def forward(self, B: torch.Tensor, out: torch.Tensor = None, gather: bool = True,
                 force_collective: bool = False) -> torch.Tensor:
         '''Returns C [M, N] (a view of the padded buffer), complete on every rank
         when `gather` is true; with gather=False only this rank's blocks are valid.
-        `force_collective` issues the all-gather even in a one-rank group (tests).'''
+        `force_collective` issues the collective even in a one-rank group (tests).'''
         N = B.shape[1]
         if out is None:
             out = self.alloc_output(N)
         assert out.shape == (self.padded_rows, N) and out.is_contiguous()
         works = []
-        br = self.block_rows
-        for j, (blk, rp, ci, v, nnz) in enumerate(self.blocks):
-            mine = out[blk * br:(blk + 1) * br]
-            self.mm_op(v, ci, rp, nnz, br, self.K, B, mine)
-            if gather and (self.world > 1 or force_collective):
-                span = out[j * self.world * br:(j + 1) * self.world * br]
+        collective = gather and (self.world > 1 or force_collective)
+        for j, blk in enumerate(self.blocks):
+            r0, r1 = int(self.bounds[blk[0]]), int(self.bounds[blk[0] + 1])
+            mine = out[r0:r1]
+            self._multiply(blk, B, mine, out)
+            if not collective:
+                continue
+            first = j * self.world
+            if self.split == "rows":
+                span = out[int(self.bounds[first]):int(self.bounds[first + self.world])]
                 # in place: `mine` is span[rank*br : (rank+1)*br]; the collective is
                 # ordered after the kernel above and runs beside the next step's kernel
                 works.append(dist.all_gather_into_tensor(span, mine, group=self.group, async_op=True))
+            else:
+                for r in range(self.world):  # blocks of different heights: one in-place broadcast per owner
+                    s0, s1 = int(self.bounds[first + r]), int(self.bounds[first + r + 1])
+                    if s1 > s0:
+                        works.append(dist.broadcast(out[s0:s1], src=self._src(r), group=self.group, async_op=True))
         for w in works:
             w.wait()
         return out[:self.M]

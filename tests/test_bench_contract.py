@@ -52,3 +52,60 @@ def test_c3_kernel_stats_agree_with_the_bench_line():
     # (the bench line quotes the PMC passes of the previous profile run: equal to within counter noise)
     assert abs(traffic["hbm_bytes_per_product"] - rec["roofline"]["traffic"]) < 1e-3 * rec["roofline"]["traffic"]
     assert 1.0 <= traffic["hbm_bytes_per_product"] / rec["config"]["algorithmic_bytes_per_step"] < 1.05
+
+
+# --- `python bench.py --gpus N` started plainly: the parent spawns the ranks itself ------------------
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", PROFILES.parent / "bench.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_self_launch_builds_a_torchrun_child_and_relays_rank0(monkeypatch, capsys):
+    """The parent path: no torch import, a child `python -m torch.distributed.run --nproc-per-node N
+    bench.py …` on 127.0.0.1, rank 0's JSON line relayed, the child's return code returned."""
+    import argparse
+    import subprocess
+    import sys
+    bench = _load_bench()
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 0, stdout='noise\n{"metric": "x", "n_gpus": 4}\n')
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.delitem(sys.modules, "torch", raising=False)
+    args = argparse.Namespace(gpus=4, steps=7, warmup=2, workload="c3", chunks=0, split="rows", no_cpu_baseline=True)
+    assert bench.self_launch(args) == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    tail = cmd[cmd.index(str(PROFILES.parent / "bench.py")) + 1:]
+    assert tail[:6] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and "--no-cpu-baseline" in tail
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert capsys.readouterr().out.strip() == '{"metric": "x", "n_gpus": 4}'
+
+    def failing_run(cmd, env=None, stdout=None, text=None):
+        return subprocess.CompletedProcess(cmd, 3, stdout="")
+    monkeypatch.setattr(bench.subprocess, "run", failing_run)
+    assert bench.self_launch(args) == 3
+
+
+def test_plain_multi_gpu_invocation_spawns_ranks_without_touching_hip():
+    """End to end in this GPU-less container: `python bench.py --gpus 2` must get as far as two child
+    ranks, each refusing loudly because there is no MI355X here (no CPU fallback), and hand their
+    failure back as a non-zero exit code; the parent itself never imports torch."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, MI_BENCH_TRACE_PARENT="1")
+    proc = subprocess.run([sys.executable, str(PROFILES.parent / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                           "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert proc.returncode != 0
+    assert proc.stderr.count("bench.py needs an MI355X") >= 2, proc.stderr[-2000:]
+    assert "parent: torch imported = False" in proc.stderr
+    assert not [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]

@@ -558,17 +558,124 @@ def test_fused_bias_on_the_panel_path(capi, dev, oracle_mod):
                                             K, N, d[3].data_ptr(), N, C.data_ptr(), N,
                                             torch.cuda.current_stream().cuda_stream) == 0
         assert np.array_equal(C.cpu().numpy(), expect)
-    # unsorted columns inside a row: the panel path still gives the right product (order of the
-    # fmaf chain then follows (panel, CSR position), so compare at the reference tolerance)
-    perm = np.concatenate([np.random.Generator(np.random.PCG64(r)).permutation(np.arange(rowptr[r], rowptr[r + 1]))
-                           for r in range(M)])
-    colp, valp = col[perm], val[perm]
-    C = torch.empty(M, N, device=dev)
-    assert capi.mi_spmm_csr_f32_variant(7, d[0].data_ptr(), t(colp, dev).data_ptr(), t(valp, dev).data_ptr(), len(val),
-                                        M, K, N, d[3].data_ptr(), N, C.data_ptr(), N,
+    # unsorted columns inside a row (legal CSR): every pass detects such rows on the col entries it
+    # scans anyway, the first pass sums them in plain CSR order and the later passes leave them alone,
+    # so the panel plans equal the CSR-order oracle bit for bit here too.  Mixed: most rows shuffled,
+    # some left sorted, one with only its last two entries swapped, duplicates of a column.
+    g = np.random.Generator(np.random.PCG64(9))
+    colp, valp = col.copy(), val.copy()
+    for r in range(M):
+        s0, e0 = rowptr[r], rowptr[r + 1]
+        if r % 3 != 0 and e0 - s0 > 1:
+            perm = g.permutation(e0 - s0)
+            colp[s0:e0], valp[s0:e0] = col[s0:e0][perm], val[s0:e0][perm]
+    s0, e0 = rowptr[300], rowptr[301]
+    colp[s0:e0], valp[s0:e0] = col[s0:e0], val[s0:e0]
+    colp[[e0 - 2, e0 - 1]] = colp[[e0 - 1, e0 - 2]]
+    colp[rowptr[3] + 1] = colp[rowptr[3]]  # a duplicate column in a sorted row
+    expect_p = oracle_mod.spmm_csr(rowptr, colp, valp, M, K, B)
+    for variant in (7, 8, 12, 15):  # 2, 3, 8 panels; 15 = column tiles x panels (one 256-column tile here)
+        C = torch.full((M, N), float("nan"), device=dev)
+        assert capi.mi_spmm_csr_f32_variant(variant, d[0].data_ptr(), t(colp, dev).data_ptr(), t(valp, dev).data_ptr(),
+                                            len(val), M, K, N, d[3].data_ptr(), N, C.data_ptr(), N,
+                                            torch.cuda.current_stream().cuda_stream) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(C.cpu().numpy(), expect_p), variant
+    # two column tiles x panels, unsorted rows
+    B2 = g.random((K, 512), dtype=np.float32)
+    C = torch.full((M, 512), float("nan"), device=dev)
+    assert capi.mi_spmm_csr_f32_variant(15, d[0].data_ptr(), t(colp, dev).data_ptr(), t(valp, dev).data_ptr(), len(val),
+                                        M, K, 512, t(B2, dev).data_ptr(), 512, C.data_ptr(), 512,
                                         torch.cuda.current_stream().cuda_stream) == 0
     torch.cuda.synchronize()
-    assert np.allclose(C.cpu().numpy(), expect, rtol=RTOL, atol=ATOL)
+    assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr(rowptr, colp, valp, M, K, B2))
+
+
+def _sub_csr(rowptr, col, val, rows):
+    """CSR of the selected rows (rows of a product are independent: the oracle on this equals the
+    oracle on the whole matrix restricted to these rows)."""
+    lens = [int(rowptr[r + 1] - rowptr[r]) for r in rows]
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = np.concatenate([np.arange(rowptr[r], rowptr[r + 1]) for r in rows]) if rows else np.zeros(0, np.int64)
+    return rp, col[idx], val[idx]
+
+
+def _moderately_dense_with_hub_rows(M, K, density, hubs, seed):
+    g = np.random.Generator(np.random.PCG64(seed))
+    mask = g.random((M, K), dtype=np.float32) < density
+    mask[hubs] = True
+    rows, col = np.nonzero(mask)
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=M))]).astype(np.int32)
+    return rowptr, col.astype(np.int32), g.random(len(col), dtype=np.float32) - 0.5
+
+
+def test_long_row_rule_pinned_by_the_caller(cmm, dev, oracle_mod):
+    """custom_mm.naive_spmm_ex: under a SLAB plan (which by itself never splits) mode 1 sums the rows
+    beyond 8192 non-zeros in the split order, modes 0 / -1 keep the CSR-order chain; rows up to the
+    threshold are the same bits in every mode."""
+    M, K, N = 4096, 12000, 1024
+    hubs = [3, 2500, M - 1]
+    rowptr, col, val = _moderately_dense_with_hub_rows(M, K, 0.5, hubs, 31)
+    B = np.random.Generator(np.random.PCG64(32)).random((K, N), dtype=np.float32)
+    d = [t(x, dev) for x in (val, col, rowptr)]
+    d_B = t(B, dev)
+    C = torch.empty(M, N, device=dev)
+    variant, name, launches, splits = cmm.spmm_plan(len(val), M, K, d_B, C)
+    assert name == "spmm_slab_kernel" and launches == 1 and splits is False
+    assert cmm.long_row_threshold() == 8192
+    sample = hubs + [0, 4, 1000, 4000]
+    sp = _sub_csr(rowptr, col, val, sample)
+    chain = oracle_mod.spmm_csr(*sp, len(sample), K, B)
+    split = oracle_mod.spmm_csr_long(*sp, len(sample), K, B)
+    assert not np.array_equal(chain[:3], split[:3]) and np.array_equal(chain[3:], split[3:])
+    idx = torch.tensor(sample, device=dev)
+    for mode, want in ((1, split), (0, chain), (-1, chain)):
+        C.fill_(float("nan"))
+        cmm.naive_spmm_ex(*d, len(val), M, K, d_B, C, mode)
+        assert np.array_equal(C[idx].cpu().numpy(), want), mode
+    full_auto = C.clone()
+    cmm.naive_spmm(*d, len(val), M, K, d_B, C)
+    assert torch.equal(C, full_auto)
+    with pytest.raises(ValueError):
+        cmm.naive_spmm_ex(*d, len(val), M, K, d_B, C, 2)
+
+
+def test_sharded_hub_rows_follow_the_whole_problems_rule(cmm, dev, oracle_mod):
+    """Row shards pick their own kernels (a 512-row shard of a SLAB-plan matrix runs a row-split plan),
+    but rows beyond 8192 non-zeros are summed the way the WHOLE matrix's plan sums them, so the
+    sharded result is bit-identical to the single-GPU one in both regimes."""
+    import sharded
+    # (a) whole problem: SLAB plan (no split) — shards: row-split plans, must not split either
+    M, K, N = 4096, 12000, 1024
+    rowptr, col, val = _moderately_dense_with_hub_rows(M, K, 0.5, [3, 2500, M - 1], 41)
+    d_B = t(np.random.Generator(np.random.PCG64(42)).random((K, N), dtype=np.float32), dev)
+    single = torch.empty(M, N, device=dev)
+    assert cmm.spmm_plan(len(val), M, K, d_B, single)[3] is False
+    cmm.naive_spmm(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, d_B, single)
+    for split in ("rows", "nnz"):
+        op = sharded.ShardedSpMM(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), M, K, dev,
+                                 chunks=8, split=split)
+        assert sum(b[6] for b in op.blocks) == 3  # three blocks hold a hub row
+        assert cmm.spmm_plan(op.blocks[0][4], op.blocks[0][5], K, d_B, single[:op.blocks[0][5]])[1] != "spmm_slab_kernel"
+        assert torch.equal(op.forward(d_B), single), split
+    # (b) whole problem: row-split plan that splits its long rows — shards must split them too
+    M, K, N = 301, 30000, 256
+    g = np.random.Generator(np.random.PCG64(43))
+    lens = g.integers(0, 200, size=M)
+    lens[5], lens[17], lens[18], lens[150], lens[300] = K, 8193, 8192, 20011, 9000
+    cols = [np.sort(g.choice(K, size=int(n), replace=False)).astype(np.int32) for n in lens]
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col, val = np.concatenate(cols), g.random(int(lens.sum()), dtype=np.float32)
+    B = g.random((K, N), dtype=np.float32)
+    d_B = t(B, dev)
+    single = torch.empty(M, N, device=dev)
+    assert cmm.spmm_plan(len(val), M, K, d_B, single)[3] is True
+    cmm.naive_spmm(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, d_B, single)
+    assert np.array_equal(single.cpu().numpy(), oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B))
+    for split in ("rows", "nnz"):
+        op = sharded.ShardedSpMM(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), M, K, dev,
+                                 chunks=4, split=split)
+        assert torch.equal(op.forward(d_B), single), split
 
 
 def test_fc_layer_modules_on_device(mm, dev):

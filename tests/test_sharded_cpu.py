@@ -29,7 +29,18 @@ def _oracle_mm_op(vals, cols, offs, nnz, rows, kcols, B, C):
     return C
 
 
-def _worker(rank, world, port, M, K, N, chunks, out_dir):
+def _skewed_csr(M, K):
+    """Row r has about K/(r+1) non-zeros: a few heavy rows at the top, a long light tail."""
+    rng = np.random.Generator(np.random.PCG64(7))
+    lens = np.maximum(1, K // (np.arange(M) + 1))
+    lens[M // 2::5] = 0  # some empty rows, too
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate([np.sort(rng.choice(K, n, replace=False)) for n in lens]).astype(np.int32)
+    val = rng.random(len(col), dtype=np.float32)
+    return rowptr, col, val
+
+
+def _worker(rank, world, port, M, K, N, chunks, out_dir, split="rows", skew=False):
     for p in (str(REPO), str(REPO / "matrix-multiplication_amd")):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -37,17 +48,18 @@ def _worker(rank, world, port, M, K, N, chunks, out_dir):
     try:
         import oracle
         import sharded
-        rowptr, col, val = oracle.make_csr(M, K, 0.05, seed=0)
+        rowptr, col, val = _skewed_csr(M, K) if skew else oracle.make_csr(M, K, 0.05, seed=0)
         B = torch.from_numpy(np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32))
         op = sharded.ShardedSpMM(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), M, K, "cpu",
-                                 chunks=chunks, mm_op=_oracle_mm_op)
+                                 chunks=chunks, mm_op=_oracle_mm_op, split=split)
         # integer artefacts: block ownership and rebased rowptrs
         assert [b[0] for b in op.blocks] == [j * world + rank for j in range(chunks)]
-        for blk, rp, ci, v, nnz in op.blocks:
-            r0, r1 = min(blk * op.block_rows, M), min((blk + 1) * op.block_rows, M)
+        for blk, rp, ci, v, nnz, rows, has_long in op.blocks:
+            r0, r1 = min(int(op.bounds[blk]), M), min(int(op.bounds[blk + 1]), M)
             expect = (rowptr[r0:r1 + 1].astype(np.int64) - rowptr[r0]).astype(np.int32)
             got = rp.numpy()
-            assert got.dtype == np.int32 and got[0] == 0 and len(got) == op.block_rows + 1
+            assert rows == int(op.bounds[blk + 1] - op.bounds[blk]) and not has_long
+            assert got.dtype == np.int32 and got[0] == 0 and len(got) == rows + 1
             assert np.array_equal(got[:r1 - r0 + 1], expect) and np.all(got[r1 - r0:] == expect[-1])
             assert nnz == rowptr[r1] - rowptr[r0] and np.array_equal(ci.numpy(), col[rowptr[r0]:rowptr[r1]])
         total = torch.tensor([op.local_nnz])
@@ -70,6 +82,44 @@ def test_two_rank_gather_equals_single_rank(tmp_path, oracle_mod, M, chunks):
         got = np.load(tmp_path / f"c_{r}.npy")
         assert got.shape == (M, N)
         assert np.array_equal(got, single), f"rank {r}: gathered C differs from the single-rank result"
+
+
+@pytest.mark.parametrize("M,chunks,skew", [(96, 2, True), (101, 3, True), (40, 4, False)])
+def test_two_rank_nnz_balanced_split_equals_single_rank(tmp_path, oracle_mod, M, chunks, skew):
+    """split="nnz": blocks of different heights, exchanged with in-place broadcasts."""
+    K, N, world = 64, 24, 2
+    mp.spawn(_worker, args=(world, _free_port(), M, K, N, chunks, str(tmp_path), "nnz", skew), nprocs=world, join=True)
+    rowptr, col, val = _skewed_csr(M, K) if skew else oracle_mod.make_csr(M, K, 0.05, seed=0)
+    B = np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32)
+    single = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    for r in range(world):
+        got = np.load(tmp_path / f"c_{r}.npy")
+        assert got.shape == (M, N) and np.array_equal(got, single), f"rank {r}"
+
+
+def test_balanced_boundaries_are_exact_lower_bounds():
+    """Integer artefact of the nnz-balanced split: boundary i is the FIRST row whose offset reaches
+    i*nnz // nblocks (lower_bound), checked against a plain Python scan."""
+    sys.path.insert(0, str(REPO / "matrix-multiplication_amd"))
+    import sharded
+    rng = np.random.Generator(np.random.PCG64(3))
+    for M, nblocks in [(1, 1), (5, 8), (64, 4), (1000, 16), (257, 6)]:
+        lens = rng.integers(0, 50, size=M) * (rng.random(M) < 0.7)
+        lens[rng.integers(0, M)] += 5000  # a hub row
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        b = sharded.balanced_boundaries(rowptr, nblocks)
+        nnz = int(rowptr[-1])
+        assert b.dtype == np.int64 and len(b) == nblocks + 1 and b[0] == 0 and b[-1] == M
+        assert np.all(np.diff(b) >= 0)
+        for i in range(1, nblocks):
+            target = i * nnz // nblocks
+            first = next(r for r in range(M + 1) if rowptr[r] >= target)
+            assert b[i] == first, (M, nblocks, i)
+        # balance: no block exceeds its share by more than one row's worth of non-zeros
+        per = np.diff(rowptr[b].astype(np.int64))
+        assert per.sum() == nnz and per.max() <= -(-nnz // nblocks) + lens.max()
+    uniform = np.arange(0, 1001, 10, dtype=np.int32)  # 100 rows of 10
+    assert sharded.balanced_boundaries(uniform, 4).tolist() == [0, 25, 50, 75, 100]
 
 
 def test_single_process_layout(oracle_mod):
