@@ -247,16 +247,26 @@ int mi_dense_to_csr_fill(const float* dense, int32_t batch, int32_t rows,
 
 /* ------------------------------------------------------------------------ *
  * Device CSR transpose (A M×K → Aᵀ K×M, columns ascending within each row of
- * Aᵀ, stable): used by the backward pass  grad_B = Aᵀ · dC.
- * `workspace` ≥ mi_csr_transpose_workspace_bytes(M, K, nnz) (≈ 20 bytes per non-zero plus the
- * sort's scratch), 16-byte aligned.  No counterpart in the reference (its backward re-sparsifies a strided view,
- * matmuls.py:319-325, SURVEY.md §8a defect 1).
+ * Aᵀ, stable for duplicates): used by the backward pass  grad_B = Aᵀ · dC.
+ * Hand-written least-significant-digit counting passes over the column index (csr_transpose.hip):
+ * two passes for K·batch ≤ 2²⁰, three beyond; no atomics, deterministic.
+ * `workspace` ≥ mi_csr_transpose_workspace_bytes(M, K, nnz) (≈ 8–12 bytes per non-zero plus the
+ * per-tile digit tables), 16-byte aligned.  No counterpart in the reference (its backward
+ * re-sparsifies a strided view, matmuls.py:319-325, SURVEY.md §8a defect 1).
+ * Batched form: `batch` matrices in the batched-CSR layout of mi_spmm_csr_batched_f32 (rowptr
+ * [batch, M+1] with global offsets) → t_rowptr [batch, K+1] in the same layout, item b's
+ * transposed entries at t_rowptr[b*(K+1)] … ; one set of launches for the whole batch.
  * ------------------------------------------------------------------------ */
 size_t mi_csr_transpose_workspace_bytes(int32_t M, int32_t K, int64_t nnz);
 int mi_csr_transpose_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                          int64_t nnz, int32_t M, int32_t K, int32_t* t_rowptr,
                          int32_t* t_col, float* t_val, void* workspace,
                          size_t workspace_bytes, mi_stream_t stream);
+size_t mi_csr_transpose_batched_workspace_bytes(int32_t batch, int32_t M, int32_t K, int64_t nnz);
+int mi_csr_transpose_batched_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                                 int64_t nnz, int32_t batch, int32_t M, int32_t K,
+                                 int32_t* t_rowptr, int32_t* t_col, float* t_val,
+                                 void* workspace, size_t workspace_bytes, mi_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * SDDMM on A's pattern:  out[p] = Σ_j dC[row(p), j] · B[col[p], j]

@@ -1,10 +1,8 @@
 // Format-side kernels of the SpMM path (include/mi_spmm.h):
 //   dense 2-D transpose, column-major SpMM executor, device dense→CSR
-//   (count / scan / fill, batched), device CSR transpose, SDDMM.
+//   (count / scan / fill, batched), column sums, SDDMM.  (CSR transpose: csr_transpose.hip.)
 // Reference counterparts are cited at each entry point.
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "mi_common.h"
 
@@ -236,41 +234,6 @@ __global__ __launch_bounds__(256) void fill_csr_kernel(const float* __restrict__
       out += __builtin_popcountll(mask);
     }
   }
-}
-
-// --------------------------------------------------------------------------
-// CSR transpose helpers.
-// --------------------------------------------------------------------------
-// CSR transpose helpers.  Every entry travels through the sort as an 8-byte payload
-// {row of A, value bits}, so the result needs no gather afterwards.
-__global__ __launch_bounds__(256) void pack_row_val_kernel(const int* __restrict__ rowptr, int M,
-                                                          const float* __restrict__ val,
-                                                          unsigned long long* __restrict__ payload) {
-  const int lane = threadIdx.x & 63;
-  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += (long)gridDim.x * 4) {
-    const int start = rowptr[row], end = rowptr[row + 1];
-    for (int p = start + lane; p < end; p += 64)
-      payload[p] = (unsigned long long)(unsigned)row |
-                   ((unsigned long long)__builtin_bit_cast(unsigned, val[p]) << 32);
-  }
-}
-
-// After the stable sort by column: split the payload, and write the row offsets of Aᵀ from the
-// run boundaries of the sorted keys (t_rowptr[c] = first position whose key is ≥ c).
-__global__ __launch_bounds__(256) void unpack_transposed_kernel(const int* __restrict__ keys,
-                                                               const unsigned long long* __restrict__ payload,
-                                                               long nnz, int K, int* __restrict__ t_rowptr,
-                                                               int* __restrict__ t_col, float* __restrict__ t_val) {
-  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nnz) return;
-  const unsigned long long w = payload[q];
-  t_col[q] = (int)(unsigned)w;
-  t_val[q] = __builtin_bit_cast(float, (unsigned)(w >> 32));
-  const int key = keys[q];
-  const int prev = q > 0 ? keys[q - 1] : -1;
-  for (int c = prev + 1; c <= key && c <= K; ++c) t_rowptr[c] = (int)q;  // empty columns in between start here too
-  if (q == nnz - 1)
-    for (int c = key + 1; c <= K; ++c) t_rowptr[c] = (int)nnz;
 }
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -566,60 +529,6 @@ int mi_dense_to_csr_fill(const float* dense, int32_t batch, int32_t rows, int32_
   else
     hipLaunchKernelGGL(fill_csr_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, dense, n, rows, cols,
                        ld, stride, rowptr, col, val);
-  return mi::check_launch();
-}
-
-// Workspace: sorted keys | payload in | payload out | rocPRIM temp.
-static size_t transpose_sort_temp_bytes(int64_t nnz) {
-  size_t bytes = 0;
-  if (nnz > 0 &&
-      rocprim::radix_sort_pairs(nullptr, bytes, (const int*)nullptr, (int*)nullptr,
-                                (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)nnz, 0,
-                                32, (hipStream_t)0) != hipSuccess)
-    return 0;
-  return bytes;
-}
-
-size_t mi_csr_transpose_workspace_bytes(int32_t M, int32_t K, int64_t nnz) {
-  if (M < 0 || K < 0 || nnz < 0) return 0;
-  return align_up((size_t)nnz * 4) + 2 * align_up((size_t)nnz * 8) + align_up(transpose_sort_temp_bytes(nnz));
-}
-
-int mi_csr_transpose_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
-                         int32_t M, int32_t K, int32_t* t_rowptr, int32_t* t_col, float* t_val,
-                         void* workspace, size_t workspace_bytes, mi_stream_t stream) {
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (M < 0 || K < 0 || nnz < 0) return MI_EINVAL;
-  if (nnz > 0x7fffffffLL) return MI_ERANGE;
-  if (!t_rowptr) return MI_EINVAL;
-  if (nnz == 0 || K == 0) {
-    MI_HIP_TRY(hipMemsetAsync(t_rowptr, 0, sizeof(int32_t) * ((size_t)K + 1), s));
-    return MI_OK;
-  }
-  if (!rowptr || !col || !val || !t_col || !t_val) return MI_EINVAL;
-  if (workspace_bytes < mi_csr_transpose_workspace_bytes(M, K, nnz)) return MI_ENOMEM;
-  if (!workspace || !mi::aligned16(workspace)) return MI_EINVAL;
-  char* w = static_cast<char*>(workspace);
-  int* keys_out = reinterpret_cast<int*>(w);
-  w += align_up((size_t)nnz * 4);
-  unsigned long long* pay_in = reinterpret_cast<unsigned long long*>(w);
-  w += align_up((size_t)nnz * 8);
-  unsigned long long* pay_out = reinterpret_cast<unsigned long long*>(w);
-  w += align_up((size_t)nnz * 8);
-  size_t temp_bytes = transpose_sort_temp_bytes(nnz);
-
-  // {row, value} per entry, written coalesced by one wave per row of A
-  const long row_blocks = ((long)M + 3) / 4;
-  hipLaunchKernelGGL(pack_row_val_kernel, dim3((unsigned)(row_blocks < 65536 * 16 ? row_blocks : 65536 * 16)),
-                     dim3(256), 0, s, rowptr, M, val, pay_in);
-  // stable sort by column: inside a row of Aᵀ the entries keep ascending original order
-  // (= ascending row of A); only the bits a column index can have take part
-  int end_bit = 1;
-  while (end_bit < 32 && (1LL << end_bit) < (long long)K) ++end_bit;
-  MI_HIP_TRY(rocprim::radix_sort_pairs(w, temp_bytes, col, keys_out, pay_in, pay_out, (size_t)nnz, 0, end_bit, s));
-  const unsigned nb = (unsigned)((nnz + 255) / 256);
-  hipLaunchKernelGGL(unpack_transposed_kernel, dim3(nb), dim3(256), 0, s, keys_out, pay_out, (long)nnz, K, t_rowptr,
-                     t_col, t_val);
   return mi::check_launch();
 }
 

@@ -1,0 +1,737 @@
+// Device CSR transpose for gfx950 (include/mi_spmm.h: mi_csr_transpose_f32, mi_csr_transpose_batched_f32)
+//   A (M×K, CSR) → Aᵀ (K×M, CSR), columns of Aᵀ (= rows of A) ascending inside every row, stable.
+// Used by the backward pass grad_B = Aᵀ·dC; no counterpart in the reference (its backward
+// re-sparsifies a strided view, matmuls.py:319-325, SURVEY.md §8a defect 1).
+//
+// A transpose is a stable sort of the entries by column.  This file does it with hand-written
+// least-significant-digit counting passes over the column index (10 bits per pass: two passes for
+// K·batch ≤ 2²⁰, e.g. the 1M × 1M matrix of BASELINE config C3), built for the memory system
+// rather than around a generic sort:
+//   * the entry travels as 8 bytes {remaining key bits | row, value}; the first pass reads the CSR
+//     arrays directly (row ids come from a bounded binary search in rowptr, no expanded row array)
+//     and the last pass writes t_col / t_val directly — no pack / unpack passes;
+//   * a workgroup owns a tile of 8192 consecutive entries: 16 waves rank their 512 entries each with
+//     wave-private 16-bit LDS counters (ballot "peer" masks give the rank among equal digits, in
+//     entry order → stable, no atomics), the per-wave counts are prefixed per digit, the tile is
+//     reordered by digit in LDS and written out so that every digit's entries leave as one
+//     contiguous run;
+//   * per-(tile, digit) counts live in a tile-major table that is prefixed column-wise by three
+//     small launches (digit-major order of the scan, coalesced accesses);
+//   * for two passes the tiles of the last pass never straddle two low-digit bins, so the row
+//     offsets of Aᵀ fall out of the scanned table:  t_rowptr[hi·2^b + lo] = offset(hi, first tile of
+//     bin lo) — no histogram over K columns, no atomics anywhere, results are deterministic.
+// Larger key spaces (K·batch > 2²⁰) take three passes and keep the full key to find the row
+// boundaries with one extra pass; entries that do not fit the 8-byte form ((remaining key bits) +
+// (row bits) > 32) or an 11-bit digit take a simpler path that scatters straight from registers.
+#include "mi_common.h"
+
+namespace {
+
+constexpr int TR_TILE = 8192;
+constexpr int TR_THREADS = 1024;
+constexpr int TR_WAVES = TR_THREADS / 64;
+constexpr int TR_PER = TR_TILE / TR_THREADS;  // entries per thread
+constexpr int TR_GROUPS = 64;                 // tile groups of the column-wise table scan
+
+__host__ __device__ inline int bits_for(unsigned long long n) {  // bits needed for values 0 … n-1
+  int b = 0;
+  while (b < 63 && (1ULL << b) < n) ++b;
+  return b < 1 ? 1 : b;
+}
+
+struct TrArgs {
+  // problem
+  const int* rowptr;  // [batch][M+1], global offsets
+  const int* col;
+  const float* val;
+  long nnz;
+  int batch, M, K;
+  // pass description
+  int shift, bits;       // digit = (keyfield >> shift) & ((1 << bits) - 1)
+  int row_bits;          // packed form: a = (keyfield << row_bits) | row
+  int drop_after_first;  // two-pass packed: low digit dropped from the key after the first pass
+  // tiling of this pass's input
+  const int2* desc;  // per tile {start, len}, or nullptr: tile t = [t·TR_TILE, …)
+  int ntiles;        // grid size (an upper bound when desc is given; unused tiles have len 0)
+  // tables
+  int* table;            // [ntiles + 1][1 << bits], counts then (after the scan) global offsets
+  int* tile_row;         // first pass: flat rowptr index of the row holding the tile's first entry
+  // intermediate arrays (input of non-first passes / output of non-last passes)
+  const uint2* in_packed;
+  uint2* out_packed;
+  const unsigned *in_key, *in_row;
+  const float* in_val;
+  unsigned *out_key, *out_row;
+  float* out_val;
+  // final output
+  int* t_col;
+  float* t_val;
+  unsigned* keys_out;  // three passes: full key per output position (row boundaries), else nullptr
+};
+
+// flat rowptr index i (in [lo, hi]) of the row that holds entry e: the last i with rowptr[i] ≤ e.
+// (In the batched layout an item's end slot equals the next item's first slot, so "the last i"
+// is never an end slot for e < nnz.)
+__device__ __forceinline__ int row_of(const int* __restrict__ rowptr, int lo, int hi, int e) {
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo + 1) >> 1);
+    if (rowptr[mid] <= e) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+struct Entry {
+  unsigned key;  // key field of this pass (digit = (key >> shift) & mask)
+  unsigned row;
+  float val;
+};
+
+// tile bounds of workgroup t
+__device__ __forceinline__ void tile_bounds(const TrArgs& a, int t, long& start, int& len) {
+  if (a.desc) {
+    const int2 d = a.desc[t];
+    start = d.x;
+    len = d.y;
+  } else {
+    start = (long)t * TR_TILE;
+    const long rest = a.nnz - start;
+    len = rest < 0 ? 0 : (rest < TR_TILE ? (int)rest : TR_TILE);
+  }
+}
+
+template <bool FIRST, bool PACKED>
+__device__ __forceinline__ Entry load_entry(const TrArgs& a, long p, int row_lo, int row_hi) {
+  Entry e;
+  if (FIRST) {
+    const int idx = row_of(a.rowptr, row_lo, row_hi, (int)p);
+    unsigned c = (unsigned)a.col[p];
+    unsigned r = (unsigned)idx;
+    if (a.batch > 1) {
+      const unsigned item = (unsigned)idx / (unsigned)(a.M + 1);
+      r = (unsigned)idx - item * (unsigned)(a.M + 1);
+      c += item * (unsigned)a.K;
+    }
+    e.key = c;
+    e.row = r;
+    e.val = a.val[p];
+  } else if (PACKED) {
+    const uint2 w = a.in_packed[p];
+    e.key = w.x >> a.row_bits;
+    e.row = w.x & ((1u << a.row_bits) - 1u);
+    e.val = __builtin_bit_cast(float, w.y);
+  } else {
+    e.key = a.in_key[p];
+    e.row = a.in_row[p];
+    e.val = a.in_val[p];
+  }
+  return e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Count: per-tile digit histogram (LDS atomics), written tile-major.  The first pass also records
+// the row that holds the tile's first entry (one thread's binary search, hidden behind the rest).
+// ---------------------------------------------------------------------------------------------
+template <bool FIRST, bool PACKED>
+__global__ __launch_bounds__(256) void tr_count_kernel(TrArgs a) {
+  extern __shared__ int hist[];
+  const int nb = 1 << a.bits;
+  const int t = blockIdx.x;
+  for (int d = threadIdx.x; d < nb; d += 256) hist[d] = 0;
+  long start;
+  int len;
+  tile_bounds(a, t, start, len);
+  if (FIRST && threadIdx.x == 0) {
+    const int last = a.batch * (a.M + 1) - 1;
+    a.tile_row[t] = start < a.nnz ? row_of(a.rowptr, 0, last, (int)start) : last;
+    if (t == (int)gridDim.x - 1) a.tile_row[t + 1] = last;
+  }
+  __syncthreads();
+  const unsigned mask = (unsigned)nb - 1u;
+  if (FIRST && a.batch == 1) {
+    for (int i = threadIdx.x; i < len; i += 256)
+      atomicAdd(&hist[((unsigned)a.col[start + i] >> a.shift) & mask], 1);
+  } else if (FIRST) {
+    // batched: the key includes the item, i.e. needs the row; two threads bound the tile's rows first
+    __shared__ int row_bounds[2];
+    const int last = a.batch * (a.M + 1) - 1;
+    if (threadIdx.x < 2 && len > 0)
+      row_bounds[threadIdx.x] = row_of(a.rowptr, 0, last, (int)(threadIdx.x == 0 ? start : start + len - 1));
+    __syncthreads();
+    for (int i = threadIdx.x; i < len; i += 256) {
+      const Entry e = load_entry<true, PACKED>(a, start + i, row_bounds[0], row_bounds[1]);
+      atomicAdd(&hist[(e.key >> a.shift) & mask], 1);
+    }
+  } else {
+    for (int i = threadIdx.x; i < len; i += 256) {
+      const unsigned key = PACKED ? (a.in_packed[start + i].x >> a.row_bits) : a.in_key[start + i];
+      atomicAdd(&hist[(key >> a.shift) & mask], 1);
+    }
+  }
+  __syncthreads();
+  int* out = a.table + (long)t * nb;
+  for (int d = threadIdx.x; d < nb; d += 256) out[d] = hist[d];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column-wise scan of the tile-major table:  table[t][d] ← base[d] + Σ_{t' < t} table[t'][d],
+// base = exclusive scan over d of the column sums — i.e. the exclusive scan in (digit major, tile
+// minor) order.  rows = ntiles + 1 (the extra all-zero row ends up holding every digit's end).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tr_group_sums_kernel(const int* __restrict__ table, int rows, int nb,
+                                                            int* __restrict__ gsum) {
+  const int d = blockIdx.y * 256 + threadIdx.x;
+  if (d >= nb) return;
+  const int per = (rows + TR_GROUPS - 1) / TR_GROUPS;
+  const int t0 = blockIdx.x * per, t1 = t0 + per < rows ? t0 + per : rows;
+  int s = 0;
+#pragma unroll 4
+  for (int t = t0; t < t1; ++t) s += table[(long)t * nb + d];
+  gsum[blockIdx.x * nb + d] = s;
+}
+
+__global__ __launch_bounds__(1024) void tr_group_bases_kernel(int* __restrict__ gsum, int nb) {
+  // one workgroup: gsum[g][d] ← base[d] + Σ_{g' < g} gsum[g'][d]
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int d0 = 0; d0 < nb; d0 += 1024) {
+    const int d = d0 + threadIdx.x;
+    int tot = 0;
+    if (d < nb) {
+      for (int g = 0; g < TR_GROUPS; ++g) {
+        const int v = gsum[g * nb + d];
+        gsum[g * nb + d] = tot;
+        tot += v;
+      }
+    }
+    // exclusive scan of tot over the 1024 threads (+ carry from earlier chunks of digits)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = tot;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const int v = __shfl_up(incl, s, 64);
+      if (lane >= s) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int wbase = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int v = wsum[w];
+      if (w < wave) wbase += v;
+      all += v;
+    }
+    const int base = carry_s + wbase + incl - tot;
+    if (d < nb)
+      for (int g = 0; g < TR_GROUPS; ++g) gsum[g * nb + d] += base;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += all;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void tr_apply_kernel(int* __restrict__ table, int rows, int nb,
+                                                       const int* __restrict__ gsum) {
+  const int d = blockIdx.y * 256 + threadIdx.x;
+  if (d >= nb) return;
+  const int per = (rows + TR_GROUPS - 1) / TR_GROUPS;
+  const int t0 = blockIdx.x * per, t1 = t0 + per < rows ? t0 + per : rows;
+  int run = gsum[blockIdx.x * nb + d];
+#pragma unroll 4
+  for (int t = t0; t < t1; ++t) {
+    const int v = table[(long)t * nb + d];
+    table[(long)t * nb + d] = run;
+    run += v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tiles of the last of two passes: bin lo of the first pass occupies positions
+// [off(lo, tile 0), off(lo + 1, tile 0)) of the intermediate array; cut every bin into tiles of its
+// own so that no tile holds two low digits.  first_tile[lo] (and [nb0] = total) + desc[t].
+// One workgroup; tiles are written cooperatively bin by bin.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void tr_bin_tiles_kernel(const int* __restrict__ table0, int nb0, long nnz,
+                                                            int max_tiles, int* __restrict__ first_tile,
+                                                            int2* __restrict__ desc) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int d0 = 0; d0 < nb0; d0 += 1024) {
+    const int lo = d0 + threadIdx.x;
+    int nt = 0;
+    long b0 = 0, b1 = 0;
+    if (lo < nb0) {
+      b0 = table0[lo];  // row 0 of the scanned table: offset of (lo, tile 0)
+      b1 = lo + 1 < nb0 ? table0[lo + 1] : nnz;
+      nt = (int)((b1 - b0 + TR_TILE - 1) / TR_TILE);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = nt;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const int v = __shfl_up(incl, s, 64);
+      if (lane >= s) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int wbase = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int v = wsum[w];
+      if (w < wave) wbase += v;
+      all += v;
+    }
+    const int first = carry_s + wbase + incl - nt;
+    if (lo < nb0) {
+      first_tile[lo] = first;
+      for (int j = 0; j < nt && first + j < max_tiles; ++j) {
+        const long s = b0 + (long)j * TR_TILE;
+        desc[first + j] = make_int2((int)s, (int)(b1 - s < TR_TILE ? b1 - s : TR_TILE));
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += all;
+    __syncthreads();
+  }
+  const int total = carry_s;
+  if (threadIdx.x == 0) first_tile[nb0] = total;
+  for (int t = total + threadIdx.x; t < max_tiles; t += 1024) desc[t] = make_int2(0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scatter: one workgroup per tile, 16 waves × 512 entries.
+// ---------------------------------------------------------------------------------------------
+template <bool FIRST, bool LAST, bool PACKED, bool STAGED>
+__global__ __launch_bounds__(TR_THREADS) void tr_scatter_kernel(TrArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nb = 1 << a.bits;
+  unsigned short* cntw = reinterpret_cast<unsigned short*>(smem);  // [TR_WAVES][nb]
+  int* binstart = reinterpret_cast<int*>(smem + (size_t)TR_WAVES * nb * 2);  // [nb] tile-local start of a digit
+  int* gadj = binstart + nb;                                                  // [nb] global offset − binstart
+  uint2* sorted = reinterpret_cast<uint2*>(gadj + nb);                        // [TR_TILE]   (STAGED)
+  unsigned short* sorted_d = reinterpret_cast<unsigned short*>(sorted + TR_TILE);  // [TR_TILE] (STAGED)
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+
+  const int t = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  long start;
+  int len;
+  tile_bounds(a, t, start, len);
+  if (len == 0) return;  // block-uniform
+  const unsigned mask = (unsigned)nb - 1u;
+
+  for (int i = tid; i < TR_WAVES * nb / 2; i += TR_THREADS) reinterpret_cast<unsigned*>(cntw)[i] = 0u;
+  if (tid == 0) carry_s = 0;
+
+  int row_lo = 0, row_hi = 0;
+  if (FIRST) {
+    row_lo = a.tile_row[t];
+    row_hi = a.tile_row[t + 1];
+  }
+  Entry e[TR_PER];
+  unsigned dg[TR_PER];
+  int lrank[TR_PER];
+#pragma unroll
+  for (int c = 0; c < TR_PER; ++c) {
+    const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
+    if (i < len) e[c] = load_entry<FIRST, PACKED>(a, start + i, row_lo, row_hi);
+  }
+  __syncthreads();  // counters zeroed
+
+  // rank inside the wave: lanes holding the same digit ("peers") found with one ballot per digit bit;
+  // a lane's rank is the wave's running count of the digit + the number of peers below it
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  unsigned short* mycnt = cntw + wave * nb;
+#pragma unroll
+  for (int c = 0; c < TR_PER; ++c) {
+    const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
+    const bool valid = i < len;
+    const unsigned d = valid ? ((e[c].key >> a.shift) & mask) : 0u;
+    dg[c] = d;
+    unsigned long long peers = __ballot(valid);
+    for (int b = 0; b < a.bits; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    const int below = __builtin_popcountll(peers & lt);
+    int base = 0;
+    if (valid) base = mycnt[d];
+    if (valid && below == 0) mycnt[d] = (unsigned short)(base + __builtin_popcountll(peers));
+    lrank[c] = base + below;
+  }
+  __syncthreads();
+
+  // per digit: exclusive prefix over the waves (in place), tile total; then the exclusive scan of
+  // the totals over the digits and the digit's global offset
+  for (int d0 = 0; d0 < nb; d0 += TR_THREADS) {
+    const int d = d0 + tid;
+    int tot = 0;
+    if (d < nb) {
+#pragma unroll
+      for (int w = 0; w < TR_WAVES; ++w) {
+        const int v = cntw[w * nb + d];
+        cntw[w * nb + d] = (unsigned short)tot;
+        tot += v;
+      }
+    }
+    int incl = tot;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const int v = __shfl_up(incl, s, 64);
+      if (lane >= s) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int wbase = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int v = wsum[w];
+      if (w < wave) wbase += v;
+      all += v;
+    }
+    if (d < nb) {
+      const int bs = carry_s + wbase + incl - tot;
+      binstart[d] = bs;
+      gadj[d] = a.table[(long)t * nb + d] - bs;
+    }
+    __syncthreads();
+    if (tid == 0) carry_s += all;
+    __syncthreads();
+  }
+
+  // what leaves this pass for an entry
+  auto packed_out = [&](const Entry& x) {
+    const unsigned keep = a.drop_after_first ? (x.key >> a.bits) : x.key;  // two passes: drop the low digit
+    return make_uint2((keep << a.row_bits) | x.row, __builtin_bit_cast(unsigned, x.val));
+  };
+
+  if (STAGED) {
+    // reorder the tile by digit in LDS, then stream it out: each digit's entries leave as one run
+#pragma unroll
+    for (int c = 0; c < TR_PER; ++c) {
+      const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
+      if (i < len) {
+        const int s = binstart[dg[c]] + cntw[wave * nb + dg[c]] + lrank[c];
+        sorted[s] = LAST ? make_uint2(e[c].row, __builtin_bit_cast(unsigned, e[c].val)) : packed_out(e[c]);
+        sorted_d[s] = (unsigned short)dg[c];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < len; i += TR_THREADS) {
+      const uint2 w = sorted[i];
+      const long dst = (long)gadj[sorted_d[i]] + i;
+      if (LAST) {
+        a.t_col[dst] = (int)w.x;
+        a.t_val[dst] = __builtin_bit_cast(float, w.y);
+      } else {
+        a.out_packed[dst] = w;
+      }
+    }
+  } else {
+    // straight from registers (wide keys / rows, 11-bit digits): correct for every size, but the
+    // stores of a wave go to up to 64 different places
+#pragma unroll
+    for (int c = 0; c < TR_PER; ++c) {
+      const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
+      if (i < len) {
+        const long dst = (long)gadj[dg[c]] + binstart[dg[c]] + cntw[wave * nb + dg[c]] + lrank[c];
+        if (LAST) {
+          a.t_col[dst] = (int)e[c].row;
+          a.t_val[dst] = e[c].val;
+          if (a.keys_out) a.keys_out[dst] = e[c].key;
+        } else if (PACKED) {
+          a.out_packed[dst] = packed_out(e[c]);
+        } else {
+          a.out_key[dst] = a.drop_after_first ? (e[c].key >> a.bits) : e[c].key;
+          a.out_row[dst] = e[c].row;
+          a.out_val[dst] = e[c].val;
+        }
+      }
+    }
+  }
+}
+
+// Row offsets of Aᵀ, [batch][K+1] with global offsets, from the scanned tables (≤ 2 passes).
+//   one pass : offset(key) = table0[0][key]
+//   two      : offset(key) = table1[first_tile[lo]][hi]
+__global__ __launch_bounds__(256) void tr_rowptr_kernel(const int* __restrict__ table0, const int* __restrict__ table1,
+                                                        const int* __restrict__ first_tile, int bits0, int bits1,
+                                                        int passes, int batch, int K, long nnz,
+                                                        int* __restrict__ t_rowptr) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)batch * ((long)K + 1);
+  if (idx >= total) return;
+  const long b = idx / ((long)K + 1);
+  const long key = b * K + (idx - b * ((long)K + 1));
+  int v;
+  if (key >= (long)batch * K) {
+    v = (int)nnz;
+  } else if (passes == 1) {
+    v = table0[key];
+  } else {
+    const int lo = (int)(key & ((1L << bits0) - 1)), hi = (int)(key >> bits0);
+    v = table1[(long)first_tile[lo] * (1L << bits1) + hi];
+  }
+  t_rowptr[idx] = v;
+}
+
+// Three passes: row offsets from the run boundaries of the sorted full keys.
+__global__ __launch_bounds__(256) void tr_boundaries_kernel(const unsigned* __restrict__ keys, long nnz, int batch,
+                                                            int K, int* __restrict__ t_rowptr) {
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= nnz) return;
+  const long key = keys[q];
+  const long prev = q > 0 ? (long)keys[q - 1] : -1;
+  // every key in (prev, key] starts at q; a key's slot is key + (its item) in the [batch][K+1] layout
+  for (long k = prev + 1; k <= key; ++k) {
+    const long b = k / K;
+    t_rowptr[k + b] = (int)q;
+    if (k - b * K == 0 && b > 0) t_rowptr[k + b - 1] = (int)q;  // the previous item's end slot
+  }
+  if (q == nnz - 1) {
+    const long allk = (long)batch * K;
+    for (long k = key + 1; k <= allk; ++k) {
+      if (k < allk) {
+        const long b = k / K;
+        t_rowptr[k + b] = (int)nnz;
+        if (k - b * K == 0 && b > 0) t_rowptr[k + b - 1] = (int)nnz;
+      } else {
+        t_rowptr[allk + batch - 1] = (int)nnz;
+      }
+    }
+  }
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct TrPlan {
+  int passes, key_bits, row_bits;
+  int bits[3], shift[3];
+  bool packed, staged[3], drop;
+  long ntiles0, ntiles_max[3];
+};
+
+TrPlan make_plan(int batch, int M, int K, long nnz) {
+  TrPlan p{};
+  p.key_bits = bits_for((unsigned long long)batch * (unsigned long long)(K > 0 ? K : 1));
+  p.row_bits = bits_for((unsigned long long)(M > 0 ? M : 1));
+  if (p.key_bits <= 10) {
+    p.passes = 1;
+    p.bits[0] = p.key_bits;
+  } else if (p.key_bits <= 20) {
+    p.passes = 2;
+    p.bits[0] = (p.key_bits + 1) / 2;
+    p.bits[1] = p.key_bits - p.bits[0];
+  } else {
+    p.passes = 3;
+    p.bits[0] = (p.key_bits + 2) / 3;
+    p.bits[1] = (p.key_bits - p.bits[0] + 1) / 2;
+    p.bits[2] = p.key_bits - p.bits[0] - p.bits[1];
+  }
+  p.drop = p.passes == 2;  // the key field loses its low digit after the first of two passes
+  const int carried_bits = p.passes == 2 ? p.key_bits - p.bits[0] : p.key_bits;  // key bits an intermediate entry keeps
+  p.packed = p.passes == 1 || carried_bits + p.row_bits <= 32;
+  int sh = 0;
+  for (int i = 0; i < p.passes; ++i) {
+    p.shift[i] = (p.drop && i == 1) ? 0 : sh;
+    sh += p.bits[i];
+    // LDS staging needs the 8-byte entry and a 10-bit digit; the last of three passes must also hand
+    // out full keys, which the staged form does not carry
+    p.staged[i] = p.packed && p.bits[i] <= 10 && !(p.passes == 3 && i == 2);
+  }
+  p.ntiles0 = (nnz + TR_TILE - 1) / TR_TILE;
+  for (int i = 0; i < 3; ++i) p.ntiles_max[i] = p.ntiles0;
+  if (p.passes == 2) p.ntiles_max[1] = p.ntiles0 + (1L << p.bits[0]);
+  return p;
+}
+
+struct TrWs {
+  size_t inter[2], tables[3], gsum, tile_row, desc, first_tile, keys, total;
+};
+
+TrWs ws_layout(const TrPlan& p, long nnz) {
+  TrWs w{};
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off += align256(bytes);
+    return o;
+  };
+  const size_t entry = p.packed ? 8 : 12;
+  w.inter[0] = take(p.passes >= 2 ? (size_t)nnz * entry : 0);
+  w.inter[1] = take(p.passes >= 3 ? (size_t)nnz * entry : 0);
+  for (int i = 0; i < 3; ++i)
+    w.tables[i] = take(i < p.passes ? (size_t)(p.ntiles_max[i] + 1) * ((size_t)1 << p.bits[i]) * 4 : 0);
+  w.gsum = take((size_t)TR_GROUPS * 2048 * 4);
+  w.tile_row = take((size_t)(p.ntiles0 + 2) * 4);
+  w.desc = take(p.passes == 2 ? (size_t)p.ntiles_max[1] * 8 : 0);
+  w.first_tile = take(p.passes == 2 ? (((size_t)1 << p.bits[0]) + 1) * 4 : 0);
+  w.keys = take(p.passes == 3 ? (size_t)nnz * 4 : 0);
+  w.total = off;
+  return w;
+}
+
+template <bool FIRST, bool LAST>
+int launch_scatter(const TrArgs& a, bool packed, bool staged, hipStream_t s) {
+  const int nb = 1 << a.bits;
+  size_t lds = (size_t)TR_WAVES * nb * 2 + (size_t)nb * 8;
+  if (staged) lds += (size_t)TR_TILE * 8 + (size_t)TR_TILE * 2;
+#define MI_TR(P_, S_)                                                                                              \
+  do {                                                                                                             \
+    auto k = tr_scatter_kernel<FIRST, LAST, P_, S_>;                                                               \
+    if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(k, dim3((unsigned)a.ntiles), dim3(TR_THREADS), lds, s, a);                                   \
+  } while (0)
+  if (packed && staged) MI_TR(true, true);
+  else if (packed) MI_TR(true, false);
+  else MI_TR(false, false);
+#undef MI_TR
+  return mi::check_launch();
+}
+
+int transpose_impl(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz, int32_t batch, int32_t M,
+                   int32_t K, int32_t* t_rowptr, int32_t* t_col, float* t_val, void* workspace, size_t workspace_bytes,
+                   hipStream_t s) {
+  if (batch < 0 || M < 0 || K < 0 || nnz < 0) return MI_EINVAL;
+  if (nnz > 0x7fffffffLL || (long)batch * ((long)M + 1) > 0x7fffffffLL || (long)batch * (long)K > 0x7fffffffLL ||
+      (long)batch * ((long)K + 1) > 0x7fffffffLL)
+    return MI_ERANGE;
+  if (batch == 0) return MI_OK;
+  if (!t_rowptr) return MI_EINVAL;
+  if (nnz == 0 || K == 0) {
+    MI_HIP_TRY(hipMemsetAsync(t_rowptr, 0, sizeof(int32_t) * (size_t)batch * ((size_t)K + 1), s));
+    return MI_OK;
+  }
+  if (!rowptr || !col || !val || !t_col || !t_val || M == 0) return MI_EINVAL;
+  const TrPlan p = make_plan(batch, M, K, nnz);
+  const TrWs w = ws_layout(p, nnz);
+  if (workspace_bytes < w.total) return MI_ENOMEM;
+  if (!workspace || !mi::aligned16(workspace)) return MI_EINVAL;
+  char* base = static_cast<char*>(workspace);
+
+  TrArgs a{};
+  a.rowptr = rowptr;
+  a.col = col;
+  a.val = val;
+  a.nnz = nnz;
+  a.batch = batch;
+  a.M = M;
+  a.K = K;
+  a.row_bits = p.row_bits;
+  a.tile_row = reinterpret_cast<int*>(base + w.tile_row);
+  a.t_col = t_col;
+  a.t_val = t_val;
+  a.keys_out = p.passes == 3 ? reinterpret_cast<unsigned*>(base + w.keys) : nullptr;
+  int* gsum = reinterpret_cast<int*>(base + w.gsum);
+  int* tables[3];
+  for (int i = 0; i < 3; ++i) tables[i] = reinterpret_cast<int*>(base + w.tables[i]);
+  int* first_tile = reinterpret_cast<int*>(base + w.first_tile);
+  int2* desc = reinterpret_cast<int2*>(base + w.desc);
+
+  auto set_inter = [&](int which, bool as_input) {
+    char* q = base + w.inter[which];
+    if (p.packed) {
+      if (as_input) a.in_packed = reinterpret_cast<const uint2*>(q);
+      else a.out_packed = reinterpret_cast<uint2*>(q);
+    } else {
+      unsigned* k = reinterpret_cast<unsigned*>(q);
+      unsigned* r = k + nnz;
+      float* v = reinterpret_cast<float*>(r + nnz);
+      if (as_input) {
+        a.in_key = k;
+        a.in_row = r;
+        a.in_val = v;
+      } else {
+        a.out_key = k;
+        a.out_row = r;
+        a.out_val = v;
+      }
+    }
+  };
+
+  for (int pass = 0; pass < p.passes; ++pass) {
+    const bool first = pass == 0, last = pass == p.passes - 1;
+    const int nb = 1 << p.bits[pass];
+    a.shift = p.shift[pass];
+    a.bits = p.bits[pass];
+    a.drop_after_first = (p.drop && first) ? 1 : 0;
+    a.table = tables[pass];
+    a.desc = nullptr;
+    a.ntiles = (int)p.ntiles0;
+    if (!first) set_inter(pass - 1, true);
+    if (!last) set_inter(pass, false);
+    if (p.passes == 2 && pass == 1) {
+      // tiles that do not straddle the low-digit bins (→ row offsets straight from the table)
+      hipLaunchKernelGGL(tr_bin_tiles_kernel, dim3(1), dim3(1024), 0, s, tables[0], 1 << p.bits[0], (long)nnz,
+                         (int)p.ntiles_max[1], first_tile, desc);
+      a.desc = desc;
+      a.ntiles = (int)p.ntiles_max[1];
+    }
+    const int rows = a.ntiles + 1;
+    // the extra last row must read as zeros before the scan
+    MI_HIP_TRY(hipMemsetAsync(tables[pass] + (size_t)a.ntiles * nb, 0, (size_t)nb * 4, s));
+    const size_t hist_lds = (size_t)nb * 4;
+    if (first) {
+      if (p.packed) hipLaunchKernelGGL((tr_count_kernel<true, true>), dim3((unsigned)a.ntiles), dim3(256), hist_lds, s, a);
+      else hipLaunchKernelGGL((tr_count_kernel<true, false>), dim3((unsigned)a.ntiles), dim3(256), hist_lds, s, a);
+    } else {
+      if (p.packed) hipLaunchKernelGGL((tr_count_kernel<false, true>), dim3((unsigned)a.ntiles), dim3(256), hist_lds, s, a);
+      else hipLaunchKernelGGL((tr_count_kernel<false, false>), dim3((unsigned)a.ntiles), dim3(256), hist_lds, s, a);
+    }
+    const dim3 sg(TR_GROUPS, (unsigned)((nb + 255) / 256));
+    hipLaunchKernelGGL(tr_group_sums_kernel, sg, dim3(256), 0, s, tables[pass], rows, nb, gsum);
+    hipLaunchKernelGGL(tr_group_bases_kernel, dim3(1), dim3(1024), 0, s, gsum, nb);
+    hipLaunchKernelGGL(tr_apply_kernel, sg, dim3(256), 0, s, tables[pass], rows, nb, gsum);
+    int st = mi::check_launch();
+    if (st != MI_OK) return st;
+    if (first && last) st = launch_scatter<true, true>(a, p.packed, p.staged[pass], s);
+    else if (first) st = launch_scatter<true, false>(a, p.packed, p.staged[pass], s);
+    else if (last) st = launch_scatter<false, true>(a, p.packed, p.staged[pass], s);
+    else st = launch_scatter<false, false>(a, p.packed, p.staged[pass], s);
+    if (st != MI_OK) return st;
+  }
+  if (p.passes <= 2) {
+    const long total = (long)batch * ((long)K + 1);
+    hipLaunchKernelGGL(tr_rowptr_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, tables[0],
+                       p.passes == 2 ? tables[1] : tables[0], first_tile, p.bits[0], p.bits[1], p.passes, batch, K,
+                       (long)nnz, t_rowptr);
+  } else {
+    hipLaunchKernelGGL(tr_boundaries_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s, a.keys_out, (long)nnz,
+                       batch, K, t_rowptr);
+  }
+  return mi::check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mi_csr_transpose_batched_workspace_bytes(int32_t batch, int32_t M, int32_t K, int64_t nnz) {
+  if (batch <= 0 || M < 0 || K < 0 || nnz < 0) return 0;
+  return ws_layout(make_plan(batch, M, K, nnz), nnz).total;
+}
+
+size_t mi_csr_transpose_workspace_bytes(int32_t M, int32_t K, int64_t nnz) {
+  return mi_csr_transpose_batched_workspace_bytes(1, M, K, nnz);
+}
+
+int mi_csr_transpose_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz, int32_t M,
+                         int32_t K, int32_t* t_rowptr, int32_t* t_col, float* t_val, void* workspace,
+                         size_t workspace_bytes, mi_stream_t stream) {
+  return transpose_impl(rowptr, col, val, nnz, 1, M, K, t_rowptr, t_col, t_val, workspace, workspace_bytes,
+                        static_cast<hipStream_t>(stream));
+}
+
+int mi_csr_transpose_batched_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
+                                 int32_t batch, int32_t M, int32_t K, int32_t* t_rowptr, int32_t* t_col,
+                                 float* t_val, void* workspace, size_t workspace_bytes, mi_stream_t stream) {
+  return transpose_impl(rowptr, col, val, nnz, batch, M, K, t_rowptr, t_col, t_val, workspace, workspace_bytes,
+                        static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

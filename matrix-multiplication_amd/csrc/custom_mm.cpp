@@ -326,7 +326,9 @@ torch::Tensor column_sums(torch::Tensor src) {
 // dense [..., rows, cols] → (values f32[nnz], columns i32[nnz], offsets i32[batch, rows+1]);
 // offsets are global over the batch ("rowptr of rowptrs", include/mi_spmm.h).
 // Device counterpart of dense_to_csr (reference src/baseline_mm.cu:218-264).
-std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> dense_to_csr(torch::Tensor dense) {
+// Step 1 alone: the row offsets [batch, rows+1] (global over the batch; the last entry is the total
+// nnz) — no host read-back, so a caller can look at the density before paying for the fill.
+torch::Tensor dense_row_offsets(torch::Tensor dense) {
   check_device_f32(dense, "dense");
   TORCH_CHECK(dense.dim() >= 2, "dense_to_csr: expected at least a 2-d tensor");
   torch::Tensor d = dense.contiguous();
@@ -347,16 +349,38 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> dense_to_csr(torch::Tens
                                      rows * cols, offsets.data_ptr<int32_t>(), ws.data_ptr(), ws_bytes,
                                      stream_of(d)),
                "dense_to_csr(count)");
-  // one host read-back per call (not per slice) to size col / val
-  const int64_t nnz = batch > 0 ? offsets.view({-1})[batch * (rows + 1) - 1].item<int32_t>() : 0;
-  torch::Tensor columns = torch::empty({nnz}, iopt);
+  return offsets;
+}
+
+// Step 2: (values, columns) for offsets produced by dense_row_offsets on the same tensor; nnz is
+// the caller's host copy of offsets[-1, -1].
+std::tuple<torch::Tensor, torch::Tensor> dense_to_csr_fill(torch::Tensor dense, torch::Tensor offsets, int64_t nnz) {
+  check_device_f32(dense, "dense");
+  check_device_i32(offsets, "offsets");
+  check_same_device(dense, offsets, "dense_to_csr_fill");
+  TORCH_CHECK(dense.dim() >= 2 && nnz >= 0 && nnz <= dense.numel(), "dense_to_csr_fill: bad arguments");
+  torch::Tensor d = dense.contiguous();
+  const int64_t rows = d.size(-2), cols = d.size(-1);
+  const int64_t batch = rows * cols > 0 ? d.numel() / (rows * cols) : 0;
+  TORCH_CHECK(offsets.is_contiguous() && offsets.numel() == batch * (rows + 1) || nnz == 0,
+              "dense_to_csr_fill: offsets must be the [batch, rows + 1] tensor of dense_row_offsets");
+  c10::hip::HIPGuard guard(d.device().index());
+  torch::Tensor columns = torch::empty({nnz}, torch::dtype(torch::kInt32).device(d.device()));
   torch::Tensor values = torch::empty({nnz}, torch::dtype(torch::kFloat32).device(d.device()));
   if (nnz > 0)
     check_status(mi_dense_to_csr_fill(d.data_ptr<float>(), (int32_t)batch, (int32_t)rows, (int32_t)cols, cols,
                                       rows * cols, offsets.data_ptr<int32_t>(), columns.data_ptr<int32_t>(),
                                       values.data_ptr<float>(), stream_of(d)),
                  "dense_to_csr(fill)");
-  return std::make_tuple(values, columns, offsets);
+  return std::make_tuple(values, columns);
+}
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> dense_to_csr(torch::Tensor dense) {
+  torch::Tensor offsets = dense_row_offsets(dense);
+  // one host read-back per call (not per slice) to size col / val
+  const int64_t nnz = offsets.numel() > 0 ? offsets.view({-1})[offsets.numel() - 1].item<int32_t>() : 0;
+  auto vc = dense_to_csr_fill(dense, offsets, nnz);
+  return std::make_tuple(std::get<0>(vc), std::get<1>(vc), offsets);
 }
 
 // C[b] = A[b]·B[b] for a batched CSR (offsets [batch, A_rows+1], global) in one
@@ -484,6 +508,41 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> csr_transpose(torch::Ten
                                     A_values.data_ptr<float>(), nnzA, (int32_t)A_rows, (int32_t)A_cols,
                                     t_off.data_ptr<int32_t>(), t_col.data_ptr<int32_t>(), t_val.data_ptr<float>(),
                                     ws.data_ptr(), ws_bytes, stream_of(A_values)),
+               what);
+  return std::make_tuple(t_val, t_col, t_off);
+}
+
+// Batched CSR (offsets [batch, A_rows+1], global) → the batched CSR of the transposes
+// (values, columns, offsets [batch, A_cols+1]); one set of launches for the whole batch.
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> csr_transpose_batched(torch::Tensor A_values,
+                                                                              torch::Tensor A_columns,
+                                                                              torch::Tensor A_offsets, int64_t nnzA,
+                                                                              int64_t batch, int64_t A_rows,
+                                                                              int64_t A_cols) {
+  const char* what = "csr_transpose_batched";
+  check_device_f32(A_values, "A_values");
+  check_device_i32(A_columns, "A_columns");
+  check_device_i32(A_offsets, "A_offsets");
+  check_same_device(A_values, A_columns, what);
+  check_same_device(A_values, A_offsets, what);
+  TORCH_CHECK(batch >= 0 && A_rows >= 0 && A_cols >= 0 && nnzA >= 0 && A_rows <= INT32_MAX && A_cols <= INT32_MAX &&
+                  batch <= INT32_MAX,
+              what, ": bad size");
+  TORCH_CHECK(A_values.is_contiguous() && A_columns.is_contiguous() && A_offsets.is_contiguous(), what,
+              ": CSR arrays must be contiguous");
+  TORCH_CHECK(A_offsets.numel() == batch * (A_rows + 1) && A_values.numel() >= nnzA && A_columns.numel() >= nnzA, what,
+              ": CSR array sizes do not match");
+  c10::hip::HIPGuard guard(A_values.device().index());
+  auto iopt = torch::dtype(torch::kInt32).device(A_values.device());
+  torch::Tensor t_off = torch::empty({batch, A_cols + 1}, iopt);
+  torch::Tensor t_col = torch::empty({nnzA}, iopt);
+  torch::Tensor t_val = torch::empty({nnzA}, A_values.options());
+  const size_t ws_bytes = mi_csr_transpose_batched_workspace_bytes((int32_t)batch, (int32_t)A_rows, (int32_t)A_cols, nnzA);
+  torch::Tensor ws = torch::empty({(int64_t)std::max<size_t>(ws_bytes, 1)}, torch::dtype(torch::kUInt8).device(A_values.device()));
+  check_status(mi_csr_transpose_batched_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
+                                            A_values.data_ptr<float>(), nnzA, (int32_t)batch, (int32_t)A_rows,
+                                            (int32_t)A_cols, t_off.data_ptr<int32_t>(), t_col.data_ptr<int32_t>(),
+                                            t_val.data_ptr<float>(), ws.data_ptr(), ws_bytes, stream_of(A_values)),
                what);
   return std::make_tuple(t_val, t_col, t_off);
 }
@@ -734,8 +793,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
 
   // additions (not in the reference): one-launch batching and the sparse backward
   m.def("dense_to_csr", &dense_to_csr, "Device dense -> batched CSR (values, columns, offsets)");
+  m.def("dense_row_offsets", &dense_row_offsets, "Device dense -> row offsets [batch, rows+1] only (no host sync)");
+  m.def("dense_to_csr_fill", &dense_to_csr_fill, "(values, columns) for the offsets of dense_row_offsets");
   m.def("naive_spmm_batched", &naive_spmm_batched, "Batched CSR x dense in one launch");
   m.def("csr_transpose", &csr_transpose, "Device CSR transpose (values, columns, offsets)");
+  m.def("csr_transpose_batched", &csr_transpose_batched, "Batched device CSR transpose (values, columns, offsets [batch, cols+1])");
   m.def("sddmm", &sddmm, "Sampled dense-dense product on a CSR pattern");
   m.def("naive_spmm_dense", &naive_spmm_dense,
         "A·B with A dense, zeros skipped in the kernel; False if the shape is not covered");

@@ -61,43 +61,86 @@ class _LinearBias(InplaceFunction):
         return grad_inp, grad_w, grad_b
 
 
+def sparse_forward_pays(nnz, tokens, in_features, out_features, fused=False):
+    '''Forward cost model of `cusparseLinear` (fitted on MI355X, tools/bench_fc.py,
+    profiles/r02_fc_layer_timings.log): the exact-fp32 MFMA product runs at ≈130 TFLOP/s on these
+    shapes, the row-split SpMM of ReLU-sparse activations at ≈15 TFLOP/s of useful flops, plus the
+    passes over the activations the route needs after the count (CSR route: the fill reads them again
+    and writes col/val, ≈2 passes; fused zero-skipping kernel: its own read, 1 pass).  Sparse is
+    taken only when the model gives it a 10 % lead.'''
+    t_dense = 2.0 * tokens * in_features * out_features / 130e12
+    passes = 1.0 if fused else 2.0
+    t_sparse = 2.0 * nnz * out_features / 15e12 + passes * tokens * in_features * 4 / 4e12
+    return t_sparse < 0.9 * t_dense
+
+
 class _SparseLinearBias(InplaceFunction):
-    '''y = sparse(x)·Wᵀ (+ bias): the activations' exact zeros are skipped (CSR on the device).'''
+    '''y = sparse(x)·Wᵀ (+ bias): the activations' exact zeros are skipped when that pays.
+
+    The non-zeros are counted on the device first (one pass, one host read-back — the reference's
+    cusparseDenseToSparse analysis step syncs as well, src/baseline_mm.cu:232-247); with the count
+    the layer takes the CSR route (conversion + row-split kernel, bias fused), the fused
+    zero-skipping kernel (out_features ≤ 256: no CSR at all) or — when the activations are not
+    sparse enough — the dense MFMA product.  All three sum the same terms in the same (column)
+    order, the skipped ones being exact zeros, so the result does not depend on the route.
+    Under stream capture nothing may be read back: the fused kernel or the dense product is used.'''
 
     @staticmethod
     def forward(ctx, inp, weight, bias):
-        ctx.save_for_backward(inp, weight)
         ctx.has_bias = bias is not None
         x2 = inp.reshape(-1, inp.shape[-1])
-        values, columns, offsets = custom_mm.dense_to_csr(x2)
-        ctx.x_density = values.numel() / max(1, x2.numel())
-        wt = weight.t().contiguous()                                     # [in, out] row-major B operand
-        out = torch.empty((x2.shape[0], weight.shape[0]), device=inp.device, dtype=torch.float32)
-        if bias is not None:
-            custom_mm.naive_spmm_bias(values, columns, offsets.view(-1), values.numel(), x2.shape[0], x2.shape[1],
-                                      wt, bias, out)
-        else:
-            custom_mm.naive_spmm(values, columns, offsets.view(-1), values.numel(), x2.shape[0], x2.shape[1], wt, out)
-        return out.view(tuple(inp.shape[:-1]) + (weight.shape[0],))
+        tokens, fin, fout = x2.shape[0], x2.shape[1], weight.shape[0]
+        out = torch.empty((tokens, fout), device=inp.device, dtype=torch.float32)
+        csr = None
+        capturing = inp.is_cuda and torch.cuda.is_current_stream_capturing()
+        nnz = None
+        if not capturing and x2.numel() > 0:
+            offsets = custom_mm.dense_row_offsets(x2)
+            nnz = int(offsets.view(-1)[-1])
+        ctx.x_density = 1.0 if nnz is None else nnz / max(1, x2.numel())
+        fused_ok = fout <= 256 and fout % 4 == 0
+        sparse = nnz is not None and sparse_forward_pays(nnz, tokens, fin, fout, fused_ok)
+        done = False
+        if (sparse or capturing) and fused_ok:
+            wt = weight.t().contiguous()                                 # [in, out] row-major B operand
+            done = (custom_mm.naive_spmm_dense_bias(x2, wt, bias, out) if bias is not None
+                    else custom_mm.naive_spmm_dense(x2, wt, out))
+        if not done and sparse:
+            values, columns = custom_mm.dense_to_csr_fill(x2, offsets, nnz)
+            csr = (values, columns, offsets.view(-1))
+            wt = weight.t().contiguous()
+            if bias is not None:
+                custom_mm.naive_spmm_bias(values, columns, csr[2], nnz, tokens, fin, wt, bias, out)
+            else:
+                custom_mm.naive_spmm(values, columns, csr[2], nnz, tokens, fin, wt, out)
+            done = True
+        if not done:
+            if bias is not None:
+                custom_mm.cublas_mmul_bias(x2, weight, bias, out, False, True)
+            else:
+                custom_mm.cublas_mmul(x2, weight, out, False, True)
+        ctx.has_csr = csr is not None
+        ctx.save_for_backward(inp, weight, *(csr or ()))
+        return out.view(tuple(inp.shape[:-1]) + (fout,))
 
     @staticmethod
     def backward(ctx, grad_output):
-        inp, weight = ctx.saved_tensors
+        inp, weight = ctx.saved_tensors[:2]
         g2 = grad_output.reshape(-1, grad_output.shape[-1])
         x2 = inp.reshape(-1, inp.shape[-1])
         grad_inp = grad_w = grad_b = None
         if ctx.needs_input_grad[0]:
             grad_inp = custom_matmul(g2, weight).view(inp.shape)       # dense gradient, as torch autograd gives
-        if ctx.needs_input_grad[1] and ctx.x_density > 0.12:
+        if ctx.needs_input_grad[1] and (ctx.x_density > 0.12 or not ctx.has_csr):
             # x is not sparse enough for the sparse route to pay (in × out is a small output: few
             # workgroups): the dense product sums the same terms in the same token order, the
             # skipped ones being exact zeros.  Measured at 16384 tokens, 3072 → 768, half zeros:
             # forward + backward 9.1 → 3.6 ms (tools/bench_fc.py).
             grad_w = custom_matmul(g2, x2, transa=True)
         elif ctx.needs_input_grad[1]:
-            # dYᵀ·x = (xᵀ·dY)ᵀ with x sparse: CSR transpose, then the row-split kernel
-            values, columns, offsets = custom_mm.dense_to_csr(x2)
-            t_val, t_col, t_off = custom_mm.csr_transpose(values, columns, offsets.view(-1), values.numel(),
+            # dYᵀ·x = (xᵀ·dY)ᵀ with x sparse: the CSR kept from forward, transposed, then the row-split kernel
+            values, columns, offsets = ctx.saved_tensors[2:]
+            t_val, t_col, t_off = custom_mm.csr_transpose(values, columns, offsets, values.numel(),
                                                           x2.shape[0], x2.shape[1])
             gwt = torch.empty((x2.shape[1], g2.shape[1]), device=g2.device, dtype=torch.float32)
             custom_mm.naive_spmm(t_val, t_col, t_off, values.numel(), x2.shape[1], x2.shape[0], g2, gwt)

@@ -51,6 +51,19 @@ def cusparse_mmul(vals, cols, offs, nnz, rows, kcols, B, C):
     return _spmm("cusparse_mmul", vals, cols, offs, nnz, rows, kcols, B, C)
 
 
+def dense_row_offsets(dense):
+    calls.append(("dense_row_offsets", tuple(dense.shape)))
+    rp, _, _ = oracle.dense_to_csr(_np(dense))
+    return torch.from_numpy(rp.copy())
+
+
+def dense_to_csr_fill(dense, offsets, nnz):
+    calls.append(("dense_to_csr_fill", tuple(dense.shape)))
+    rp, c, v = oracle.dense_to_csr(_np(dense))
+    assert np.array_equal(rp, offsets.numpy()) and len(v) == nnz
+    return torch.from_numpy(v.copy()), torch.from_numpy(c.copy())
+
+
 def dense_to_csr(dense):
     calls.append(("dense_to_csr", tuple(dense.shape)))
     rp, c, v = oracle.dense_to_csr(_np(dense))

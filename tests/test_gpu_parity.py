@@ -229,6 +229,106 @@ def test_csr_transpose_bit_exact(cmm, dev, oracle_mod, M, K, density):
     assert np.array_equal(t_val.cpu().numpy(), e_val)
 
 
+def _random_rows_csr(M, K, lens, seed, shuffle=0.0, duplicates=False):
+    g = np.random.Generator(np.random.PCG64(seed))
+    cols = []
+    lens = np.asarray(lens)
+    for r in np.nonzero(lens)[0]:
+        n = int(lens[r])
+        c = g.integers(0, K, size=n) if (duplicates or n > K) else g.choice(K, size=n, replace=False)
+        c = np.sort(c)
+        if shuffle and g.random() < shuffle:
+            c = g.permutation(c)
+        cols.append(c.astype(np.int32))
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate(cols) if cols else np.zeros(0, np.int32)
+    return rowptr, col, (g.random(len(col), dtype=np.float32) - 0.5)
+
+
+@pytest.mark.parametrize("M,K,nnz_per_row,what", [
+    (500, 1000, 40, "one pass (K <= 1024), several tiles"),
+    (20000, 70000, 30, "two passes, ragged digit split (17 bits), many tiles"),
+    (3000, 1 << 20, 300, "two passes, 10 + 10 bits"),
+    (2000, 3_000_000, 25, "three passes, full keys + boundary pass"),
+    (5_000_000, 600_000, 0, "two passes, rows too wide for the 8-byte entry (register scatter path)"),
+    (40, 1_200_000_000, 50, "31-bit keys: three passes with an 11-bit digit"),
+])
+def test_csr_transpose_pass_structures(cmm, dev, oracle_mod, M, K, nnz_per_row, what):
+    """Every plan of csr_transpose.hip — 1 / 2 / 3 counting passes, LDS-staged and register-scatter
+    entries — against the oracle, with a fifth of the rows shuffled out of column order and duplicate
+    columns allowed (the transpose must be stable: equal columns keep their row / position order)."""
+    g = np.random.Generator(np.random.PCG64(M + K))
+    if nnz_per_row:
+        lens = g.integers(0, 2 * nnz_per_row, size=M)
+    else:  # a few thousand short rows scattered over five million
+        lens = np.zeros(M, np.int64)
+        lens[g.choice(M, size=4000, replace=False)] = g.integers(1, 30, size=4000)
+    rowptr, col, val = _random_rows_csr(M, K, lens, seed=K % 1000, shuffle=0.2, duplicates=True)
+    t_val, t_col, t_off = cmm.csr_transpose(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K)
+    if K > 10_000_000:
+        # the oracle's dense row-offset array would be 8 GB: check through the sorted entries instead
+        order = np.argsort(col, kind="stable")
+        rows = np.repeat(np.arange(M, dtype=np.int32), np.diff(rowptr))
+        assert np.array_equal(t_col.cpu().numpy(), rows[order]) and np.array_equal(t_val.cpu().numpy(), val[order])
+        off = t_off.cpu().numpy()
+        assert off[0] == 0 and off[-1] == len(val) and np.all(np.diff(off[::4096]) >= 0)
+        used = np.unique(col)
+        assert np.array_equal(off[used], np.searchsorted(col[order], used, side="left"))
+        assert np.array_equal(off[used + 1], np.searchsorted(col[order], used, side="right"))
+        return
+    e_rp, e_col, e_val = oracle_mod.csr_transpose(rowptr, col, val, M, K)
+    assert np.array_equal(t_off.cpu().numpy(), e_rp), what
+    assert np.array_equal(t_col.cpu().numpy(), e_col) and np.array_equal(t_val.cpu().numpy(), e_val), what
+
+
+@pytest.mark.parametrize("batch,M,K,density", [(6, 50, 70, 0.3), (384, 64, 512, 0.1), (3, 700, 5000, 0.01), (5, 1, 9, 0.5),
+                                               (4, 300, 300000, 0.001)])
+def test_csr_transpose_batched_bit_exact(cmm, dev, oracle_mod, batch, M, K, density):
+    """The batched CSR ("rowptr of rowptrs") of dense_to_csr transposed in one set of launches equals
+    the per-item oracle transposes laid out the same way."""
+    g = np.random.Generator(np.random.PCG64(batch * M + K))
+    dense = (g.random((batch, M, K), dtype=np.float32) - 0.5) * (g.random((batch, M, K), dtype=np.float32) < density)
+    dense[batch // 2] = 0  # an empty item
+    values, columns, offsets = cmm.dense_to_csr(t(dense, dev))
+    nnz = values.numel()
+    t_val, t_col, t_off = cmm.csr_transpose_batched(values, columns, offsets, nnz, batch, M, K)
+    assert t_off.shape == (batch, K + 1)
+    off = offsets.cpu().numpy()
+    col, val = columns.cpu().numpy(), values.cpu().numpy()
+    want_off, want_col, want_val = [], [], []
+    for b in range(batch):
+        s0, s1 = off[b, 0], off[b, M]
+        rp, c, v = oracle_mod.csr_transpose((off[b] - s0).astype(np.int32), col[s0:s1], val[s0:s1], M, K)
+        want_off.append(rp.astype(np.int64) + s0)
+        want_col.append(c)
+        want_val.append(v)
+    assert np.array_equal(t_off.cpu().numpy(), np.stack(want_off).astype(np.int32))
+    assert np.array_equal(t_col.cpu().numpy(), np.concatenate(want_col))
+    assert np.array_equal(t_val.cpu().numpy(), np.concatenate(want_val))
+    # and it feeds the batched kernel: C[b] = A[b]ᵀ · G[b]
+    G = g.random((batch, M, 8), dtype=np.float32)
+    C = torch.empty(batch, K, 8, device=dev)
+    cmm.naive_spmm_batched(t_val, t_col, t_off, nnz, batch, K, M, t(G, dev), C)
+    assert np.allclose(C.cpu().numpy(), np.einsum("bmk,bmn->bkn", dense.astype(np.float64), G.astype(np.float64)),
+                       rtol=1e-4, atol=1e-5)
+
+
+def test_csr_transpose_config_c3_shape(cmm, dev, oracle_mod):
+    """The transpose at BASELINE config C3's matrix (1M x 1M, 110 M non-zeros): integer artefacts
+    (offsets, row indices) and values bit-exact against numpy's stable argsort of the columns."""
+    import synthetic
+    M = K = 1 << 20
+    rowptr, col, val = synthetic.make_csr(M, K, 1e-4, seed=0)
+    t_val, t_col, t_off = cmm.csr_transpose(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K)
+    torch.cuda.synchronize()
+    order = np.argsort(col, kind="stable")
+    rows = np.repeat(np.arange(M, dtype=np.int32), np.diff(rowptr))
+    assert np.array_equal(t_col.cpu().numpy(), rows[order])
+    assert np.array_equal(t_val.cpu().numpy(), val[order])
+    want_off = np.concatenate([[0], np.cumsum(np.bincount(col, minlength=K))]).astype(np.int32)
+    assert np.array_equal(t_off.cpu().numpy(), want_off)
+
+
 @pytest.mark.parametrize("N", [1, 8, 64, 100, 256, 300, 512, 777, 1024, 1500, 4100])
 def test_sddmm_bit_exact(cmm, dev, oracle_mod, N):
     """Rows of 0 … 400 pattern entries (batches of 64 with a ragged tail), every register-pass count

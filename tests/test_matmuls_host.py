@@ -232,8 +232,17 @@ def test_fc_layer_modules_host_logic(mm):
     matmuls, fake = mm
     sys.modules.pop("fc_layers", None)
     import fc_layers
+    _model = fc_layers.sparse_forward_pays
     g = torch.Generator().manual_seed(31)
-    for cls in (fc_layers.cublasLinear, fc_layers.cusparseLinear):
+    # the cost model of cusparseLinear: ReLU-sparse wide layers go sparse, dense-ish or narrow ones do not
+    assert fc_layers.sparse_forward_pays(int(0.01 * 16384 * 3072), 16384, 3072, 768)
+    assert not fc_layers.sparse_forward_pays(int(0.5 * 16384 * 3072), 16384, 3072, 768)
+    assert not fc_layers.sparse_forward_pays(int(0.1 * 16384 * 3072), 16384, 3072, 768)
+    assert fc_layers.sparse_forward_pays(int(0.1 * 4096 * 4096), 4096, 4096, 4096)
+    assert not fc_layers.sparse_forward_pays(10, 15, 12, 7)
+    for cls, force_sparse in ((fc_layers.cublasLinear, False), (fc_layers.cusparseLinear, True),
+                              (fc_layers.cusparseLinear, False)):
+        fc_layers.sparse_forward_pays = (lambda *a: True) if force_sparse else _model
         for bias in (True, False):
             layer = cls(12, 7, bias=bias)
             ref = torch.nn.Linear(12, 7, bias=bias)
@@ -251,5 +260,6 @@ def test_fc_layer_modules_host_logic(mm):
                 assert torch.allclose(ref.bias.grad, layer.bias.grad, rtol=RTOL, atol=1e-6)
         assert "in_features=12, out_features=7" in repr(layer)
         assert layer(torch.rand(2, 5)) == 0  # wrong width: prints and returns 0, like the reference
+    fc_layers.sparse_forward_pays = _model
     names = [c[0] for c in fake.calls]
-    assert "cublas_mmul_bias" in names and "naive_spmm_bias" in names
+    assert "cublas_mmul_bias" in names and "naive_spmm_bias" in names and "dense_to_csr_fill" in names

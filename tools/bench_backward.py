@@ -34,8 +34,8 @@ t = timeit(lambda: custom_mm.naive_spmm(val, col, rowptr, nnz, M, K, B, C))
 print(f"forward spmm        {t:8.3f} ms  ({(gb + 4e-9 * M * N) / t * 1e3:7.0f} GB/s algorithmic)")
 t = timeit(lambda: custom_mm.sddmm(col, rowptr, nnz, M, K, dC, B))
 print(f"sddmm (grad values) {t:8.3f} ms  ({(gb + 4e-9 * M * N) / t * 1e3:7.0f} GB/s: B-row gather + dC read + 4 B out per non-zero)")
-t = timeit(lambda: custom_mm.csr_transpose(val, col, rowptr, nnz, M, K), iters=3)
-print(f"csr_transpose       {t:8.3f} ms")
+t = timeit(lambda: custom_mm.csr_transpose(val, col, rowptr, nnz, M, K), iters=5)
+print(f"csr_transpose       {t:8.3f} ms  ({nnz * 16 / t / 1e6:7.0f} GB/s of the 16 B per non-zero a transpose must move)")
 tv, tc, to = custom_mm.csr_transpose(val, col, rowptr, nnz, M, K)
 t = timeit(lambda: custom_mm.naive_spmm(tv, tc, to.view(-1), nnz, K, M, dC, C))
 print(f"At x dC (grad B)    {t:8.3f} ms")

@@ -22,8 +22,8 @@ def timeit(fn, iters=10):
     return e0.elapsed_time(e1) / iters
 
 
-for (tokens, fin, fout, zero_frac) in [(32 * 512, 768, 3072, 0.5), (32 * 512, 3072, 768, 0.5), (32 * 512, 3072, 768, 0.9),
-                                       (4096, 4096, 4096, 0.9)]:
+SHAPES = [(32 * 512, 768, 3072), (32 * 512, 3072, 768), (4096, 4096, 4096), (32 * 512, 3072, 256)]
+for (tokens, fin, fout, zero_frac) in [(t, i, o, z) for (t, i, o) in SHAPES for z in (0.5, 0.75, 0.9, 0.99)]:
     g = torch.Generator(device=dev).manual_seed(0)
     x = torch.rand(tokens, fin, device=dev, generator=g)
     x = x * (torch.rand(tokens, fin, device=dev, generator=g) >= zero_frac)
