@@ -32,6 +32,7 @@ constexpr int TR_THREADS = 1024;
 constexpr int TR_WAVES = TR_THREADS / 64;
 constexpr int TR_PER = TR_TILE / TR_THREADS;  // entries per thread
 constexpr int TR_GROUPS = 64;                 // tile groups of the column-wise table scan
+constexpr int TR_GRID = 256;                  // persistent scatter workgroups: one per CU of an MI355X
 
 __host__ __device__ inline int bits_for(unsigned long long n) {  // bits needed for values 0 … n-1
   int b = 0;
@@ -148,8 +149,14 @@ __global__ __launch_bounds__(256) void tr_count_kernel(TrArgs a) {
   __syncthreads();
   const unsigned mask = (unsigned)nb - 1u;
   if (FIRST && a.batch == 1) {
-    for (int i = threadIdx.x; i < len; i += 256)
-      atomicAdd(&hist[((unsigned)a.col[start + i] >> a.shift) & mask], 1);
+    for (int i = threadIdx.x; i < len; i += 2048) {  // eight independent loads in flight per thread
+      unsigned k[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) k[u] = i + u * 256 < len ? (unsigned)a.col[start + i + u * 256] : 0u;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i + u * 256 < len) atomicAdd(&hist[(k[u] >> a.shift) & mask], 1);
+    }
   } else if (FIRST) {
     // batched: the key includes the item, i.e. needs the row; two threads bound the tile's rows first
     __shared__ int row_bounds[2];
@@ -162,9 +169,14 @@ __global__ __launch_bounds__(256) void tr_count_kernel(TrArgs a) {
       atomicAdd(&hist[(e.key >> a.shift) & mask], 1);
     }
   } else {
-    for (int i = threadIdx.x; i < len; i += 256) {
-      const unsigned key = PACKED ? (a.in_packed[start + i].x >> a.row_bits) : a.in_key[start + i];
-      atomicAdd(&hist[(key >> a.shift) & mask], 1);
+    for (int i = threadIdx.x; i < len; i += 2048) {
+      unsigned k[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        k[u] = i + u * 256 < len ? (PACKED ? (a.in_packed[start + i + u * 256].x >> a.row_bits) : a.in_key[start + i + u * 256]) : 0u;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i + u * 256 < len) atomicAdd(&hist[(k[u] >> a.shift) & mask], 1);
     }
   }
   __syncthreads();
@@ -302,8 +314,45 @@ __global__ __launch_bounds__(1024) void tr_bin_tiles_kernel(const int* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// Scatter: one workgroup per tile, 16 waves × 512 entries.
+// Scatter: 16 waves × 512 entries per tile.  The kernel is persistent — one workgroup per CU walks
+// tiles blockIdx.x, blockIdx.x + gridDim.x, … (a fixed trip count, no inter-workgroup dependence) —
+// so that the NEXT tile's entries (and, in the first pass, their row searches) are in flight while
+// the current tile streams out of LDS: a tile's phases are separated by barriers and a workgroup
+// fills the CU's LDS, so without this the load latency and the launch gap of every tile are exposed
+// (measured: 39 / 24 µs per tile for the first / last pass as one-tile workgroups).
 // ---------------------------------------------------------------------------------------------
+#ifdef MI_TR_TIMING
+__device__ unsigned long long g_tr_phase[16];
+#define TR_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g_tr_phase[k], now_ - stamp_); stamp_ = now_; } while (0)
+#else
+#define TR_STAMP(k) do {} while (0)
+#endif
+
+// An entry as the scatter kernel carries it: already in the form it leaves the pass in, plus its
+// digit — 3 registers on the main path (a 1024-thread workgroup has 128 VGPRs per lane; the first
+// form kept key, row, value, digit and rank apart and spilled to scratch inside the rank loop, which
+// is what made a tile take 24–39 µs).
+struct Slot {
+  unsigned a;    // LAST: row | PACKED: the packed word | else: key as the next pass wants it
+  unsigned b;    // !PACKED: row;  LAST with keys_out: the full key
+  float val;
+  unsigned d;    // digit of this pass; the rank is kept in the upper half once known
+};
+
+template <bool FIRST, bool LAST, bool PACKED>
+__device__ __forceinline__ Slot load_slot(const TrArgs& a, long p, int row_lo, int row_hi, unsigned mask) {
+  const Entry e = load_entry<FIRST, PACKED>(a, p, row_lo, row_hi);
+  Slot s;
+  s.d = (e.key >> a.shift) & mask;
+  s.val = e.val;
+  const unsigned keep = a.drop_after_first ? (e.key >> a.bits) : e.key;  // two passes: the low digit is dropped
+  s.b = LAST ? e.key : e.row;
+  if (LAST) s.a = e.row;
+  else if (PACKED) s.a = (keep << a.row_bits) | e.row;
+  else s.a = keep;
+  return s;
+}
+
 template <bool FIRST, bool LAST, bool PACKED, bool STAGED>
 __global__ __launch_bounds__(TR_THREADS) void tr_scatter_kernel(TrArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -313,145 +362,240 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_kernel(TrArgs a) {
   int* gadj = binstart + nb;                                                  // [nb] global offset − binstart
   uint2* sorted = reinterpret_cast<uint2*>(gadj + nb);                        // [TR_TILE]   (STAGED)
   unsigned short* sorted_d = reinterpret_cast<unsigned short*>(sorted + TR_TILE);  // [TR_TILE] (STAGED)
+  // first pass: flat rowptr index of the row holding each entry of the tile, filled row by row
+  unsigned* rowid = reinterpret_cast<unsigned*>(smem + (size_t)TR_WAVES * nb * 2 + (size_t)nb * 8 +
+                                                (STAGED ? (size_t)TR_TILE * 10 : 0));  // [TR_TILE] (FIRST)
   __shared__ int wsum[16];
   __shared__ int carry_s;
 
-  const int t = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  long start;
-  int len;
-  tile_bounds(a, t, start, len);
-  if (len == 0) return;  // block-uniform
   const unsigned mask = (unsigned)nb - 1u;
-
-  for (int i = tid; i < TR_WAVES * nb / 2; i += TR_THREADS) reinterpret_cast<unsigned*>(cntw)[i] = 0u;
-  if (tid == 0) carry_s = 0;
-
-  int row_lo = 0, row_hi = 0;
-  if (FIRST) {
-    row_lo = a.tile_row[t];
-    row_hi = a.tile_row[t + 1];
-  }
-  Entry e[TR_PER];
-  unsigned dg[TR_PER];
-  int lrank[TR_PER];
-#pragma unroll
-  for (int c = 0; c < TR_PER; ++c) {
-    const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
-    if (i < len) e[c] = load_entry<FIRST, PACKED>(a, start + i, row_lo, row_hi);
-  }
-  __syncthreads();  // counters zeroed
-
-  // rank inside the wave: lanes holding the same digit ("peers") found with one ballot per digit bit;
-  // a lane's rank is the wave's running count of the digit + the number of peers below it
-  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   unsigned short* mycnt = cntw + wave * nb;
-#pragma unroll
-  for (int c = 0; c < TR_PER; ++c) {
-    const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
-    const bool valid = i < len;
-    const unsigned d = valid ? ((e[c].key >> a.shift) & mask) : 0u;
-    dg[c] = d;
-    unsigned long long peers = __ballot(valid);
-    for (int b = 0; b < a.bits; ++b) {
-      const bool bit = (d >> b) & 1u;
-      const unsigned long long m = __ballot(bit);
-      peers &= bit ? m : ~m;
-    }
-    const int below = __builtin_popcountll(peers & lt);
-    int base = 0;
-    if (valid) base = mycnt[d];
-    if (valid && below == 0) mycnt[d] = (unsigned short)(base + __builtin_popcountll(peers));
-    lrank[c] = base + below;
-  }
-  __syncthreads();
+  constexpr int GPT = 2;  // digits per thread in the prefix phase (nb ≤ 2048)
 
-  // per digit: exclusive prefix over the waves (in place), tile total; then the exclusive scan of
-  // the totals over the digits and the digit's global offset
-  for (int d0 = 0; d0 < nb; d0 += TR_THREADS) {
-    const int d = d0 + tid;
-    int tot = 0;
-    if (d < nb) {
-#pragma unroll
-      for (int w = 0; w < TR_WAVES; ++w) {
-        const int v = cntw[w * nb + d];
-        cntw[w * nb + d] = (unsigned short)tot;
-        tot += v;
+  Slot e[TR_PER];
+  int goff[GPT];
+  int len = 0;
+  long start = 0;
+  int row_lo = 0, row_hi = 0, rp0 = 0, rp1 = 0;  // first pass: the tile's rows; this lane's row bounds
+  // fetch a tile's entries and its row of the offset table into registers
+  auto fetch = [&](int t) {
+    tile_bounds(a, t, start, len);
+    if (FIRST) {
+      // the rows come later, from LDS (rowid): a per-entry binary search in rowptr here cost 8 × ~8
+      // dependent global loads per lane and was the larger half of this kernel's time.  Lane l of
+      // wave w prefetches the bounds of row row_lo + 16·l + w (the first 1024 rows of the tile).
+      row_lo = a.tile_row[t];
+      row_hi = a.tile_row[t + 1];
+      const int r = row_lo + lane * TR_WAVES + wave;
+      if (r <= row_hi) {
+        rp0 = a.rowptr[r];
+        rp1 = a.rowptr[r + 1];
       }
-    }
-    int incl = tot;
 #pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-      const int v = __shfl_up(incl, s, 64);
-      if (lane >= s) incl += v;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int wbase = 0, all = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-      const int v = wsum[w];
-      if (w < wave) wbase += v;
-      all += v;
-    }
-    if (d < nb) {
-      const int bs = carry_s + wbase + incl - tot;
-      binstart[d] = bs;
-      gadj[d] = a.table[(long)t * nb + d] - bs;
-    }
-    __syncthreads();
-    if (tid == 0) carry_s += all;
-    __syncthreads();
-  }
-
-  // what leaves this pass for an entry
-  auto packed_out = [&](const Entry& x) {
-    const unsigned keep = a.drop_after_first ? (x.key >> a.bits) : x.key;  // two passes: drop the low digit
-    return make_uint2((keep << a.row_bits) | x.row, __builtin_bit_cast(unsigned, x.val));
-  };
-
-  if (STAGED) {
-    // reorder the tile by digit in LDS, then stream it out: each digit's entries leave as one run
-#pragma unroll
-    for (int c = 0; c < TR_PER; ++c) {
-      const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
-      if (i < len) {
-        const int s = binstart[dg[c]] + cntw[wave * nb + dg[c]] + lrank[c];
-        sorted[s] = LAST ? make_uint2(e[c].row, __builtin_bit_cast(unsigned, e[c].val)) : packed_out(e[c]);
-        sorted_d[s] = (unsigned short)dg[c];
-      }
-    }
-    __syncthreads();
-    for (int i = tid; i < len; i += TR_THREADS) {
-      const uint2 w = sorted[i];
-      const long dst = (long)gadj[sorted_d[i]] + i;
-      if (LAST) {
-        a.t_col[dst] = (int)w.x;
-        a.t_val[dst] = __builtin_bit_cast(float, w.y);
-      } else {
-        a.out_packed[dst] = w;
-      }
-    }
-  } else {
-    // straight from registers (wide keys / rows, 11-bit digits): correct for every size, but the
-    // stores of a wave go to up to 64 different places
-#pragma unroll
-    for (int c = 0; c < TR_PER; ++c) {
-      const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
-      if (i < len) {
-        const long dst = (long)gadj[dg[c]] + binstart[dg[c]] + cntw[wave * nb + dg[c]] + lrank[c];
-        if (LAST) {
-          a.t_col[dst] = (int)e[c].row;
-          a.t_val[dst] = e[c].val;
-          if (a.keys_out) a.keys_out[dst] = e[c].key;
-        } else if (PACKED) {
-          a.out_packed[dst] = packed_out(e[c]);
-        } else {
-          a.out_key[dst] = a.drop_after_first ? (e[c].key >> a.bits) : e[c].key;
-          a.out_row[dst] = e[c].row;
-          a.out_val[dst] = e[c].val;
+      for (int c = 0; c < TR_PER; ++c) {
+        const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
+        if (i < len) {
+          e[c].a = (unsigned)a.col[start + i];
+          e[c].val = a.val[start + i];
         }
       }
+    } else {
+#pragma unroll
+      for (int c = 0; c < TR_PER; ++c) {
+        const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
+        if (i < len) e[c] = load_slot<FIRST, LAST, PACKED>(a, start + i, 0, 0, mask);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < GPT; ++g) {
+      const int d = g * TR_THREADS + tid;
+      goff[g] = d < nb ? a.table[(long)t * nb + d] : 0;
+    }
+  };
+
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (private L2).  Give every XCD a CONTIGUOUS
+  // range of tiles and let its 32 workgroups walk it together: at any time an XCD then writes 32
+  // consecutive tiles' runs of every digit — pieces that are adjacent in memory — so whole lines
+  // assemble in ITS L2 before they are written back.
+  int t = blockIdx.x, t_end = a.ntiles, t_step = gridDim.x;
+  if (gridDim.x == TR_GRID) {
+    const int per = (a.ntiles + 7) / 8, xcd = blockIdx.x & 7;
+    t = xcd * per + (blockIdx.x >> 3);
+    t_end = (xcd + 1) * per < a.ntiles ? (xcd + 1) * per : a.ntiles;
+    t_step = TR_GRID / 8;
+  }
+#ifdef MI_TR_TIMING
+  unsigned long long stamp_ = __builtin_readcyclecounter();
+#endif
+  if (t < t_end) fetch(t);
+  for (; t < t_end; t += t_step) {
+    const int cur_len = len;  // block-uniform
+    if (cur_len > 0) {
+      TR_STAMP(0);
+      for (int i = tid; i < TR_WAVES * nb / 2; i += TR_THREADS) reinterpret_cast<unsigned*>(cntw)[i] = 0u;
+      if (tid == 0) carry_s = 0;
+      if (FIRST) {
+        // every row of the tile writes its flat index over its own entries (wave-uniform bounds, 64
+        // positions per instruction); each position of the tile belongs to exactly one row
+        const long t_lo = start, t_hi = start + cur_len;
+        auto fill = [&](int r, long b, long en) {
+          b = b < t_lo ? t_lo : b;
+          en = en > t_hi ? t_hi : en;
+          for (long q = b + lane; q < en; q += 64) rowid[q - t_lo] = (unsigned)r;
+        };
+        const int span = row_hi - row_lo + 1;
+        for (int k = 0; k < 64 && k * TR_WAVES + wave < span; ++k)
+          fill(row_lo + k * TR_WAVES + wave, __builtin_amdgcn_readlane(rp0, k), __builtin_amdgcn_readlane(rp1, k));
+        for (int r = row_lo + 64 * TR_WAVES + wave; r <= row_hi; r += TR_WAVES)  // tiles spanning > 1024 rows
+          fill(r, a.rowptr[r], a.rowptr[r + 1]);
+      }
+      __syncthreads();  // counters zeroed (rows known); the previous tile's LDS reads are complete
+      if (FIRST) {
+#pragma unroll
+        for (int c = 0; c < TR_PER; ++c) {
+          const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
+          if (i < cur_len) {
+            unsigned idx = rowid[i], key = e[c].a, r = idx;
+            if (a.batch > 1) {
+              const unsigned item = idx / (unsigned)(a.M + 1);
+              r = idx - item * (unsigned)(a.M + 1);
+              key += item * (unsigned)a.K;
+            }
+            e[c].d = (key >> a.shift) & mask;
+            const unsigned keep = a.drop_after_first ? (key >> a.bits) : key;
+            e[c].b = LAST ? key : r;
+            e[c].a = LAST ? r : (PACKED ? ((keep << a.row_bits) | r) : keep);
+          }
+        }
+      }
+      TR_STAMP(1);
+
+      // rank inside the wave: lanes holding the same digit ("peers") found with one ballot per digit
+      // bit; a lane's rank is the wave's running count of the digit + the number of peers below it
+#pragma unroll
+      for (int c = 0; c < TR_PER; ++c) {
+        const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
+        const bool valid = i < cur_len;
+        const unsigned d = valid ? e[c].d : 0u;
+        unsigned long long peers = __ballot(valid);
+        for (int b = 0; b < a.bits; ++b) {
+          const bool bit = (d >> b) & 1u;
+          const unsigned long long m = __ballot(bit);
+          peers &= bit ? m : ~m;
+        }
+        const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0));
+        int base = 0;
+        if (valid) base = mycnt[d];
+        if (valid && below == 0) mycnt[d] = (unsigned short)(base + __builtin_popcountll(peers));
+        e[c].d = d | ((unsigned)(base + below) << 16);
+      }
+      TR_STAMP(2);
+      __syncthreads();
+      TR_STAMP(3);
+
+      // per digit: exclusive prefix over the waves (in place), tile total; then the exclusive scan of
+      // the totals over the digits and the digit's global offset
+#pragma unroll
+      for (int g = 0; g < GPT; ++g) {
+        if (g * TR_THREADS < nb) {  // block-uniform
+          const int d = g * TR_THREADS + tid;
+          int tot = 0;
+          if (d < nb) {
+            int v[TR_WAVES];
+#pragma unroll
+            for (int w = 0; w < TR_WAVES; ++w) v[w] = cntw[w * nb + d];
+#pragma unroll
+            for (int w = 0; w < TR_WAVES; ++w) {
+              cntw[w * nb + d] = (unsigned short)tot;
+              tot += v[w];
+            }
+          }
+          int incl = tot;
+#pragma unroll
+          for (int s2 = 1; s2 < 64; s2 <<= 1) {
+            const int v = __shfl_up(incl, s2, 64);
+            if (lane >= s2) incl += v;
+          }
+          if (lane == 63) wsum[wave] = incl;
+          __syncthreads();
+          int wbase = 0, all = 0;
+#pragma unroll
+          for (int w = 0; w < 16; ++w) {
+            const int v = wsum[w];
+            if (w < wave) wbase += v;
+            all += v;
+          }
+          if (d < nb) {
+            const int bs = carry_s + wbase + incl - tot;
+            binstart[d] = bs;
+            gadj[d] = goff[g] - bs;
+          }
+          __syncthreads();
+          if (tid == 0) carry_s += all;
+          __syncthreads();
+        }
+      }
+
+      TR_STAMP(4);
+      if (STAGED) {
+        // reorder the tile by digit in LDS …
+#pragma unroll
+        for (int c = 0; c < TR_PER; ++c) {
+          const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
+          if (i < cur_len) {
+            const unsigned d = e[c].d & 0xffffu;
+            const int s2 = binstart[d] + cntw[wave * nb + d] + (int)(e[c].d >> 16);
+            sorted[s2] = make_uint2(e[c].a, __builtin_bit_cast(unsigned, e[c].val));
+            sorted_d[s2] = (unsigned short)d;
+          }
+        }
+        TR_STAMP(5);
+        __syncthreads();
+        TR_STAMP(6);
+        // … the next tile's loads go out now (the registers are free) …
+        if (t + t_step < t_end) fetch(t + t_step); else len = 0;
+        TR_STAMP(7);
+        // … and the tile streams out: each digit's entries leave as one contiguous run
+#pragma unroll 2
+        for (int i = tid; i < cur_len; i += TR_THREADS) {
+          const uint2 w = sorted[i];
+          const long dst = (long)gadj[sorted_d[i]] + i;
+          if (LAST) {
+            a.t_col[dst] = (int)w.x;
+            a.t_val[dst] = __builtin_bit_cast(float, w.y);
+          } else {
+            a.out_packed[dst] = w;
+          }
+        }
+        TR_STAMP(8);
+      } else {
+        // straight from registers (wide keys / rows, 11-bit digits): correct for every size, but the
+        // stores of a wave go to up to 64 different places
+#pragma unroll
+        for (int c = 0; c < TR_PER; ++c) {
+          const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
+          if (i < cur_len) {
+            const unsigned d = e[c].d & 0xffffu;
+            const long dst = (long)gadj[d] + binstart[d] + cntw[wave * nb + d] + (long)(e[c].d >> 16);
+            if (LAST) {
+              a.t_col[dst] = (int)e[c].a;
+              a.t_val[dst] = e[c].val;
+              if (a.keys_out) a.keys_out[dst] = e[c].b;
+            } else if (PACKED) {
+              a.out_packed[dst] = make_uint2(e[c].a, __builtin_bit_cast(unsigned, e[c].val));
+            } else {
+              a.out_key[dst] = e[c].a;
+              a.out_row[dst] = e[c].b;
+              a.out_val[dst] = e[c].val;
+            }
+          }
+        }
+        __syncthreads();  // binstart / gadj / cntw are rewritten by the next tile
+        if (t + t_step < t_end) fetch(t + t_step); else len = 0;
+      }
+    } else {
+      if (t + t_step < t_end) fetch(t + t_step); else len = 0;
     }
   }
 }
@@ -581,11 +725,12 @@ int launch_scatter(const TrArgs& a, bool packed, bool staged, hipStream_t s) {
   const int nb = 1 << a.bits;
   size_t lds = (size_t)TR_WAVES * nb * 2 + (size_t)nb * 8;
   if (staged) lds += (size_t)TR_TILE * 8 + (size_t)TR_TILE * 2;
+  if (FIRST) lds += (size_t)TR_TILE * 4;  // rowid
 #define MI_TR(P_, S_)                                                                                              \
   do {                                                                                                             \
     auto k = tr_scatter_kernel<FIRST, LAST, P_, S_>;                                                               \
     if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(k, dim3((unsigned)a.ntiles), dim3(TR_THREADS), lds, s, a);                                   \
+    hipLaunchKernelGGL(k, dim3((unsigned)(a.ntiles < TR_GRID ? a.ntiles : TR_GRID)), dim3(TR_THREADS), lds, s, a);  \
   } while (0)
   if (packed && staged) MI_TR(true, true);
   else if (packed) MI_TR(true, false);

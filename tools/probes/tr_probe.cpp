@@ -1,0 +1,41 @@
+// Developer probe (not part of the product): per-phase cycle counts of the transpose scatter kernels.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DMI_TR_TIMING -Iinclude -Imatrix-multiplication_amd/csrc tools/probes/tr_probe.cpp -o /tmp/tr_probe
+#include "../../matrix-multiplication_amd/csrc/mi_status.hip"
+#include "../../matrix-multiplication_amd/csrc/csr_transpose.hip"
+#include <cstdio>
+#include <random>
+#include <vector>
+#include <algorithm>
+int main() {
+  const int M = 1 << 20, K = 1 << 20, per = 105;
+  std::mt19937_64 g(1);
+  std::vector<int> rowptr(M + 1), col((size_t)M * per);
+  std::vector<float> val((size_t)M * per, 1.f);
+  for (int r = 0; r < M; ++r) {
+    rowptr[r] = r * per;
+    for (int j = 0; j < per; ++j) col[(size_t)r * per + j] = (int)(g() % K);
+    std::sort(col.begin() + (size_t)r * per, col.begin() + (size_t)(r + 1) * per);
+  }
+  rowptr[M] = M * per;
+  const long nnz = (long)M * per;
+  int *d_rp, *d_col, *t_rp, *t_col; float *d_val, *t_val; void* ws;
+  hipMalloc(&d_rp, (M + 1) * 4); hipMalloc(&d_col, nnz * 4); hipMalloc(&d_val, nnz * 4);
+  hipMalloc(&t_rp, (K + 1) * 4); hipMalloc(&t_col, nnz * 4); hipMalloc(&t_val, nnz * 4);
+  const size_t wsb = mi_csr_transpose_workspace_bytes(M, K, nnz);
+  hipMalloc(&ws, wsb);
+  hipMemcpy(d_rp, rowptr.data(), (M + 1) * 4, hipMemcpyHostToDevice);
+  hipMemcpy(d_col, col.data(), nnz * 4, hipMemcpyHostToDevice);
+  hipMemcpy(d_val, val.data(), nnz * 4, hipMemcpyHostToDevice);
+  for (int it = 0; it < 2; ++it) {
+    unsigned long long zero[16] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(g_tr_phase), zero, sizeof(zero));
+    int st = mi_csr_transpose_f32(d_rp, d_col, d_val, nnz, M, K, t_rp, t_col, t_val, ws, wsb, nullptr);
+    hipDeviceSynchronize();
+    unsigned long long ph[16];
+    hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_tr_phase), sizeof(ph));
+    printf("status %d; cycles per workgroup (both scatter passes summed, /256 WGs, 100 MHz counter?):\n", st);
+    const char* names[] = {"fetch-wait/loop top", "zero+barrier", "rank", "barrier", "prefix", "stage", "barrier", "fetch issue", "output"};
+    for (int k = 0; k < 9; ++k) printf("  %-20s %12.1f\n", names[k], ph[k] / 256.0);
+  }
+  return 0;
+}
