@@ -86,7 +86,16 @@ int mi_spmm_csr_ws_f32(const int32_t* rowptr, const int32_t* col, const float* v
  * (mi_spmm_auto_splits_long_rows on the WHOLE problem gives the rule), which keeps the
  * row-sharded multi-GPU result bit-identical to the single-GPU one (sharded.py).
  * No counterpart in the reference (single device, one wave per row: src/naive_sparse_mm.cu:24-101). */
-enum { MI_LONG_ROWS_AUTO = -1, MI_LONG_ROWS_NONE = 0, MI_LONG_ROWS_SPLIT = 1 };
+/* MI_LONG_ROWS_PREPARED: as SPLIT, and the list of long rows in `workspace` was already built by
+ * mi_spmm_long_rows_prepare for this matrix (same nnz and N): the per-call memset + list-building
+ * launch are skipped — the inspector–executor form (custom_mm.cusparse_inspect / tiledspmm_inspect_*). */
+enum { MI_LONG_ROWS_AUTO = -1, MI_LONG_ROWS_NONE = 0, MI_LONG_ROWS_SPLIT = 1, MI_LONG_ROWS_PREPARED = 2 };
+/* Inspector step for MI_LONG_ROWS_PREPARED: lists the rows beyond the threshold once.  workspace ≥
+ * mi_spmm_csr_workspace_bytes(nnz, N); it must stay untouched between the products that use it,
+ * and products sharing one workspace must be ordered on one stream (the partial-row area is reused).
+ * Replaces what TiledSpMM_inspect amortises in the reference (src/sparse_mm.cu:137-368). */
+int mi_spmm_long_rows_prepare(const int32_t* rowptr, int32_t M, int64_t nnz, int32_t N,
+                              void* workspace, size_t workspace_bytes, mi_stream_t stream);
 int mi_spmm_csr_ex_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                        int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
                        int64_t ldb, const float* bias, float* C, int64_t ldc, int long_rows,
@@ -171,6 +180,16 @@ int mi_spmm_csr_colmajor_f32(const int32_t* rowptr, const int32_t* col,
                              int32_t N, const float* B, int64_t ldb, float* C,
                              int64_t ldc, void* workspace, size_t workspace_bytes,
                              mi_stream_t stream);
+/* The same executor with the long-row rule of mi_spmm_csr_ex_f32 (MI_LONG_ROWS_*) and its own
+ * long-row workspace (mi_spmm_csr_workspace_bytes(nnz, N); may be NULL for MI_LONG_ROWS_NONE, which
+ * is what the plain entry above uses): skewed weight matrices reach the split path through the
+ * inspector handles, which prepare the list once (MI_LONG_ROWS_PREPARED). */
+int mi_spmm_csr_colmajor_ex_f32(const int32_t* rowptr, const int32_t* col,
+                                const float* val, int64_t nnz, int32_t M, int32_t K,
+                                int32_t N, const float* B, int64_t ldb, float* C,
+                                int64_t ldc, int long_rows, void* long_rows_workspace,
+                                size_t long_rows_workspace_bytes, void* workspace,
+                                size_t workspace_bytes, mi_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * K5 — dense fp32 product, row-major, optional batch and transposes:

@@ -428,10 +428,6 @@ __global__ __launch_bounds__(256) void sddmm_kernel(const int* __restrict__ rowp
 
 }  // namespace
 
-// Defined in spmm_csr.hip.
-extern "C" int mi_spmm_csr_f32(const int32_t*, const int32_t*, const float*, int64_t, int32_t,
-                               int32_t, int32_t, const float*, int64_t, float*, int64_t,
-                               mi_stream_t);
 
 extern "C" {
 
@@ -452,10 +448,11 @@ size_t mi_spmm_colmajor_workspace_bytes(int32_t M, int32_t K, int32_t N) {
   return align_up((size_t)K * N * 4) + align_up((size_t)M * N * 4);
 }
 
-int mi_spmm_csr_colmajor_f32(const int32_t* rowptr, const int32_t* col, const float* val,
-                             int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
-                             int64_t ldb, float* C, int64_t ldc, void* workspace,
-                             size_t workspace_bytes, mi_stream_t stream) {
+int mi_spmm_csr_colmajor_ex_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                                int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
+                                int64_t ldb, float* C, int64_t ldc, int long_rows, void* long_rows_workspace,
+                                size_t long_rows_workspace_bytes, void* workspace, size_t workspace_bytes,
+                                mi_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (M < 0 || K < 0 || N < 0 || nnz < 0) return MI_EINVAL;
   if (M == 0 || N == 0) return MI_OK;
@@ -468,10 +465,19 @@ int mi_spmm_csr_colmajor_f32(const int32_t* rowptr, const int32_t* col, const fl
   // column-major K×N with ldb  ==  row-major [N, ldb]; its transpose is [K, N].
   int st = launch_transpose(B, N, K, ldb, Bt, N, s);
   if (st != MI_OK) return st;
-  st = mi_spmm_csr_f32(rowptr, col, val, nnz, M, K, N, Bt, N, Ct, N, stream);
+  st = mi_spmm_csr_ex_f32(rowptr, col, val, nnz, M, K, N, Bt, N, nullptr, Ct, N, long_rows, long_rows_workspace,
+                          long_rows_workspace_bytes, stream);
   if (st != MI_OK) return st;
   // row-major [M, N] → row-major [N, ldc]  ==  column-major M×N with ldc.
   return launch_transpose(Ct, M, N, N, C, ldc, s);
+}
+
+int mi_spmm_csr_colmajor_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                             int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
+                             int64_t ldb, float* C, int64_t ldc, void* workspace,
+                             size_t workspace_bytes, mi_stream_t stream) {
+  return mi_spmm_csr_colmajor_ex_f32(rowptr, col, val, nnz, M, K, N, B, ldb, C, ldc, MI_LONG_ROWS_NONE, nullptr, 0,
+                                     workspace, workspace_bytes, stream);
 }
 
 size_t mi_dense_to_csr_workspace_bytes(int32_t batch, int32_t rows) {

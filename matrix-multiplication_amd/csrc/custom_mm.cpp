@@ -576,37 +576,129 @@ torch::Tensor sddmm(torch::Tensor A_columns, torch::Tensor A_offsets, int64_t nn
 }
 
 // ---- inspector–executor registries -----------------------------------------
+// What `*_inspect` amortises here (reference: TiledSpMM_inspect builds its tiled-ELL image once,
+// src/sparse_mm.cu:137-368; cusparse_inspect caches descriptors, src/custom_mm.cpp:236-257):
+//   * the CSR arrays, owned (tensor references) and VALIDATED once (offsets monotone, columns in range);
+//   * Aᵀ in CSR — the backward product of a sparse-weight layer (`*_mmul_opt_t`) and any Aᵀ·G need it,
+//     and a transpose costs about a sixth of a product at the C3 shape;
+//   * the longest row of A and of Aᵀ, and — only when a row exceeds the split threshold — the prepared
+//     list of long rows (MI_LONG_ROWS_PREPARED: no per-call memset + list-building launch); without
+//     long rows every product is ONE kernel launch between the two operand transposes;
+//   * the executor's transposed-operand buffers (no allocation per call).
+// Calls on one handle must be ordered on one stream (they share those buffers), as with a cuSPARSE handle.
+
+struct CsrSide {
+  int64_t rows = 0, cols = 0;      // this side's matrix is rows × cols
+  torch::Tensor rowptr, col, val;  // device, int32 / int32 / float32 — owned references
+  int64_t max_row = 0;             // longest row (host-known since inspect)
+  torch::Tensor long_ws;           // prepared long-row list + partial rows (defined iff max_row > threshold)
+};
 
 struct CsrHandle {
   int64_t M = 0, K = 0, N = 0;  // A is M×K, dense width N
   int64_t nnz = 0;
-  torch::Tensor rowptr, col, val;  // device, int32 / int32 / float32 — owned references
+  CsrSide a, at;                // A and Aᵀ
+  torch::Tensor ws;             // executor workspace: Bt [K,N] | Ct [M,N] (either orientation)
 };
 
 std::mutex g_registry_mutex;
 std::unordered_map<std::string, CsrHandle> g_cusparse_layers;  // cusparse_inspect / _mmul_opt
 std::unordered_map<std::string, CsrHandle> g_tiled_layers;     // tiledspmm_*
 
-// Column-major executor shared by cusparse_mmul_opt and tiledspmm_mm:
-// C (M×N col-major) = A · B (K×N col-major); tensors of any shape with the
+int64_t longest_row(const torch::Tensor& rowptr) {
+  if (rowptr.numel() < 2) return 0;
+  return (rowptr.slice(0, 1) - rowptr.slice(0, 0, rowptr.numel() - 1)).max().item<int32_t>();
+}
+
+void prepare_side(CsrSide& side, int64_t nnz, int64_t N, const char* what) {
+  side.max_row = longest_row(side.rowptr);
+  if (side.max_row > mi_spmm_long_row_threshold() && N > 0) {
+    const size_t bytes = mi_spmm_csr_workspace_bytes(nnz, (int32_t)N);
+    side.long_ws = torch::empty({(int64_t)bytes}, torch::dtype(torch::kUInt8).device(side.val.device()));
+    check_status(mi_spmm_long_rows_prepare(side.rowptr.data_ptr<int32_t>(), (int32_t)side.rows, nnz, (int32_t)N,
+                                           side.long_ws.data_ptr(), bytes, stream_of(side.val)),
+                 what);
+  }
+}
+
+// Shared inspector: device CSR (already int32 / float32, contiguous) → a complete handle.
+CsrHandle build_handle(int64_t M, int64_t K, int64_t N, int64_t nnz, torch::Tensor rowptr, torch::Tensor col,
+                       torch::Tensor val, const char* what) {
+  check_same_device(rowptr, val, what);
+  check_same_device(col, val, what);
+  c10::hip::HIPGuard guard(val.device().index());
+  // validate once what every later product trusts (the kernels index B with these columns)
+  if (M > 0) {
+    TORCH_CHECK(rowptr[0].item<int32_t>() == 0 && rowptr[M].item<int32_t>() == nnz, what,
+                ": offsets must start at 0 and end at nnz");
+    TORCH_CHECK((rowptr.slice(0, 1) - rowptr.slice(0, 0, M)).min().item<int32_t>() >= 0, what,
+                ": offsets must not decrease");
+  }
+  if (nnz > 0) {
+    torch::Tensor c = col.slice(0, 0, nnz);
+    TORCH_CHECK(c.min().item<int32_t>() >= 0 && c.max().item<int32_t>() < K, what, ": column index out of range");
+  }
+  CsrHandle h;
+  h.M = M;
+  h.K = K;
+  h.N = N;
+  h.nnz = nnz;
+  h.a.rows = M;
+  h.a.cols = K;
+  h.a.rowptr = rowptr;
+  h.a.col = col.slice(0, 0, nnz);
+  h.a.val = val.slice(0, 0, nnz);
+  // Aᵀ
+  auto iopt = torch::dtype(torch::kInt32).device(val.device());
+  h.at.rows = K;
+  h.at.cols = M;
+  h.at.rowptr = torch::empty({K + 1}, iopt);
+  h.at.col = torch::empty({nnz}, iopt);
+  h.at.val = torch::empty({nnz}, val.options());
+  {
+    const size_t bytes = mi_csr_transpose_workspace_bytes((int32_t)M, (int32_t)K, nnz);
+    torch::Tensor tws = torch::empty({(int64_t)std::max<size_t>(bytes, 1)}, torch::dtype(torch::kUInt8).device(val.device()));
+    check_status(mi_csr_transpose_f32(h.a.rowptr.data_ptr<int32_t>(), h.a.col.data_ptr<int32_t>(), h.a.val.data_ptr<float>(),
+                                      nnz, (int32_t)M, (int32_t)K, h.at.rowptr.data_ptr<int32_t>(),
+                                      h.at.col.data_ptr<int32_t>(), h.at.val.data_ptr<float>(), tws.data_ptr(), bytes,
+                                      stream_of(val)),
+                 what);
+  }
+  prepare_side(h.a, nnz, N, what);
+  prepare_side(h.at, nnz, N, what);
+  const size_t ws_bytes = mi_spmm_colmajor_workspace_bytes((int32_t)M, (int32_t)K, (int32_t)N);
+  h.ws = torch::empty({(int64_t)std::max<size_t>(ws_bytes, 16)}, torch::dtype(torch::kUInt8).device(val.device()));
+  return h;
+}
+
+// Column-major executor shared by cusparse_mmul_opt and tiledspmm_mm (and their `_t` forms on Aᵀ):
+// C (rows×N col-major) = S · B (cols×N col-major), S = A or Aᵀ; tensors of any shape with the
 // right element count are accepted, as in the reference (raw data_ptr()).
-void colmajor_mm(const CsrHandle& h, const torch::Tensor& B, torch::Tensor& C, const char* what) {
+void colmajor_mm(const CsrHandle& h, bool transposed, const torch::Tensor& B, torch::Tensor& C, const char* what) {
+  const CsrSide& s = transposed ? h.at : h.a;
   check_device_f32(B, "B");
   check_device_f32(C, "C");
   check_same_device(B, C, what);
-  check_same_device(h.val, C, what);
+  check_same_device(s.val, C, what);
   TORCH_CHECK(B.is_contiguous() && C.is_contiguous(), what, ": B and C must be contiguous");
-  TORCH_CHECK(B.numel() == h.K * h.N, what, ": B must hold K*N = ", h.K * h.N, " elements, got ",
-              B.numel());
-  TORCH_CHECK(C.numel() == h.M * h.N, what, ": C must hold M*N = ", h.M * h.N, " elements, got ",
-              C.numel());
+  TORCH_CHECK(B.numel() == s.cols * h.N, what, ": B must hold ", s.cols * h.N, " elements, got ", B.numel());
+  TORCH_CHECK(C.numel() == s.rows * h.N, what, ": C must hold ", s.rows * h.N, " elements, got ", C.numel());
   c10::hip::HIPGuard guard(C.device().index());
-  const size_t ws_bytes = mi_spmm_colmajor_workspace_bytes((int32_t)h.M, (int32_t)h.K, (int32_t)h.N);
-  torch::Tensor ws = torch::empty({(int64_t)ws_bytes}, torch::dtype(torch::kUInt8).device(C.device()));
-  const int st = mi_spmm_csr_colmajor_f32(
-      h.rowptr.data_ptr<int32_t>(), h.col.data_ptr<int32_t>(), h.val.data_ptr<float>(), h.nnz,
-      (int32_t)h.M, (int32_t)h.K, (int32_t)h.N, B.data_ptr<float>(), h.K, C.data_ptr<float>(), h.M,
-      ws.data_ptr(), ws_bytes, stream_of(C));
+  const size_t ws_bytes = mi_spmm_colmajor_workspace_bytes((int32_t)s.rows, (int32_t)s.cols, (int32_t)h.N);
+  TORCH_INTERNAL_ASSERT((size_t)h.ws.numel() >= ws_bytes);
+  // the same summation rule as cusparse_mmul / naive_spmm on this matrix: long rows are split iff the
+  // AUTO plan of the (row-major) product would split them — with the list prepared at inspect time
+  int mode = MI_LONG_ROWS_NONE;
+  if (s.long_ws.defined()) {
+    const float* bt = static_cast<const float*>(h.ws.data_ptr());
+    if (mi_spmm_auto_splits_long_rows(h.nnz, (int32_t)s.rows, (int32_t)s.cols, (int32_t)h.N, bt, h.N, bt, h.N) == 1)
+      mode = MI_LONG_ROWS_PREPARED;
+  }
+  const int st = mi_spmm_csr_colmajor_ex_f32(
+      s.rowptr.data_ptr<int32_t>(), s.col.data_ptr<int32_t>(), s.val.data_ptr<float>(), h.nnz, (int32_t)s.rows,
+      (int32_t)s.cols, (int32_t)h.N, B.data_ptr<float>(), s.cols, C.data_ptr<float>(), s.rows, mode,
+      mode == MI_LONG_ROWS_NONE ? nullptr : s.long_ws.data_ptr(), mode == MI_LONG_ROWS_NONE ? 0 : (size_t)s.long_ws.numel(),
+      h.ws.data_ptr(), (size_t)h.ws.numel(), stream_of(C));
   check_status(st, what);
 }
 
@@ -627,14 +719,7 @@ void cusparse_inspect(torch::Tensor displ, torch::Tensor colindex, torch::Tensor
   TORCH_CHECK(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "cusparse_inspect: negative size");
   TORCH_CHECK(displ.numel() == (int64_t)M + 1, "cusparse_inspect: displ must have M + 1 entries");
   TORCH_CHECK(colindex.numel() >= nnz && value.numel() >= nnz, "cusparse_inspect: nnz exceeds the CSR arrays");
-  CsrHandle h;
-  h.M = M;
-  h.K = K;
-  h.N = N;
-  h.nnz = nnz;
-  h.rowptr = displ.contiguous();
-  h.col = colindex.contiguous();
-  h.val = value.contiguous();
+  CsrHandle h = build_handle(M, K, N, nnz, displ.contiguous(), colindex.contiguous(), value.contiguous(), "cusparse_inspect");
   std::lock_guard<std::mutex> lock(g_registry_mutex);
   g_cusparse_layers[layer] = std::move(h);
 }
@@ -645,8 +730,41 @@ torch::Tensor cusparse_mmul_opt(torch::Tensor B, torch::Tensor C, std::string la
     std::lock_guard<std::mutex> lock(g_registry_mutex);
     h = lookup(g_cusparse_layers, layer, "cusparse_mmul_opt");
   }
-  colmajor_mm(h, B, C, "cusparse_mmul_opt");
+  colmajor_mm(h, false, B, C, "cusparse_mmul_opt");
   return C;
+}
+
+// Addition: C (K×N col-major) = Aᵀ · B (M×N col-major) with the Aᵀ cached by cusparse_inspect — the
+// input gradient of a sparse-weight layer (Y = X·Aᵀ  ⇒  dX = dY·A, i.e. dXᵀ = Aᵀ·dYᵀ).
+torch::Tensor cusparse_mmul_opt_t(torch::Tensor B, torch::Tensor C, std::string layer) {
+  CsrHandle h;
+  {
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    h = lookup(g_cusparse_layers, layer, "cusparse_mmul_opt_t");
+  }
+  colmajor_mm(h, true, B, C, "cusparse_mmul_opt_t");
+  return C;
+}
+
+// What a handle holds (tests / diagnostics): sizes, longest rows, whether long-row lists were prepared.
+pybind11::dict inspect_info(const std::string& layer, bool tiled) {
+  CsrHandle h;
+  {
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    h = lookup(tiled ? g_tiled_layers : g_cusparse_layers, layer, "inspect_info");
+  }
+  pybind11::dict d;
+  d["M"] = h.M;
+  d["K"] = h.K;
+  d["N"] = h.N;
+  d["nnz"] = h.nnz;
+  d["max_row"] = h.a.max_row;
+  d["max_row_transposed"] = h.at.max_row;
+  d["long_rows_prepared"] = h.a.long_ws.defined();
+  d["long_rows_prepared_transposed"] = h.at.long_ws.defined();
+  d["transpose"] = std::make_tuple(h.at.val, h.at.col, h.at.rowptr);
+  d["workspace_bytes"] = (int64_t)h.ws.numel();
+  return d;
 }
 
 void cusparse_clean() {
@@ -659,14 +777,9 @@ void cusparse_clean() {
 void register_tiled(int64_t M, int64_t N, int64_t K, torch::Tensor rowptr_cpu_i32,
                     torch::Tensor col_cpu_i32, torch::Tensor val_cpu, const std::string& layer) {
   const auto dev = torch::Device(torch::kCUDA, c10::hip::current_device());
-  CsrHandle h;
-  h.M = M;
-  h.K = N;  // inner dimension
-  h.N = K;  // dense width
-  h.nnz = val_cpu.numel();
-  h.rowptr = rowptr_cpu_i32.to(dev);
-  h.col = col_cpu_i32.to(dev);
-  h.val = val_cpu.to(dev);
+  // TiledSpMM convention: inner dimension = N, dense width = K (CsrHandle: K = inner, N = width)
+  CsrHandle h = build_handle(M, /*inner=*/N, /*width=*/K, val_cpu.numel(), rowptr_cpu_i32.to(dev), col_cpu_i32.to(dev),
+                             val_cpu.to(dev), "tiledspmm_inspect");
   std::lock_guard<std::mutex> lock(g_registry_mutex);
   g_tiled_layers[layer] = std::move(h);
 }
@@ -731,7 +844,16 @@ void tiledspmm_mm(torch::Tensor B, torch::Tensor C, std::string layer) {
     std::lock_guard<std::mutex> lock(g_registry_mutex);
     h = lookup(g_tiled_layers, layer, "tiledspmm_mm");
   }
-  colmajor_mm(h, B, C, "tiledspmm_mm");
+  colmajor_mm(h, false, B, C, "tiledspmm_mm");
+}
+
+void tiledspmm_mm_t(torch::Tensor B, torch::Tensor C, std::string layer) {
+  CsrHandle h;
+  {
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    h = lookup(g_tiled_layers, layer, "tiledspmm_mm_t");
+  }
+  colmajor_mm(h, true, B, C, "tiledspmm_mm_t");
 }
 
 void tiledspmm_clean() {
@@ -790,6 +912,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("cusparse_inspect", &cusparse_inspect, "Inspect function for CuSPARSE with CSR input");
   m.def("cusparse_mmul_opt", &cusparse_mmul_opt, "MM function for CuSPARSE");
   m.def("cusparse_clean", &cusparse_clean, "Cleanup function for CuSPARSE");
+  m.def("cusparse_mmul_opt_t", &cusparse_mmul_opt_t, "column-major product with the cached transpose: C = A^T B");
+  m.def("tiledspmm_mm_t", &tiledspmm_mm_t, "column-major product with the cached transpose: C = A^T B");
+  m.def("inspect_info", &inspect_info, "what an inspector handle holds (layer, tiled)");
 
   // additions (not in the reference): one-launch batching and the sparse backward
   m.def("dense_to_csr", &dense_to_csr, "Device dense -> batched CSR (values, columns, offsets)");

@@ -926,7 +926,7 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
                   int long_mode = MI_LONG_ROWS_AUTO) {
   if (M < 0 || K < 0 || N < 0 || nnz < 0 || batch < 0) return MI_EINVAL;
   if (variant < 0 || variant >= MI_SPMM_VARIANT_COUNT) return MI_EINVAL;
-  if (long_mode < MI_LONG_ROWS_AUTO || long_mode > MI_LONG_ROWS_SPLIT) return MI_EINVAL;
+  if (long_mode < MI_LONG_ROWS_AUTO || long_mode > MI_LONG_ROWS_PREPARED) return MI_EINVAL;
   if (nnz > 0x7fffffffLL) return MI_ERANGE;  // int32 rowptr entries
   if (batch > 65535) return MI_ERANGE;       // grid.y
   if (M == 0 || N == 0 || batch == 0) return MI_OK;
@@ -947,16 +947,18 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
   // MI_LONG_ROWS_SPLIT / _NONE pin the rule whatever the plan (a row shard must sum its rows the way
   // the whole matrix would: sharded.py); N < 4 keeps the narrow kernel's own order in every mode.
   const bool split = workspace != nullptr && batch == 1 && nnz > kLongRow && variant != MI_SPMM_NARROW &&
-                     long_mode != MI_LONG_ROWS_NONE && (variant != MI_SPMM_SLAB || long_mode == MI_LONG_ROWS_SPLIT);
+                     long_mode != MI_LONG_ROWS_NONE && (variant != MI_SPMM_SLAB || long_mode >= MI_LONG_ROWS_SPLIT);
   int* ws = static_cast<int*>(workspace);
   const LongWs lw = long_ws_layout(nnz, N);
   if (split) {
     if (workspace_bytes < lw.bytes) return MI_ENOMEM;
     if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return MI_EINVAL;
-    // counters, entries and the slot → entry map (a few KB per 10⁶ non-zeros)
-    MI_HIP_TRY(hipMemsetAsync(ws, 0, lw.partial_off, s));
-    hipLaunchKernelGGL(find_long_rows_kernel, dim3((unsigned)(((long)M + 255) / 256)), dim3(256), 0, s, rowptr, M,
-                       ws, (int)lw.cap_e, (int)lw.cap_s, (int)lw.cap_p);
+    if (long_mode != MI_LONG_ROWS_PREPARED) {  // else: the list was built once by mi_spmm_long_rows_prepare
+      // counters, entries and the slot → entry map (a few KB per 10⁶ non-zeros)
+      MI_HIP_TRY(hipMemsetAsync(ws, 0, lw.partial_off, s));
+      hipLaunchKernelGGL(find_long_rows_kernel, dim3((unsigned)(((long)M + 255) / 256)), dim3(256), 0, s, rowptr, M,
+                         ws, (int)lw.cap_e, (int)lw.cap_s, (int)lw.cap_p);
+    }
   }
   int st = launch_variant(variant, sh, rowptr, col, val, nnz, batch, M, K, N, B, ldb, strideB, C, ldc, strideC,
                           bias, split ? kLongRow : 0x7fffffff, s);
@@ -1007,6 +1009,22 @@ int mi_spmm_csr_ex_f32(const int32_t* rowptr, const int32_t* col, const float* v
   if (long_rows == MI_LONG_ROWS_SPLIT && workspace == nullptr && nnz > kLongRow) return MI_EINVAL;
   return spmm_dispatch(MI_SPMM_AUTO, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0, bias, workspace,
                        workspace_bytes, static_cast<hipStream_t>(stream), long_rows);
+}
+
+int mi_spmm_long_rows_prepare(const int32_t* rowptr, int32_t M, int64_t nnz, int32_t N, void* workspace,
+                              size_t workspace_bytes, mi_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (M < 0 || nnz < 0 || N < 0) return MI_EINVAL;
+  if (nnz > 0x7fffffffLL) return MI_ERANGE;
+  if (nnz <= kLongRow || M == 0 || N == 0) return MI_OK;  // no row can be long: the list is never read
+  if (!rowptr || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return MI_EINVAL;
+  const LongWs lw = long_ws_layout(nnz, N);
+  if (workspace_bytes < lw.bytes) return MI_ENOMEM;
+  int* ws = static_cast<int*>(workspace);
+  MI_HIP_TRY(hipMemsetAsync(ws, 0, lw.partial_off, s));
+  hipLaunchKernelGGL(find_long_rows_kernel, dim3((unsigned)(((long)M + 255) / 256)), dim3(256), 0, s, rowptr, M, ws,
+                     (int)lw.cap_e, (int)lw.cap_s, (int)lw.cap_p);
+  return mi::check_launch();
 }
 
 int mi_spmm_auto_splits_long_rows(int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,

@@ -346,30 +346,61 @@ def naive_matmul(a: torch.Tensor,
     return _spmm_dispatch(a, b, mm_op, custom_mm.naive_spmm)
 
 
+def _csr_cached(m1: torch.Tensor):
+    '''(values, columns i32, offsets i32, nnz, rows, cols) and the CSR of m1ᵀ for a CSR tensor, kept
+    ON the tensor object between calls: in a training loop A's pattern is static, and the device
+    transpose (≈2.5 ms at the 1M × 1M config) would otherwise be paid on every backward.  The entry is
+    keyed on the component tensors' storage and version counters, so an in-place update of the values
+    (or a different tensor) rebuilds it; it dies with the tensor.'''
+    vals, crow, ccol = torch.Tensor.values(m1), torch.Tensor.crow_indices(m1), torch.Tensor.col_indices(m1)
+    key = (vals.data_ptr(), crow.data_ptr(), ccol.data_ptr(), vals._version, crow._version, ccol._version,
+           tuple(m1.shape), vals.numel())
+    hit = getattr(m1, '_mi_csr_cache', None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    props = get_sparse_tensor_properties(m1)
+    values, columns, offsets, nnz, rows, cols = props
+    transposed = custom_mm.csr_transpose(values, columns, offsets, nnz, rows, cols)
+    try:
+        m1._mi_csr_cache = (key, props, transposed)
+    except (AttributeError, RuntimeError):
+        pass  # a tensor type that takes no attributes: just no caching
+    return props, transposed
+
+
 def _sparse_backward(ctx, grad_output):
     '''Gradients of C = m1 @ m2 with m1 taken as sparse.
 
     grad_m2 = m1ᵀ·dC.  grad_m1 = dC·m2ᵀ: dense when m1 is a dense tensor (what
     torch autograd of torch.matmul gives), sampled on m1's pattern (SDDMM) when
     m1 is a CSR tensor — a dense M×K gradient cannot exist at the sizes CSR
-    inputs are used for.'''
+    inputs are used for.  A CSR m1 may meet a batched m2 ([..., K, N], the forward's
+    `A · [K, batch·N]` form, reference call shape matmuls.py:245-256): both gradients are taken
+    on the same flattened operands — grad_m2[i] = m1ᵀ·dC[i] is one product with N·batch columns, and
+    the SDDMM sums over every item's columns, which is exactly Σ_i dC[i]·m2[i]ᵀ on the pattern.'''
     m1, m2 = ctx.saved_tensors
     grad_m1 = grad_m2 = None
 
     if m1.is_sparse_csr:
-        values, columns, offsets, nnz, rows, cols = get_sparse_tensor_properties(m1)
-        g = grad_output.reshape(rows, -1) if m2.dim() == 1 else grad_output
-        b = m2.unsqueeze(-1) if m2.dim() == 1 else m2
-        if b.dim() != 2:
-            raise RuntimeError('backward of a CSR tensor times a batched operand is not supported')
+        (values, columns, offsets, nnz, rows, cols), (t_val, t_col, t_off) = _csr_cached(m1)
+        if m2.dim() == 1:
+            g, b = grad_output.reshape(rows, 1), m2.unsqueeze(-1)
+        elif m2.dim() == 2:
+            g, b = grad_output, m2
+        else:
+            # [..., K, N] → [K, batch·N] and [..., M, N] → [M, batch·N], item-major columns
+            n = m2.shape[-1]
+            b = m2.reshape(-1, cols, n).permute(1, 0, 2).reshape(cols, -1)
+            g = grad_output.reshape(-1, rows, n).permute(1, 0, 2).reshape(rows, -1)
         if ctx.needs_input_grad[0]:
             gvals = custom_mm.sddmm(columns, offsets, nnz, rows, cols, g, b)
             grad_m1 = torch.sparse_csr_tensor(torch.Tensor.crow_indices(m1), torch.Tensor.col_indices(m1),
                                               gvals.to(m1.device), size=m1.shape)
         if ctx.needs_input_grad[1]:
-            t_val, t_col, t_off = custom_mm.csr_transpose(values, columns, offsets, nnz, rows, cols)
             gb = torch.empty((cols, g.shape[-1]), device=g.device, dtype=torch.float32)
             gb = custom_mm.naive_spmm(t_val, t_col, t_off, nnz, cols, rows, g, gb)
+            if m2.dim() > 2:
+                gb = gb.view(cols, -1, m2.shape[-1]).permute(1, 0, 2)
             grad_m2 = gb.reshape(m2.shape)
         return grad_m1, grad_m2
 

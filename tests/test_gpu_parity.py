@@ -467,6 +467,112 @@ def test_tiledspmm_inspect_and_multiply(cmm, dev, oracle_mod, n):
                                   torch.ones(2), "bad")
 
 
+def test_inspect_handles_amortise_transpose_and_long_rows(cmm, dev, oracle_mod):
+    """What `cusparse_inspect` / `tiledspmm_inspect_*` keep: the validated CSR, Aᵀ,
+    and the prepared long-row lists.  A weight matrix with hub rows AND a hub column: the executor
+    sums long rows in the split order (same bits as cusparse_mmul on the same data, restated by
+    oracle.spmm_csr_long), `*_mmul_opt_t` runs the product with the cached Aᵀ, repeated products on
+    the handle give the same bits, and malformed CSR is refused at inspect time."""
+    M, K, N = 300, 20000, 64
+    g = np.random.Generator(np.random.PCG64(77))
+    lens = g.integers(0, 120, size=M)
+    lens[4], lens[100], lens[299] = 20000, 9000, 8193           # hub rows (> 8192 non-zeros)
+    cols = [np.sort(g.choice(K, size=int(n), replace=False)).astype(np.int32) for n in lens]
+    for c in cols[150:]:                                         # a hub column: every later row holds column 7
+        if len(c) and c[0] != 7:
+            c[0] = 7
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col = np.concatenate(cols)
+    val = g.random(len(col), dtype=np.float32) - 0.5
+    nnz = len(val)
+    x = g.random((N, K), dtype=np.float32)                       # activations [N, K] == B col-major K×N
+    cmm.cusparse_inspect(t(rowptr, dev), t(col, dev), t(val, dev), nnz, M, N, K, "hub")
+    info = cmm.inspect_info("hub", False)
+    assert info["max_row"] == 20000 and info["long_rows_prepared"] is True
+    assert info["max_row_transposed"] <= M and info["long_rows_prepared_transposed"] is False
+    e_rp, e_col, e_val = oracle_mod.csr_transpose(rowptr, col, val, M, K)
+    t_val, t_col, t_rp = info["transpose"]
+    assert np.array_equal(t_rp.cpu().numpy(), e_rp) and np.array_equal(t_col.cpu().numpy(), e_col)
+    assert np.array_equal(t_val.cpu().numpy(), e_val)
+    y = torch.full((N, M), float("nan"), device=dev)
+    cmm.cusparse_mmul_opt(t(x, dev), y, "hub")
+    want = oracle_mod.spmm_csr_long(rowptr, col, val, M, K, np.ascontiguousarray(x.T)).T   # [N, M]
+    assert np.array_equal(y.cpu().numpy(), want)
+    plain = torch.empty(M, N, device=dev)                         # the non-inspect path on the same data
+    cmm.cusparse_mmul(t(val, dev), t(col, dev), t(rowptr, dev), nnz, M, K, t(np.ascontiguousarray(x.T), dev), plain)
+    assert np.array_equal(plain.cpu().numpy().T, y.cpu().numpy())
+    y2 = torch.full((N, M), float("nan"), device=dev)
+    cmm.cusparse_mmul_opt(t(x, dev), y2, "hub")                   # the prepared list is not consumed
+    assert torch.equal(y, y2)
+    # transposed product: dX [N, K] from dY [N, M]  (dXᵀ = Aᵀ·dYᵀ)
+    dy = g.random((N, M), dtype=np.float32)
+    dx = torch.full((N, K), float("nan"), device=dev)
+    cmm.cusparse_mmul_opt_t(t(dy, dev), dx, "hub")
+    want_t = oracle_mod.spmm_csr(e_rp, e_col, e_val, K, M, np.ascontiguousarray(dy.T)).T
+    assert np.array_equal(dx.cpu().numpy(), want_t)
+    assert np.allclose(dx.cpu().numpy(), dy.astype(np.float64) @ _dense_of(rowptr, col, val, M, K), rtol=1e-4, atol=1e-4)
+    # a hub COLUMN long enough to make a long row of Aᵀ: the transposed side prepares its own list
+    M2, K2 = 9000, 50
+    lens2 = np.full(M2, 3)
+    cols2 = [np.array([0, 1 + r % 20, 30 + r % 20], dtype=np.int32) for r in range(M2)]   # column 0 in every row
+    rowptr2 = np.concatenate([[0], np.cumsum(lens2)]).astype(np.int32)
+    col2, val2 = np.concatenate(cols2), g.random(3 * M2, dtype=np.float32)
+    cmm.tiledspmm_inspect_csr(M2, K2, 8, torch.from_numpy(rowptr2.astype(np.int64)), torch.from_numpy(col2.astype(np.int64)),
+                              torch.from_numpy(val2), "hubcol")
+    info2 = cmm.inspect_info("hubcol", True)
+    assert info2["max_row"] == 3 and info2["max_row_transposed"] == M2 and info2["long_rows_prepared_transposed"] is True
+    dy2 = g.random((8, M2), dtype=np.float32)
+    dx2 = torch.full((8, K2), float("nan"), device=dev)
+    cmm.tiledspmm_mm_t(t(dy2, dev), dx2, "hubcol")
+    t2 = oracle_mod.csr_transpose(rowptr2, col2, val2, M2, K2)
+    assert np.array_equal(dx2.cpu().numpy(), oracle_mod.spmm_csr_long(*t2, K2, M2, np.ascontiguousarray(dy2.T)).T)
+    # malformed CSR is refused once, at inspect time
+    bad_col = col.copy()
+    bad_col[5] = K
+    with pytest.raises(RuntimeError, match="column index out of range"):
+        cmm.cusparse_inspect(t(rowptr, dev), t(bad_col, dev), t(val, dev), nnz, M, N, K, "bad")
+    bad_rp = rowptr.copy()
+    bad_rp[10] = bad_rp[11] + 1
+    with pytest.raises(RuntimeError, match="must not decrease"):
+        cmm.cusparse_inspect(t(bad_rp, dev), t(col, dev), t(val, dev), nnz, M, N, K, "bad")
+    with pytest.raises(RuntimeError, match="Invalid handle_id"):
+        cmm.inspect_info("bad", False)
+    cmm.cusparse_clean()
+    cmm.tiledspmm_clean()
+
+
+def _dense_of(rowptr, col, val, M, K):
+    A = np.zeros((M, K), np.float64)
+    rows = np.repeat(np.arange(M), np.diff(rowptr))
+    np.add.at(A, (rows, col), val)
+    return A
+
+
+def test_matmuls_csr_times_batched_operand_on_device(mm, dev):
+    """naiveSpMM / cusparseMM with a CSR m1 and a batched m2: forward + both gradients vs torch
+    autograd of the dense product; the cached transpose is reused across backward passes."""
+    g = torch.Generator().manual_seed(5)
+    a = torch.rand(70, 90, generator=g) * (torch.rand(70, 90, generator=g) < 0.1)
+    for cls in (mm.naiveSpMM, mm.cusparseMM):
+        for bshape in ((4, 90, 32), (2, 3, 90, 20), (90, 64)):
+            b = torch.rand(*bshape, generator=g)
+            a_csr = a.to(dev).to_sparse_csr().requires_grad_(True)
+            b1 = b.to(dev).requires_grad_(True)
+            out = cls.apply(a_csr, b1)
+            a2, b2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            ref = torch.matmul(a2, b2)
+            assert torch.allclose(ref, out.cpu(), rtol=RTOL, atol=1e-6)
+            dc = torch.rand(ref.shape, generator=g)
+            for _ in range(2):   # second pass: transpose from the cache on the tensor
+                b1.grad = None
+                a_csr.grad = None
+                cls.apply(a_csr, b1).backward(dc.to(dev))
+            ref.backward(dc)
+            assert torch.allclose(b2.grad, b1.grad.cpu(), rtol=RTOL, atol=1e-5)
+            assert torch.allclose(a2.grad * (a != 0), a_csr.grad.to_dense().cpu(), rtol=RTOL, atol=1e-5)
+            assert getattr(a_csr, "_mi_csr_cache", None) is not None
+
+
 def test_dummy_kernel_and_streams(cmm, dev, oracle_mod, capfd):
     cmm.dummy_kernel()
     assert "0..4095 ok" in capfd.readouterr().out

@@ -170,6 +170,41 @@ def test_sparse_csr_tensor_input_and_pattern_gradient(mm):
     assert ("csr_transpose", (10, 20)) in fake.calls and ("sddmm", (10, 20)) in fake.calls
 
 
+def test_csr_times_batched_operand_backward_and_transpose_cache(mm):
+    """A CSR m1 against a batched m2 ([..., K, N]; reference call shape matmuls.py:245-256): forward
+    and both gradients equal torch autograd of the dense product; the device transpose of A is built
+    once per CSR tensor and reused by later backward passes until the values change in place."""
+    matmuls, fake = mm
+    g = torch.Generator().manual_seed(21)
+    a = sparsify(g, 9, 14, density=0.3)
+    for bshape in ((3, 14, 5), (2, 3, 14, 4)):
+        b = rand(g, *bshape)
+        a_csr = a.to_sparse_csr().requires_grad_(True)
+        b1 = b.clone().requires_grad_(True)
+        out = matmuls.naiveSpMM.apply(a_csr, b1)
+        a2, b2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ref = torch.matmul(a2, b2)
+        assert out.shape == ref.shape and torch.allclose(ref, out, rtol=RTOL, atol=ATOL)
+        dc = rand(g, *ref.shape)
+        out.backward(dc)
+        ref.backward(dc)
+        assert torch.allclose(b2.grad, b1.grad, rtol=RTOL, atol=1e-6)
+        assert torch.allclose(a2.grad * (a != 0), a_csr.grad.to_dense(), rtol=RTOL, atol=1e-6)
+    # the transpose cache: second backward on the same CSR tensor does not transpose again
+    a_csr = a.to_sparse_csr().requires_grad_(True)
+    b = rand(g, 14, 6)
+    n0 = sum(c[0] == "csr_transpose" for c in fake.calls)
+    for _ in range(3):
+        matmuls.cusparseMM.apply(a_csr, b.clone().requires_grad_(True)).sum().backward()
+    assert sum(c[0] == "csr_transpose" for c in fake.calls) == n0 + 1
+    with torch.no_grad():
+        torch.Tensor.values(a_csr).mul_(2.0)  # in-place update of the values: the entry is rebuilt
+    b3 = b.clone().requires_grad_(True)
+    matmuls.cusparseMM.apply(a_csr, b3).sum().backward()
+    assert sum(c[0] == "csr_transpose" for c in fake.calls) == n0 + 2
+    assert torch.allclose(b3.grad, (2 * a).t() @ torch.ones(9, 6), rtol=RTOL, atol=1e-6)
+
+
 def test_get_sparse_tensor_properties_contract(mm):
     """Argument order = naive_spmm / cusparse_mmul signature (reference matmuls.py:178-187)."""
     matmuls, _ = mm
