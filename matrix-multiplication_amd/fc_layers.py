@@ -61,29 +61,33 @@ class _LinearBias(InplaceFunction):
         return grad_inp, grad_w, grad_b
 
 
-def sparse_forward_pays(nnz, tokens, in_features, out_features, fused=False):
+def sparse_forward_pays(nnz, tokens, in_features, out_features):
     '''Forward cost model of `cusparseLinear` (fitted on MI355X, tools/bench_fc.py,
     profiles/r02_fc_layer_timings.log): the exact-fp32 MFMA product runs at ≈130 TFLOP/s on these
-    shapes, the row-split SpMM of ReLU-sparse activations at ≈15 TFLOP/s of useful flops, plus the
-    passes over the activations the route needs after the count (CSR route: the fill reads them again
-    and writes col/val, ≈2 passes; fused zero-skipping kernel: its own read, 1 pass).  Sparse is
-    taken only when the model gives it a 10 % lead.'''
+    shapes, the row-split SpMM of ReLU-sparse activations at ≈15 TFLOP/s of useful flops, plus three
+    passes over the activations for the exact count and the fill.  Sparse is taken only when the
+    model gives it a 10 % lead.'''
     t_dense = 2.0 * tokens * in_features * out_features / 130e12
-    passes = 1.0 if fused else 2.0
-    t_sparse = 2.0 * nnz * out_features / 15e12 + passes * tokens * in_features * 4 / 4e12
+    t_sparse = 2.0 * nnz * out_features / 15e12 + 3.0 * tokens * in_features * 4 / 4e12
     return t_sparse < 0.9 * t_dense
+
+
+_SAMPLE_ROWS = 512
 
 
 class _SparseLinearBias(InplaceFunction):
     '''y = sparse(x)·Wᵀ (+ bias): the activations' exact zeros are skipped when that pays.
 
-    The non-zeros are counted on the device first (one pass, one host read-back — the reference's
-    cusparseDenseToSparse analysis step syncs as well, src/baseline_mm.cu:232-247); with the count
-    the layer takes the CSR route (conversion + row-split kernel, bias fused), the fused
-    zero-skipping kernel (out_features ≤ 256: no CSR at all) or — when the activations are not
-    sparse enough — the dense MFMA product.  All three sum the same terms in the same (column)
-    order, the skipped ones being exact zeros, so the result does not depend on the route.
-    Under stream capture nothing may be read back: the fused kernel or the dense product is used.'''
+    The layer first estimates the density from an evenly spaced sample of ≤ 512 token rows (one small
+    count kernel and one host read-back — the reference's cusparseDenseToSparse analysis step syncs as
+    well, src/baseline_mm.cu:232-247).  Only when the model says the sparse route wins does it pay for
+    the exact count and the fill (CSR route: conversion + row-split kernel, bias fused); otherwise the
+    dense MFMA product runs, at the cost of that sample (measured: the full count alone cost 10–25 % of
+    a cheap layer's forward).  Both routes sum the same terms in the same (column) order, the skipped
+    ones being exact zeros, so the result does not depend on the route.  Under stream capture nothing
+    may be read back: the dense product is used.  (The fused zero-skipping kernel of naiveSpMM is not
+    used here: it scans every element of x per 64 output columns and lost to both routes at FC sizes —
+    0.46 ms vs 0.20 ms dense at 16384 × 3072 → 256, 99 % zeros.)'''
 
     @staticmethod
     def forward(ctx, inp, weight, bias):
@@ -93,32 +97,29 @@ class _SparseLinearBias(InplaceFunction):
         out = torch.empty((tokens, fout), device=inp.device, dtype=torch.float32)
         csr = None
         capturing = inp.is_cuda and torch.cuda.is_current_stream_capturing()
-        nnz = None
+        ctx.x_density = 1.0
         if not capturing and x2.numel() > 0:
-            offsets = custom_mm.dense_row_offsets(x2)
-            nnz = int(offsets.view(-1)[-1])
-        ctx.x_density = 1.0 if nnz is None else nnz / max(1, x2.numel())
-        fused_ok = fout <= 256 and fout % 4 == 0
-        sparse = nnz is not None and sparse_forward_pays(nnz, tokens, fin, fout, fused_ok)
-        done = False
-        if (sparse or capturing) and fused_ok:
+            step = max(1, tokens // _SAMPLE_ROWS)
+            sample = x2[::step][:_SAMPLE_ROWS]
+            est = int(custom_mm.dense_row_offsets(sample).view(-1)[-1]) / sample.numel()
+            ctx.x_density = est
+            if sparse_forward_pays(est * x2.numel(), tokens, fin, fout):
+                offsets = custom_mm.dense_row_offsets(x2)
+                nnz = int(offsets.view(-1)[-1])
+                ctx.x_density = nnz / x2.numel()
+                if sparse_forward_pays(nnz, tokens, fin, fout):
+                    values, columns = custom_mm.dense_to_csr_fill(x2, offsets, nnz)
+                    csr = (values, columns, offsets.view(-1))
+        if csr is not None:
             wt = weight.t().contiguous()                                 # [in, out] row-major B operand
-            done = (custom_mm.naive_spmm_dense_bias(x2, wt, bias, out) if bias is not None
-                    else custom_mm.naive_spmm_dense(x2, wt, out))
-        if not done and sparse:
-            values, columns = custom_mm.dense_to_csr_fill(x2, offsets, nnz)
-            csr = (values, columns, offsets.view(-1))
-            wt = weight.t().contiguous()
             if bias is not None:
-                custom_mm.naive_spmm_bias(values, columns, csr[2], nnz, tokens, fin, wt, bias, out)
+                custom_mm.naive_spmm_bias(csr[0], csr[1], csr[2], csr[0].numel(), tokens, fin, wt, bias, out)
             else:
-                custom_mm.naive_spmm(values, columns, csr[2], nnz, tokens, fin, wt, out)
-            done = True
-        if not done:
-            if bias is not None:
-                custom_mm.cublas_mmul_bias(x2, weight, bias, out, False, True)
-            else:
-                custom_mm.cublas_mmul(x2, weight, out, False, True)
+                custom_mm.naive_spmm(csr[0], csr[1], csr[2], csr[0].numel(), tokens, fin, wt, out)
+        elif bias is not None:
+            custom_mm.cublas_mmul_bias(x2, weight, bias, out, False, True)
+        else:
+            custom_mm.cublas_mmul(x2, weight, out, False, True)
         ctx.has_csr = csr is not None
         ctx.save_for_backward(inp, weight, *(csr or ()))
         return out.view(tuple(inp.shape[:-1]) + (fout,))

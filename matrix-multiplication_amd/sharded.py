@@ -81,12 +81,18 @@ class ShardedSpMM:
         default: ``custom_mm.naive_spmm_ex`` with the long-row rule of the whole problem.
     '''
 
-    def __init__(self, rowptr, col, val, M, K, device, group=None, chunks=4, mm_op=None, split="rows"):
+    def __init__(self, rowptr, col, val, M, K, device, group=None, chunks=4, mm_op=None, split="rows",
+                 layout=None):
         if split not in ("rows", "nnz"):
             raise ValueError("split must be 'rows' or 'nnz'")
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if layout is not None:
+            # (rank, world) of a rank that is only being MODELLED: its share of the rows without a
+            # process group (tools/c4_model.py times one rank's blocks on one GPU); gather must stay off
+            self.rank, self.world = int(layout[0]), int(layout[1])
+        self.modelled = layout is not None
         self.M, self.K = int(M), int(K)
         self.chunks = max(1, int(chunks))
         self.device = torch.device(device)
@@ -159,6 +165,8 @@ class ShardedSpMM:
         assert out.shape == (self.padded_rows, N) and out.is_contiguous()
         works = []
         collective = gather and (self.world > 1 or force_collective)
+        if collective and self.modelled:
+            raise RuntimeError("a modelled layout has no process group: call forward(..., gather=False)")
         for j, blk in enumerate(self.blocks):
             r0, r1 = int(self.bounds[blk[0]]), int(self.bounds[blk[0] + 1])
             mine = out[r0:r1]

@@ -273,7 +273,7 @@ def test_fc_layer_modules_host_logic(mm):
     assert fc_layers.sparse_forward_pays(int(0.01 * 16384 * 3072), 16384, 3072, 768)
     assert not fc_layers.sparse_forward_pays(int(0.5 * 16384 * 3072), 16384, 3072, 768)
     assert not fc_layers.sparse_forward_pays(int(0.1 * 16384 * 3072), 16384, 3072, 768)
-    assert fc_layers.sparse_forward_pays(int(0.1 * 4096 * 4096), 4096, 4096, 4096)
+    assert fc_layers.sparse_forward_pays(int(0.05 * 4096 * 4096), 4096, 4096, 4096)
     assert not fc_layers.sparse_forward_pays(10, 15, 12, 7)
     for cls, force_sparse in ((fc_layers.cublasLinear, False), (fc_layers.cusparseLinear, True),
                               (fc_layers.cusparseLinear, False)):

@@ -1,0 +1,89 @@
+"""BASELINE config C4 on a one-GPU box: MEASURED per-rank compute of the row-sharded product (one rank's
+block-cyclic share of the C3 matrix, timed on one MI355X for G = 2, 4, 8) + an explicitly labelled MODEL of
+the all-gather leg from link rates.  Writes profiles/r02_c4_model.json.  Nothing here is a multi-GPU
+measurement; the driver's 8-GPU node gives those (bench.py --gpus N).
+
+    python tools/c4_model.py [--steps 20]
+"""
+import argparse
+import json
+import sys
+from pathlib import Path
+
+import torch
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "matrix-multiplication_amd"))
+import custom_mm  # noqa: E402
+import sharded  # noqa: E402
+import synthetic  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=20)
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+M = K = 1 << 20
+N = 256
+rowptr, col, val = synthetic.make_csr(M, K, 1e-4, seed=0)
+nnz = int(rowptr[-1])
+B = torch.from_numpy(synthetic.make_dense(K, N, seed=1)).to(dev)
+rp_t, col_t, val_t = torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val)
+
+
+def timed(fn, steps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+d = [x.to(dev) for x in (val_t, col_t, rp_t)]
+C1 = torch.empty(M, N, device=dev)
+t1 = timed(lambda: custom_mm.naive_spmm(d[0], d[1], d[2], nnz, M, K, B, C1), args.steps)
+rec = {"what": "C4 (1M x 1M CSR at 0.01 % x 1M x 256, A row-sharded over G GPUs, RCCL all-gather of C)",
+       "single_gpu_ms": round(t1, 4), "nnz": nnz, "ranks": {}}
+# link-rate assumptions of the MODEL (task statement / SURVEY.md §8e): 7 xGMI links per GPU, fully connected,
+# ~153 GB/s per link; RCCL's achieved all-gather bus bandwidth is unknown here — 300 GB/s is SURVEY's "typical" figure
+LINK_GBS, RING_BUS_GBS = 153.0, 300.0
+for G in (2, 4, 8):
+    chunks = 4 if G <= 4 else 8
+    per_rank = {}
+    for r in sorted({0, G // 2, G - 1}):
+        op = sharded.ShardedSpMM(rp_t, col_t, val_t, M, K, dev, chunks=chunks, layout=(r, G))
+        C = op.alloc_output(N)
+        per_rank[r] = timed(lambda: op.forward(B, out=C, gather=False), args.steps)
+        plan = custom_mm.spmm_plan(op.blocks[0][4], op.blocks[0][5], K, B, C[:op.blocks[0][5]])
+        del op, C
+    compute = max(per_rank.values())
+    shard_bytes = M * N * 4 / G
+    direct_ms = shard_bytes / (LINK_GBS * 1e9) * 1e3              # every peer link carries one shard, all in parallel
+    ring_ms = (G - 1) * shard_bytes / (RING_BUS_GBS * 1e9) * 1e3  # ring at the assumed bus bandwidth
+    first_chunk = compute / chunks
+    rec["ranks"][str(G)] = {
+        "chunks": chunks, "block_plan": plan[1], "launches_per_block": plan[2],
+        "MEASURED_compute_ms_per_rank": {str(k): round(v, 4) for k, v in per_rank.items()},
+        "MEASURED_compute_ms_max": round(compute, 4),
+        "ideal_compute_ms (single / G)": round(t1 / G, 4),
+        "compute_vs_ideal": round(compute / (t1 / G), 4),
+        "compute_only_speedup": round(t1 / compute, 3),
+        "MODEL_allgather_ms_direct_links": round(direct_ms, 3),
+        "MODEL_allgather_ms_ring_300GBs": round(ring_ms, 3),
+        # block-cyclic overlap: the gather of step j runs beside the compute of step j+1, so the step costs the
+        # first block's compute plus the longer of (remaining compute, whole gather)
+        "MODEL_end_to_end_ms_direct": round(first_chunk + max(compute - first_chunk, direct_ms), 3),
+        "MODEL_end_to_end_ms_ring": round(first_chunk + max(compute - first_chunk, ring_ms), 3),
+        "MODEL_speedup_direct": round(t1 / (first_chunk + max(compute - first_chunk, direct_ms)), 2),
+        "MODEL_speedup_ring": round(t1 / (first_chunk + max(compute - first_chunk, ring_ms)), 2),
+    }
+rec["label"] = ("compute figures are MEASURED on one MI355X (one rank's share at a time); every *MODEL* figure is an "
+                "estimate from assumed link rates, not a measurement — RCCL kernels also take CUs and HBM bandwidth "
+                "from the concurrent SpMM, which this model ignores")
+out = REPO / "profiles" / "r02_c4_model.json"
+out.write_text(json.dumps(rec, indent=1))
+print(json.dumps(rec, indent=1))
