@@ -75,6 +75,12 @@ def sparse_forward_pays(nnz, tokens, in_features, out_features):
 _SAMPLE_ROWS = 512
 
 
+def worth_sampling(tokens, in_features, out_features):
+    '''A layer whose dense product takes under a quarter of a millisecond cannot win back the sample's
+    launches + read-back (≈0.03 ms): measured 0.232 vs 0.200 ms at 16384 × 3072 → 256.'''
+    return 2.0 * tokens * in_features * out_features / 130e12 >= 0.25e-3
+
+
 class _SparseLinearBias(InplaceFunction):
     '''y = sparse(x)·Wᵀ (+ bias): the activations' exact zeros are skipped when that pays.
 
@@ -98,10 +104,7 @@ class _SparseLinearBias(InplaceFunction):
         csr = None
         capturing = inp.is_cuda and torch.cuda.is_current_stream_capturing()
         ctx.x_density = 1.0
-        # a layer whose dense product takes under a quarter of a millisecond cannot win back the sample's
-        # launches + read-back (≈0.03 ms): measured 0.232 vs 0.200 ms at 16384 × 3072 → 256
-        worth_asking = 2.0 * tokens * fin * fout / 130e12 >= 0.25e-3
-        if not capturing and x2.numel() > 0 and worth_asking:
+        if not capturing and x2.numel() > 0 and worth_sampling(tokens, fin, fout):
             step = max(1, tokens // _SAMPLE_ROWS)
             sample = x2[::step][:_SAMPLE_ROWS]
             est = int(custom_mm.dense_row_offsets(sample).view(-1)[-1]) / sample.numel()

@@ -278,6 +278,7 @@ def test_fc_layer_modules_host_logic(mm):
     for cls, force_sparse in ((fc_layers.cublasLinear, False), (fc_layers.cusparseLinear, True),
                               (fc_layers.cusparseLinear, False)):
         fc_layers.sparse_forward_pays = (lambda *a: True) if force_sparse else _model
+        fc_layers.worth_sampling = lambda *a: True  # tiny test layers: take the decision path anyway
         for bias in (True, False):
             layer = cls(12, 7, bias=bias)
             ref = torch.nn.Linear(12, 7, bias=bias)
