@@ -14,7 +14,10 @@
 //    the legacy default stream (reference naive_sparse_mm.cu:117,133);
 //  * dtype, device, shape and layout are checked (the reference reads
 //    data_ptr() of whatever it is given, README.md:44); strided / transposed
-//    views are handled through leading dimensions or copied, never misread;
+//    views are handled through leading dimensions or copied, never misread.
+//    The CONTENTS of CSR arrays (columns in range, offsets monotone) are trusted on
+//    the per-product entry points, as in the reference; `validate_csr` checks them on
+//    request and the inspector entry points check them once at inspect time;
 //  * the inspect-style registries hold tensor references (the reference keeps
 //    raw pointers and later cudaFree()s torch memory, custom_mm.cpp:249-251,
 //    :272-277), are mutex-protected, and an unknown layer name raises instead
@@ -299,6 +302,37 @@ std::tuple<int, std::string, int, bool> spmm_plan(int64_t nnz, int64_t M, int64_
 
 int long_row_threshold() { return mi_spmm_long_row_threshold(); }
 
+// Opt-in check of a CSR's CONTENTS (the hot-path entry points validate sizes, dtypes, devices and
+// layout, but trust the indices like the reference does, src/naive_sparse_mm.cu:60-92: a column
+// outside [0, A_cols) or decreasing offsets read B out of bounds).  Raises on the first violation;
+// costs a few reductions and one host read-back, so call it where the matrix is built, not per product.
+// The inspector entry points (cusparse_inspect / tiledspmm_inspect_*) run the same checks once.
+void validate_csr(torch::Tensor A_values, torch::Tensor A_columns, torch::Tensor A_offsets, int64_t nnzA,
+                  int64_t A_rows, int64_t A_cols) {
+  const char* what = "validate_csr";
+  check_device_f32(A_values, "A_values");
+  check_device_i32(A_columns, "A_columns");
+  check_device_i32(A_offsets, "A_offsets");
+  check_same_device(A_values, A_columns, what);
+  check_same_device(A_values, A_offsets, what);
+  TORCH_CHECK(A_rows >= 0 && A_cols >= 0 && nnzA >= 0, what, ": negative size");
+  TORCH_CHECK(A_offsets.numel() == A_rows + 1, what, ": A_offsets must have A_rows + 1 entries");
+  TORCH_CHECK(A_values.numel() >= nnzA && A_columns.numel() >= nnzA, what, ": nnzA exceeds the CSR arrays");
+  torch::Tensor off = A_offsets.reshape({-1});
+  if (A_rows > 0) {
+    TORCH_CHECK(off[0].item<int32_t>() == 0 && off[A_rows].item<int32_t>() == nnzA, what,
+                ": offsets must start at 0 and end at nnz");
+    TORCH_CHECK((off.slice(0, 1) - off.slice(0, 0, A_rows)).min().item<int32_t>() >= 0, what,
+                ": offsets must not decrease");
+  } else {
+    TORCH_CHECK(nnzA == 0, what, ": a matrix without rows has no non-zeros");
+  }
+  if (nnzA > 0) {
+    torch::Tensor c = A_columns.reshape({-1}).slice(0, 0, nnzA);
+    TORCH_CHECK(c.min().item<int32_t>() >= 0 && c.max().item<int32_t>() < A_cols, what, ": column index out of range");
+  }
+}
+
 // Column sums of a 2-d tensor (bias gradient of the FC layers): returns a [n] tensor.
 torch::Tensor column_sums(torch::Tensor src) {
   check_device_f32(src, "src");
@@ -456,6 +490,7 @@ bool spmm_dense_impl(const torch::Tensor& A, const torch::Tensor& B, const torch
   torch::Tensor bias_keep;
   if (bias != nullptr && bias->defined()) {
     check_device_f32(*bias, "bias");
+    check_same_device(*bias, C, what);
     TORCH_CHECK(bias->dim() == 1 && bias->size(0) == N, what, ": bias must have ", N, " entries");
     bias_keep = bias->contiguous();
     bias_ptr = bias_keep.data_ptr<float>();
@@ -932,5 +967,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("naive_spmm_bias", &naive_spmm_bias, "CSR x dense + bias, fused epilogue");
   m.def("naive_spmm_ex", &naive_spmm_ex, "naive_spmm with the long-row rule pinned (-1 auto, 0 none, 1 split)");
   m.def("spmm_plan", &spmm_plan, "(variant, kernel name, launches, splits_long_rows) of the AUTO plan");
+  m.def("validate_csr", &validate_csr, "opt-in check of CSR contents (offsets monotone, columns in range); raises");
   m.def("long_row_threshold", &long_row_threshold, "rows with more non-zeros are 'long' (split rule)");
 }

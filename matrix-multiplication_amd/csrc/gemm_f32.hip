@@ -39,6 +39,10 @@
 // cost, half L2-miss latency beyond the one-tile prefetch distance).
 #include "mi_common.h"
 
+#ifndef MI_GEMM_ABL
+#define MI_GEMM_ABL 0  // developer probes only (tools/probes/gemm_probe.cpp): 1 no C stores, 2 no MFMAs, 4 no operand loads
+#endif
+
 namespace {
 
 using mi::f32x4;
@@ -160,7 +164,7 @@ __device__ __forceinline__ void tile_coords(int tile, int tiles_n, int tiles_m, 
 
 // Epilogue shared by both kernels.  D' = Cᵀ tile: lane&31 = row m inside the tile, register r
 // holds column n = (r&3) + 8·(r>>2) + 4·(lane>>5).
-template <int BM, int BN, int TM, int TN>
+template <int BM, int BN, int TM, int TN, bool ALIGNED = false>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds, float* __restrict__ C, int m, int n,
                                               long ldc, int m0, int n0, int wm, int wn, int wave, int lane, bool vecC,
                                               const float* __restrict__ bias) {
@@ -191,7 +195,14 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
         const int rr = (lane >> 3) + 8 * pass;
         const int row = tile_row0 + rr;
         f32x4 v = *reinterpret_cast<const f32x4*>(patch + rr * PLD + c4);
-        if (row < m && col < n) {
+        if (ALIGNED) {  // every tile whole, C rows 16-B aligned: no bounds, no scalar tail
+          if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
+          if (MI_GEMM_ABL & 1) {
+            if (v.x == 12345.678f) C[(long)row * ldc + col] = v.x;
+          } else {
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(C + (long)row * ldc + col));
+          }
+        } else if (row < m && col < n) {
           float* dst = C + (long)row * ldc + col;
           if (bias) {
             if (col + 0 < n) v.x += bias[col + 0];
@@ -199,7 +210,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
             if (col + 2 < n) v.z += bias[col + 2];
             if (col + 3 < n) v.w += bias[col + 3];
           }
-          if (vecC && col + 3 < n) {
+          if (MI_GEMM_ABL & 1) {
+            if (v.x == 12345.678f) dst[0] = v.x;  // keeps the accumulators live
+          } else if (vecC && col + 3 < n) {
             __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
           } else {
             if (col + 0 < n) __builtin_nontemporal_store(v.x, dst + 0);
@@ -214,8 +227,18 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
     }
 }
 
-template <int BM, int BN, bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(
+#ifdef MI_GEMM_TIMING
+__device__ unsigned long long g_gemm_phase[16];
+#define GEMM_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g_gemm_phase[k], now_ - stamp_); stamp_ = now_; } while (0)
+#else
+#define GEMM_STAMP(k) do {} while (0)
+#endif
+
+#ifndef MI_GEMM_SHORTK_WAVES
+#define MI_GEMM_SHORTK_WAVES 3
+#endif
+template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI_GEMM_SHORTK_WAVES, MI_GEMM_SHORTK_WAVES))) void gemm_f32_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int m, int n,
     int k, long lda, long ldb, long ldc, long strideA, long strideB, long strideC, int tiles_n,
     int tiles_per_item, bool vecA, bool vecB, bool vecC, const float* __restrict__ bias) {
@@ -257,19 +280,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#ifdef MI_GEMM_TIMING
+  unsigned long long stamp_ = __builtin_readcyclecounter();
+#endif
   f32x4 ra[LA::VECS], rb[LB::VECS];
-  LA::load(ra, A, lda, m0, 0, m, k, vecA, tid);
-  LB::load(rb, B, ldb, n0, 0, n, k, vecB, tid);
-
   const int l31 = lane & 31, lhi = lane >> 5;
-  for (int k0 = 0; k0 < k; k0 += BK) {
-    LA::store(ra, As, tid);
-    LB::store(rb, Bs, tid);
-    __syncthreads();
-    if (k0 + BK < k) {
-      LA::load(ra, A, lda, m0, k0 + BK, m, k, vecA, tid);
-      LB::load(rb, B, ldb, n0, k0 + BK, n, k, vecB, tid);
-    }
+  // block-uniform: whole tiles (inside C, k a multiple of BK, 16-B loads) take unconditional vector
+  // loads; the bounds-checked loader (≈50 scalar / branch instructions per float4) only at the edges
+  // ALIGNED: the launcher saw that EVERY tile is interior, and the edge code is compiled out (it is
+  // what sets the kernel's register count otherwise)
+  const bool interior = ALIGNED || (vecA && vecB && m0 + BM <= m && n0 + BN <= n && k % BK == 0);
+  auto mfma_tile = [&]() {
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a[TM], b[TN];
@@ -283,12 +304,47 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(
         for (int j = 0; j < TN; ++j)
           // operands swapped: the accumulator tile is Cᵀ (lane ↔ row m of C, registers ↔ 4-column
           // groups of n), so the epilogue can move 16 B per lane; a·b = b·a keeps every bit.
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
+          if (!(MI_GEMM_ABL & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
+  };
+  if (interior) {
+    if (!(MI_GEMM_ABL & 4)) {
+      LA::load_fast(ra, A, lda, m0, 0, tid);
+      LB::load_fast(rb, B, ldb, n0, 0, tid);
+    }
+    for (int k0 = 0; k0 < k; k0 += BK) {
+      LA::store(ra, As, tid);
+      LB::store(rb, Bs, tid);
+      GEMM_STAMP(0);  // operand tile landed and written to LDS
+      __syncthreads();
+      GEMM_STAMP(1);
+      if (k0 + BK < k && !(MI_GEMM_ABL & 4)) {
+        LA::load_fast(ra, A, lda, m0, k0 + BK, tid);
+        LB::load_fast(rb, B, ldb, n0, k0 + BK, tid);
+      }
+      mfma_tile();
+      GEMM_STAMP(2);  // MFMAs of the tile issued
+      __syncthreads();
+      GEMM_STAMP(3);
+    }
+  } else if (!ALIGNED) {
+    LA::load(ra, A, lda, m0, 0, m, k, vecA, tid);
+    LB::load(rb, B, ldb, n0, 0, n, k, vecB, tid);
+    for (int k0 = 0; k0 < k; k0 += BK) {
+      LA::store(ra, As, tid);
+      LB::store(rb, Bs, tid);
+      __syncthreads();
+      if (k0 + BK < k) {
+        LA::load(ra, A, lda, m0, k0 + BK, m, k, vecA, tid);
+        LB::load(rb, B, ldb, n0, k0 + BK, n, k, vecB, tid);
+      }
+      mfma_tile();
+      __syncthreads();
+    }
   }
 
-  gemm_epilogue<BM, BN, TM, TN>(acc, lds, C, m, n, ldc, m0, n0, wm, wn, wave, lane, vecC, bias);
+  gemm_epilogue<BM, BN, TM, TN, ALIGNED>(acc, lds, C, m, n, ldc, m0, n0, wm, wn, wave, lane, vecC, bias);
+  GEMM_STAMP(4);  // epilogue issued
 }
 
 // Pipelined form: two LDS buffers, ONE barrier per k-tile.  While the MFMAs of tile t run out of
@@ -344,6 +400,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
     const int k_last = k - BK;  // start of the last tile: later "prefetches" re-read it (never used)
     auto load_tile = [&](f32x4 (&ra)[LA::VECS], f32x4 (&rb)[LB::VECS], int k0) {
       const int kk = k0 < k_last ? k0 : k_last;
+      if (MI_GEMM_ABL & 4) return;
       LA::load_fast(ra, A, lda, m0, kk, tid);
       LB::load_fast(rb, B, ldb, n0, kk, tid);
     };
@@ -390,7 +447,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s & 1][h][j], a[s & 1][h][i], acc[i][j], 0, 0, 0);
+              if (!(MI_GEMM_ABL & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s & 1][h][j], a[s & 1][h][i], acc[i][j], 0, 0, 0);
         // Fence the scheduler per batch: hipcc otherwise sinks the operand reads next to their
         // use and the global loads to the end of the tile (right in front of the waits on them).
         if (s == 0) {
@@ -463,8 +520,11 @@ int launch(const float* A, const float* B, float* C, int m, int n, int k, long l
     hipLaunchKernelGGL((gemm_f32_pipe_kernel<BM, BN, TA, TB>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m,
                        n, k, lda, ldb, ldc, sA, sB, sC, (int)tiles_n, (int)(tiles_m * tiles_n), vecA, vecB, vecC,
                        bias);
+  else if (vecA && vecB && vecC && m % BM == 0 && n % BN == 0 && k % BK == 0)
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, true>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m, n, k,
+                       lda, ldb, ldc, sA, sB, sC, (int)tiles_n, (int)(tiles_m * tiles_n), vecA, vecB, vecC, bias);
   else
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m, n, k,
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, false>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m, n, k,
                        lda, ldb, ldc, sA, sB, sC, (int)tiles_n, (int)(tiles_m * tiles_n), vecA, vecB, vecC, bias);
   return mi::check_launch();
 }

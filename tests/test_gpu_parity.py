@@ -423,6 +423,57 @@ def test_gemm_bert_base_attention_shapes(cmm, dev, oracle_mod):
 
 # ------------------------------------------------ inspector–executor APIs ----
 
+def test_config_c5_bert_base_attention_full_size_forward_and_backward(mm, dev, oracle_mod):
+    """BASELINE config C5 at full size (B 32, H 12, S 512, D 64) through the drop-in wrappers, forward
+    AND backward: scores = cublasTransbMM.apply(q, k), ctx = cublasMM.apply(probs, v) (reference
+    README.md:69-77) against torch autograd of torch.matmul at rtol 1e-5 (north_star's tolerance), and
+    bit-exact against the sequential-k oracle on sampled heads — forward outputs and every gradient."""
+    Bz, H, S, D = 32, 12, 512, 64
+    g = torch.Generator(device=dev).manual_seed(0)
+    q, k, v = (torch.rand(Bz, H, S, D, device=dev, generator=g) for _ in range(3))
+    probs = torch.softmax(torch.rand(Bz, H, S, S, device=dev, generator=g) * 4, dim=-1)
+    # positive upstream gradients, like the reference tests' torch.rand operands: no cancellation, so a
+    # RELATIVE tolerance is well-posed for every element
+    d_scores = torch.rand(Bz, H, S, S, device=dev, generator=g)
+    d_ctx = torch.rand(Bz, H, S, D, device=dev, generator=g)
+    heads = [(0, 0), (17, 5), (31, 11)]
+
+    def leaf(*ts):
+        return [x.clone().requires_grad_(True) for x in ts]
+
+    # scores = q.kT
+    q1, k1 = leaf(q, k)
+    scores = mm.cublasTransbMM.apply(q1, k1)
+    scores.backward(d_scores)
+    q2, k2 = leaf(q, k)
+    ref = torch.matmul(q2, k2.transpose(-1, -2))
+    ref.backward(d_scores)
+    assert scores.shape == (Bz, H, S, S)
+    for got, want in ((scores, ref), (q1.grad, q2.grad), (k1.grad, k2.grad)):
+        assert torch.allclose(want, got, rtol=1e-5, atol=1e-8)
+    for (b, h) in heads:
+        qh, kh, dsh = (x[b, h].cpu().numpy() for x in (q, k, d_scores))
+        assert np.array_equal(scores[b, h].detach().cpu().numpy(), oracle_mod.gemm(qh, kh, False, True))
+        assert np.array_equal(q1.grad[b, h].cpu().numpy(), oracle_mod.gemm(dsh, kh))               # dQ = dS.K
+        assert np.array_equal(k1.grad[b, h].cpu().numpy(), oracle_mod.gemm(dsh, qh, True, False))  # dK = dST.Q
+    del scores, ref, q1, k1, q2, k2
+
+    # ctx = probs.v
+    p1, v1 = leaf(probs, v)
+    ctx = mm.cublasMM.apply(p1, v1)
+    ctx.backward(d_ctx)
+    p2, v2 = leaf(probs, v)
+    ref = torch.matmul(p2, v2)
+    ref.backward(d_ctx)
+    for got, want in ((ctx, ref), (p1.grad, p2.grad), (v1.grad, v2.grad)):
+        assert torch.allclose(want, got, rtol=1e-5, atol=1e-8)
+    for (b, h) in heads:
+        ph, vh, dch = (x[b, h].cpu().numpy() for x in (probs, v, d_ctx))
+        assert np.array_equal(ctx[b, h].detach().cpu().numpy(), oracle_mod.gemm(ph, vh))
+        assert np.array_equal(p1.grad[b, h].cpu().numpy(), oracle_mod.gemm(dch, vh, False, True))  # dP = dC.VT
+        assert np.array_equal(v1.grad[b, h].cpu().numpy(), oracle_mod.gemm(ph, dch, True, False))  # dV = PT.dC
+
+
 def test_cusparse_inspect_and_mmul_opt_column_major(cmm, dev, golden, oracle_mod):
     c = golden.case("colmajor/fc")
     M, K = c["a"].shape
