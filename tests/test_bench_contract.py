@@ -12,7 +12,8 @@ REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "s
             "config": dict, "roofline": dict}
 
 
-@pytest.mark.parametrize("name", ["r01_bench_c3.json", "r01_bench_c2.json", "r01_bench_c5.json"])
+@pytest.mark.parametrize("name", ["r01_bench_c3.json", "r01_bench_c2.json", "r01_bench_c5.json",
+                                  "r02_bench_c3.json", "r02_bench_c2.json", "r02_bench_c5.json"])
 def test_recorded_bench_lines_follow_the_contract(name):
     rec = json.loads((PROFILES / name).read_text())
     for key, typ in REQUIRED.items():
@@ -23,11 +24,18 @@ def test_recorded_bench_lines_follow_the_contract(name):
     roof = rec["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in roof, (name, key)
-    assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
+    assert roof["bound"] in ("hbm", "mfma", "cache") and roof["unit"] in ("GB/s", "TFLOP/s")
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
-    if roof["bound"] == "hbm":
-        assert roof["peak"] == 8000.0
+    if name.startswith("r02"):
+        # a cache-resident B (C2) is priced against the cache-gather figure, never as an HBM fraction > 1
+        assert roof["frac"] <= 1.0 and (roof["bound"] == "cache") == ("64k" in rec["config"]["workload"])
+    if roof["bound"] in ("hbm", "cache"):
+        assert roof["peak"] == (8000.0 if roof["bound"] == "hbm" else 8600.0)
         cpu = rec["cpu_baseline"]
+        if name.startswith("r02"):
+            # every core the process may use, the whole matrix, 1 warm-up + best of 3
+            assert cpu["cores"] == cpu["usable_cpus"] <= cpu["host_logical_cpus"] and "whole matrix" in cpu["sample"]
+            assert "torch_cpu_csr_matmul_gflops" in cpu and "host_cpu" in cpu
         for key in ("value", "unit", "cores", "kind", "sample"):
             assert key in cpu, (name, key)
         assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1
@@ -39,11 +47,12 @@ def test_recorded_bench_lines_follow_the_contract(name):
         assert abs(roof["achieved"] - alg / (roof["kernel_ms_per_step"] * 1e-3) / 1e9) / roof["achieved"] < 0.01
 
 
-def test_c3_kernel_stats_agree_with_the_bench_line():
+@pytest.mark.parametrize("rnd", ["r01", "r02"])
+def test_c3_kernel_stats_agree_with_the_bench_line(rnd):
     """rocprofv3's average launch durations (same command) add up to bench.py's HIP-event time per product."""
     import csv
-    rec = json.loads((PROFILES / "r01_bench_c3.json").read_text())
-    rows = list(csv.DictReader(open(PROFILES / "r01_bench_c3_kernel_stats.csv")))
+    rec = json.loads((PROFILES / f"{rnd}_bench_c3.json").read_text())
+    rows = list(csv.DictReader(open(PROFILES / f"{rnd}_bench_c3_kernel_stats.csv")))
     main = [r for r in rows if "spmm_wave_row_panel_kernel" in r["Name"]]
     assert len(main) == rec["roofline"]["launches_per_step"] == 2
     total_ms = sum(float(r["AverageNs"]) for r in main) / 1e6
@@ -51,6 +60,7 @@ def test_c3_kernel_stats_agree_with_the_bench_line():
     traffic = json.loads((PROFILES / "pmc_traffic.json").read_text())["c3"]
     # (the bench line quotes the PMC passes of the previous profile run: equal to within counter noise)
     assert abs(traffic["hbm_bytes_per_product"] - rec["roofline"]["traffic"]) < 1e-3 * rec["roofline"]["traffic"]
+    assert rnd == "r01" or traffic["round"] == "r02"
     assert 1.0 <= traffic["hbm_bytes_per_product"] / rec["config"]["algorithmic_bytes_per_step"] < 1.05
 
 
