@@ -516,7 +516,10 @@ int launch(const float* A, const float* B, float* C, int m, int n, int k, long l
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   // long k: the pipelined kernel (its prologue and double LDS buffer pay off from ≈8 k-tiles);
   // short k (BERT q·kᵀ, k = 64): the single-buffer kernel, which keeps 3–4 workgroups per CU
-  if (k >= 8 * BK)
+#ifndef MI_GEMM_PIPE_MIN_TILES
+#define MI_GEMM_PIPE_MIN_TILES 8  // developer probes may override
+#endif
+  if (k >= MI_GEMM_PIPE_MIN_TILES * BK)
     hipLaunchKernelGGL((gemm_f32_pipe_kernel<BM, BN, TA, TB>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m,
                        n, k, lda, ldb, ldc, sA, sB, sC, (int)tiles_n, (int)(tiles_m * tiles_n), vecA, vecB, vecC,
                        bias);
@@ -541,6 +544,12 @@ int pick_tile(const float* A, const float* B, float* C, int m, int n, int k, lon
   const long want = 2L * 256;
 #define MI_TILE(BM_, BN_) \
   return launch<BM_, BN_, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, vecC, bias, s)
+#ifdef MI_GEMM_FORCE_TILE  // developer probes only
+  if (MI_GEMM_FORCE_TILE == 1) MI_TILE(128, 128);
+  if (MI_GEMM_FORCE_TILE == 2) MI_TILE(128, 64);
+  if (MI_GEMM_FORCE_TILE == 3) MI_TILE(64, 128);
+  if (MI_GEMM_FORCE_TILE == 4) MI_TILE(64, 64);
+#endif
   if (m > 64 && n > 64 && blocks_for(128, 128) >= want) MI_TILE(128, 128);
   if (m > 64 && blocks_for(128, 64) >= want) MI_TILE(128, 64);
   if (n > 64 && blocks_for(64, 128) >= want) MI_TILE(64, 128);

@@ -85,5 +85,7 @@ rec["label"] = ("compute figures are MEASURED on one MI355X (one rank's share at
                 "estimate from assumed link rates, not a measurement — RCCL kernels also take CUs and HBM bandwidth "
                 "from the concurrent SpMM, which this model ignores")
 out = REPO / "profiles" / "r02_c4_model.json"
+(REPO / "gpurun_out").mkdir(exist_ok=True)
+(REPO / "gpurun_out" / "r02_c4_model.json").write_text(json.dumps(rec, indent=1))
 out.write_text(json.dumps(rec, indent=1))
 print(json.dumps(rec, indent=1))
