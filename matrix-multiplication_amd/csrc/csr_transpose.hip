@@ -565,8 +565,8 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_kernel(TrArgs a) {
             a.t_col[dst] = (int)w.x;
             a.t_val[dst] = __builtin_bit_cast(float, w.y);
           } else {
-            a.out_packed[dst] = w;
-          }
+            a.out_packed[dst] = w;  // plain stores: the runs of neighbouring tiles merge in the XCD's L2
+          }                         // (non-temporal stores measured 3.9 ms vs 2.6 ms for the whole transpose)
         }
         TR_STAMP(8);
       } else {
