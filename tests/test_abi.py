@@ -33,8 +33,9 @@ def lib(built):
 
 def test_header_declares_the_expected_entry_points():
     names = declared_functions()
-    assert len(names) >= 33, names
-    for must in ("mi_spmm_csr_ex_f32", "mi_spmm_auto_splits_long_rows", "mi_spmm_long_row_threshold", "mi_spmm_csr_f32", "mi_spmm_csr_batched_f32", "mi_spmm_csr_colmajor_f32", "mi_gemm_f32",
+    assert len(names) >= 37, names
+    for must in ("mi_csr_transpose_batched_f32", "mi_csr_transpose_batched_workspace_bytes", "mi_spmm_long_rows_prepare",
+                 "mi_spmm_csr_colmajor_ex_f32", "mi_spmm_csr_ex_f32", "mi_spmm_auto_splits_long_rows", "mi_spmm_long_row_threshold", "mi_spmm_csr_f32", "mi_spmm_csr_batched_f32", "mi_spmm_csr_colmajor_f32", "mi_gemm_f32",
                  "mi_dense_to_csr_count", "mi_dense_to_csr_fill", "mi_csr_transpose_f32", "mi_sddmm_csr_f32",
                  "mi_coo_to_csr_host", "mi_dummy_kernel"):
         assert must in names
@@ -74,6 +75,46 @@ def test_argument_validation_needs_no_gpu(lib):
     lib.mi_dense_to_csr_workspace_bytes.restype = ctypes.c_size_t
     lib.mi_dense_to_csr_workspace_bytes.argtypes = [i32, i32]
     assert lib.mi_dense_to_csr_workspace_bytes(3, 7) >= 4 * 21
+
+
+def test_round2_entry_points_validate_without_a_gpu(lib):
+    """The entries added in round 2 — pinned long-row rule, prepared lists, batched transpose, the
+    column-major executor with its long-row workspace — refuse bad arguments before any HIP call, and
+    the workspace queries are plain host functions."""
+    i64, i32, vp, sz = ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t
+    lib.mi_spmm_csr_ex_f32.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, i64, vp, vp, i64, ctypes.c_int, vp, sz, vp]
+    ex = lib.mi_spmm_csr_ex_f32
+    assert ex(None, None, None, 0, 4, 4, 4, None, 4, None, None, 4, 3, None, 0, None) == -1    # unknown mode
+    assert ex(None, None, None, 0, 4, 4, 4, None, 4, None, None, 4, -2, None, 0, None) == -1
+    assert ex(None, None, None, 10000, 4, 4, 4, None, 4, None, None, 4, 1, None, 0, None) == -1  # SPLIT needs a workspace
+    assert ex(None, None, None, 0, 0, 4, 4, None, 4, None, None, 4, 0, None, 0, None) == 0      # M == 0
+    assert lib.mi_spmm_long_row_threshold() == 8192
+    lib.mi_spmm_auto_splits_long_rows.argtypes = [i64, i32, i32, i32, vp, i64, vp, i64]
+    assert lib.mi_spmm_auto_splits_long_rows(100, 10, 10, 64, None, 64, None, 64) == 0        # nnz <= threshold
+    assert lib.mi_spmm_auto_splits_long_rows(10 ** 6, 1000, 30000, 64, None, 64, None, 64) == 1
+    assert lib.mi_spmm_auto_splits_long_rows(10 ** 6, 1000, 30000, 2, None, 2, None, 2) == 0  # narrow kernel: own order
+    lib.mi_spmm_long_rows_prepare.argtypes = [vp, i32, i64, i32, vp, sz, vp]
+    assert lib.mi_spmm_long_rows_prepare(None, 10, 100, 8, None, 0, None) == 0                # no row can be long
+    assert lib.mi_spmm_long_rows_prepare(None, 10, 100000, 8, None, 0, None) == -1            # null rowptr / workspace
+    assert lib.mi_spmm_long_rows_prepare(None, -1, 100, 8, None, 0, None) == -1
+    lib.mi_csr_transpose_batched_workspace_bytes.restype = sz
+    lib.mi_csr_transpose_batched_workspace_bytes.argtypes = [i32, i32, i32, i64]
+    lib.mi_csr_transpose_workspace_bytes.restype = sz
+    lib.mi_csr_transpose_workspace_bytes.argtypes = [i32, i32, i64]
+    one = lib.mi_csr_transpose_workspace_bytes(1 << 20, 1 << 20, 110_000_000)
+    assert 8 * 110_000_000 <= one < 12 * 110_000_000       # the 8-byte intermediate + tables, not 20 B per entry
+    assert lib.mi_csr_transpose_batched_workspace_bytes(1, 1 << 20, 1 << 20, 110_000_000) == one
+    assert lib.mi_csr_transpose_batched_workspace_bytes(0, 5, 5, 10) == 0
+    lib.mi_csr_transpose_batched_f32.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, sz, vp]
+    tr = lib.mi_csr_transpose_batched_f32
+    assert tr(None, None, None, 0, 0, 4, 4, None, None, None, None, 0, None) == 0             # batch == 0
+    assert tr(None, None, None, 5, -1, 4, 4, None, None, None, None, 0, None) == -1
+    assert tr(None, None, None, 5, 2, 4, 4, None, None, None, None, 0, None) == -1            # null t_rowptr
+    assert tr(None, None, None, 5, 70000, 70000, 4, None, None, None, None, 0, None) == -2   # batch*(M+1) beyond int32
+    lib.mi_spmm_csr_colmajor_ex_f32.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, i64, vp, i64, ctypes.c_int, vp, sz, vp, sz, vp]
+    cm = lib.mi_spmm_csr_colmajor_ex_f32
+    assert cm(None, None, None, 0, 0, 4, 4, None, 4, None, 4, 0, None, 0, None, 0, None) == 0  # M == 0
+    assert cm(None, None, None, 0, 4, 4, 4, None, 4, None, 4, 0, None, 0, None, 0, None) == -1  # null rowptr / C
 
 
 def test_every_variant_id_has_a_kernel_name_and_the_plan_query_needs_no_gpu(lib):
