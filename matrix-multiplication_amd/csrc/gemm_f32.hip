@@ -290,8 +290,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI_GEMM_SHO
   // ALIGNED: the launcher saw that EVERY tile is interior, and the edge code is compiled out (it is
   // what sets the kernel's register count otherwise)
   const bool interior = ALIGNED || (vecA && vecB && m0 + BM <= m && n0 + BN <= n && k % BK == 0);
+#ifndef MI_GEMM_KK_UNROLL
+#define MI_GEMM_KK_UNROLL 16
+#endif
   auto mfma_tile = [&]() {
-#pragma unroll
+#pragma unroll MI_GEMM_KK_UNROLL
     for (int kk = 0; kk < BK; kk += 2) {
       float a[TM], b[TN];
 #pragma unroll
