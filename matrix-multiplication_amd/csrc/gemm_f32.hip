@@ -37,6 +37,8 @@
 // 0.144 ms (was 0.156; rocBLAS 0.131).  Ablation of the pipelined kernel at 8192³: MFMAs alone
 // 7.13 ms; + operand reads 7.34; + LDS writes 7.52; + global loads 7.80 (half of that is issue
 // cost, half L2-miss latency beyond the one-tile prefetch distance).
+#include <type_traits>
+
 #include "mi_common.h"
 
 #ifndef MI_GEMM_ABL
@@ -510,6 +512,141 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
   gemm_epilogue<BM, BN, TM, TN>(acc, lds, C, m, n, ldc, m0, n0, wm, wn, wave, lane, vecC, bias);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Short k, whole tiles: TWO output tiles per workgroup (the pair (tile_m, 2j), (tile_m, 2j+1)), so
+// that the first tile's epilogue — accumulators → LDS patch → 128-byte row segments → global — is
+// issued between the MFMAs of the second tile instead of after its own.  With k = 64 a wave has
+// only 128 MFMAs per tile; in the one-tile kernel their 0.082 ms of matrix-pipe time and the 0.030 ms
+// staging + epilogue skeleton simply add up (tools/probes/gemm_probe.cpp), because co-resident
+// workgroups run in step.  Here the skeleton of tile 0 rides inside tile 1's MFMA stream of the SAME
+// wave (two accumulator sets, the patch beside the operand buffer), and the pair's stages form one
+// prefetch chain (tile 1's first operands are requested during tile 0's last MFMAs).  Same k order
+// per element as every other kernel here → same bits.  NK = k / 32 is a template parameter so that
+// the epilogue phases land at fixed places of the unrolled MFMA stream.
+// ---------------------------------------------------------------------------------------------
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+template <int BM, int BN, bool TA, bool TB, int NK>
+__global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int m, int n, int k, long lda,
+    long ldb, long ldc, long strideA, long strideB, long strideC, int pairs_n, int pairs_per_item,
+    const float* __restrict__ bias) {
+  constexpr int TM = BM / 64, TN = BN / 64, NT = TM * TN;
+  constexpr int PHASES = 2 * NT;            // per tile: write the patch, then read it back and store
+  static_assert(PHASES % NK == 0 && (BK / 2) % (PHASES / NK) == 0, "phases must divide the MFMA steps of a stage");
+  constexpr int PPS = PHASES / NK;          // phases per stage
+  constexpr int GAP = (BK / 2) / PPS;       // MFMA k-steps between two phases
+  typedef TileLoader<BM, !TA> LA;
+  typedef TileLoader<BN, TB> LB;
+  constexpr int kOperandFloats = LA::LDS_FLOATS + LB::LDS_FLOATS;
+  constexpr int PLD = 36;
+  __shared__ __attribute__((aligned(16))) float lds[kOperandFloats + 4 * 32 * PLD];
+  float* As = lds;
+  float* Bs = lds + LA::LDS_FLOATS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  float* patch = lds + kOperandFloats + wave * (32 * PLD);
+  const unsigned total = gridDim.x, bid = blockIdx.x;
+  const unsigned q8 = total / 8, rem = total % 8, xcd = bid % 8, pos = bid / 8;
+  const unsigned work = xcd * q8 + (xcd < rem ? xcd : rem) + pos;
+  const long item = work / pairs_per_item;
+  const int pr = work % pairs_per_item;
+  int tile_m, pair_n;
+  tile_coords(pr, pairs_n, pairs_per_item / pairs_n, tile_m, pair_n);
+  const int m0 = tile_m * BM;
+  A += item * strideA;
+  B += item * strideB;
+  C += item * strideC;
+
+  f32x16 acc[2][TM][TN];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+
+  // one epilogue phase of accumulator set T: phase 2q writes 32×32 tile q to the patch, phase 2q+1
+  // reads it back row-major and stores four 128-byte row segments per lane group (+ bias)
+  auto phase = [&](auto T_, auto P_) {
+    constexpr int T = decltype(T_)::value, P = decltype(P_)::value;
+    constexpr int q = P / 2, i = q / TN, j = q % TN;
+    const int n0 = (2 * pair_n + T) * BN;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (P % 2 == 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = f32x4{acc[T][i][j][4 * g], acc[T][i][j][4 * g + 1], acc[T][i][j][4 * g + 2], acc[T][i][j][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(patch + l31 * PLD + 8 * g + 4 * lhi) = v;
+      }
+    } else {
+      const int tile_row0 = m0 + wm * (BM / 2) + i * 32;
+      const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 7) * 4;
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int rr = (lane >> 3) + 8 * pass;
+        f32x4 v = *reinterpret_cast<const f32x4*>(patch + rr * PLD + (lane & 7) * 4);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
+        if (MI_GEMM_ABL & 1) {
+          if (v.x == 12345.678f) C[(long)(tile_row0 + rr) * ldc + col] = v.x;
+        } else {
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(C + (long)(tile_row0 + rr) * ldc + col));
+        }
+      }
+    }
+  };
+
+  f32x4 ra[LA::VECS], rb[LB::VECS];
+  LA::load_fast(ra, A, lda, m0, 0, tid);
+  LB::load_fast(rb, B, ldb, 2 * pair_n * BN, 0, tid);
+
+  static_for<2>([&](auto T_) {
+    constexpr int T = decltype(T_)::value;
+    static_for<NK>([&](auto KT_) {
+      constexpr int KT = decltype(KT_)::value;
+      LA::store(ra, As, tid);
+      LB::store(rb, Bs, tid);
+      __syncthreads();
+      // the next stage's operands: the next k-tile of this output tile, or the first of the second one
+      if constexpr (KT + 1 < NK) {
+        LA::load_fast(ra, A, lda, m0, (KT + 1) * BK, tid);
+        LB::load_fast(rb, B, ldb, (2 * pair_n + T) * BN, (KT + 1) * BK, tid);
+      } else if constexpr (T == 0) {
+        LA::load_fast(ra, A, lda, m0, 0, tid);
+        LB::load_fast(rb, B, ldb, (2 * pair_n + 1) * BN, 0, tid);
+      }
+      static_for<BK / 2>([&](auto S_) {
+        constexpr int S = decltype(S_)::value;  // MFMA k-step of this stage
+        if constexpr (T == 1 && S % GAP == 0) phase(std::integral_constant<int, 0>{}, std::integral_constant<int, KT * PPS + S / GAP>{});
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = LA::at(As, wm * (BM / 2) + i * 32 + l31, 2 * S + lhi);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = LB::at(Bs, wn * (BN / 2) + j * 32 + l31, 2 * S + lhi);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            if (!(MI_GEMM_ABL & 2)) acc[T][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[T][i][j], 0, 0, 0);
+      });
+      __syncthreads();
+    });
+  });
+  // the second tile's own epilogue (nothing left to hide it behind)
+  static_for<PHASES>([&](auto P_) { phase(std::integral_constant<int, 1>{}, P_); });
+}
+
 template <int BM, int BN, bool TA, bool TB>
 int launch(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb,
            long ldc, long sA, long sB, long sC, int batch, bool vecA, bool vecB, bool vecC,
@@ -526,9 +663,32 @@ int launch(const float* A, const float* B, float* C, int m, int n, int k, long l
     hipLaunchKernelGGL((gemm_f32_pipe_kernel<BM, BN, TA, TB>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m,
                        n, k, lda, ldb, ldc, sA, sB, sC, (int)tiles_n, (int)(tiles_m * tiles_n), vecA, vecB, vecC,
                        bias);
-  else if (vecA && vecB && vecC && m % BM == 0 && n % BN == 0 && k % BK == 0)
+  else if (vecA && vecB && vecC && m % BM == 0 && n % BN == 0 && k % BK == 0) {
+#ifndef MI_GEMM_NO_PAIR
+    if (BM == 128 && BN == 128 && tiles_n % 2 == 0 && (bias == nullptr || mi::aligned16(bias))) {
+      // two output tiles per workgroup, the first one's epilogue inside the second one's MFMAs
+      const unsigned pblocks = (unsigned)(blocks / 2);
+      const int pn = (int)(tiles_n / 2), ppi = (int)(tiles_m * tiles_n / 2);
+      if (k == BK) {
+        hipLaunchKernelGGL((gemm_f32_pair_kernel<128, 128, TA, TB, 1>), dim3(pblocks), dim3(256), 0, s, A, B, C, m, n, k, lda,
+                           ldb, ldc, sA, sB, sC, pn, ppi, bias);
+        return mi::check_launch();
+      }
+      if (k == 2 * BK) {
+        hipLaunchKernelGGL((gemm_f32_pair_kernel<128, 128, TA, TB, 2>), dim3(pblocks), dim3(256), 0, s, A, B, C, m, n, k, lda,
+                           ldb, ldc, sA, sB, sC, pn, ppi, bias);
+        return mi::check_launch();
+      }
+      if (k == 4 * BK) {
+        hipLaunchKernelGGL((gemm_f32_pair_kernel<128, 128, TA, TB, 4>), dim3(pblocks), dim3(256), 0, s, A, B, C, m, n, k, lda,
+                           ldb, ldc, sA, sB, sC, pn, ppi, bias);
+        return mi::check_launch();
+      }
+    }
+#endif
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, true>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m, n, k,
                        lda, ldb, ldc, sA, sB, sC, (int)tiles_n, (int)(tiles_m * tiles_n), vecA, vecB, vecC, bias);
+  }
   else
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, false>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m, n, k,
                        lda, ldb, ldc, sA, sB, sC, (int)tiles_n, (int)(tiles_m * tiles_n), vecA, vecB, vecC, bias);
