@@ -532,10 +532,10 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int BM, int BN, bool TA, bool TB, int NK>
+template <int BM, int BN, bool TA, bool TB, int NK, int CHAIN>
 __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int m, int n, int k, long lda,
-    long ldb, long ldc, long strideA, long strideB, long strideC, int pairs_n, int pairs_per_item,
+    long ldb, long ldc, long strideA, long strideB, long strideC, int groups_n, int groups_per_item,
     const float* __restrict__ bias) {
   constexpr int TM = BM / 64, TN = BN / 64, NT = TM * TN;
   constexpr int PHASES = 2 * NT;            // per tile: write the patch, then read it back and store
@@ -557,37 +557,29 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
   const unsigned total = gridDim.x, bid = blockIdx.x;
   const unsigned q8 = total / 8, rem = total % 8, xcd = bid % 8, pos = bid / 8;
   const unsigned work = xcd * q8 + (xcd < rem ? xcd : rem) + pos;
-  const long item = work / pairs_per_item;
-  const int pr = work % pairs_per_item;
-  int tile_m, pair_n;
-  tile_coords(pr, pairs_n, pairs_per_item / pairs_n, tile_m, pair_n);
+  const long item = work / groups_per_item;
+  const int gr = work % groups_per_item;
+  int tile_m, group_n;  // the workgroup owns tiles (tile_m, CHAIN·group_n … CHAIN·group_n + CHAIN − 1)
+  tile_coords(gr, groups_n, groups_per_item / groups_n, tile_m, group_n);
   const int m0 = tile_m * BM;
   A += item * strideA;
   B += item * strideB;
   C += item * strideC;
 
-  f32x16 acc[2][TM][TN];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+  f32x16 acc[2][TM][TN];  // tile T of the chain accumulates in set T % 2
 
-  // one epilogue phase of accumulator set T: phase 2q writes 32×32 tile q to the patch, phase 2q+1
-  // reads it back row-major and stores four 128-byte row segments per lane group (+ bias)
+  // one epilogue phase of chain tile T: phase 2q writes 32×32 tile q of its accumulators to the patch,
+  // phase 2q+1 reads it back row-major and stores four 128-byte row segments per lane group (+ bias)
   auto phase = [&](auto T_, auto P_) {
     constexpr int T = decltype(T_)::value, P = decltype(P_)::value;
-    constexpr int q = P / 2, i = q / TN, j = q % TN;
-    const int n0 = (2 * pair_n + T) * BN;
+    constexpr int q = P / 2, i = q / TN, j = q % TN, SET = T % 2;
+    const int n0 = (CHAIN * group_n + T) * BN;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     if constexpr (P % 2 == 0) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        f32x4 v = f32x4{acc[T][i][j][4 * g], acc[T][i][j][4 * g + 1], acc[T][i][j][4 * g + 2], acc[T][i][j][4 * g + 3]};
+        f32x4 v = f32x4{acc[SET][i][j][4 * g], acc[SET][i][j][4 * g + 1], acc[SET][i][j][4 * g + 2], acc[SET][i][j][4 * g + 3]};
         *reinterpret_cast<f32x4*>(patch + l31 * PLD + 8 * g + 4 * lhi) = v;
       }
     } else {
@@ -609,26 +601,28 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
 
   f32x4 ra[LA::VECS], rb[LB::VECS];
   LA::load_fast(ra, A, lda, m0, 0, tid);
-  LB::load_fast(rb, B, ldb, 2 * pair_n * BN, 0, tid);
+  LB::load_fast(rb, B, ldb, CHAIN * group_n * BN, 0, tid);
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  static_for<2>([&](auto T_) {
-    constexpr int T = decltype(T_)::value;
+  static_for<CHAIN>([&](auto T_) {
+    constexpr int T = decltype(T_)::value, SET = T % 2;
     static_for<NK>([&](auto KT_) {
       constexpr int KT = decltype(KT_)::value;
       LA::store(ra, As, tid);
       LB::store(rb, Bs, tid);
       __syncthreads();
-      // the next stage's operands: the next k-tile of this output tile, or the first of the second one
+      // the next stage's operands: the next k-tile of this output tile, or the first of the next one
       if constexpr (KT + 1 < NK) {
         LA::load_fast(ra, A, lda, m0, (KT + 1) * BK, tid);
-        LB::load_fast(rb, B, ldb, (2 * pair_n + T) * BN, (KT + 1) * BK, tid);
-      } else if constexpr (T == 0) {
+        LB::load_fast(rb, B, ldb, (CHAIN * group_n + T) * BN, (KT + 1) * BK, tid);
+      } else if constexpr (T + 1 < CHAIN) {
         LA::load_fast(ra, A, lda, m0, 0, tid);
-        LB::load_fast(rb, B, ldb, (2 * pair_n + 1) * BN, 0, tid);
+        LB::load_fast(rb, B, ldb, (CHAIN * group_n + T + 1) * BN, 0, tid);
       }
       static_for<BK / 2>([&](auto S_) {
         constexpr int S = decltype(S_)::value;  // MFMA k-step of this stage
-        if constexpr (T == 1 && S % GAP == 0) phase(std::integral_constant<int, 0>{}, std::integral_constant<int, KT * PPS + S / GAP>{});
+        // the previous tile's epilogue rides here (its accumulators are the other set)
+        if constexpr (T > 0 && S % GAP == 0) phase(std::integral_constant<int, T - 1>{}, std::integral_constant<int, KT * PPS + S / GAP>{});
         float a[TM], b[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[i] = LA::at(As, wm * (BM / 2) + i * 32 + l31, 2 * S + lhi);
@@ -637,14 +631,22 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            if (!(MI_GEMM_ABL & 2)) acc[T][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[T][i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) {
+            if (MI_GEMM_ABL & 2) {
+              if (KT == 0 && S == 0) acc[SET][i][j] = zero16;
+            } else if constexpr (KT == 0 && S == 0) {
+              // a tile's first product starts its accumulators (set reused from tile T − 2) from zero
+              acc[SET][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], zero16, 0, 0, 0);
+            } else {
+              acc[SET][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[SET][i][j], 0, 0, 0);
+            }
+          }
       });
       __syncthreads();
     });
   });
-  // the second tile's own epilogue (nothing left to hide it behind)
-  static_for<PHASES>([&](auto P_) { phase(std::integral_constant<int, 1>{}, P_); });
+  // the last tile's own epilogue (nothing left to hide it behind)
+  static_for<PHASES>([&](auto P_) { phase(std::integral_constant<int, CHAIN - 1>{}, P_); });
 }
 
 template <int BM, int BN, bool TA, bool TB>
@@ -665,25 +667,29 @@ int launch(const float* A, const float* B, float* C, int m, int n, int k, long l
                        bias);
   else if (vecA && vecB && vecC && m % BM == 0 && n % BN == 0 && k % BK == 0) {
 #ifndef MI_GEMM_NO_PAIR
-    if (BM == 128 && BN == 128 && tiles_n % 2 == 0 && (bias == nullptr || mi::aligned16(bias))) {
-      // two output tiles per workgroup, the first one's epilogue inside the second one's MFMAs
-      const unsigned pblocks = (unsigned)(blocks / 2);
-      const int pn = (int)(tiles_n / 2), ppi = (int)(tiles_m * tiles_n / 2);
-      if (k == BK) {
-        hipLaunchKernelGGL((gemm_f32_pair_kernel<128, 128, TA, TB, 1>), dim3(pblocks), dim3(256), 0, s, A, B, C, m, n, k, lda,
-                           ldb, ldc, sA, sB, sC, pn, ppi, bias);
-        return mi::check_launch();
+#ifndef MI_GEMM_CHAIN_MAX
+#define MI_GEMM_CHAIN_MAX 4
+#endif
+    if (BM == 128 && BN == 128 && tiles_n % 2 == 0 && (k == BK || k == 2 * BK || k == 4 * BK) &&
+        (bias == nullptr || mi::aligned16(bias))) {
+      // CHAIN output tiles of one tile row per workgroup, each tile's epilogue inside the next one's MFMAs
+      const int chain = (tiles_n % 4 == 0 && MI_GEMM_CHAIN_MAX >= 4) ? 4 : 2;
+      const unsigned gblocks = (unsigned)(blocks / chain);
+      const int gn = (int)(tiles_n / chain), gpi = (int)(tiles_m * tiles_n / chain);
+#define MI_PAIR(NK_, CH_)                                                                                         \
+  hipLaunchKernelGGL((gemm_f32_pair_kernel<128, 128, TA, TB, NK_, CH_>), dim3(gblocks), dim3(256), 0, s, A, B, C, m, n, \
+                     k, lda, ldb, ldc, sA, sB, sC, gn, gpi, bias)
+      if (chain == 4) {
+        if (k == BK) MI_PAIR(1, 4);
+        else if (k == 2 * BK) MI_PAIR(2, 4);
+        else MI_PAIR(4, 4);
+      } else {
+        if (k == BK) MI_PAIR(1, 2);
+        else if (k == 2 * BK) MI_PAIR(2, 2);
+        else MI_PAIR(4, 2);
       }
-      if (k == 2 * BK) {
-        hipLaunchKernelGGL((gemm_f32_pair_kernel<128, 128, TA, TB, 2>), dim3(pblocks), dim3(256), 0, s, A, B, C, m, n, k, lda,
-                           ldb, ldc, sA, sB, sC, pn, ppi, bias);
-        return mi::check_launch();
-      }
-      if (k == 4 * BK) {
-        hipLaunchKernelGGL((gemm_f32_pair_kernel<128, 128, TA, TB, 4>), dim3(pblocks), dim3(256), 0, s, A, B, C, m, n, k, lda,
-                           ldb, ldc, sA, sB, sC, pn, ppi, bias);
-        return mi::check_launch();
-      }
+#undef MI_PAIR
+      return mi::check_launch();
     }
 #endif
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, true>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m, n, k,
