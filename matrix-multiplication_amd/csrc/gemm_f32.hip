@@ -37,6 +37,7 @@
 // 0.144 ms (was 0.156; rocBLAS 0.131).  Ablation of the pipelined kernel at 8192³: MFMAs alone
 // 7.13 ms; + operand reads 7.34; + LDS writes 7.52; + global loads 7.80 (half of that is issue
 // cost, half L2-miss latency beyond the one-tile prefetch distance).
+#include <atomic>
 #include <type_traits>
 
 #include "mi_common.h"
@@ -243,7 +244,7 @@ template <int BM, int BN, bool TA, bool TB, bool ALIGNED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI_GEMM_SHORTK_WAVES, MI_GEMM_SHORTK_WAVES))) void gemm_f32_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int m, int n,
     int k, long lda, long ldb, long ldc, long strideA, long strideB, long strideC, int tiles_n,
-    int tiles_per_item, bool vecA, bool vecB, bool vecC, const float* __restrict__ bias) {
+    int tiles_per_item, bool vecA, bool vecB, bool vecC, const float* __restrict__ bias, int reverse) {
   constexpr int TM = BM / 64;  // 32×32 tiles per wave along m (2×2 waves)
   constexpr int TN = BN / 64;
   typedef TileLoader<BM, !TA> LA;  // A not transposed → contiguous along k
@@ -264,7 +265,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI_GEMM_SHO
   // being fetched by up to 8 of them.  Bijective for any grid size; speed only.
   const unsigned total = gridDim.x, bid = blockIdx.x;
   const unsigned q = total / 8, rem = total % 8, xcd = bid % 8, pos = bid / 8;
-  const unsigned work = xcd * q + (xcd < rem ? xcd : rem) + pos;
+  const unsigned work0 = xcd * q + (xcd < rem ? xcd : rem) + pos;
+  const unsigned work = reverse ? total - 1u - work0 : work0;  // see launch(): alternate launches walk the items backwards
   const long item = work / tiles_per_item;
   const int tile = work % tiles_per_item;
   int tile_m, tile_n;
@@ -360,7 +362,7 @@ template <int BM, int BN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int m, int n,
     int k, long lda, long ldb, long ldc, long strideA, long strideB, long strideC, int tiles_n,
-    int tiles_per_item, bool vecA, bool vecB, bool vecC, const float* __restrict__ bias) {
+    int tiles_per_item, bool vecA, bool vecB, bool vecC, const float* __restrict__ bias, int reverse) {
   constexpr int TM = BM / 64;
   constexpr int TN = BN / 64;
   typedef TileLoader<BM, !TA> LA;
@@ -375,7 +377,8 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
   const int wm = wave >> 1, wn = wave & 1;
   const unsigned total = gridDim.x, bid = blockIdx.x;
   const unsigned q = total / 8, rem = total % 8, xcd = bid % 8, pos = bid / 8;
-  const unsigned work = xcd * q + (xcd < rem ? xcd : rem) + pos;
+  const unsigned work0 = xcd * q + (xcd < rem ? xcd : rem) + pos;
+  const unsigned work = reverse ? total - 1u - work0 : work0;  // see launch(): alternate launches walk the items backwards
   const long item = work / tiles_per_item;
   const int tile = work % tiles_per_item;
   int tile_m, tile_n;
@@ -536,7 +539,7 @@ template <int BM, int BN, bool TA, bool TB, int NK, int CHAIN>
 __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int m, int n, int k, long lda,
     long ldb, long ldc, long strideA, long strideB, long strideC, int groups_n, int groups_per_item,
-    const float* __restrict__ bias) {
+    const float* __restrict__ bias, int reverse) {
   constexpr int TM = BM / 64, TN = BN / 64, NT = TM * TN;
   constexpr int PHASES = 2 * NT;            // per tile: write the patch, then read it back and store
   static_assert(PHASES % NK == 0 && (BK / 2) % (PHASES / NK) == 0, "phases must divide the MFMA steps of a stage");
@@ -556,7 +559,8 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
   float* patch = lds + kOperandFloats + wave * (32 * PLD);
   const unsigned total = gridDim.x, bid = blockIdx.x;
   const unsigned q8 = total / 8, rem = total % 8, xcd = bid % 8, pos = bid / 8;
-  const unsigned work = xcd * q8 + (xcd < rem ? xcd : rem) + pos;
+  const unsigned work0 = xcd * q8 + (xcd < rem ? xcd : rem) + pos;
+  const unsigned work = reverse ? total - 1u - work0 : work0;
   const long item = work / groups_per_item;
   const int gr = work % groups_per_item;
   int tile_m, group_n;  // the workgroup owns tiles (tile_m, CHAIN·group_n … CHAIN·group_n + CHAIN − 1)
@@ -649,6 +653,8 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
   static_for<PHASES>([&](auto P_) { phase(std::integral_constant<int, CHAIN - 1>{}, P_); });
 }
 
+std::atomic<unsigned> g_launch_counter{0};  // one counter for every instantiation of launch()
+
 template <int BM, int BN, bool TA, bool TB>
 int launch(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb,
            long ldc, long sA, long sB, long sC, int batch, bool vecA, bool vecB, bool vecC,
@@ -656,6 +662,16 @@ int launch(const float* A, const float* B, float* C, int m, int n, int k, long l
   const long tiles_m = (m + BM - 1) / BM, tiles_n = (n + BN - 1) / BN;
   const long blocks = tiles_m * tiles_n * batch;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
+  // Boustrophedon over launches: every other product walks its work list backwards.  Two consecutive
+  // products that stream the same large operand (the two gradients of one matmul both read the
+  // upstream gradient: 403 MB of dScores at BERT-base attention, more than the 256 MiB Infinity Cache)
+  // then meet its most recently read half still in the cache instead of evicting it in lock step.
+  // Tile order never affects values.
+#ifdef MI_GEMM_NO_REVERSE
+  const int rev = 0;
+#else
+  const int rev = (int)(g_launch_counter.fetch_add(1, std::memory_order_relaxed) & 1u);
+#endif
   // long k: the pipelined kernel (its prologue and double LDS buffer pay off from ≈8 k-tiles);
   // short k (BERT q·kᵀ, k = 64): the single-buffer kernel, which keeps 3–4 workgroups per CU
 #ifndef MI_GEMM_PIPE_MIN_TILES
@@ -664,7 +680,7 @@ int launch(const float* A, const float* B, float* C, int m, int n, int k, long l
   if (k >= MI_GEMM_PIPE_MIN_TILES * BK)
     hipLaunchKernelGGL((gemm_f32_pipe_kernel<BM, BN, TA, TB>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m,
                        n, k, lda, ldb, ldc, sA, sB, sC, (int)tiles_n, (int)(tiles_m * tiles_n), vecA, vecB, vecC,
-                       bias);
+                       bias, rev);
   else if (vecA && vecB && vecC && m % BM == 0 && n % BN == 0 && k % BK == 0) {
 #ifndef MI_GEMM_NO_PAIR
 #ifndef MI_GEMM_CHAIN_MAX
@@ -678,7 +694,7 @@ int launch(const float* A, const float* B, float* C, int m, int n, int k, long l
       const int gn = (int)(tiles_n / chain), gpi = (int)(tiles_m * tiles_n / chain);
 #define MI_PAIR(NK_, CH_)                                                                                         \
   hipLaunchKernelGGL((gemm_f32_pair_kernel<128, 128, TA, TB, NK_, CH_>), dim3(gblocks), dim3(256), 0, s, A, B, C, m, n, \
-                     k, lda, ldb, ldc, sA, sB, sC, gn, gpi, bias)
+                     k, lda, ldb, ldc, sA, sB, sC, gn, gpi, bias, rev)
       if (chain == 4) {
         if (k == BK) MI_PAIR(1, 4);
         else if (k == 2 * BK) MI_PAIR(2, 4);
@@ -693,11 +709,11 @@ int launch(const float* A, const float* B, float* C, int m, int n, int k, long l
     }
 #endif
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, true>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m, n, k,
-                       lda, ldb, ldc, sA, sB, sC, (int)tiles_n, (int)(tiles_m * tiles_n), vecA, vecB, vecC, bias);
+                       lda, ldb, ldc, sA, sB, sC, (int)tiles_n, (int)(tiles_m * tiles_n), vecA, vecB, vecC, bias, rev);
   }
   else
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, false>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m, n, k,
-                       lda, ldb, ldc, sA, sB, sC, (int)tiles_n, (int)(tiles_m * tiles_n), vecA, vecB, vecC, bias);
+                       lda, ldb, ldc, sA, sB, sC, (int)tiles_n, (int)(tiles_m * tiles_n), vecA, vecB, vecC, bias, rev);
   return mi::check_launch();
 }
 
