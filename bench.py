@@ -302,8 +302,10 @@ def main():
     import sharded
     import synthetic
 
-    if args.chunks <= 0:
+    auto_chunks = args.chunks <= 0
+    if auto_chunks:
         args.chunks = 4 if world <= 4 else 8
+    chunk_trials = None
     M, K, density, N, desc = WORKLOADS[args.workload]
     t0 = time.perf_counter()
     rowptr, col, val = synthetic.make_csr(M, K, density, seed=0)
@@ -324,8 +326,31 @@ def main():
         kernel_name, launches_per_step = spmm_plan(nnz, M, K, B, C)
         local_bytes_alg = bytes_alg
     else:
-        op = sharded.ShardedSpMM(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), M, K, dev,
-                                 chunks=args.chunks, split=args.split)
+        rp_t, col_t, val_t = torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val)
+        if auto_chunks:
+            # Before anything is timed: how finely to cut a rank's rows is a trade between starting the
+            # first all-gather early (many chunks) and RCCL's efficiency on larger messages (few chunks); it
+            # depends on the node's fabric, so try the candidates for a few steps each and keep the fastest
+            # (max over ranks, so every rank decides alike).  Setup, like the warm-up: not in the timed region.
+            chunk_trials = {}
+            for cand in ((2, 4) if world <= 2 else (2, 4, 8)):
+                trial = sharded.ShardedSpMM(rp_t, col_t, val_t, M, K, dev, chunks=cand, split=args.split)
+                Ct = trial.alloc_output(N)
+                for _ in range(2):
+                    trial.forward(B, out=Ct)
+                dist.barrier()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    trial.forward(B, out=Ct)
+                torch.cuda.synchronize()
+                tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                chunk_trials[cand] = float(tt) / 3 * 1e3
+                del trial, Ct
+            args.chunks = min(chunk_trials, key=chunk_trials.get)
+            torch.cuda.empty_cache()
+        op = sharded.ShardedSpMM(rp_t, col_t, val_t, M, K, dev, chunks=args.chunks, split=args.split)
         C = op.alloc_output(N)
 
         def step():
@@ -410,6 +435,8 @@ def main():
                                f"A row-sharded over {world} GPUs ({args.split}-balanced blocks), block-cyclic "
                                f"x{args.chunks}, RCCL all-gather of C",
                 "rccl_ranks": world if world > 1 else None,
+                "chunks": None if world == 1 else args.chunks,
+                "chunk_trials_ms_per_step": None if not chunk_trials else {str(c): round(v, 4) for c, v in chunk_trials.items()},
                 "collective_backend": None if world == 1 else ("gloo (rehearsal)" if rehearse else
                                                                 "rccl " + ".".join(str(x) for x in torch.cuda.nccl.version())),
                 "flops_per_step": flops, "algorithmic_bytes_per_step": bytes_alg,
