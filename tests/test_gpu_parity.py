@@ -1244,3 +1244,33 @@ def test_column_sums(cmm, dev, rows, n):
     assert got.shape == (n,) and np.allclose(got, x.astype(np.float64).sum(0), rtol=1e-5, atol=1e-6)
     wide = torch.rand(rows, 2 * n + 3, device=dev)
     assert torch.allclose(cmm.column_sums(wide[:, 1:n + 1]), wide[:, 1:n + 1].double().sum(0).float(), rtol=1e-5, atol=1e-6)
+
+
+def test_bench_multi_gpu_path_rehearsal(dev):
+    """`python bench.py --gpus 2` started plainly: the parent spawns two child ranks itself (here both on
+    the one GPU over gloo, MI_BENCH_REHEARSE=1 — a functional rehearsal, labelled as such, never a
+    measurement), the ranks shard A's rows, exchange C block-cyclically, check a peer's block bit for
+    bit, pick a chunk count from the pre-timing trial, and rank 0 prints ONE JSON line."""
+    import json
+    import os
+    import subprocess
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, MI_BENCH_REHEARSE="1")
+    proc = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                           "--workload", "c2"], capture_output=True, text=True, timeout=600, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and "REHEARSAL" in rec["data"]
+    cfg = rec["config"]
+    assert cfg["rccl_ranks"] == 2 and cfg["chunks"] in (2, 4) and set(cfg["chunk_trials_ms_per_step"]) == {"2", "4"}
+    assert cfg["compute_only_ms_per_step"] > 0 and rec["value"] > 0 and "cpu_baseline" not in rec
+    # and the nnz-balanced split (in-place broadcasts) through the same driver
+    proc = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                           "--workload", "c2", "--split", "nnz", "--chunks", "3"], capture_output=True, text=True,
+                          timeout=600, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    rec = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')][0])
+    assert rec["config"]["chunks"] == 3 and "nnz-balanced" in rec["config"]["parallelism"]
