@@ -184,6 +184,12 @@ int mi_spmm_csr_colmajor_f32(const int32_t* rowptr, const int32_t* col,
  * long-row workspace (mi_spmm_csr_workspace_bytes(nnz, N); may be NULL for MI_LONG_ROWS_NONE, which
  * is what the plain entry above uses): skewed weight matrices reach the split path through the
  * inspector handles, which prepare the list once (MI_LONG_ROWS_PREPARED). */
+/* 1 when the executor runs its NATIVE form for this problem (MI_LONG_ROWS_NONE only): the LDS-slab
+ * kernel reading B column-major and writing C column-major directly — transposing slab loads, transposed
+ * tile store, no transposed copies; 0 when it transposes B in and C out around the row-major kernel.
+ * Host-side decision (plan + a cost comparison), no GPU work; the result bits are the same either way. */
+int mi_spmm_colmajor_native_form(int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
+                                 int64_t ldb, const float* C, int64_t ldc);
 int mi_spmm_csr_colmajor_ex_f32(const int32_t* rowptr, const int32_t* col,
                                 const float* val, int64_t nnz, int32_t M, int32_t K,
                                 int32_t N, const float* B, int64_t ldb, float* C,

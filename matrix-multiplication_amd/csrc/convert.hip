@@ -448,6 +448,27 @@ size_t mi_spmm_colmajor_workspace_bytes(int32_t M, int32_t K, int32_t N) {
   return align_up((size_t)K * N * 4) + align_up((size_t)M * N * 4);
 }
 
+// Native form: when the product is one the LDS-slab plan serves (moderate density, enough tiles), the slab
+// kernel reads X = Bᵀ and writes Y = Cᵀ directly (transposing slab loads, transposed tile store) — no
+// transposed copies, the workspace stays untouched.  Same CSR-order chain per element as every other plan,
+// so the bits do not depend on which form ran.  The transposing loads and the swizzled reads cost the slab
+// kernel ≈17 % (measured, 4096² × 16384 at 10 %: 3.46 vs 2.95 ms); the two tile transposes cost their
+// 16·(K+M)·N bytes at ≈3.7 TB/s: the native form is taken where that is the smaller price
+// (3072 × 768 × 16384 at 10 %: 0.52 vs 0.75 ms).
+int mi_spmm_colmajor_native_form(int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,
+                                 const float* C, int64_t ldc) {
+  if (M <= 0 || N <= 0 || K < 4 || nnz <= 0) return 0;
+  if (N % 4 != 0 || ldb % 4 != 0 || ldc % 4 != 0 || !mi::aligned16(B) || !mi::aligned16(C)) return 0;
+  // the plan of the row-major product on 16-byte aligned operands of leading dimension N
+  alignas(16) static const float probe[4] = {0.f, 0.f, 0.f, 0.f};
+  if (mi_spmm_csr_f32_plan(nnz, M, K, N, probe, N, probe, N) != MI_SPMM_SLAB) return 0;
+  const double wgs = (double)(((long)M + 127) / 128) * (double)(((long)N + 255) / 256);
+  const double density = (double)nnz / ((double)M * (double)K);
+  const double t_slab = (wgs <= 256.0 ? 1.0 : wgs / 256.0) * (double)(((long)K + 63) / 64) * (2.35e-6 + 34e-6 * density);
+  const double t_transposes = 16.0 * ((double)K + (double)M) * (double)N / 3.7e12;
+  return 0.17 * t_slab < t_transposes ? 1 : 0;
+}
+
 int mi_spmm_csr_colmajor_ex_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                                 int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
                                 int64_t ldb, float* C, int64_t ldc, int long_rows, void* long_rows_workspace,
@@ -460,6 +481,8 @@ int mi_spmm_csr_colmajor_ex_f32(const int32_t* rowptr, const int32_t* col, const
   if (K > 0 && (!B || ldb < K)) return MI_EINVAL;
   if (workspace_bytes < mi_spmm_colmajor_workspace_bytes(M, K, N)) return MI_ENOMEM;
   if (!workspace || !mi::aligned16(workspace)) return MI_EINVAL;
+  if (long_rows == MI_LONG_ROWS_NONE && mi_spmm_colmajor_native_form(nnz, M, K, N, B, ldb, C, ldc))
+    return mi::launch_spmm_slab_colmajor(rowptr, col, val, B, C, M, K, N, ldb, ldc, s);
   float* Bt = static_cast<float*>(workspace);  // [K, N] row-major
   float* Ct = reinterpret_cast<float*>(static_cast<char*>(workspace) + align_up((size_t)K * N * 4));
   // column-major K×N with ldb  ==  row-major [N, ldb]; its transpose is [K, N].

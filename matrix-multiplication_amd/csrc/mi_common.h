@@ -34,6 +34,10 @@ int launch_spmm_slab(const int32_t* rowptr, const int32_t* col, const float* val
                      int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t ldc, const float* bias,
                      int long_thresh, hipStream_t s);
 
+// the same kernel on column-major operands (X = Bᵀ [N, ldx], Y = Cᵀ [N, ldy]); caller checks the requirements
+int launch_spmm_slab_colmajor(const int32_t* rowptr, const int32_t* col, const float* val, const float* X, float* Y,
+                              int32_t M, int32_t K, int32_t N, int64_t ldx, int64_t ldy, hipStream_t s);
+
 }  // namespace mi
 
 #define MI_HIP_TRY(expr)                                  \

@@ -52,7 +52,18 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
+// TR (column-major operands, the executor behind cusparse_mmul_opt / tiledspmm_mm): B is given as the
+// caller's activations X = Bᵀ, row-major [N, ldb] (element B[k][n] = X[n·ldb + k]), and C is produced
+// as Y = Cᵀ, row-major [N, ldc] — no transposed copies in memory:
+//  * the slab loader reads 256-byte pieces of X rows (16 lanes per row, coalesced) and writes them
+//    TRANSPOSED into the same [k][n] LDS image, scalar by scalar; the 4-column groups of an LDS row are
+//    stored at position g XOR ((k >> 2) & 7), which spreads a write instruction's lanes over all banks
+//    (2-way instead of 16-way conflicts) while the compute side still reads ONE ds_read_b128 per lane —
+//    lane l just reads position l XOR ((k >> 2) & 7);
+//  * the epilogue stages the 128 × 256 tile through the (now free) slab buffers as [n][m] and writes
+//    512-byte row segments of Y.
 // grid: 1-D over (column tile, row block), dealt XCD-contiguously (below).
+template <bool TR>
 __global__ __launch_bounds__(kWaves * 64) void spmm_slab_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ B, float* __restrict__ C, int M, int K, int N, long ldb, long ldc,
@@ -121,15 +132,42 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_slab_kernel(
   auto load_slab = [&](f32x4 (&st)[kStage], int s) {
 #pragma unroll
     for (int v = 0; v < kStage; ++v) {
-      int kr = s * kSlab + wave + kWaves * v;
-      kr = kr < K ? kr : K - 1;  // rows past K are never referenced: any valid address will do
-      st[v] = *reinterpret_cast<const f32x4*>(bcol + (long)kr * ldb);
+      if (TR) {
+        // float4 f of the slab: row n = f / 16 of X (column of B), k = 4·(f % 16) … +3
+        const int f = v * (kWaves * 64) + (int)threadIdx.x;
+        int n = c0 + f / 16;
+        n = n < N ? n : N - 1;                 // columns past N belong to lanes that are off
+        int kk = s * kSlab + (f % 16) * 4;
+        kk = kk + 3 < K ? kk : (K >= 4 ? K - 4 : 0);  // k past K is never referenced: any valid address will do
+        st[v] = *reinterpret_cast<const f32x4*>(B + (long)n * ldb + kk);
+      } else {
+        int kr = s * kSlab + wave + kWaves * v;
+        kr = kr < K ? kr : K - 1;  // rows past K are never referenced: any valid address will do
+        st[v] = *reinterpret_cast<const f32x4*>(bcol + (long)kr * ldb);
+      }
     }
   };
   auto store_slab = [&](const f32x4 (&st)[kStage], int buf) {
 #pragma unroll
-    for (int v = 0; v < kStage; ++v) lds[(buf * kSlab + wave + kWaves * v) * 64 + lane] = st[v];
+    for (int v = 0; v < kStage; ++v) {
+      if (TR) {
+        const int f = v * (kWaves * 64) + (int)threadIdx.x;
+        const int nl = f / 16, kq = f % 16;     // local column, k quad
+        float* base = reinterpret_cast<float*>(lds);
+        const float comp[4] = {st[v].x, st[v].y, st[v].z, st[v].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kl = 4 * kq + j;            // k inside the slab; (kl >> 2) & 7 == kq & 7
+          base[((buf * kSlab + kl) * 64 + ((nl >> 2) ^ (kq & 7))) * 4 + (nl & 3)] = comp[j];
+        }
+      } else {
+        lds[(buf * kSlab + wave + kWaves * v) * 64 + lane] = st[v];
+      }
+    }
   };
+  // LDS position of this lane's 4-column group in LDS row r (TR: XOR-swizzled by the row, see above;
+  // the all-zero row reads as zeros at any position)
+  auto at = [&](int r) { return TR ? lds[r * 64 + (lane ^ ((r >> 2) & 7))] : lds[r * 64 + lane]; };
 
   // One slab: every row consumes its entries with column < slab_end from LDS buffer `cur`, then
   // the registers holding slab s+1 go to the other buffer and are refilled with slab s+3.
@@ -156,7 +194,7 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_slab_kernel(
             v[u] = readlane_f(wval[i], pos[i] + j + u);
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) x[u] = lds[r[u] * 64 + lane];
+          for (int u = 0; u < 4; ++u) x[u] = at(r[u]);
 #pragma unroll
           for (int u = 0; u < 4; ++u) acc[i] = fma4(v[u], x[u], acc[i]);
         }
@@ -171,8 +209,8 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_slab_kernel(
           const float v0 = readlane_f(wval[i], p0);
           const float v1r = readlane_f(wval[i], p1);
           const float v1 = two ? v1r : -0.0f;
-          const f32x4 x0 = lds[r0 * 64 + lane];
-          const f32x4 x1 = lds[r1 * 64 + lane];
+          const f32x4 x0 = at(r0);
+          const f32x4 x1 = at(r1);
           acc[i] = fma4(v0, x0, acc[i]);
           acc[i] = fma4(v1, x1, acc[i]);
         }
@@ -227,7 +265,16 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_slab_kernel(
         for (int j = 0; j < cnt; ++j) {
           const int cc = __builtin_amdgcn_readlane(myc, j);
           const float vv = readlane_f(myv, j);
-          if (on) a = fma4(vv, *reinterpret_cast<const f32x4*>(bcol + (long)cc * ldb), a);
+          if (on) {
+            f32x4 bx;
+            if (TR) {
+              const float* xp = B + (long)(c0 + lane * 4) * ldb + cc;
+              bx = f32x4{xp[0], xp[ldb], xp[2 * ldb], xp[3 * ldb]};
+            } else {
+              bx = *reinterpret_cast<const f32x4*>(bcol + (long)cc * ldb);
+            }
+            a = fma4(vv, bx, a);
+          }
         }
       }
       acc[i] = a;
@@ -237,6 +284,45 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_slab_kernel(
   // ---- epilogue
   f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
   if (bias && on) bv = *reinterpret_cast<const f32x4*>(bias + c0 + lane * 4);
+  if (TR) {
+    // Y[n][m]: stage the tile as [n][128] floats (m contiguous) in the slab buffers — the 4-row groups of
+    // a column n sit at position q XOR ((n >> 2) & 31), so the 64 lanes of a staging write (64 different
+    // n, the same q) spread over the banks — then every 32 lanes write one 512-byte row segment of Y
+    constexpr int SLD = kWaves * kRows;  // 128
+    float* tile = reinterpret_cast<float*>(lds);
+    __syncthreads();  // (the k loop ended with a barrier; rows recomputed above did not touch LDS)
+    if (on) {
+      const float comp[kRows][4] = {{acc[0].x, acc[0].y, acc[0].z, acc[0].w}, {acc[1].x, acc[1].y, acc[1].z, acc[1].w},
+                                    {acc[2].x, acc[2].y, acc[2].z, acc[2].w}, {acc[3].x, acc[3].y, acc[3].z, acc[3].w},
+                                    {acc[4].x, acc[4].y, acc[4].z, acc[4].w}, {acc[5].x, acc[5].y, acc[5].z, acc[5].w},
+                                    {acc[6].x, acc[6].y, acc[6].z, acc[6].w}, {acc[7].x, acc[7].y, acc[7].z, acc[7].w}};
+      const float bcomp[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int n = lane * 4 + c, sw = (n >> 2) & 31;
+        float* row = tile + n * SLD;
+        const float b = bias ? bcomp[c] : 0.f;
+        *reinterpret_cast<f32x4*>(row + 4 * ((wave * 2) ^ sw)) = f32x4{comp[0][c] + b, comp[1][c] + b, comp[2][c] + b, comp[3][c] + b};
+        *reinterpret_cast<f32x4*>(row + 4 * ((wave * 2 + 1) ^ sw)) = f32x4{comp[4][c] + b, comp[5][c] + b, comp[6][c] + b, comp[7][c] + b};
+      }
+    }
+    __syncthreads();
+    const int mbase = (int)rb * (kWaves * kRows);
+    // 32 lanes cover the 128 rows (m) of one n: thread t → n = t / 32 + 32·pass, m quad = t % 32
+    for (int nn = (int)threadIdx.x / 32; nn < ncols; nn += kWaves * 2) {
+      const int mq = (int)threadIdx.x % 32, mg = mq * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tile + nn * SLD + 4 * (mq ^ ((nn >> 2) & 31)));
+      float* yrow = C + (long)(c0 + nn) * ldc + mbase + mg;
+      if (mbase + mg + 3 < M) {
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(yrow));
+      } else {
+        if (mbase + mg + 0 < M) yrow[0] = v.x;
+        if (mbase + mg + 1 < M) yrow[1] = v.y;
+        if (mbase + mg + 2 < M) yrow[2] = v.z;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < kRows; ++i) {
     if ((skip >> i) & 1u) continue;
@@ -261,11 +347,28 @@ int launch_spmm_slab(const int32_t* rowptr, const int32_t* col, const float* val
   const int ctiles = (N + kTileCols - 1) / kTileCols;
   const long blocks = (long)ctiles * row_blocks;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_slab_kernel),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_slab_kernel<false>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
   if (attr != hipSuccess) return record_hip_error(attr);
-  hipLaunchKernelGGL(spmm_slab_kernel, dim3((unsigned)blocks), dim3(kWaves * 64), kLdsBytes, s, rowptr, col, val, B, C, M,
-                     K, N, (long)ldb, (long)ldc, bias, ctiles, (unsigned)row_blocks, long_thresh);
+  hipLaunchKernelGGL(spmm_slab_kernel<false>, dim3((unsigned)blocks), dim3(kWaves * 64), kLdsBytes, s, rowptr, col, val, B,
+                     C, M, K, N, (long)ldb, (long)ldc, bias, ctiles, (unsigned)row_blocks, long_thresh);
+  return check_launch();
+}
+
+// Column-major operands: X = Bᵀ row-major [N, ldx ≥ K], Y = Cᵀ row-major [N, ldy ≥ M] (see the kernel's TR
+// notes).  Requirements (checked by the caller, convert.hip): N % 4 == 0, K ≥ 4, ldx % 4 == 0, ldy % 4 == 0,
+// X / Y 16-byte aligned, no row left to the long-row kernel (it writes row-major C).
+int launch_spmm_slab_colmajor(const int32_t* rowptr, const int32_t* col, const float* val, const float* X, float* Y,
+                              int32_t M, int32_t K, int32_t N, int64_t ldx, int64_t ldy, hipStream_t s) {
+  const long row_blocks = ((long)M + kWaves * kRows - 1) / (kWaves * kRows);
+  const int ctiles = (N + kTileCols - 1) / kTileCols;
+  const long blocks = (long)ctiles * row_blocks;
+  if (blocks > 0x7fffffffL) return MI_ERANGE;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_slab_kernel<true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+  if (attr != hipSuccess) return record_hip_error(attr);
+  hipLaunchKernelGGL(spmm_slab_kernel<true>, dim3((unsigned)blocks), dim3(kWaves * 64), kLdsBytes, s, rowptr, col, val, X,
+                     Y, M, K, N, (long)ldx, (long)ldy, (const float*)nullptr, ctiles, (unsigned)row_blocks, 0x7fffffff);
   return check_launch();
 }
 

@@ -592,6 +592,41 @@ def test_inspect_handles_amortise_transpose_and_long_rows(cmm, dev, oracle_mod):
     cmm.tiledspmm_clean()
 
 
+@pytest.mark.parametrize("M,K,N,density,native", [(1024, 256, 4096, 0.5, True), (1100, 300, 4100, 0.6, True),
+                                                  (12301, 1030, 260, 0.25, False)])
+def test_column_major_executor_native_slab_form(cmm, capi, dev, oracle_mod, M, K, N, density, native):
+    """Where the LDS-slab plan serves the product, the column-major executor reads the activations
+    X = Bᵀ [N, K] and writes Y = Cᵀ [N, M] directly (transposing slab loads, transposed tile store, no
+    transposed copies): bit-identical to the CSR-order oracle, ragged edges, empty rows and rows whose
+    columns do not ascend included; the transposed product with the cached Aᵀ takes whichever form its own
+    shape selects and is checked the same way."""
+    g = np.random.Generator(np.random.PCG64(M + N))
+    rowptr, col, val = oracle_mod.make_csr(M, K, density, seed=M % 97)
+    col, val = col.copy(), val.copy() - 0.5
+    for r in (0, 5, M // 2, M - 1):                      # a few rows out of column order
+        s0, e0 = rowptr[r], rowptr[r + 1]
+        perm = g.permutation(e0 - s0)
+        col[s0:e0], val[s0:e0] = col[s0:e0][perm], val[s0:e0][perm]
+    x = g.random((N, K), dtype=np.float32) - 0.5
+    probe_b, probe_c = torch.empty(K, N, device=dev), torch.empty(M, N, device=dev)
+    assert cmm.spmm_plan(len(val), M, K, probe_b, probe_c)[1] == "spmm_slab_kernel"
+    cmm.cusparse_inspect(t(rowptr, dev), t(col, dev), t(val, dev), len(val), M, N, K, "slabcm")
+    y = torch.full((N, M), float("nan"), device=dev)
+    d_x = t(x, dev)
+    capi.mi_spmm_colmajor_native_form.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+    assert capi.mi_spmm_colmajor_native_form(len(val), M, K, N, d_x.data_ptr(), K, y.data_ptr(), M) == int(native)
+    cmm.cusparse_mmul_opt(t(x, dev), y, "slabcm")
+    want = oracle_mod.spmm_csr_colmajor(rowptr, col, val, M, K, N, x).reshape(N, M)
+    assert np.array_equal(y.cpu().numpy(), want)
+    dy = g.random((N, M), dtype=np.float32) - 0.5
+    dx = torch.full((N, K), float("nan"), device=dev)
+    cmm.cusparse_mmul_opt_t(t(dy, dev), dx, "slabcm")
+    t_rp, t_col, t_val = oracle_mod.csr_transpose(rowptr, col, val, M, K)
+    assert np.array_equal(dx.cpu().numpy(), oracle_mod.spmm_csr_colmajor(t_rp, t_col, t_val, K, M, N, dy).reshape(N, K))
+    cmm.cusparse_clean()
+
+
 def _dense_of(rowptr, col, val, M, K):
     A = np.zeros((M, K), np.float64)
     rows = np.repeat(np.arange(M), np.diff(rowptr))
