@@ -451,10 +451,11 @@ size_t mi_spmm_colmajor_workspace_bytes(int32_t M, int32_t K, int32_t N) {
 // Native form: when the product is one the LDS-slab plan serves (moderate density, enough tiles), the slab
 // kernel reads X = Bᵀ and writes Y = Cᵀ directly (transposing slab loads, transposed tile store) — no
 // transposed copies, the workspace stays untouched.  Same CSR-order chain per element as every other plan,
-// so the bits do not depend on which form ran.  The transposing loads and the swizzled reads cost the slab
-// kernel ≈17 % (measured, 4096² × 16384 at 10 %: 3.46 vs 2.95 ms); the two tile transposes cost their
-// 16·(K+M)·N bytes at ≈3.7 TB/s: the native form is taken where that is the smaller price
-// (3072 × 768 × 16384 at 10 %: 0.52 vs 0.75 ms).
+// so the bits do not depend on which form ran.  The transposing (scalar) LDS writes cost the slab kernel
+// ≈5 % (measured, 4096² × 16384 at 10 %: 3.13 vs 2.97 ms for the row-major kernel alone); the two tile
+// transposes cost their 16·(K+M)·N bytes at ≈3.7 TB/s (0.55 ms there): the native form is taken where that
+// is the larger price — in practice wherever the slab plan runs (3072 × 768 × 16384 at 10 %: 0.475 vs
+// 0.44 + 0.30 ms).
 int mi_spmm_colmajor_native_form(int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,
                                  const float* C, int64_t ldc) {
   if (M <= 0 || N <= 0 || K < 4 || nnz <= 0) return 0;
@@ -466,7 +467,7 @@ int mi_spmm_colmajor_native_form(int64_t nnz, int32_t M, int32_t K, int32_t N, c
   const double density = (double)nnz / ((double)M * (double)K);
   const double t_slab = (wgs <= 256.0 ? 1.0 : wgs / 256.0) * (double)(((long)K + 63) / 64) * (2.35e-6 + 34e-6 * density);
   const double t_transposes = 16.0 * ((double)K + (double)M) * (double)N / 3.7e12;
-  return 0.17 * t_slab < t_transposes ? 1 : 0;
+  return 0.06 * t_slab < t_transposes ? 1 : 0;
 }
 
 int mi_spmm_csr_colmajor_ex_f32(const int32_t* rowptr, const int32_t* col, const float* val,

@@ -55,11 +55,12 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
 // TR (column-major operands, the executor behind cusparse_mmul_opt / tiledspmm_mm): B is given as the
 // caller's activations X = Bᵀ, row-major [N, ldb] (element B[k][n] = X[n·ldb + k]), and C is produced
 // as Y = Cᵀ, row-major [N, ldc] — no transposed copies in memory:
-//  * the slab loader reads 256-byte pieces of X rows (16 lanes per row, coalesced) and writes them
-//    TRANSPOSED into the same [k][n] LDS image, scalar by scalar; the 4-column groups of an LDS row are
-//    stored at position g XOR ((k >> 2) & 7), which spreads a write instruction's lanes over all banks
-//    (2-way instead of 16-way conflicts) while the compute side still reads ONE ds_read_b128 per lane —
-//    lane l just reads position l XOR ((k >> 2) & 7);
+//  * the slab loader reads 64-byte pieces of X rows (a wave instruction: 16 rows × 4 k-quads; the four
+//    instructions of a wave cover 256 contiguous bytes of each of its 16 rows) and writes them TRANSPOSED
+//    into the same [k][n] LDS image, scalar by scalar; LDS rows are padded to 65 float4, which with that
+//    lane mapping makes a write instruction 2-way conflicted (16-way on unpadded rows) while the compute
+//    side keeps its ONE plain ds_read_b128 per lane (a first version XOR-swizzled the column groups
+//    instead: two more vector instructions per non-zero on an issue-bound kernel, +17 %);
 //  * the epilogue stages the 128 × 256 tile through the (now free) slab buffers as [n][m] and writes
 //    512-byte row segments of Y.
 // grid: 1-D over (column tile, row block), dealt XCD-contiguously (below).
@@ -83,8 +84,9 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_slab_kernel(
   const int ncols = N - c0 < kTileCols ? N - c0 : kTileCols;
   const bool on = lane * 4 < ncols;  // N % 4 == 0: a lane's four columns are all in or all out
   const int row0 = (int)rb * (kWaves * kRows) + wave * kRows;
-  constexpr int kZeroRow = 2 * kSlab;  // row index (in 64-float4 rows) of the zero row
-  if (wave == 0) lds[kZeroRow * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int kRowVec = TR ? 65 : 64;  // float4 per LDS row (TR: padded, see above)
+  constexpr int kZeroRow = 2 * kSlab;    // row index of the zero row
+  if (wave == 0) lds[kZeroRow * kRowVec + lane] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- per-row state: window of 64 entries, cursor, accumulators
   int base[kRows], endp[kRows], pos[kRows], next[kRows];
@@ -133,11 +135,10 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_slab_kernel(
 #pragma unroll
     for (int v = 0; v < kStage; ++v) {
       if (TR) {
-        // float4 f of the slab: row n = f / 16 of X (column of B), k = 4·(f % 16) … +3
-        const int f = v * (kWaves * 64) + (int)threadIdx.x;
-        int n = c0 + f / 16;
+        // wave w, lane l, piece v: row n = 16·w + (l & 15) of X (column of B), k quad = 4·v + (l >> 4)
+        int n = c0 + wave * 16 + (lane & 15);
         n = n < N ? n : N - 1;                 // columns past N belong to lanes that are off
-        int kk = s * kSlab + (f % 16) * 4;
+        int kk = s * kSlab + (4 * v + (lane >> 4)) * 4;
         kk = kk + 3 < K ? kk : (K >= 4 ? K - 4 : 0);  // k past K is never referenced: any valid address will do
         st[v] = *reinterpret_cast<const f32x4*>(B + (long)n * ldb + kk);
       } else {
@@ -151,23 +152,18 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_slab_kernel(
 #pragma unroll
     for (int v = 0; v < kStage; ++v) {
       if (TR) {
-        const int f = v * (kWaves * 64) + (int)threadIdx.x;
-        const int nl = f / 16, kq = f % 16;     // local column, k quad
+        const int nl = wave * 16 + (lane & 15), kq = 4 * v + (lane >> 4);  // local column, k quad
         float* base = reinterpret_cast<float*>(lds);
         const float comp[4] = {st[v].x, st[v].y, st[v].z, st[v].w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int kl = 4 * kq + j;            // k inside the slab; (kl >> 2) & 7 == kq & 7
-          base[((buf * kSlab + kl) * 64 + ((nl >> 2) ^ (kq & 7))) * 4 + (nl & 3)] = comp[j];
-        }
+        for (int j = 0; j < 4; ++j) base[(buf * kSlab + 4 * kq + j) * (kRowVec * 4) + nl] = comp[j];
       } else {
-        lds[(buf * kSlab + wave + kWaves * v) * 64 + lane] = st[v];
+        lds[(buf * kSlab + wave + kWaves * v) * kRowVec + lane] = st[v];
       }
     }
   };
-  // LDS position of this lane's 4-column group in LDS row r (TR: XOR-swizzled by the row, see above;
-  // the all-zero row reads as zeros at any position)
-  auto at = [&](int r) { return TR ? lds[r * 64 + (lane ^ ((r >> 2) & 7))] : lds[r * 64 + lane]; };
+  // this lane's 4-column group of LDS row r
+  auto at = [&](int r) { return lds[r * kRowVec + lane]; };
 
   // One slab: every row consumes its entries with column < slab_end from LDS buffer `cur`, then
   // the registers holding slab s+1 go to the other buffer and are refilled with slab s+3.
@@ -364,10 +360,11 @@ int launch_spmm_slab_colmajor(const int32_t* rowptr, const int32_t* col, const f
   const int ctiles = (N + kTileCols - 1) / kTileCols;
   const long blocks = (long)ctiles * row_blocks;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
+  constexpr size_t kLdsBytesTr = (size_t)(2 * kSlab * 65 + 65) * sizeof(f32x4);  // padded rows
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_slab_kernel<true>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytesTr);
   if (attr != hipSuccess) return record_hip_error(attr);
-  hipLaunchKernelGGL(spmm_slab_kernel<true>, dim3((unsigned)blocks), dim3(kWaves * 64), kLdsBytes, s, rowptr, col, val, X,
+  hipLaunchKernelGGL(spmm_slab_kernel<true>, dim3((unsigned)blocks), dim3(kWaves * 64), kLdsBytesTr, s, rowptr, col, val, X,
                      Y, M, K, N, (long)ldx, (long)ldy, (const float*)nullptr, ctiles, (unsigned)row_blocks, 0x7fffffff);
   return check_launch();
 }

@@ -1,0 +1,48 @@
+"""Developer probe: the column-major executor (cusparse_inspect + cusparse_mmul_opt) at FC-layer shapes —
+which form it takes, beside the row-major kernel alone, two plain transposes and the dense product."""
+import ctypes
+import sys
+from pathlib import Path
+import torch
+PKG = Path(__file__).resolve().parent.parent / "matrix-multiplication_amd"
+sys.path.insert(0, str(PKG))
+import custom_mm  # noqa: E402
+lib = ctypes.CDLL(str(PKG / "libmi_spmm.so"))
+lib.mi_spmm_colmajor_native_form.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                             ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+dev = torch.device("cuda")
+
+
+def timeit(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+g = torch.Generator(device=dev).manual_seed(0)
+for (M, K, N, d) in [(4096, 4096, 16384, 0.1), (4096, 4096, 16384, 0.2), (3072, 768, 16384, 0.1), (768, 3072, 16384, 0.1),
+                     (4096, 4096, 4096, 0.1), (4096, 4096, 512, 0.05)]:
+    w = torch.rand(M, K, device=dev, generator=g) * (torch.rand(M, K, device=dev, generator=g) < d)
+    vals, cols, offs = custom_mm.dense_to_csr(w)
+    nnz = vals.numel()
+    custom_mm.cusparse_inspect(offs.view(-1), cols, vals, nnz, M, N, K, "w")
+    x = torch.rand(N, K, device=dev, generator=g)
+    y = torch.empty(N, M, device=dev)
+    native = lib.mi_spmm_colmajor_native_form(nnz, M, K, N, x.data_ptr(), K, y.data_ptr(), M)
+    t_exec = timeit(lambda: custom_mm.cusparse_mmul_opt(x, y, "w"))
+    xt = x.t().contiguous()
+    c = torch.empty(M, N, device=dev)
+    plan = custom_mm.spmm_plan(nnz, M, K, xt, c)[1]
+    t_row = timeit(lambda: custom_mm.naive_spmm_ex(vals, cols, offs.view(-1), nnz, M, K, xt, c, 0))
+    t_tr = timeit(lambda: (x.t().contiguous(), c.t().contiguous()))
+    t_dense = timeit(lambda: torch.matmul(x, w.t(), out=y))
+    print(f"{M}x{K} d={d} N={N}: plan {plan}, form {'native' if native else 'transposes'}; cusparse_mmul_opt {t_exec:.3f} ms; "
+          f"row-major kernel alone {t_row:.3f}; two torch transposes {t_tr:.3f}; dense torch {t_dense:.3f}", flush=True)
+    custom_mm.cusparse_clean()
