@@ -25,6 +25,11 @@
 // 0.812 ms at 100 %) — occupancy, not the L2 round trip, is what this kernel needs.
 #include "mi_common.h"
 
+#ifndef MI_SKIP_ABL
+#define MI_SKIP_ABL 0  // developer probes only (timing, wrong results): 1 no B gathers in the walk, 2 no list building AND no walk
+                       // (a walk over an unwritten list would gather from garbage addresses), 4 no walk
+#endif
+
 namespace {
 
 using mi::f32x4;
@@ -114,10 +119,12 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_dense_skip_kernel(
                                m3 = __ballot(n3) & gm;
       // rank in ascending column order: everything held by lower lanes of the group, then own
       int rank = fill + lanes_below(m0) + lanes_below(m1) + lanes_below(m2) + lanes_below(m3);
+      if (!(MI_SKIP_ABL & 2)) {
       if (n0) list[rank++] = Pair{kc + 0, a.x};
       if (n1) list[rank++] = Pair{kc + 1, a.y};
       if (n2) list[rank++] = Pair{kc + 2, a.z};
       if (n3) list[rank] = Pair{kc + 3, a.w};
+      }
       fill += __builtin_popcountll(m0) + __builtin_popcountll(m1) + __builtin_popcountll(m2) +
               __builtin_popcountll(m3);
       // walk the list once it could not take another chunk, or at the end of the row
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_dense_skip_kernel(
       // same-wave LDS traffic is executed in order; only the compiler must not reorder
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-      for (int i = 0; __any(i < fill); i += 4) {
+      for (int i = 0; __any(i < fill) && !(MI_SKIP_ABL & 6); i += 4) {
         Pair p[4];
         f32x4 x[4];
 #pragma unroll
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_dense_skip_kernel(
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const bool take = on && i + u < fill;
-          x[u] = take ? *reinterpret_cast<const f32x4*>(Bi + (long)p[u].k * ldb + gl * 4)
+          x[u] = (take && !(MI_SKIP_ABL & 1)) ? *reinterpret_cast<const f32x4*>(Bi + (long)p[u].k * ldb + gl * 4)
                       : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
