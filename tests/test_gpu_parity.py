@@ -250,6 +250,7 @@ def _random_rows_csr(M, K, lens, seed, shuffle=0.0, duplicates=False):
     (20000, 70000, 30, "two passes, ragged digit split (17 bits), many tiles"),
     (3000, 1 << 20, 300, "two passes, 10 + 10 bits"),
     (2000, 3_000_000, 25, "three passes, full keys + boundary pass"),
+    (500, 3_000_000, 60, "three passes with 8-byte entries: staged passes, then the register-scatter last pass"),
     (5_000_000, 600_000, 0, "two passes, rows too wide for the 8-byte entry (register scatter path)"),
     (40, 1_200_000_000, 50, "31-bit keys: three passes with an 11-bit digit"),
 ])
