@@ -816,7 +816,14 @@ def test_sharded_collective_on_a_one_rank_rccl_group(cmm, dev, oracle_mod):
                                  chunks=3)
         C = op.forward(B, force_collective=True)
         torch.cuda.synchronize()
-        assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr(rowptr, col, val, M, K, B.cpu().numpy()))
+        want = oracle_mod.spmm_csr(rowptr, col, val, M, K, B.cpu().numpy())
+        assert np.array_equal(C.cpu().numpy(), want)
+        # the nnz-balanced split exchanges with in-place RCCL broadcasts (blocks of different heights)
+        op2 = sharded.ShardedSpMM(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), M, K, dev,
+                                  chunks=5, split="nnz")
+        C2 = op2.forward(B, force_collective=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(C2.cpu().numpy(), want)
     finally:
         dist.destroy_process_group()
 
