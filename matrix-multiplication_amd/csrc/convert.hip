@@ -336,12 +336,19 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 // live registers and after six levels lane i holds the finished out[p0 + i] — 63 exchanges for 64
 // results instead of 6 × 64, and one coalesced 256-B store.  The pairing is exactly the butterfly's,
 // so the bits are the same as a per-non-zero butterfly would give.
-template <int T, bool VEC>
+//
+// PANEL (Infinity-Cache blocking, as in the forward product's two-panel plan, spmm_csr.hip): a launch
+// handles only the non-zeros with c_lo ≤ column < c_hi, so that all CUs gather from one slice of a B far
+// larger than the cache at the same time.  An output value depends on ONE row of B, so nothing is carried
+// between the panel launches (unlike the forward product's C): each launch compacts the chunk's in-panel
+// entries (ballot, in CSR order), runs the same gathers and the same joint tree on them, and hands every
+// result back to the lane that holds its non-zero.  Per-value arithmetic is untouched → same bits.
+template <int T, bool VEC, bool PANEL>
 __global__ __launch_bounds__(256) void sddmm_kernel(const int* __restrict__ rowptr,
                                                     const int* __restrict__ col, int M, int N,
                                                     const float* __restrict__ dC, long lddc,
                                                     const float* __restrict__ B, long ldb,
-                                                    float* __restrict__ out) {
+                                                    float* __restrict__ out, int c_lo, int c_hi) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (row >= M) return;
@@ -365,8 +372,16 @@ __global__ __launch_bounds__(256) void sddmm_kernel(const int* __restrict__ rowp
   constexpr int U = 8;
   const float* xrow = dC + row * lddc;
   for (int p0 = start; p0 < end; p0 += 64) {
-    const int cnt = end - p0 < 64 ? end - p0 : 64;
+    int cnt = end - p0 < 64 ? end - p0 : 64;
     const int mycol = lane < cnt ? col[p0 + lane] : 0;
+    unsigned long long pmask = ~0ull;  // PANEL: lanes whose non-zero belongs to this launch
+    bool mine = lane < cnt;
+    if (PANEL) {
+      mine = mine && (unsigned)(mycol - c_lo) < (unsigned)(c_hi - c_lo);
+      pmask = __ballot(mine);
+      cnt = __builtin_popcountll(pmask);  // results are computed for the compacted entries 0 … cnt-1
+      if (cnt == 0) continue;
+    }
     float s[64];
 #pragma unroll
     for (int i = 0; i < 64; ++i) s[i] = 0.f;
@@ -375,13 +390,19 @@ __global__ __launch_bounds__(256) void sddmm_kernel(const int* __restrict__ rowp
       mi::f32x4 x[T];
 #pragma unroll
       for (int t = 0; t < T; ++t) x[t] = load4(xrow, t0 + t);
+      unsigned long long walk = pmask;  // PANEL: compacted entry i+u is the (i+u)-th set bit
 #pragma unroll
       for (int i = 0; i < 64; i += U) {
         if (i < cnt) {
           mi::f32x4 y[U][T];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            const float* brow = B + (long)__builtin_amdgcn_readlane(mycol, i + u) * ldb;  // row 0 when past cnt
+            int src_lane = i + u;
+            if (PANEL) {
+              src_lane = walk ? __builtin_ctzll(walk) : 0;  // past the last entry: any lane (its sum is never stored)
+              walk &= walk - 1;
+            }
+            const float* brow = B + (long)__builtin_amdgcn_readlane(mycol, src_lane) * ldb;  // row 0 when past cnt
 #pragma unroll
             for (int t = 0; t < T; ++t) y[u][t] = load4(brow, t0 + t);
           }
@@ -422,7 +443,14 @@ __global__ __launch_bounds__(256) void sddmm_kernel(const int* __restrict__ rowp
         s[k] = keep + __shfl_xor(send, w, 64);
       }
     }
-    if (lane < cnt) out[p0 + lane] = s[0];
+    if (PANEL) {
+      // lane i holds the result of compacted entry i; the lane holding that non-zero is the i-th set bit
+      const int rank = lanes_below(pmask);
+      const float v = __shfl(s[0], rank, 64);
+      if (mine) out[p0 + lane] = v;
+    } else if (lane < cnt) {
+      out[p0 + lane] = s[0];
+    }
   }
 }
 
@@ -598,8 +626,7 @@ int mi_colsum_f32(const float* src, int32_t rows, int32_t n, int64_t ld, float* 
 int mi_sddmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz, int32_t M, int32_t K,
                      int32_t N, const float* dC, int64_t lddc, const float* B, int64_t ldb,
                      float* out_val, mi_stream_t stream) {
-  (void)K;
-  if (M < 0 || N < 0 || nnz < 0) return MI_EINVAL;
+  if (M < 0 || N < 0 || K < 0 || nnz < 0) return MI_EINVAL;
   if (M == 0 || nnz == 0) return MI_OK;
   if (!rowptr || !col || !out_val) return MI_EINVAL;
   if (N > 0 && (!dC || !B || lddc < N || ldb < N)) return MI_EINVAL;
@@ -609,8 +636,18 @@ int mi_sddmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz, int
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int T = N <= 256 ? 1 : 2;  // wider rows: chunks of 512 columns
 #define MI_SDDMM(T_, V_)                                                                                    \
-  hipLaunchKernelGGL((sddmm_kernel<T_, V_>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, M, N, dC, \
-                     (long)lddc, B, (long)ldb, out_val)
+  hipLaunchKernelGGL((sddmm_kernel<T_, V_, false>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, M, N, dC, \
+                     (long)lddc, B, (long)ldb, out_val, 0, 0)
+  // B far beyond the 256 MiB Infinity Cache and rows long enough to re-touch a panel (the conditions of the
+  // forward product's two-panel plan): two launches, one per half of K
+  if (vec && T == 1 && (long)K * ldb * 4 >= (768L << 20) && nnz >= 32L * M && nnz * (long)N >= 8L * K * ldb) {
+    const int half = (K + 1) / 2;
+    hipLaunchKernelGGL((sddmm_kernel<1, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, M, N, dC,
+                       (long)lddc, B, (long)ldb, out_val, 0, half);
+    hipLaunchKernelGGL((sddmm_kernel<1, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, M, N, dC,
+                       (long)lddc, B, (long)ldb, out_val, half, K);
+    return mi::check_launch();
+  }
   if (vec) {
     if (T == 1) MI_SDDMM(1, true);
     else MI_SDDMM(2, true);
