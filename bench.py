@@ -296,7 +296,12 @@ def main():
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+            # "nccl" is RCCL on ROCm.  Its kernels go on a HIGH-PRIORITY stream: the all-gather of block j runs
+            # beside the SpMM of block j+1, which fills every CU — at normal priority the collective's
+            # workgroups would queue behind it and the overlap the layout is built for would be lost
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=opts)
 
     import custom_mm
     import sharded

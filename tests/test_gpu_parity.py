@@ -829,7 +829,9 @@ def test_sharded_collective_on_a_one_rank_rccl_group(cmm, dev, oracle_mod):
     import sharded
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    opts = dist.ProcessGroupNCCL.Options()
+    opts.is_high_priority_stream = True   # as bench.py creates it: the gather must not queue behind the SpMM
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=opts)
     try:
         M, K, N = 4099, 3000, 256
         rowptr, col, val = oracle_mod.make_csr(M, K, 0.01, seed=6)
