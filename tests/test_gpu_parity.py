@@ -314,6 +314,47 @@ def test_csr_transpose_batched_bit_exact(cmm, dev, oracle_mod, batch, M, K, dens
                        rtol=1e-4, atol=1e-5)
 
 
+def test_csr_transpose_shape_fuzz(cmm, dev, oracle_mod):
+    """Seeded random shapes around the plan boundaries of csr_transpose.hip (K·batch at 2^10 and 2^20 ± 1,
+    tiles of exactly / just over 8192 entries, rows spanning many tiles, runs of empty rows, duplicates,
+    unsorted rows), single and batched: always the oracle's stable transpose."""
+    rng = np.random.Generator(np.random.PCG64(20260))
+    shapes = [(1, 1, 1), (1, 3, 1024), (1, 3, 1025), (1, 700, 1023), (1, 9000, 1024), (1, 300, (1 << 20) - 1),
+              (1, 300, 1 << 20), (1, 300, (1 << 20) + 1), (1, 1, 50000), (1, 50000, 1), (3, 64, 341), (3, 64, 342),
+              (7, 100, 149797), (7, 100, 149798), (2, 5000, 600), (1, 8192, 2), (1, 8193, 2)]
+    for case, (batch, M, K) in enumerate(shapes):
+        for density in (0.0, 0.002, 0.05, 0.6):
+            target = int(min(batch * M * K * density, 300_000))
+            if density > 0 and target == 0:
+                target = min(batch * M * K, 5)
+            lens = rng.multinomial(target, rng.dirichlet(np.full(batch * M, 0.3))) if target else np.zeros(batch * M, np.int64)
+            lens = np.minimum(lens, 4 * K)                      # rows longer than K: duplicate columns
+            cols = []
+            for n in lens:
+                c = np.sort(rng.integers(0, K, size=int(n)))
+                if n > 1 and rng.random() < 0.3:
+                    c = rng.permutation(c)
+                cols.append(c.astype(np.int32))
+            col = np.concatenate(cols) if len(cols) else np.zeros(0, np.int32)
+            val = rng.random(len(col), dtype=np.float32) - 0.5
+            off = np.zeros((batch, M + 1), np.int64)
+            off[:, 1:] = np.cumsum(lens).reshape(batch, M)
+            off[1:, 0] = off[:-1, M]
+            off = off.astype(np.int32)
+            tag = (case, batch, M, K, density, len(col))
+            if batch == 1:
+                t_val, t_col, t_off = cmm.csr_transpose(t(val, dev), t(col, dev), t(off[0], dev), len(col), M, K)
+                t_off = t_off.view(1, -1)
+            else:
+                t_val, t_col, t_off = cmm.csr_transpose_batched(t(val, dev), t(col, dev), t(off, dev), len(col), batch, M, K)
+            got_off, got_col, got_val = t_off.cpu().numpy(), t_col.cpu().numpy(), t_val.cpu().numpy()
+            for b in range(batch):
+                s0, s1 = off[b, 0], off[b, M]
+                rp, c, v = oracle_mod.csr_transpose((off[b] - s0).astype(np.int32), col[s0:s1], val[s0:s1], M, K)
+                assert np.array_equal(got_off[b], rp.astype(np.int64) + s0), tag
+                assert np.array_equal(got_col[s0:s1], c) and np.array_equal(got_val[s0:s1], v), tag
+
+
 def test_sddmm_config_c3_two_panel_launches_bit_exact(cmm, dev, oracle_mod):
     """SDDMM at BASELINE config C3's shape (B = 1 GiB, beyond the Infinity Cache) runs as two column-panel
     launches; every value still comes from the same per-value chain + tree: bit-exact against the oracle
