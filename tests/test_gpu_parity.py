@@ -956,6 +956,52 @@ def test_fused_bias_on_the_panel_path(capi, dev, oracle_mod):
     assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr(rowptr, colp, valp, M, K, B2))
 
 
+def test_panel_plans_detect_a_descent_across_the_64_entry_chunk_boundary(capi, dev, oracle_mod):
+    """The panel kernels scan a row 64 entries at a time; the only out-of-order pair of a row may straddle
+    two chunks (entries 63|64 or 127|128), or sit in the last, partial chunk: each must still send the row
+    to the plain CSR-order chain.  Rows of 130–200 entries, exactly one descent each, at those places."""
+    K, N = 5000, 256
+    g = np.random.Generator(np.random.PCG64(64))
+    spots = [63, 127, 0, 62, 64, 128, 129, 191]          # index i: entry i+1 < entry i
+    cols, M = [], 0
+    split = (K + 1) // 2                                  # boundary of the two-panel plan
+    for spot in spots + [None, None]:                     # two fully sorted rows as well
+        n = int(g.integers(max(131, (spot or 0) + 3), 200))
+        below = (spot + 1) if spot is not None else n // 2   # entries left of the panel boundary
+        c = np.concatenate([np.sort(g.choice(split, size=below, replace=False)),
+                            split + np.sort(g.choice(K - split, size=n - below, replace=False))]).astype(np.int32)
+        if spot is not None:
+            c[spot], c[spot + 1] = c[spot + 1], c[spot]   # the single descent straddles the panel boundary
+        cols.append(c)
+        M += 1
+    rowptr = np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int32)
+    col = np.concatenate(cols)
+    val = g.random(len(col), dtype=np.float32) - 0.5
+    B = g.random((K, N), dtype=np.float32) - 0.5
+    want = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    d = [t(x, dev) for x in (rowptr, col, val, B)]
+    for variant in (7, 8, 12):
+        C = torch.full((M, N), float("nan"), device=dev)
+        assert capi.mi_spmm_csr_f32_variant(variant, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(val), M, K, N,
+                                            d[3].data_ptr(), N, C.data_ptr(), N, torch.cuda.current_stream().cuda_stream) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(C.cpu().numpy(), want), variant
+    # sanity of the construction: consumed panel by panel WITHOUT the check, these rows would get other bits
+    panel_order = oracle_mod.spmm_csr(rowptr, *_panel_sorted(rowptr, col, val, split), M, K, B)
+    differing = [r for r in range(len(spots)) if not np.array_equal(panel_order[r], want[r])]
+    assert len(differing) >= len(spots) - 1 and np.array_equal(panel_order[len(spots):], want[len(spots):])
+
+
+def _panel_sorted(rowptr, col, val, split):
+    """Entries of each row reordered the way two unchecked panel passes would consume them."""
+    c2, v2 = col.copy(), val.copy()
+    for r in range(len(rowptr) - 1):
+        s0, e0 = rowptr[r], rowptr[r + 1]
+        order = np.argsort(col[s0:e0] >= split, kind="stable")
+        c2[s0:e0], v2[s0:e0] = col[s0:e0][order], val[s0:e0][order]
+    return c2, v2
+
+
 def _sub_csr(rowptr, col, val, rows):
     """CSR of the selected rows (rows of a product are independent: the oracle on this equals the
     oracle on the whole matrix restricted to these rows)."""
