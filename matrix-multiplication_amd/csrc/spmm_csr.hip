@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
     int before = __shfl_up(myc, 1, 64);
     if (lane == 0) before = prev_last;
     descends |= __ballot(myc < before) != 0ull;
+    if (descends) break;  // no point in gathering on: the first pass redoes the row, the others drop it
     prev_last = __builtin_amdgcn_readlane(myc, 63);  // 0x7fffffff past the end: only the last chunk has such lanes
     const bool in = (unsigned)(myc - c_lo) < width && idx < end;
     const float myv = in ? val[idx] : 0.f;
