@@ -1186,6 +1186,61 @@ def test_entry_points_are_graph_capturable(cmm, dev, oracle_mod):
                               oracle_mod.spmm_csr_batched(rp2, c2, v2, 6, 96, 96, kh.reshape(6, 96, 64)))
 
 
+def test_inspector_products_and_round2_entries_are_graph_capturable(cmm, dev, oracle_mod):
+    """An inspector handle owns its buffers, so `cusparse_mmul_opt` / `_opt_t` neither allocate nor
+    synchronise and can be captured in a hipGraph — both forms of the executor (transposes around the
+    row-split kernel; native LDS-slab) — as can `naive_spmm_ex` (one launch, no workspace) and the chained
+    short-k GEMM; the graph replays on new activations."""
+    g = np.random.Generator(np.random.PCG64(21))
+    cases = []
+    for tag, (M, K, N, density) in {"rows": (900, 700, 64, 0.02), "slab": (1024, 256, 4096, 0.5)}.items():
+        rowptr, col, val = oracle_mod.make_csr(M, K, density, seed=len(tag))
+        cmm.cusparse_inspect(t(rowptr, dev), t(col, dev), t(val, dev), len(val), M, N, K, tag)
+        cases.append((tag, M, K, N, rowptr, col, val, torch.zeros(N, K, device=dev), torch.empty(N, M, device=dev),
+                      torch.zeros(N, M, device=dev), torch.empty(N, K, device=dev)))
+    M0, K0 = 2000, 1500
+    rp0, c0, v0 = oracle_mod.make_csr(M0, K0, 0.01, seed=3)
+    d0 = [t(v0, dev), t(c0, dev), t(rp0, dev)]
+    B0, C0 = torch.zeros(K0, 256, device=dev), torch.empty(M0, 256, device=dev)
+    q, kk, S = torch.zeros(4, 256, 64, device=dev), torch.zeros(4, 256, 64, device=dev), torch.empty(4, 256, 256, device=dev)
+
+    def run():
+        for tag, M, K, N, *_rest, x, y, dy, dx in cases:
+            cmm.cusparse_mmul_opt(x, y, tag)
+            cmm.cusparse_mmul_opt_t(dy, dx, tag)
+        cmm.naive_spmm_ex(*d0, len(v0), M0, K0, B0, C0, 0)
+        cmm.cublas_bmm(q, kk, S, 3, False, True)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()  # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run()
+    for _ in range(2):
+        fresh = []
+        for tag, M, K, N, rowptr, col, val, x, y, dy, dx in cases:
+            xh, dyh = g.random((N, K), dtype=np.float32), g.random((N, M), dtype=np.float32)
+            x.copy_(torch.from_numpy(xh))
+            dy.copy_(torch.from_numpy(dyh))
+            fresh.append((xh, dyh))
+        Bh, qh, kh = g.random((K0, 256), dtype=np.float32), g.random(q.shape, dtype=np.float32), g.random(kk.shape, dtype=np.float32)
+        B0.copy_(torch.from_numpy(Bh))
+        q.copy_(torch.from_numpy(qh))
+        kk.copy_(torch.from_numpy(kh))
+        graph.replay()
+        torch.cuda.synchronize()
+        for (tag, M, K, N, rowptr, col, val, x, y, dy, dx), (xh, dyh) in zip(cases, fresh):
+            assert np.array_equal(y.cpu().numpy(), oracle_mod.spmm_csr_colmajor(rowptr, col, val, M, K, N, xh).reshape(N, M)), tag
+            t_rp, t_col, t_val = oracle_mod.csr_transpose(rowptr, col, val, M, K)
+            assert np.array_equal(dx.cpu().numpy(), oracle_mod.spmm_csr_colmajor(t_rp, t_col, t_val, K, M, N, dyh).reshape(N, K)), tag
+        assert np.array_equal(C0.cpu().numpy(), oracle_mod.spmm_csr(rp0, c0, v0, M0, K0, Bh))
+        assert np.array_equal(S.cpu().numpy(), oracle_mod.gemm(qh, kh, False, True))
+    cmm.cusparse_clean()
+
+
 def test_wide_n_column_tiled_launch_is_bit_exact(capi, cmm, dev, oracle_mod):
     """Wide N with a B that fits neither one L2 nor 8 MiB: AUTO takes the XCD-aware column-tiled launch
     (variant 14); every output element still sees its row's non-zeros in CSR order."""
