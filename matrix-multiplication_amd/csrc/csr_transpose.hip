@@ -54,6 +54,7 @@ struct TrArgs {
   // tiling of this pass's input
   const int2* desc;  // per tile {start, len}, or nullptr: tile t = [t·TR_TILE, …)
   int ntiles;        // grid size (an upper bound when desc is given; unused tiles have len 0)
+  const int* used_tiles;  // device count of the tiles in desc that are in use (they come first), or nullptr
   // tables
   int* table;            // [ntiles + 1][1 << bits], counts then (after the scan) global offsets
   int* tile_row;         // first pass: flat rowptr index of the row holding the tile's first entry
@@ -86,6 +87,18 @@ struct Entry {
   unsigned row;
   float val;
 };
+
+// Loads of block-uniform metadata through the scalar unit.  The tables were written by EARLIER launches,
+// so they are constant for this kernel; the compiler cannot see that (the kernel stores to global
+// memory) and would use vector loads — whose s_waitcnt vmcnt(0) also waits for every older store.
+typedef const __attribute__((address_space(4))) int* tr_kptr;
+typedef int tr_int2v __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) tr_int2v* tr_kptr2;
+__device__ __forceinline__ int sload(const int* p) { return *(tr_kptr)(unsigned long long)p; }
+__device__ __forceinline__ int2 sload(const int2* p) {
+  const tr_int2v v = *(tr_kptr2)(unsigned long long)p;
+  return make_int2(v.x, v.y);
+}
 
 // tile bounds of workgroup t
 __device__ __forceinline__ void tile_bounds(const TrArgs& a, int t, long& start, int& len) {
@@ -314,12 +327,11 @@ __global__ __launch_bounds__(1024) void tr_bin_tiles_kernel(const int* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-// Scatter: 16 waves × 512 entries per tile.  The kernel is persistent — one workgroup per CU walks
-// tiles blockIdx.x, blockIdx.x + gridDim.x, … (a fixed trip count, no inter-workgroup dependence) —
-// so that the NEXT tile's entries (and, in the first pass, their row searches) are in flight while
-// the current tile streams out of LDS: a tile's phases are separated by barriers and a workgroup
-// fills the CU's LDS, so without this the load latency and the launch gap of every tile are exposed
-// (measured: 39 / 24 µs per tile for the first / last pass as one-tile workgroups).
+// Scatter, generic form (entries that do not fit 8 bytes, 11-bit digits, the last of three passes):
+// 16 waves × 512 entries per tile, ranked as described above and scattered straight from registers.
+// Persistent — one workgroup per CU walks a fixed list of tiles, no inter-workgroup dependence — so the
+// next tile's entries are in flight while the current tile's stores drain.  The main path is
+// tr_scatter_staged_kernel below.
 // ---------------------------------------------------------------------------------------------
 #ifdef MI_TR_TIMING
 __device__ unsigned long long g_tr_phase[16];
@@ -353,18 +365,15 @@ __device__ __forceinline__ Slot load_slot(const TrArgs& a, long p, int row_lo, i
   return s;
 }
 
-template <bool FIRST, bool LAST, bool PACKED, bool STAGED>
+template <bool FIRST, bool LAST, bool PACKED>
 __global__ __launch_bounds__(TR_THREADS) void tr_scatter_kernel(TrArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int nb = 1 << a.bits;
   unsigned short* cntw = reinterpret_cast<unsigned short*>(smem);  // [TR_WAVES][nb]
   int* binstart = reinterpret_cast<int*>(smem + (size_t)TR_WAVES * nb * 2);  // [nb] tile-local start of a digit
   int* gadj = binstart + nb;                                                  // [nb] global offset − binstart
-  uint2* sorted = reinterpret_cast<uint2*>(gadj + nb);                        // [TR_TILE]   (STAGED)
-  unsigned short* sorted_d = reinterpret_cast<unsigned short*>(sorted + TR_TILE);  // [TR_TILE] (STAGED)
   // first pass: flat rowptr index of the row holding each entry of the tile, filled row by row
-  unsigned* rowid = reinterpret_cast<unsigned*>(smem + (size_t)TR_WAVES * nb * 2 + (size_t)nb * 8 +
-                                                (STAGED ? (size_t)TR_TILE * 10 : 0));  // [TR_TILE] (FIRST)
+  unsigned* rowid = reinterpret_cast<unsigned*>(gadj + nb);  // [TR_TILE] (FIRST)
   __shared__ int wsum[16];
   __shared__ int carry_s;
 
@@ -538,38 +547,7 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_kernel(TrArgs a) {
       }
 
       TR_STAMP(4);
-      if (STAGED) {
-        // reorder the tile by digit in LDS …
-#pragma unroll
-        for (int c = 0; c < TR_PER; ++c) {
-          const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
-          if (i < cur_len) {
-            const unsigned d = e[c].d & 0xffffu;
-            const int s2 = binstart[d] + cntw[wave * nb + d] + (int)(e[c].d >> 16);
-            sorted[s2] = make_uint2(e[c].a, __builtin_bit_cast(unsigned, e[c].val));
-            sorted_d[s2] = (unsigned short)d;
-          }
-        }
-        TR_STAMP(5);
-        __syncthreads();
-        TR_STAMP(6);
-        // … the next tile's loads go out now (the registers are free) …
-        if (t + t_step < t_end) fetch(t + t_step); else len = 0;
-        TR_STAMP(7);
-        // … and the tile streams out: each digit's entries leave as one contiguous run
-#pragma unroll 2
-        for (int i = tid; i < cur_len; i += TR_THREADS) {
-          const uint2 w = sorted[i];
-          const long dst = (long)gadj[sorted_d[i]] + i;
-          if (LAST) {
-            a.t_col[dst] = (int)w.x;
-            a.t_val[dst] = __builtin_bit_cast(float, w.y);
-          } else {
-            a.out_packed[dst] = w;  // plain stores: the runs of neighbouring tiles merge in the XCD's L2
-          }                         // (non-temporal stores measured 3.9 ms vs 2.6 ms for the whole transpose)
-        }
-        TR_STAMP(8);
-      } else {
+      {
         // straight from registers (wide keys / rows, 11-bit digits): correct for every size, but the
         // stores of a wave go to up to 64 different places
 #pragma unroll
@@ -597,6 +575,253 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_kernel(TrArgs a) {
     } else {
       if (t + t_step < t_end) fetch(t + t_step); else len = 0;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Staged scatter (8-byte entries, digits of ≤ 10 bits): the main path.  Same ranking and LDS reorder as
+// above, but software-pipelined over the tiles of a persistent workgroup so that the memory system and
+// the ranking work run side by side on ONE workgroup per CU (the tile fills the CU's LDS, so there is
+// no second workgroup to hide anything behind):
+//     top of tile t :  take over tile t's entries (loaded during tile t−1's ranking), convert them,
+//                      and at once issue tile t+1's loads into the registers that just became free;
+//     rank / prefix / reorder in LDS   (≈18 k cycles; tile t+1's loads and tile t−1's stores in flight);
+//     stream tile t out: TR_PER (×2 in the last pass) UNCONDITIONAL stores per thread.
+// vmcnt retires in order on gfx9, and the loads of tile t+1 are older than the stores of tile t, so the
+// first use of a loaded register at the top of tile t+1 needs only vmcnt(number of stores) — which the
+// compiler can only know if that number is the same on every path: the stores carry no predicate (lanes
+// beyond a short tile's end repeat its last entry: same address, same bytes), and a workgroup's loop
+// ENDS at its first empty tile (empty tiles exist only behind the last used one).  With a predicated
+// store loop every tile began with s_waitcnt vmcnt(0): load latency, then the drain of 64 KB of stores,
+// then the ranking, one after the other (measured 47 k cycles per tile, 29 k of them in that wait).
+// ---------------------------------------------------------------------------------------------
+template <bool FIRST, bool LAST>
+__global__ __launch_bounds__(TR_THREADS) void tr_scatter_staged_kernel(TrArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nb = 1 << a.bits;
+  unsigned short* cntw = reinterpret_cast<unsigned short*>(smem);  // [TR_WAVES][nb]
+  int* binstart = reinterpret_cast<int*>(smem + (size_t)TR_WAVES * nb * 2);  // [nb] tile-local start of a digit
+  int* gadj = binstart + nb;                                                  // [nb] global offset − binstart
+  uint2* sorted = reinterpret_cast<uint2*>(gadj + nb);                        // [TR_TILE]
+  unsigned short* sorted_d = reinterpret_cast<unsigned short*>(sorted + TR_TILE);  // [TR_TILE]
+  unsigned* rowid = reinterpret_cast<unsigned*>(sorted_d + TR_TILE);               // [TR_TILE] (FIRST)
+  __shared__ int wsum[16];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned mask = (unsigned)nb - 1u;
+  const unsigned rmask = (1u << a.row_bits) - 1u;
+  unsigned short* mycnt = cntw + wave * nb;
+  constexpr int GPT = 1;  // nb ≤ 1024 = TR_THREADS: one digit per thread in the prefix phase
+
+  // the tile in flight: raw words (first pass: column, value bits; later: the packed entry) + its metadata
+  unsigned rx[TR_PER], ry[TR_PER];
+  int n_goff = 0, n_len = 0, n_row_lo = 0, n_row_hi = 0, n_rp0 = 0, n_rp1 = 0;
+  long n_start = 0;
+  // All loads are UNCONDITIONAL (indices clamped into the tile): the compiler's wait for a loaded register is
+  // vmcnt(number of younger memory operations on EVERY path), so one predicated load or store turns the
+  // waits below into vmcnt(0).
+  const int last_slot = a.batch * (a.M + 1) - 1;
+  auto fetch = [&](int t) {
+    if (a.desc) {
+      const int2 d = sload(a.desc + t);
+      n_start = d.x;
+      n_len = d.y;
+    } else {
+      n_start = (long)t * TR_TILE;
+      const long rest = a.nnz - n_start;
+      n_len = rest < TR_TILE ? (int)rest : TR_TILE;
+    }
+    if (FIRST) {
+      // rows come from LDS later (rowid); lane l of wave w prefetches the bounds of row row_lo + 16·l + w
+      n_row_lo = sload(a.tile_row + t);
+      n_row_hi = sload(a.tile_row + t + 1);
+      int r = n_row_lo + lane * TR_WAVES + wave;
+      r = r < n_row_hi ? r : n_row_hi;
+      n_rp0 = a.rowptr[r];
+      n_rp1 = a.rowptr[r < last_slot ? r + 1 : last_slot];
+    }
+#pragma unroll
+    for (int c = 0; c < TR_PER; ++c) {
+      int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
+      i = i < n_len ? i : 0;
+      if (FIRST) {
+        rx[c] = (unsigned)a.col[n_start + i];
+        ry[c] = __builtin_bit_cast(unsigned, a.val[n_start + i]);
+      } else {
+        const uint2 w = a.in_packed[n_start + i];
+        rx[c] = w.x;
+        ry[c] = w.y;
+      }
+    }
+    n_goff = a.table[(long)t * nb + (tid & (nb - 1))];
+  };
+
+  // XCD-aware tile order (see tr_scatter_kernel): every XCD walks a contiguous range of the tiles in use
+  const int ntiles = a.used_tiles ? sload(a.used_tiles) : a.ntiles;
+  int t = blockIdx.x, t_end = ntiles, t_step = gridDim.x;
+  if (gridDim.x == TR_GRID) {
+    const int per = (ntiles + 7) / 8, xcd = blockIdx.x & 7;
+    t = xcd * per + (blockIdx.x >> 3);
+    t_end = (xcd + 1) * per < ntiles ? (xcd + 1) * per : ntiles;
+    t_step = TR_GRID / 8;
+  }
+#ifdef MI_TR_TIMING
+  unsigned long long stamp_ = __builtin_readcyclecounter();
+#endif
+  if (t < t_end) {
+    fetch(t);
+    // the first tile's loads are complete before the loop is entered (an empty asm that "uses" them): the
+    // loop's waits must see the same pending state from here as from its own back edge
+#pragma unroll
+    for (int c = 0; c < TR_PER; ++c) asm volatile("" : "+v"(rx[c]), "+v"(ry[c]));
+    asm volatile("" : "+v"(n_goff), "+v"(n_rp0), "+v"(n_rp1));
+  }
+  for (; t < t_end; t += t_step) {
+    const int cur_len = n_len;  // block-uniform, ≥ 1: every tile below `ntiles` is in use
+    const long start = n_start;
+    const int row_lo = n_row_lo, row_hi = n_row_hi;
+    TR_STAMP(0);
+    for (int i = tid; i < TR_WAVES * nb / 2; i += TR_THREADS) reinterpret_cast<unsigned*>(cntw)[i] = 0u;
+    if (FIRST) {
+      // every row of the tile writes its flat index over its own entries (wave-uniform bounds, 64
+      // positions per instruction); each position of the tile belongs to exactly one row
+      const int rp0 = n_rp0, rp1 = n_rp1;
+      const long t_lo = start, t_hi = start + cur_len;
+      auto fill = [&](int r, long b, long en) {
+        b = b < t_lo ? t_lo : b;
+        en = en > t_hi ? t_hi : en;
+        for (long q = b + lane; q < en; q += 64) rowid[q - t_lo] = (unsigned)r;
+      };
+      const int span = row_hi - row_lo + 1;
+      for (int k = 0; k < 64 && k * TR_WAVES + wave < span; ++k)
+        fill(row_lo + k * TR_WAVES + wave, __builtin_amdgcn_readlane(rp0, k), __builtin_amdgcn_readlane(rp1, k));
+      for (int r = row_lo + 64 * TR_WAVES + wave; r <= row_hi; r += TR_WAVES)  // tiles spanning > 1024 rows
+        fill(r, a.rowptr[r], a.rowptr[r < last_slot ? r + 1 : last_slot]);
+    }
+    __syncthreads();  // counters zeroed, rows known; every thread is past the previous tile's LDS reads
+    Slot e[TR_PER];
+#pragma unroll
+    for (int c = 0; c < TR_PER; ++c) {
+      const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
+      e[c].a = 0u;
+      e[c].d = 0u;
+      e[c].val = __builtin_bit_cast(float, ry[c]);
+      if (i < cur_len) {
+        unsigned key, r;
+        if (FIRST) {
+          const unsigned idx = rowid[i];
+          key = rx[c];
+          r = idx;
+          if (a.batch > 1) {
+            const unsigned item = idx / (unsigned)(a.M + 1);
+            r = idx - item * (unsigned)(a.M + 1);
+            key += item * (unsigned)a.K;
+          }
+        } else {
+          key = rx[c] >> a.row_bits;
+          r = rx[c] & rmask;
+        }
+        e[c].d = (key >> a.shift) & mask;
+        const unsigned keep = a.drop_after_first ? (key >> a.bits) : key;  // two passes: the low digit is dropped
+        e[c].a = LAST ? r : ((keep << a.row_bits) | r);
+      }
+    }
+    const int goff = n_goff;
+    // the raw registers are free: the next tile's loads go out now and fly during this tile's ranking
+    if (t + t_step < t_end) fetch(t + t_step);
+    TR_STAMP(1);
+
+    // rank inside the wave: lanes holding the same digit ("peers") found with one ballot per digit
+    // bit; a lane's rank is the wave's running count of the digit + the number of peers below it
+#pragma unroll
+    for (int c = 0; c < TR_PER; ++c) {
+      const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
+      const bool valid = i < cur_len;
+      const unsigned d = e[c].d;
+      unsigned long long peers = __ballot(valid);
+      for (int b = 0; b < a.bits; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long m = __ballot(bit);
+        peers &= bit ? m : ~m;
+      }
+      const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0));
+      int base = 0;
+      if (valid) base = mycnt[d];
+      if (valid && below == 0) mycnt[d] = (unsigned short)(base + __builtin_popcountll(peers));
+      e[c].d = d | ((unsigned)(base + below) << 16);
+    }
+    TR_STAMP(2);
+    __syncthreads();
+    TR_STAMP(3);
+
+    // per digit: exclusive prefix over the waves (in place), tile total; then the exclusive scan of
+    // the totals over the digits and the digit's global offset
+    {
+      const int d = tid;
+      int tot = 0;
+      if (d < nb) {
+        int v[TR_WAVES];
+#pragma unroll
+        for (int w = 0; w < TR_WAVES; ++w) v[w] = cntw[w * nb + d];
+#pragma unroll
+        for (int w = 0; w < TR_WAVES; ++w) {
+          cntw[w * nb + d] = (unsigned short)tot;
+          tot += v[w];
+        }
+      }
+      int incl = tot;
+#pragma unroll
+      for (int s2 = 1; s2 < 64; s2 <<= 1) {
+        const int v = __shfl_up(incl, s2, 64);
+        if (lane >= s2) incl += v;
+      }
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      int wbase = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {
+        const int v = wsum[w];
+        if (w < wave) wbase += v;
+      }
+      if (d < nb) {
+        const int bs = wbase + incl - tot;
+        binstart[d] = bs;
+        gadj[d] = goff - bs;
+      }
+      __syncthreads();
+    }
+    static_assert(GPT == 1, "one digit per thread");
+
+    TR_STAMP(4);
+    // reorder the tile by digit in LDS …
+#pragma unroll
+    for (int c = 0; c < TR_PER; ++c) {
+      const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
+      if (i < cur_len) {
+        const unsigned d = e[c].d & 0xffffu;
+        const int s2 = binstart[d] + cntw[wave * nb + d] + (int)(e[c].d >> 16);
+        sorted[s2] = make_uint2(e[c].a, __builtin_bit_cast(unsigned, e[c].val));
+        sorted_d[s2] = (unsigned short)d;
+      }
+    }
+    TR_STAMP(5);
+    __syncthreads();
+    TR_STAMP(6);
+    // … and stream it out: each digit's entries leave as one contiguous run.  No predicate (see above).
+#pragma unroll
+    for (int k = 0; k < TR_PER; ++k) {
+      const int i0 = k * TR_THREADS + tid;
+      const int i = i0 < cur_len ? i0 : cur_len - 1;
+      const uint2 w = sorted[i];
+      const long dst = (long)gadj[sorted_d[i]] + i;
+      if (LAST) {
+        a.t_col[dst] = (int)w.x;
+        a.t_val[dst] = __builtin_bit_cast(float, w.y);
+      } else {
+        a.out_packed[dst] = w;  // plain stores: the runs of neighbouring tiles merge in the XCD's L2
+      }                         // (non-temporal stores measured 3.9 ms vs 2.6 ms for the whole transpose)
+    }
+    TR_STAMP(7);
   }
 }
 
@@ -726,15 +951,16 @@ int launch_scatter(const TrArgs& a, bool packed, bool staged, hipStream_t s) {
   size_t lds = (size_t)TR_WAVES * nb * 2 + (size_t)nb * 8;
   if (staged) lds += (size_t)TR_TILE * 8 + (size_t)TR_TILE * 2;
   if (FIRST) lds += (size_t)TR_TILE * 4;  // rowid
-#define MI_TR(P_, S_)                                                                                              \
+  const dim3 grid((unsigned)(a.ntiles < TR_GRID ? a.ntiles : TR_GRID));
+#define MI_TR(K_)                                                                                                  \
   do {                                                                                                             \
-    auto k = tr_scatter_kernel<FIRST, LAST, P_, S_>;                                                               \
+    auto k = K_;                                                                                                   \
     if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(k, dim3((unsigned)(a.ntiles < TR_GRID ? a.ntiles : TR_GRID)), dim3(TR_THREADS), lds, s, a);  \
+    hipLaunchKernelGGL(k, grid, dim3(TR_THREADS), lds, s, a);                                                       \
   } while (0)
-  if (packed && staged) MI_TR(true, true);
-  else if (packed) MI_TR(true, false);
-  else MI_TR(false, false);
+  if (packed && staged) MI_TR((tr_scatter_staged_kernel<FIRST, LAST>));
+  else if (packed) MI_TR((tr_scatter_kernel<FIRST, LAST, true>));
+  else MI_TR((tr_scatter_kernel<FIRST, LAST, false>));
 #undef MI_TR
   return mi::check_launch();
 }
@@ -807,6 +1033,7 @@ int transpose_impl(const int32_t* rowptr, const int32_t* col, const float* val, 
     a.drop_after_first = (p.drop && first) ? 1 : 0;
     a.table = tables[pass];
     a.desc = nullptr;
+    a.used_tiles = nullptr;
     a.ntiles = (int)p.ntiles0;
     if (!first) set_inter(pass - 1, true);
     if (!last) set_inter(pass, false);
@@ -815,6 +1042,7 @@ int transpose_impl(const int32_t* rowptr, const int32_t* col, const float* val, 
       hipLaunchKernelGGL(tr_bin_tiles_kernel, dim3(1), dim3(1024), 0, s, tables[0], 1 << p.bits[0], (long)nnz,
                          (int)p.ntiles_max[1], first_tile, desc);
       a.desc = desc;
+      a.used_tiles = first_tile + (1 << p.bits[0]);
       a.ntiles = (int)p.ntiles_max[1];
     }
     const int rows = a.ntiles + 1;
