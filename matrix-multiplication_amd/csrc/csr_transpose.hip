@@ -31,7 +31,7 @@ constexpr int TR_TILE = 8192;
 constexpr int TR_THREADS = 1024;
 constexpr int TR_WAVES = TR_THREADS / 64;
 constexpr int TR_PER = TR_TILE / TR_THREADS;  // entries per thread
-constexpr int TR_GROUPS = 64;                 // tile groups of the column-wise table scan
+constexpr int TR_GROUPS = 256;                // tile groups of the column-wise table scan
 constexpr int TR_GRID = 256;                  // persistent scatter workgroups: one per CU of an MI355X
 
 __host__ __device__ inline int bits_for(unsigned long long n) {  // bits needed for values 0 … n-1
@@ -69,6 +69,7 @@ struct TrArgs {
   int* t_col;
   float* t_val;
   unsigned* keys_out;  // three passes: full key per output position (row boundaries), else nullptr
+  uint2* dump;         // [2·TR_GRID]: where a workgroup's not-yet-existing previous tile "streams out" to
 };
 
 // flat rowptr index i (in [lo, hi]) of the row that holds entry e: the last i with rowptr[i] ≤ e.
@@ -209,61 +210,81 @@ __global__ __launch_bounds__(256) void tr_group_sums_kernel(const int* __restric
   const int per = (rows + TR_GROUPS - 1) / TR_GROUPS;
   const int t0 = blockIdx.x * per, t1 = t0 + per < rows ? t0 + per : rows;
   int s = 0;
-#pragma unroll 4
+#pragma unroll 8
   for (int t = t0; t < t1; ++t) s += table[(long)t * nb + d];
   gsum[blockIdx.x * nb + d] = s;
 }
 
-__global__ __launch_bounds__(1024) void tr_group_bases_kernel(int* __restrict__ gsum, int nb) {
-  // one workgroup: gsum[g][d] ← base[d] + Σ_{g' < g} gsum[g'][d]
-  __shared__ int wsum[16];
-  __shared__ int carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
+// One workgroup per 64 digits: wave w scans groups [w·G/16, (w+1)·G/16) of its digits (lane = digit),
+// the waves' partial sums meet in LDS.  gsum[g][d] ← Σ_{g' < g} gsum[g'][d];  dtot[d] ← Σ_g gsum[g][d].
+// (As one workgroup walking the groups one after the other this took 19–31 µs per pass.)
+__global__ __launch_bounds__(1024) void tr_group_bases_kernel(int* __restrict__ gsum, int nb, int* __restrict__ dtot) {
+  constexpr int PER = TR_GROUPS / 16;
+  __shared__ int part[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = blockIdx.x * 64 + lane;
+  int v[PER];
+  int tot = 0;
+  if (d < nb) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) v[u] = gsum[(wave * PER + u) * nb + d];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) tot += v[u];
+  }
+  part[wave][lane] = tot;
   __syncthreads();
-  for (int d0 = 0; d0 < nb; d0 += 1024) {
-    const int d = d0 + threadIdx.x;
-    int tot = 0;
-    if (d < nb) {
-      for (int g = 0; g < TR_GROUPS; ++g) {
-        const int v = gsum[g * nb + d];
-        gsum[g * nb + d] = tot;
-        tot += v;
-      }
+  int before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const int p = part[w][lane];
+    if (w < wave) before += p;
+    all += p;
+  }
+  if (d < nb) {
+    int run = before;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      gsum[(wave * PER + u) * nb + d] = run;
+      run += v[u];
     }
-    // exclusive scan of tot over the 1024 threads (+ carry from earlier chunks of digits)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) dtot[d] = all;
+  }
+}
+
+__global__ __launch_bounds__(256) void tr_apply_kernel(int* __restrict__ table, int rows, int nb,
+                                                       const int* __restrict__ gsum, const int* __restrict__ dtot) {
+  // base of this thread's digit: Σ dtot[d'] over d' < d (digits in chunks of 256, this block's chunk last)
+  __shared__ int wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int carry = 0, base = 0;
+  for (int c = 0; c <= (int)blockIdx.y; ++c) {
+    const int dd = c * 256 + threadIdx.x;
+    const int tot = dd < nb ? dtot[dd] : 0;
     int incl = tot;
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
       const int v = __shfl_up(incl, s, 64);
       if (lane >= s) incl += v;
     }
+    __syncthreads();
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     int wbase = 0, all = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
+    for (int w = 0; w < 4; ++w) {
       const int v = wsum[w];
       if (w < wave) wbase += v;
       all += v;
     }
-    const int base = carry_s + wbase + incl - tot;
-    if (d < nb)
-      for (int g = 0; g < TR_GROUPS; ++g) gsum[g * nb + d] += base;
-    __syncthreads();
-    if (threadIdx.x == 0) carry_s += all;
-    __syncthreads();
+    base = carry + wbase + incl - tot;
+    carry += all;
   }
-}
-
-__global__ __launch_bounds__(256) void tr_apply_kernel(int* __restrict__ table, int rows, int nb,
-                                                       const int* __restrict__ gsum) {
   const int d = blockIdx.y * 256 + threadIdx.x;
   if (d >= nb) return;
   const int per = (rows + TR_GROUPS - 1) / TR_GROUPS;
   const int t0 = blockIdx.x * per, t1 = t0 + per < rows ? t0 + per : rows;
-  int run = gsum[blockIdx.x * nb + d];
-#pragma unroll 4
+  int run = gsum[blockIdx.x * nb + d] + base;
+#pragma unroll 8
   for (int t = t0; t < t1; ++t) {
     const int v = table[(long)t * nb + d];
     table[(long)t * nb + d] = run;
@@ -334,10 +355,17 @@ __global__ __launch_bounds__(1024) void tr_bin_tiles_kernel(const int* __restric
 // tr_scatter_staged_kernel below.
 // ---------------------------------------------------------------------------------------------
 #ifdef MI_TR_TIMING
-__device__ unsigned long long g_tr_phase[16];
-#define TR_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g_tr_phase[k], now_ - stamp_); stamp_ = now_; } while (0)
+// per-phase cycle sums of wave 0 (tools/probes/tr_probe.cpp).  The sums are kept in scalar registers and
+// written once when the workgroup ends: an atomic per stamp sits in the same in-order memory queue as
+// the tile's loads and stores and slows exactly what is being measured.
+__device__ unsigned long long g_tr_phase[16];  // [0, 8): later passes, [8, 16): first pass
+#define TR_STAMP_INIT unsigned long long stamp_ = __builtin_readcyclecounter(), acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TR_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); acc_[k] += now_ - stamp_; stamp_ = now_; } while (0)
+#define TR_STAMP_FLUSH(first) do { if (threadIdx.x == 0) for (int k_ = 0; k_ < 8; ++k_) atomicAdd(&g_tr_phase[k_ + ((first) ? 8 : 0)], acc_[k_]); } while (0)
 #else
+#define TR_STAMP_INIT do {} while (0)
 #define TR_STAMP(k) do {} while (0)
+#define TR_STAMP_FLUSH(first) do {} while (0)
 #endif
 
 // An entry as the scatter kernel carries it: already in the form it leaves the pass in, plus its
@@ -434,9 +462,7 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_kernel(TrArgs a) {
     t_end = (xcd + 1) * per < a.ntiles ? (xcd + 1) * per : a.ntiles;
     t_step = TR_GRID / 8;
   }
-#ifdef MI_TR_TIMING
-  unsigned long long stamp_ = __builtin_readcyclecounter();
-#endif
+  TR_STAMP_INIT;
   if (t < t_end) fetch(t);
   for (; t < t_end; t += t_step) {
     const int cur_len = len;  // block-uniform
@@ -576,52 +602,65 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_kernel(TrArgs a) {
       if (t + t_step < t_end) fetch(t + t_step); else len = 0;
     }
   }
+  TR_STAMP_FLUSH(FIRST);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Staged scatter (8-byte entries, digits of ≤ 10 bits): the main path.  Same ranking and LDS reorder as
-// above, but software-pipelined over the tiles of a persistent workgroup so that the memory system and
-// the ranking work run side by side on ONE workgroup per CU (the tile fills the CU's LDS, so there is
-// no second workgroup to hide anything behind):
-//     top of tile t :  take over tile t's entries (loaded during tile t−1's ranking), convert them,
-//                      and at once issue tile t+1's loads into the registers that just became free;
-//     rank / prefix / reorder in LDS   (≈18 k cycles; tile t+1's loads and tile t−1's stores in flight);
-//     stream tile t out: TR_PER (×2 in the last pass) UNCONDITIONAL stores per thread.
-// vmcnt retires in order on gfx9, and the loads of tile t+1 are older than the stores of tile t, so the
-// first use of a loaded register at the top of tile t+1 needs only vmcnt(number of stores) — which the
-// compiler can only know if that number is the same on every path: the stores carry no predicate (lanes
-// beyond a short tile's end repeat its last entry: same address, same bytes), and a workgroup's loop
-// ENDS at its first empty tile (empty tiles exist only behind the last used one).  With a predicated
-// store loop every tile began with s_waitcnt vmcnt(0): load latency, then the drain of 64 KB of stores,
-// then the ranking, one after the other (measured 47 k cycles per tile, 29 k of them in that wait).
+// Staged scatter (8-byte entries, digits of ≤ 10 bits): the main path.  Same ranking as above, the tile
+// is then reordered by digit in LDS so that every digit's entries leave as one contiguous run.  One
+// workgroup fills a CU's LDS, so there is no second workgroup to hide memory time behind: the kernel is
+// software-pipelined over the tiles of a persistent workgroup instead.  While tile t is RANKED (the
+// issue-bound phase, ≈9 k cycles), each of its TR_PER steps also
+//     * streams out one slice of tile t−1 (still staged in LDS: `sorted`, `sorted_d`, `gadj` are not
+//       rewritten before tile t's prefix phase), and
+//     * loads one slice of tile t+1 into the raw registers tile t gave up when it was converted,
+// so loads, stores and ranking share the CU all the time and the vector-memory queue never holds more
+// than a slice per wave.  (Issued as blocks — all loads, then all stores — a tile's 64 KB of stores back
+// up the in-order memory pipeline and the next block of loads cannot even be ISSUED until they drain:
+// measured 35 k cycles per tile against ≈18 k of compute; before any pipelining 47 k.)
+// The compiler's waits: vmcnt retires in order on gfx9 and a wait is computed from the number of younger
+// memory operations on EVERY path, so all loads and stores here are unconditional — indices are clamped
+// into the tile (lanes beyond a short tile's end repeat its last entry: same address, same bytes; a
+// workgroup's first tile "streams out" to a dump slot) — and block-uniform metadata comes through the
+// scalar unit.  One predicated store turned every wait into vmcnt(0).
 // ---------------------------------------------------------------------------------------------
+#ifndef MI_TR_INTERLEAVE
+#define MI_TR_INTERLEAVE 1
+#endif
+// Where slice k of the previous tile streams out: 0 = top of the tile, 1+c = after ranking step c,
+// 9 / 10 = prefix phase before its first / second barrier.  (C3 shape, whole transpose, one box: all
+// eight as one block before the ranking 2.16 ms, one per ranking step 2.04 ms, spread over the three
+// phases 1.93–1.97 ms with ≈2 % between the spreads tried; boxes differ by more than that.)
+#ifndef MI_TR_SLICE_PLAN
+#define MI_TR_SLICE_PLAN {0, 0, 3, 7, 9, 9, 10, 10}
+#endif
+#ifndef MI_TR_ABL  // timing-only builds (tools/probes/tr_time.cpp): 1 = no global stores, 3 = no tile loads either
+#define MI_TR_ABL 0
+#endif
 template <bool FIRST, bool LAST>
 __global__ __launch_bounds__(TR_THREADS) void tr_scatter_staged_kernel(TrArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int nb = 1 << a.bits;
   unsigned short* cntw = reinterpret_cast<unsigned short*>(smem);  // [TR_WAVES][nb]
   int* binstart = reinterpret_cast<int*>(smem + (size_t)TR_WAVES * nb * 2);  // [nb] tile-local start of a digit
-  int* gadj = binstart + nb;                                                  // [nb] global offset − binstart
-  uint2* sorted = reinterpret_cast<uint2*>(gadj + nb);                        // [TR_TILE]
+  int* gadj2 = binstart + nb;  // [2][nb] global offset − binstart, of this tile and of the one streaming out
+  uint2* sorted = reinterpret_cast<uint2*>(gadj2 + 2 * nb);                   // [TR_TILE]
   unsigned short* sorted_d = reinterpret_cast<unsigned short*>(sorted + TR_TILE);  // [TR_TILE]
   unsigned* rowid = reinterpret_cast<unsigned*>(sorted_d + TR_TILE);               // [TR_TILE] (FIRST)
   __shared__ int wsum[16];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in a scalar register: loops over "my rows" stay scalar
   const unsigned mask = (unsigned)nb - 1u;
   const unsigned rmask = (1u << a.row_bits) - 1u;
   unsigned short* mycnt = cntw + wave * nb;
-  constexpr int GPT = 1;  // nb ≤ 1024 = TR_THREADS: one digit per thread in the prefix phase
+  const int last_slot = a.batch * (a.M + 1) - 1;
 
   // the tile in flight: raw words (first pass: column, value bits; later: the packed entry) + its metadata
   unsigned rx[TR_PER], ry[TR_PER];
   int n_goff = 0, n_len = 0, n_row_lo = 0, n_row_hi = 0, n_rp0 = 0, n_rp1 = 0;
   long n_start = 0;
-  // All loads are UNCONDITIONAL (indices clamped into the tile): the compiler's wait for a loaded register is
-  // vmcnt(number of younger memory operations on EVERY path), so one predicated load or store turns the
-  // waits below into vmcnt(0).
-  const int last_slot = a.batch * (a.M + 1) - 1;
-  auto fetch = [&](int t) {
+  auto fetch_meta = [&](int t) {
     if (a.desc) {
       const int2 d = sload(a.desc + t);
       n_start = d.x;
@@ -640,20 +679,55 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_staged_kernel(TrArgs a)
       n_rp0 = a.rowptr[r];
       n_rp1 = a.rowptr[r < last_slot ? r + 1 : last_slot];
     }
-#pragma unroll
-    for (int c = 0; c < TR_PER; ++c) {
-      int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
-      i = i < n_len ? i : 0;
-      if (FIRST) {
-        rx[c] = (unsigned)a.col[n_start + i];
-        ry[c] = __builtin_bit_cast(unsigned, a.val[n_start + i]);
-      } else {
-        const uint2 w = a.in_packed[n_start + i];
-        rx[c] = w.x;
-        ry[c] = w.y;
-      }
-    }
     n_goff = a.table[(long)t * nb + (tid & (nb - 1))];
+  };
+  // slice c of the NEXT tile's keys (first pass: columns; later: the whole packed entry) …
+  auto fetch_slice = [&](int c) {
+    int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
+    i = i < n_len ? i : 0;
+    if (MI_TR_ABL & 2) {
+      rx[c] = (unsigned)(i * 2654435761u) >> 7;
+      ry[c] = 0;
+      return;
+    }
+    if (FIRST) {
+      rx[c] = (unsigned)a.col[n_start + i];
+    } else {
+      const uint2 w = a.in_packed[n_start + i];
+      rx[c] = w.x;
+      ry[c] = w.y;
+    }
+  };
+  // … and, first pass only, slice c of the CURRENT tile's values: they are not needed before the tile is
+  // staged, so they are loaded one phase (not one tile) ahead and cost no second set of registers
+  auto fetch_values = [&](int c, long start, int len) {
+    int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
+    i = i < len ? i : 0;
+    if (MI_TR_ABL & 2) return;
+    ry[c] = __builtin_bit_cast(unsigned, a.val[start + i]);
+  };
+  // slice k of the tile staged in LDS (length plen) leaves; with no such tile (plen = 0) to the dump slot
+  int plen = 0;
+  const int* gadj_out = gadj2;  // offsets of the tile that is streaming out
+  constexpr int slice_at[TR_PER] = MI_TR_SLICE_PLAN;
+  auto store_slice = [&](int k) {
+    const int i0 = k * TR_THREADS + tid;
+    const int i = i0 < plen ? i0 : (plen > 0 ? plen - 1 : 0);
+    const uint2 w = sorted[i];
+    const long dst = (long)gadj_out[sorted_d[i] & mask] + i;
+    if (MI_TR_ABL & 1) {
+      asm volatile("" ::"v"(w.x), "v"(w.y), "v"(dst));
+      return;
+    }
+    if (LAST) {
+      int* pc = plen > 0 ? a.t_col + dst : reinterpret_cast<int*>(a.dump) + 4 * blockIdx.x;
+      float* pv = plen > 0 ? a.t_val + dst : reinterpret_cast<float*>(a.dump) + 4 * blockIdx.x + 1;
+      *pc = (int)w.x;
+      *pv = __builtin_bit_cast(float, w.y);
+    } else {
+      uint2* po = plen > 0 ? a.out_packed + dst : a.dump + 2 * blockIdx.x;
+      *po = w;  // plain stores: the runs of neighbouring tiles merge in the XCD's L2
+    }           // (non-temporal stores measured 3.9 ms vs 2.6 ms for the whole transpose)
   };
 
   // XCD-aware tile order (see tr_scatter_kernel): every XCD walks a contiguous range of the tiles in use
@@ -665,47 +739,61 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_staged_kernel(TrArgs a)
     t_end = (xcd + 1) * per < ntiles ? (xcd + 1) * per : ntiles;
     t_step = TR_GRID / 8;
   }
-#ifdef MI_TR_TIMING
-  unsigned long long stamp_ = __builtin_readcyclecounter();
-#endif
+  TR_STAMP_INIT;
   if (t < t_end) {
-    fetch(t);
+    fetch_meta(t);
+#pragma unroll
+    for (int c = 0; c < TR_PER; ++c) fetch_slice(c);
     // the first tile's loads are complete before the loop is entered (an empty asm that "uses" them): the
     // loop's waits must see the same pending state from here as from its own back edge
 #pragma unroll
-    for (int c = 0; c < TR_PER; ++c) asm volatile("" : "+v"(rx[c]), "+v"(ry[c]));
+    for (int c = 0; c < TR_PER; ++c) {
+      if (FIRST) asm volatile("" : "+v"(rx[c]));
+      else asm volatile("" : "+v"(rx[c]), "+v"(ry[c]));
+    }
     asm volatile("" : "+v"(n_goff), "+v"(n_rp0), "+v"(n_rp1));
   }
+  static_assert(TR_PER == 8, "MI_TR_SLICE_PLAN places eight slices");
+  static_assert(TR_GROUPS % 16 == 0, "tr_group_bases_kernel: sixteen waves share the groups");
+  int tile_no = 0;
   for (; t < t_end; t += t_step) {
     const int cur_len = n_len;  // block-uniform, ≥ 1: every tile below `ntiles` is in use
     const long start = n_start;
     const int row_lo = n_row_lo, row_hi = n_row_hi;
     TR_STAMP(0);
-    for (int i = tid; i < TR_WAVES * nb / 2; i += TR_THREADS) reinterpret_cast<unsigned*>(cntw)[i] = 0u;
+    int* gadj = gadj2 + ((tile_no & 1) ? nb : 0);
+#if MI_TR_INTERLEAVE
+#pragma unroll
+    for (int k = 0; k < TR_PER; ++k)
+      if (slice_at[k] == 0) store_slice(k);
+#endif
+    // every wave zeroes ITS counters (nobody else touches them between the prefix phase and here)
+    for (int i = lane; i < nb / 2; i += 64) reinterpret_cast<unsigned*>(mycnt)[i] = 0u;
     if (FIRST) {
       // every row of the tile writes its flat index over its own entries (wave-uniform bounds, 64
       // positions per instruction); each position of the tile belongs to exactly one row
       const int rp0 = n_rp0, rp1 = n_rp1;
-      const long t_lo = start, t_hi = start + cur_len;
-      auto fill = [&](int r, long b, long en) {
-        b = b < t_lo ? t_lo : b;
-        en = en > t_hi ? t_hi : en;
-        for (long q = b + lane; q < en; q += 64) rowid[q - t_lo] = (unsigned)r;
+      const int t_lo = (int)start;  // nnz < 2³¹: entry offsets fit an int
+      auto fill = [&](int r, int b, int en) {
+        b = (b < t_lo ? t_lo : b) - t_lo;
+        en = (en - t_lo > cur_len ? cur_len : en - t_lo);
+        for (int q = b + lane; q < en; q += 64) rowid[q] = (unsigned)r;
       };
       const int span = row_hi - row_lo + 1;
       for (int k = 0; k < 64 && k * TR_WAVES + wave < span; ++k)
         fill(row_lo + k * TR_WAVES + wave, __builtin_amdgcn_readlane(rp0, k), __builtin_amdgcn_readlane(rp1, k));
       for (int r = row_lo + 64 * TR_WAVES + wave; r <= row_hi; r += TR_WAVES)  // tiles spanning > 1024 rows
-        fill(r, a.rowptr[r], a.rowptr[r < last_slot ? r + 1 : last_slot]);
+        fill(r, sload(a.rowptr + r), sload(a.rowptr + (r < last_slot ? r + 1 : last_slot)));
+      __syncthreads();  // rows known
     }
-    __syncthreads();  // counters zeroed, rows known; every thread is past the previous tile's LDS reads
+    TR_STAMP(7);
     Slot e[TR_PER];
 #pragma unroll
     for (int c = 0; c < TR_PER; ++c) {
       const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
       e[c].a = 0u;
       e[c].d = 0u;
-      e[c].val = __builtin_bit_cast(float, ry[c]);
+      if (!FIRST) e[c].val = __builtin_bit_cast(float, ry[c]);
       if (i < cur_len) {
         unsigned key, r;
         if (FIRST) {
@@ -727,31 +815,68 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_staged_kernel(TrArgs a)
       }
     }
     const int goff = n_goff;
-    // the raw registers are free: the next tile's loads go out now and fly during this tile's ranking
-    if (t + t_step < t_end) fetch(t + t_step);
+    const bool more = t + t_step < t_end;  // block-uniform
+    if (more) fetch_meta(t + t_step);
     TR_STAMP(1);
 
-    // rank inside the wave: lanes holding the same digit ("peers") found with one ballot per digit
-    // bit; a lane's rank is the wave's running count of the digit + the number of peers below it
+    // Rank inside the wave.  A lane's rank among equal digits = the wave's running count of the digit
+    // (wave-private 16-bit LDS word: count in bits 0-9, ≤ 512) + the number of "peers" (lanes of this
+    // step with the same digit) below it.  With 1024 digits and 64 lanes most lanes have no peer, so
+    // the peers are found by collision instead of one ballot per digit bit: every lane tags its digit's
+    // word with its lane id (bits 10-15) and reads it back; a lane that reads another id has a peer.
+    // One ballot per COLLIDING digit value (≈2 per step for uniform digits) hands all its holders
+    // their peer mask.  Stable (ranks follow lane order), no atomics.
+    // Between the steps: one slice of the previous tile out, one slice of the next tile in.
+#if !MI_TR_INTERLEAVE
+    if (more) {
+#pragma unroll
+      for (int c = 0; c < TR_PER; ++c) fetch_slice(c);
+    }
+    if (FIRST) {
+#pragma unroll
+      for (int c = 0; c < TR_PER; ++c) fetch_values(c, start, cur_len);
+    }
+#pragma unroll
+    for (int c = 0; c < TR_PER; ++c) store_slice(c);
+#endif
 #pragma unroll
     for (int c = 0; c < TR_PER; ++c) {
       const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
       const bool valid = i < cur_len;
       const unsigned d = e[c].d;
-      unsigned long long peers = __ballot(valid);
-      for (int b = 0; b < a.bits; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const unsigned long long m = __ballot(bit);
-        peers &= bit ? m : ~m;
+      unsigned w0 = 0;
+      bool lost = false;
+      if (valid) {
+        w0 = mycnt[d] & 0x3ffu;
+        mycnt[d] = (unsigned short)(w0 | ((unsigned)lane << 10));
+        // the read-back must really go to LDS (to this thread alone it would be its own store)
+        asm volatile("" ::: "memory");
+        lost = (unsigned)(mycnt[d] >> 10) != (unsigned)lane;
+      }
+      unsigned long long coll = __ballot(lost);
+      unsigned long long peers = 0;  // the mask of a lane's peers, itself included; 0 = no peer
+      while (coll) {  // wave-uniform
+        const int holder = __builtin_ctzll(coll);
+        const unsigned dv = (unsigned)__builtin_amdgcn_readlane((int)d, holder);
+        const bool mine = valid && d == dv;
+        const unsigned long long m = __ballot(mine);
+        if (mine) peers = m;
+        coll &= ~m;
       }
       const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0));
-      int base = 0;
-      if (valid) base = mycnt[d];
-      if (valid && below == 0) mycnt[d] = (unsigned short)(base + __builtin_popcountll(peers));
-      e[c].d = d | ((unsigned)(base + below) << 16);
+      const int holders = __builtin_popcountll(peers);
+      if (valid && below == 0) mycnt[d] = (unsigned short)(w0 + (holders > 1 ? holders : 1));
+      e[c].d = d | ((w0 + (unsigned)below) << 16);
+#if MI_TR_INTERLEAVE
+#pragma unroll
+      for (int k = 0; k < TR_PER; ++k)
+        if (slice_at[k] == 1 + c) store_slice(k);
+      if (more) fetch_slice(c);
+      if (FIRST) fetch_values(c, start, cur_len);
+#endif
     }
     TR_STAMP(2);
-    __syncthreads();
+    __syncthreads();  // all counts in; every thread is past its reads of the previous tile's staging
     TR_STAMP(3);
 
     // per digit: exclusive prefix over the waves (in place), tile total; then the exclusive scan of
@@ -776,6 +901,11 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_staged_kernel(TrArgs a)
         if (lane >= s2) incl += v;
       }
       if (lane == 63) wsum[wave] = incl;
+#if MI_TR_INTERLEAVE
+#pragma unroll
+      for (int k = 0; k < TR_PER; ++k)
+        if (slice_at[k] == 9) store_slice(k);
+#endif
       __syncthreads();
       int wbase = 0;
 #pragma unroll
@@ -788,41 +918,39 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_staged_kernel(TrArgs a)
         binstart[d] = bs;
         gadj[d] = goff - bs;
       }
+#if MI_TR_INTERLEAVE
+#pragma unroll
+      for (int k = 0; k < TR_PER; ++k)
+        if (slice_at[k] == 10) store_slice(k);
+#endif
       __syncthreads();
     }
-    static_assert(GPT == 1, "one digit per thread");
 
     TR_STAMP(4);
-    // reorder the tile by digit in LDS …
+    // reorder the tile by digit in LDS; it streams out during the next tile's ranking
 #pragma unroll
     for (int c = 0; c < TR_PER; ++c) {
       const int i = wave * (TR_TILE / TR_WAVES) + c * 64 + lane;
       if (i < cur_len) {
         const unsigned d = e[c].d & 0xffffu;
         const int s2 = binstart[d] + cntw[wave * nb + d] + (int)(e[c].d >> 16);
-        sorted[s2] = make_uint2(e[c].a, __builtin_bit_cast(unsigned, e[c].val));
+        sorted[s2] = make_uint2(e[c].a, FIRST ? ry[c] : __builtin_bit_cast(unsigned, e[c].val));
         sorted_d[s2] = (unsigned short)d;
       }
     }
+    plen = cur_len;
+    gadj_out = gadj;
+    ++tile_no;
     TR_STAMP(5);
-    __syncthreads();
+    __syncthreads();  // the tile is staged (and, first pass: rowid may be refilled)
     TR_STAMP(6);
-    // … and stream it out: each digit's entries leave as one contiguous run.  No predicate (see above).
-#pragma unroll
-    for (int k = 0; k < TR_PER; ++k) {
-      const int i0 = k * TR_THREADS + tid;
-      const int i = i0 < cur_len ? i0 : cur_len - 1;
-      const uint2 w = sorted[i];
-      const long dst = (long)gadj[sorted_d[i]] + i;
-      if (LAST) {
-        a.t_col[dst] = (int)w.x;
-        a.t_val[dst] = __builtin_bit_cast(float, w.y);
-      } else {
-        a.out_packed[dst] = w;  // plain stores: the runs of neighbouring tiles merge in the XCD's L2
-      }                         // (non-temporal stores measured 3.9 ms vs 2.6 ms for the whole transpose)
-    }
-    TR_STAMP(7);
   }
+  // the last tile of this workgroup
+  if (plen > 0) {
+#pragma unroll
+    for (int k = 0; k < TR_PER; ++k) store_slice(k);
+  }
+  TR_STAMP_FLUSH(FIRST);
 }
 
 // Row offsets of Aᵀ, [batch][K+1] with global offsets, from the scanned tables (≤ 2 passes).
@@ -920,7 +1048,7 @@ TrPlan make_plan(int batch, int M, int K, long nnz) {
 }
 
 struct TrWs {
-  size_t inter[2], tables[3], gsum, tile_row, desc, first_tile, keys, total;
+  size_t inter[2], tables[3], gsum, tile_row, desc, first_tile, keys, dump, total;
 };
 
 TrWs ws_layout(const TrPlan& p, long nnz) {
@@ -936,11 +1064,12 @@ TrWs ws_layout(const TrPlan& p, long nnz) {
   w.inter[1] = take(p.passes >= 3 ? (size_t)nnz * entry : 0);
   for (int i = 0; i < 3; ++i)
     w.tables[i] = take(i < p.passes ? (size_t)(p.ntiles_max[i] + 1) * ((size_t)1 << p.bits[i]) * 4 : 0);
-  w.gsum = take((size_t)TR_GROUPS * 2048 * 4);
+  w.gsum = take((size_t)(TR_GROUPS + 1) * 2048 * 4);  // group sums + per-digit totals
   w.tile_row = take((size_t)(p.ntiles0 + 2) * 4);
   w.desc = take(p.passes == 2 ? (size_t)p.ntiles_max[1] * 8 : 0);
   w.first_tile = take(p.passes == 2 ? (((size_t)1 << p.bits[0]) + 1) * 4 : 0);
   w.keys = take(p.passes == 3 ? (size_t)nnz * 4 : 0);
+  w.dump = take((size_t)TR_GRID * 16);
   w.total = off;
   return w;
 }
@@ -949,7 +1078,7 @@ template <bool FIRST, bool LAST>
 int launch_scatter(const TrArgs& a, bool packed, bool staged, hipStream_t s) {
   const int nb = 1 << a.bits;
   size_t lds = (size_t)TR_WAVES * nb * 2 + (size_t)nb * 8;
-  if (staged) lds += (size_t)TR_TILE * 8 + (size_t)TR_TILE * 2;
+  if (staged) lds += (size_t)nb * 4 + (size_t)TR_TILE * 8 + (size_t)TR_TILE * 2;
   if (FIRST) lds += (size_t)TR_TILE * 4;  // rowid
   const dim3 grid((unsigned)(a.ntiles < TR_GRID ? a.ntiles : TR_GRID));
 #define MI_TR(K_)                                                                                                  \
@@ -998,6 +1127,7 @@ int transpose_impl(const int32_t* rowptr, const int32_t* col, const float* val, 
   a.t_col = t_col;
   a.t_val = t_val;
   a.keys_out = p.passes == 3 ? reinterpret_cast<unsigned*>(base + w.keys) : nullptr;
+  a.dump = reinterpret_cast<uint2*>(base + w.dump);
   int* gsum = reinterpret_cast<int*>(base + w.gsum);
   int* tables[3];
   for (int i = 0; i < 3; ++i) tables[i] = reinterpret_cast<int*>(base + w.tables[i]);
@@ -1058,8 +1188,9 @@ int transpose_impl(const int32_t* rowptr, const int32_t* col, const float* val, 
     }
     const dim3 sg(TR_GROUPS, (unsigned)((nb + 255) / 256));
     hipLaunchKernelGGL(tr_group_sums_kernel, sg, dim3(256), 0, s, tables[pass], rows, nb, gsum);
-    hipLaunchKernelGGL(tr_group_bases_kernel, dim3(1), dim3(1024), 0, s, gsum, nb);
-    hipLaunchKernelGGL(tr_apply_kernel, sg, dim3(256), 0, s, tables[pass], rows, nb, gsum);
+    int* dtot = gsum + (size_t)TR_GROUPS * 2048;
+    hipLaunchKernelGGL(tr_group_bases_kernel, dim3((unsigned)((nb + 63) / 64)), dim3(1024), 0, s, gsum, nb, dtot);
+    hipLaunchKernelGGL(tr_apply_kernel, sg, dim3(256), 0, s, tables[pass], rows, nb, gsum, dtot);
     int st = mi::check_launch();
     if (st != MI_OK) return st;
     if (first && last) st = launch_scatter<true, true>(a, p.packed, p.staged[pass], s);

@@ -33,9 +33,9 @@ int main() {
     hipDeviceSynchronize();
     unsigned long long ph[16];
     hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_tr_phase), sizeof(ph));
-    printf("status %d; cycles per workgroup (both scatter passes summed, /256 WGs, 100 MHz counter?):\n", st);
-    const char* names[] = {"fetch-wait/loop top", "zero+barrier", "rank", "barrier", "prefix", "stage", "barrier", "fetch issue", "output"};
-    for (int k = 0; k < 9; ++k) printf("  %-20s %12.1f\n", names[k], ph[k] / 256.0);
+    printf("status %d; cycles of wave 0 per workgroup (s_memtime), first pass | last pass:\n", st);
+    const char* names[] = {"loop top (load wait)", "convert+next meta", "rank", "barrier", "prefix", "stage", "barrier", "zero+rows+barrier"};
+    for (int k = 0; k < 8; ++k) printf("  %-22s %12.1f %12.1f\n", names[k], ph[8 + k] / 256.0, ph[k] / 256.0);
   }
   return 0;
 }
