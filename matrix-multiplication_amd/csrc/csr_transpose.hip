@@ -8,13 +8,17 @@
 // K·batch ≤ 2²⁰, e.g. the 1M × 1M matrix of BASELINE config C3), built for the memory system
 // rather than around a generic sort:
 //   * the entry travels as 8 bytes {remaining key bits | row, value}; the first pass reads the CSR
-//     arrays directly (row ids come from a bounded binary search in rowptr, no expanded row array)
-//     and the last pass writes t_col / t_val directly — no pack / unpack passes;
+//     arrays directly (row ids are filled into LDS row by row, no expanded row array, no per-entry
+//     search) and the last pass writes t_col / t_val directly — no pack / unpack passes;
 //   * a workgroup owns a tile of 8192 consecutive entries: 16 waves rank their 512 entries each with
-//     wave-private 16-bit LDS counters (ballot "peer" masks give the rank among equal digits, in
-//     entry order → stable, no atomics), the per-wave counts are prefixed per digit, the tile is
-//     reordered by digit in LDS and written out so that every digit's entries leave as one
-//     contiguous run;
+//     wave-private 16-bit LDS counters (a lane's rank = the counter + the number of lanes of the same
+//     step holding the same digit below it, found by collision: lanes tag the counter word with their
+//     id and read it back — in entry order → stable, no atomics), the per-wave counts are prefixed per
+//     digit, the tile is reordered by digit in LDS and written out so that every digit's entries
+//     leave as one contiguous run;
+//   * the scatter kernel is persistent and software-pipelined over its tiles: while a tile is ranked,
+//     the previous tile streams out of LDS and the next one is loaded, slice by slice (see
+//     tr_scatter_staged_kernel for what that takes from the compiler's wait counting);
 //   * per-(tile, digit) counts live in a tile-major table that is prefixed column-wise by three
 //     small launches (digit-major order of the scan, coalesced accesses);
 //   * for two passes the tiles of the last pass never straddle two low-digit bins, so the row
@@ -32,6 +36,10 @@ constexpr int TR_THREADS = 1024;
 constexpr int TR_WAVES = TR_THREADS / 64;
 constexpr int TR_PER = TR_TILE / TR_THREADS;  // entries per thread
 constexpr int TR_GROUPS = 256;                // tile groups of the column-wise table scan
+#ifndef MI_TR_COUNT_THREADS
+#define MI_TR_COUNT_THREADS 256
+#endif
+constexpr int TR_COUNT_THREADS = MI_TR_COUNT_THREADS;  // count kernel (512: same, 1024: first pass 133 -> 187 µs)
 constexpr int TR_GRID = 256;                  // persistent scatter workgroups: one per CU of an MI355X
 
 __host__ __device__ inline int bits_for(unsigned long long n) {  // bits needed for values 0 … n-1
@@ -147,11 +155,11 @@ __device__ __forceinline__ Entry load_entry(const TrArgs& a, long p, int row_lo,
 // the row that holds the tile's first entry (one thread's binary search, hidden behind the rest).
 // ---------------------------------------------------------------------------------------------
 template <bool FIRST, bool PACKED>
-__global__ __launch_bounds__(256) void tr_count_kernel(TrArgs a) {
+__global__ __launch_bounds__(TR_COUNT_THREADS) void tr_count_kernel(TrArgs a) {
   extern __shared__ int hist[];
   const int nb = 1 << a.bits;
   const int t = blockIdx.x;
-  for (int d = threadIdx.x; d < nb; d += 256) hist[d] = 0;
+  for (int d = threadIdx.x; d < nb; d += TR_COUNT_THREADS) hist[d] = 0;
   long start;
   int len;
   tile_bounds(a, t, start, len);
@@ -163,13 +171,13 @@ __global__ __launch_bounds__(256) void tr_count_kernel(TrArgs a) {
   __syncthreads();
   const unsigned mask = (unsigned)nb - 1u;
   if (FIRST && a.batch == 1) {
-    for (int i = threadIdx.x; i < len; i += 2048) {  // eight independent loads in flight per thread
+    for (int i = threadIdx.x; i < len; i += 8 * TR_COUNT_THREADS) {  // eight independent loads in flight per thread
       unsigned k[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) k[u] = i + u * 256 < len ? (unsigned)a.col[start + i + u * 256] : 0u;
+      for (int u = 0; u < 8; ++u) k[u] = i + u * TR_COUNT_THREADS < len ? (unsigned)a.col[start + i + u * TR_COUNT_THREADS] : 0u;
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (i + u * 256 < len) atomicAdd(&hist[(k[u] >> a.shift) & mask], 1);
+        if (i + u * TR_COUNT_THREADS < len) atomicAdd(&hist[(k[u] >> a.shift) & mask], 1);
     }
   } else if (FIRST) {
     // batched: the key includes the item, i.e. needs the row; two threads bound the tile's rows first
@@ -178,24 +186,24 @@ __global__ __launch_bounds__(256) void tr_count_kernel(TrArgs a) {
     if (threadIdx.x < 2 && len > 0)
       row_bounds[threadIdx.x] = row_of(a.rowptr, 0, last, (int)(threadIdx.x == 0 ? start : start + len - 1));
     __syncthreads();
-    for (int i = threadIdx.x; i < len; i += 256) {
+    for (int i = threadIdx.x; i < len; i += TR_COUNT_THREADS) {
       const Entry e = load_entry<true, PACKED>(a, start + i, row_bounds[0], row_bounds[1]);
       atomicAdd(&hist[(e.key >> a.shift) & mask], 1);
     }
   } else {
-    for (int i = threadIdx.x; i < len; i += 2048) {
+    for (int i = threadIdx.x; i < len; i += 8 * TR_COUNT_THREADS) {
       unsigned k[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        k[u] = i + u * 256 < len ? (PACKED ? (a.in_packed[start + i + u * 256].x >> a.row_bits) : a.in_key[start + i + u * 256]) : 0u;
+        k[u] = i + u * TR_COUNT_THREADS < len ? (PACKED ? (a.in_packed[start + i + u * TR_COUNT_THREADS].x >> a.row_bits) : a.in_key[start + i + u * TR_COUNT_THREADS]) : 0u;
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (i + u * 256 < len) atomicAdd(&hist[(k[u] >> a.shift) & mask], 1);
+        if (i + u * TR_COUNT_THREADS < len) atomicAdd(&hist[(k[u] >> a.shift) & mask], 1);
     }
   }
   __syncthreads();
   int* out = a.table + (long)t * nb;
-  for (int d = threadIdx.x; d < nb; d += 256) out[d] = hist[d];
+  for (int d = threadIdx.x; d < nb; d += TR_COUNT_THREADS) out[d] = hist[d];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -606,23 +614,29 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_kernel(TrArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Staged scatter (8-byte entries, digits of ≤ 10 bits): the main path.  Same ranking as above, the tile
-// is then reordered by digit in LDS so that every digit's entries leave as one contiguous run.  One
-// workgroup fills a CU's LDS, so there is no second workgroup to hide memory time behind: the kernel is
-// software-pipelined over the tiles of a persistent workgroup instead.  While tile t is RANKED (the
-// issue-bound phase, ≈9 k cycles), each of its TR_PER steps also
-//     * streams out one slice of tile t−1 (still staged in LDS: `sorted`, `sorted_d`, `gadj` are not
-//       rewritten before tile t's prefix phase), and
-//     * loads one slice of tile t+1 into the raw registers tile t gave up when it was converted,
-// so loads, stores and ranking share the CU all the time and the vector-memory queue never holds more
-// than a slice per wave.  (Issued as blocks — all loads, then all stores — a tile's 64 KB of stores back
-// up the in-order memory pipeline and the next block of loads cannot even be ISSUED until they drain:
-// measured 35 k cycles per tile against ≈18 k of compute; before any pipelining 47 k.)
+// Staged scatter (8-byte entries, digits of ≤ 10 bits): the main path.  The tile is ranked, then
+// reordered by digit in LDS so that every digit's entries leave as one contiguous run.  One workgroup
+// fills a CU's LDS, so there is no second workgroup to hide memory time behind: the kernel is
+// software-pipelined over the tiles of a persistent workgroup instead.  While tile t is processed,
+//     * tile t−1 streams out of LDS slice by slice — two slices at the top, some between the ranking
+//       steps, some in the prefix phase (`sorted`, `sorted_d` are rewritten only when tile t is staged;
+//       the per-digit offsets `gadj` are double-buffered), and
+//     * tile t+1 is loaded slice by slice between the ranking steps, into the raw registers tile t gave
+//       up when it was converted (first pass: its columns; the values of tile t itself are loaded one
+//       phase ahead, they are not needed before the tile is staged),
+// so loads, stores and ranking share the CU.  What it is up against (tools/probes/store_piece_probe.cpp,
+// tr_probe.cpp): the runs a tile leaves in are 32–64 bytes at arbitrary offsets, and an XCD's L2 accepts
+// such pieces at ≈5 per clock for its 32 CUs — ≈0.3 ms (first pass) and ≈0.46 ms (last pass: two 4-byte
+// arrays) for the C3 matrix whatever the kernel does; a wave whose store finds the queue full stalls
+// with its ranking work, so only the other waves' work overlaps.  Issued as blocks (all loads, then
+// all stores) a tile took 35 k cycles, 47 k before any pipelining, ≈26 k now.
 // The compiler's waits: vmcnt retires in order on gfx9 and a wait is computed from the number of younger
 // memory operations on EVERY path, so all loads and stores here are unconditional — indices are clamped
 // into the tile (lanes beyond a short tile's end repeat its last entry: same address, same bytes; a
-// workgroup's first tile "streams out" to a dump slot) — and block-uniform metadata comes through the
-// scalar unit.  One predicated store turned every wait into vmcnt(0).
+// workgroup's first tile "streams out" to a dump slot) — block-uniform metadata comes through the
+// scalar unit, and the first tile's loads are waited for before the loop.  One predicated store, or a
+// vector load of a tile descriptor, turned every wait into vmcnt(0): load latency, store drain and
+// ranking one after the other.
 // ---------------------------------------------------------------------------------------------
 #ifndef MI_TR_INTERLEAVE
 #define MI_TR_INTERLEAVE 1
@@ -1180,11 +1194,11 @@ int transpose_impl(const int32_t* rowptr, const int32_t* col, const float* val, 
     MI_HIP_TRY(hipMemsetAsync(tables[pass] + (size_t)a.ntiles * nb, 0, (size_t)nb * 4, s));
     const size_t hist_lds = (size_t)nb * 4;
     if (first) {
-      if (p.packed) hipLaunchKernelGGL((tr_count_kernel<true, true>), dim3((unsigned)a.ntiles), dim3(256), hist_lds, s, a);
-      else hipLaunchKernelGGL((tr_count_kernel<true, false>), dim3((unsigned)a.ntiles), dim3(256), hist_lds, s, a);
+      if (p.packed) hipLaunchKernelGGL((tr_count_kernel<true, true>), dim3((unsigned)a.ntiles), dim3(TR_COUNT_THREADS), hist_lds, s, a);
+      else hipLaunchKernelGGL((tr_count_kernel<true, false>), dim3((unsigned)a.ntiles), dim3(TR_COUNT_THREADS), hist_lds, s, a);
     } else {
-      if (p.packed) hipLaunchKernelGGL((tr_count_kernel<false, true>), dim3((unsigned)a.ntiles), dim3(256), hist_lds, s, a);
-      else hipLaunchKernelGGL((tr_count_kernel<false, false>), dim3((unsigned)a.ntiles), dim3(256), hist_lds, s, a);
+      if (p.packed) hipLaunchKernelGGL((tr_count_kernel<false, true>), dim3((unsigned)a.ntiles), dim3(TR_COUNT_THREADS), hist_lds, s, a);
+      else hipLaunchKernelGGL((tr_count_kernel<false, false>), dim3((unsigned)a.ntiles), dim3(TR_COUNT_THREADS), hist_lds, s, a);
     }
     const dim3 sg(TR_GROUPS, (unsigned)((nb + 255) / 256));
     hipLaunchKernelGGL(tr_group_sums_kernel, sg, dim3(256), 0, s, tables[pass], rows, nb, gsum);
