@@ -190,6 +190,12 @@ int mi_spmm_csr_colmajor_f32(const int32_t* rowptr, const int32_t* col,
  * Host-side decision (plan + a cost comparison), no GPU work; the result bits are the same either way. */
 int mi_spmm_colmajor_native_form(int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
                                  int64_t ldb, const float* C, int64_t ldc);
+/* Which form the executor takes (MI_LONG_ROWS_NONE): 1 = native (above); 2 = B transposed in, then the
+ * one-wave-per-row kernel writing C column-major from its epilogue (16 rows per workgroup meet in LDS and
+ * leave as 64-byte pieces) — no transposed copy of C; 0 = B transposed in, row-major kernel, C transposed
+ * out.  `workspace` is the executor's workspace (its address decides the vector width of the kernel). */
+int mi_spmm_colmajor_form(int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,
+                          const float* C, int64_t ldc, const void* workspace);
 int mi_spmm_csr_colmajor_ex_f32(const int32_t* rowptr, const int32_t* col,
                                 const float* val, int64_t nnz, int32_t M, int32_t K,
                                 int32_t N, const float* B, int64_t ldb, float* C,

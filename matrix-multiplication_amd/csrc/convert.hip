@@ -498,6 +498,16 @@ int mi_spmm_colmajor_native_form(int64_t nnz, int32_t M, int32_t K, int32_t N, c
   return 0.06 * t_slab < t_transposes ? 1 : 0;
 }
 
+int mi_spmm_colmajor_form(int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,
+                          const float* C, int64_t ldc, const void* workspace) {
+  if (mi_spmm_colmajor_native_form(nnz, M, K, N, B, ldb, C, ldc)) return 1;
+  if (nnz > 0 && K > 0 && M > 0 && N > 0 && workspace &&
+      mi::launch_spmm_wave_row_colmajor_out(nullptr, nullptr, nullptr, nnz, M, K, N, static_cast<const float*>(workspace),
+                                            N, nullptr, ldc, false, nullptr) == MI_OK)
+    return 2;
+  return 0;
+}
+
 int mi_spmm_csr_colmajor_ex_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                                 int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
                                 int64_t ldb, float* C, int64_t ldc, int long_rows, void* long_rows_workspace,
@@ -517,6 +527,11 @@ int mi_spmm_csr_colmajor_ex_f32(const int32_t* rowptr, const int32_t* col, const
   // column-major K×N with ldb  ==  row-major [N, ldb]; its transpose is [K, N].
   int st = launch_transpose(B, N, K, ldb, Bt, N, s);
   if (st != MI_OK) return st;
+  if (long_rows == MI_LONG_ROWS_NONE && nnz > 0 && K > 0) {
+    // one wave per row with the output transpose fused into its epilogue, where that is the plan
+    st = mi::launch_spmm_wave_row_colmajor_out(rowptr, col, val, nnz, M, K, N, Bt, N, C, ldc, true, s);
+    if (st <= MI_OK) return st;
+  }
   st = mi_spmm_csr_ex_f32(rowptr, col, val, nnz, M, K, N, Bt, N, nullptr, Ct, N, long_rows, long_rows_workspace,
                           long_rows_workspace_bytes, stream);
   if (st != MI_OK) return st;

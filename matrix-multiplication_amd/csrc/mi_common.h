@@ -38,6 +38,13 @@ int launch_spmm_slab(const int32_t* rowptr, const int32_t* col, const float* val
 int launch_spmm_slab_colmajor(const int32_t* rowptr, const int32_t* col, const float* val, const float* X, float* Y,
                               int32_t M, int32_t K, int32_t N, int64_t ldx, int64_t ldy, hipStream_t s);
 
+// spmm_csr.hip — one wave per row on row-major B with COLUMN-major output (the executor's output transpose
+// fused into the epilogue).  MI_OK = launched (or, with launch = false, "would launch"); 1 = AUTO would not
+// run the one-wave-per-row kernel here; negative = error.
+int launch_spmm_wave_row_colmajor_out(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
+                                      int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb, float* Ccm,
+                                      int64_t ldc, bool launch, hipStream_t s);
+
 }  // namespace mi
 
 #define MI_HIP_TRY(expr)                                  \

@@ -103,6 +103,82 @@ __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// The same chain, result written COLUMN-major (Ccm[n·ldc + m]) — the column-major executor's output
+// transpose fused into the epilogue (convert.hip: mi_spmm_csr_colmajor_ex_f32).  16 waves = 16
+// consecutive rows per workgroup; the 16 × N results meet in LDS (rows padded by 4 floats: the four
+// row-quads a store instruction reads sit 16 banks apart) and leave as N pieces of 16 consecutive m
+// (64 bytes; one float4 per thread).  grid = ⌈M/16⌉, block = 1024, LDS = 16·(N+4)·4 bytes.
+// ---------------------------------------------------------------------------
+template <int T, int U>
+__global__ __launch_bounds__(1024) void spmm_wave_row_ct_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+    const float* __restrict__ B, float* __restrict__ Ccm, int M, long ldb, long ldc, int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) float ct_tile[];
+  constexpr int NP = 256 * T + 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const long m0 = (long)blockIdx.x * 16;
+  const long row = m0 + wave;
+  f32x4 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (row < M) {
+    const float* Bl = B + lane * 4;
+    int p = rowptr[row];
+    const int end = rowptr[row + 1];
+    for (; p + U <= end; p += U) {
+      int c[U];
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        c[u] = col[p + u];
+        v[u] = val[p + u];
+      }
+      f32x4 x[U][T];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float* src = Bl + (long)c[u] * ldb;
+#pragma unroll
+        for (int t = 0; t < T; ++t) x[u][t] = *reinterpret_cast<const f32x4*>(src + t * 256);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = fma4(v[u], x[u][t], acc[t]);
+      }
+    }
+    for (; p < end; ++p) {
+      const int c = col[p];
+      const float v = val[p];
+      const float* src = Bl + (long)c * ldb;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        acc[t] = fma4(v, *reinterpret_cast<const f32x4*>(src + t * 256), acc[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t) *reinterpret_cast<f32x4*>(ct_tile + wave * NP + t * 256 + lane * 4) = acc[t];
+  __syncthreads();
+  const int q = threadIdx.x & 3;
+  const long m = m0 + 4 * q;
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    const int n = (threadIdx.x >> 2) + 256 * i;
+    const float* src = ct_tile + (4 * q) * NP + n;
+    const f32x4 o = {src[0], src[NP], src[2 * NP], src[3 * NP]};
+    float* dst = Ccm + (long)n * ldc + m;
+    if (vec_ok && m + 3 < M) {
+      __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dst));
+    } else {
+      if (m < M) dst[0] = o.x;
+      if (m + 1 < M) dst[1] = o.y;
+      if (m + 2 < M) dst[2] = o.z;
+      if (m + 3 < M) dst[3] = o.w;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // One wave per row, N == 256, col/val fetched 64 at a time with one coalesced
 // vector load each and handed to the scalar unit with v_readlane.
 // ---------------------------------------------------------------------------
@@ -981,6 +1057,41 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
 }
 
 }  // namespace
+
+namespace mi {
+
+// Row-major B [K, ldb], COLUMN-major C (Ccm [N, ldc]): the one-wave-per-row plan with the output transpose
+// fused into its epilogue.  Returns MI_OK after launching, 1 when AUTO would not run the one-wave-per-row
+// kernel on this problem (the caller then takes its two-transposes form), a negative status on error.
+// Every row keeps the plain CSR-order chain (MI_LONG_ROWS_NONE).
+int launch_spmm_wave_row_colmajor_out(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
+                                      int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb, float* Ccm,
+                                      int64_t ldc, bool launch, hipStream_t s) {
+  // the plan of the row-major product this stands in for (C row-major with ldc = N, as the executor's Ct)
+  const Shape sh = classify(N, ldb, N, 0, 0, B, B);
+  const int variant = choose_variant(sh, nnz, 1, M, K, N, ldb);
+  if (variant != MI_SPMM_WAVE_ROW_U8) return 1;
+  if (!launch) return MI_OK;
+  const long blocks = ((long)M + 15) / 16;
+  if (blocks > 0x7fffffffL) return MI_ERANGE;
+  const int vec_ok = (ldc % 4 == 0) && aligned16(Ccm);
+  const size_t lds = (size_t)16 * (N + 4) * sizeof(float);
+#define MI_CT(T_, U_)                                                                                           \
+  do {                                                                                                          \
+    auto k = spmm_wave_row_ct_kernel<T_, U_>;                                                                   \
+    if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(1024), lds, s, rowptr, col, val, B, Ccm, M, (long)ldb,    \
+                       (long)ldc, vec_ok);                                                                      \
+  } while (0)
+  // T, U as launch_variant runs MI_SPMM_WAVE_ROW_U8
+  if (N == 256) MI_CT(1, 8);
+  else if (N == 512) MI_CT(2, 4);
+  else MI_CT(4, 2);
+#undef MI_CT
+  return check_launch();
+}
+
+}  // namespace mi
 
 extern "C" {
 

@@ -33,9 +33,9 @@ def lib(built):
 
 def test_header_declares_the_expected_entry_points():
     names = declared_functions()
-    assert len(names) >= 37, names
+    assert len(names) >= 38, names
     for must in ("mi_csr_transpose_batched_f32", "mi_csr_transpose_batched_workspace_bytes", "mi_spmm_long_rows_prepare",
-                 "mi_spmm_csr_colmajor_ex_f32", "mi_spmm_csr_ex_f32", "mi_spmm_auto_splits_long_rows", "mi_spmm_long_row_threshold", "mi_spmm_csr_f32", "mi_spmm_csr_batched_f32", "mi_spmm_csr_colmajor_f32", "mi_gemm_f32",
+                 "mi_spmm_csr_colmajor_ex_f32", "mi_spmm_colmajor_form", "mi_spmm_csr_ex_f32", "mi_spmm_auto_splits_long_rows", "mi_spmm_long_row_threshold", "mi_spmm_csr_f32", "mi_spmm_csr_batched_f32", "mi_spmm_csr_colmajor_f32", "mi_gemm_f32",
                  "mi_dense_to_csr_count", "mi_dense_to_csr_fill", "mi_csr_transpose_f32", "mi_sddmm_csr_f32",
                  "mi_coo_to_csr_host", "mi_dummy_kernel"):
         assert must in names

@@ -697,6 +697,47 @@ def test_column_major_executor_native_slab_form(cmm, capi, dev, oracle_mod, M, K
     cmm.cusparse_clean()
 
 
+@pytest.mark.parametrize("M,K,N,density", [(4096, 4096, 512, 0.05), (1003, 700, 256, 0.02), (530, 1200, 1024, 0.01),
+                                           (37, 64, 512, 0.3)])
+def test_column_major_executor_fused_output_form(cmm, capi, dev, oracle_mod, M, K, N, density):
+    """Where the one-wave-per-row plan serves the product, the executor transposes the activations in and the
+    kernel writes Y = Cᵀ [N, M] from its epilogue (16 rows per workgroup meet in LDS, 64-byte pieces out):
+    bit-identical to the CSR-order oracle — ragged M (scalar tail, M % 4 ≠ 0), empty rows, rows out of column
+    order; the transposed product with the cached Aᵀ is checked the same way."""
+    g = np.random.Generator(np.random.PCG64(M + N))
+    rowptr, col, val = oracle_mod.make_csr(M, K, density, seed=M % 89)
+    keep = np.ones(len(col), bool)
+    empties = [2, M // 3, M - 1]
+    for r in empties:
+        keep[rowptr[r]:rowptr[r + 1]] = False
+    lens = np.diff(rowptr)
+    lens[empties] = 0
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    col, val = col[keep].copy(), val[keep].copy() - 0.5
+    for r in (0, 7, M // 2):                             # a few rows out of column order
+        s0, e0 = rowptr[r], rowptr[r + 1]
+        perm = g.permutation(e0 - s0)
+        col[s0:e0], val[s0:e0] = col[s0:e0][perm], val[s0:e0][perm]
+    x = g.random((N, K), dtype=np.float32) - 0.5
+    cmm.cusparse_inspect(t(rowptr, dev), t(col, dev), t(val, dev), len(val), M, N, K, "fusedcm")
+    y = torch.full((N, M), float("nan"), device=dev)
+    d_x = t(x, dev)
+    probe_b, probe_c = torch.empty(K, N, device=dev), torch.empty(M, N, device=dev)
+    assert cmm.spmm_plan(len(val), M, K, probe_b, probe_c)[1] == "spmm_wave_row_kernel"
+    capi.mi_spmm_colmajor_form.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                           ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    assert capi.mi_spmm_colmajor_form(len(val), M, K, N, d_x.data_ptr(), K, y.data_ptr(), M, probe_b.data_ptr()) == 2
+    cmm.cusparse_mmul_opt(d_x, y, "fusedcm")
+    want = oracle_mod.spmm_csr_colmajor(rowptr, col, val, M, K, N, x).reshape(N, M)
+    assert np.array_equal(y.cpu().numpy(), want)
+    dy = g.random((N, M), dtype=np.float32) - 0.5
+    dx = torch.full((N, K), float("nan"), device=dev)
+    cmm.cusparse_mmul_opt_t(t(dy, dev), dx, "fusedcm")
+    t_rp, t_col, t_val = oracle_mod.csr_transpose(rowptr, col, val, M, K)
+    assert np.array_equal(dx.cpu().numpy(), oracle_mod.spmm_csr_colmajor(t_rp, t_col, t_val, K, M, N, dy).reshape(N, K))
+    cmm.cusparse_clean()
+
+
 def _dense_of(rowptr, col, val, M, K):
     A = np.zeros((M, K), np.float64)
     rows = np.repeat(np.arange(M), np.diff(rowptr))

@@ -8,8 +8,9 @@ PKG = Path(__file__).resolve().parent.parent / "matrix-multiplication_amd"
 sys.path.insert(0, str(PKG))
 import custom_mm  # noqa: E402
 lib = ctypes.CDLL(str(PKG / "libmi_spmm.so"))
-lib.mi_spmm_colmajor_native_form.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
-                                             ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+lib.mi_spmm_colmajor_form.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+FORMS = {0: "transposes", 1: "native slab", 2: "transpose in + fused column-major output"}
 dev = torch.device("cuda")
 
 
@@ -28,14 +29,14 @@ def timeit(fn, iters=10):
 
 g = torch.Generator(device=dev).manual_seed(0)
 for (M, K, N, d) in [(4096, 4096, 16384, 0.1), (4096, 4096, 16384, 0.2), (3072, 768, 16384, 0.1), (768, 3072, 16384, 0.1),
-                     (4096, 4096, 4096, 0.1), (4096, 4096, 512, 0.05)]:
+                     (4096, 4096, 4096, 0.1), (4096, 4096, 512, 0.05), (3072, 768, 1024, 0.02), (4096, 4096, 256, 0.02)]:
     w = torch.rand(M, K, device=dev, generator=g) * (torch.rand(M, K, device=dev, generator=g) < d)
     vals, cols, offs = custom_mm.dense_to_csr(w)
     nnz = vals.numel()
     custom_mm.cusparse_inspect(offs.view(-1), cols, vals, nnz, M, N, K, "w")
     x = torch.rand(N, K, device=dev, generator=g)
     y = torch.empty(N, M, device=dev)
-    native = lib.mi_spmm_colmajor_native_form(nnz, M, K, N, x.data_ptr(), K, y.data_ptr(), M)
+    form = lib.mi_spmm_colmajor_form(nnz, M, K, N, x.data_ptr(), K, y.data_ptr(), M, x.data_ptr())
     t_exec = timeit(lambda: custom_mm.cusparse_mmul_opt(x, y, "w"))
     xt = x.t().contiguous()
     c = torch.empty(M, N, device=dev)
@@ -43,6 +44,6 @@ for (M, K, N, d) in [(4096, 4096, 16384, 0.1), (4096, 4096, 16384, 0.2), (3072, 
     t_row = timeit(lambda: custom_mm.naive_spmm_ex(vals, cols, offs.view(-1), nnz, M, K, xt, c, 0))
     t_tr = timeit(lambda: (x.t().contiguous(), c.t().contiguous()))
     t_dense = timeit(lambda: torch.matmul(x, w.t(), out=y))
-    print(f"{M}x{K} d={d} N={N}: plan {plan}, form {'native' if native else 'transposes'}; cusparse_mmul_opt {t_exec:.3f} ms; "
+    print(f"{M}x{K} d={d} N={N}: plan {plan}, form {FORMS[form]}; cusparse_mmul_opt {t_exec:.3f} ms; "
           f"row-major kernel alone {t_row:.3f}; two torch transposes {t_tr:.3f}; dense torch {t_dense:.3f}", flush=True)
     custom_mm.cusparse_clean()
