@@ -653,6 +653,138 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
   static_for<PHASES>([&](auto P_) { phase(std::integral_constant<int, CHAIN - 1>{}, P_); });
 }
 
+// ---------------------------------------------------------------------------------------------
+// Aᵀ·B with few output tiles and a long k (the weight gradient of an FC layer, dYᵀ·x: m = 3072, n = 768,
+// k = 16384 at BERT-base): every output element is ONE k-ordered chain (that is what makes the result
+// bit-identical to the oracle), so k cannot be split, and 128×128 tiles give 144 workgroups for 256 CUs —
+// 64×64 tiles 576, 2.25 per CU.  96×96 tiles give exactly 256.  A 96×96 tile does not divide into four
+// waves' worth of 32×32 MFMA blocks, but into 36 blocks of 16×16: v_mfma_f32_16x16x4_f32 is the same
+// k-ordered fmaf chain (tools/probes/mfma16_probe.cpp: 0 of 2²⁰ results differ) at the same flop rate,
+// nine blocks (48×48) per wave.  Both operands are contiguous along m / n ([k][m], [k][n]): k-chunks of 32
+// rows go through LDS as they lie in memory (row stride 112 floats: the four k-rows an operand read
+// touches sit 16 banks apart), double-buffered, one barrier per chunk; the next chunk's six float4 per
+// thread are loaded before the chunk's 72 MFMAs and stored after them.  The MFMA operands are swapped
+// (D = Bᵀ-block × A-block), so a lane's four accumulator registers are four consecutive n: 16-byte stores.
+// Whole tiles only (m, n multiples of 96, k of 64, 16-byte aligned rows): pick_tile() checks.
+// ---------------------------------------------------------------------------------------------
+constexpr int T16_TILE = 96, T16_KC = 32, T16_LD = 112;
+
+__global__ __launch_bounds__(256) void gemm_f32_t16_tn_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int k, long lda, long ldb,
+    long ldc, long strideA, long strideB, long strideC, int tiles_n, int tiles_per_item, int reverse) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2][T16_KC * T16_LD];  // [buffer][operand][k][m or n]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-contiguous work ids, 8-tile column groups: as gemm_f32_kernel
+  const unsigned total = gridDim.x, bid = blockIdx.x;
+  const unsigned q = total / 8, rem = total % 8, xcd = bid % 8, pos = bid / 8;
+  const unsigned work0 = xcd * q + (xcd < rem ? xcd : rem) + pos;
+  const unsigned work = reverse ? total - 1u - work0 : work0;
+  const long item = work / tiles_per_item;
+  const int tile = work % tiles_per_item;
+  int tile_m, tile_n;
+  tile_coords(tile, tiles_n, tiles_per_item / tiles_n, tile_m, tile_n);
+  const float* Ap = A + item * strideA + (long)tile_m * T16_TILE;  // A stored [k][m]
+  const float* Bp = B + item * strideB + (long)tile_n * T16_TILE;  // B stored [k][n]
+
+  f32x4 acc[3][3];  // [n block][m block]: register r ↔ n = 16·nb + 4·(lane>>4) + r, m = 16·mb + (lane&15)
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // a chunk of an operand: 32 rows × 24 float4; thread t takes float4 t, t + 256, t + 512.  Two register
+  // sets: chunk c+2 is loaded while chunk c is multiplied and goes to LDS after chunk c+1's MFMAs, so a
+  // load has two chunks' time (≈2 µs) to land; with one set (one chunk ahead) the kernel waited on memory
+  // a third of the time.  The loads carry no predicate (past the end: the last chunk again), so the
+  // compiler's wait before a store to LDS is vmcnt(6), not vmcnt(0).
+  f32x4 ra[2][3], rb[2][3];
+  const int chunks = k / T16_KC;
+  auto load_chunk = [&](int set, int c) {
+    const int k0 = (c < chunks ? c : chunks - 1) * T16_KC;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int j = tid + 256 * i, row = j / 24, c4 = j % 24;
+      if (MI_GEMM_ABL & 4) {
+        ra[set][i] = rb[set][i] = f32x4{1.f, 2.f, 3.f, (float)k0};
+        continue;
+      }
+      ra[set][i] = *reinterpret_cast<const f32x4*>(Ap + (long)(k0 + row) * lda + 4 * c4);
+      rb[set][i] = *reinterpret_cast<const f32x4*>(Bp + (long)(k0 + row) * ldb + 4 * c4);
+    }
+  };
+  auto store_chunk = [&](int set, int buf) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int j = tid + 256 * i, row = j / 24, c4 = j % 24;
+      *reinterpret_cast<f32x4*>(&lds[buf][0][row * T16_LD + 4 * c4]) = ra[set][i];
+      *reinterpret_cast<f32x4*>(&lds[buf][1][row * T16_LD + 4 * c4]) = rb[set][i];
+    }
+  };
+  const int lk = lane >> 4, lc = lane & 15;
+  // operand reads run one k-step (4 k) ahead of the MFMAs, ACROSS the chunk boundary: the last step's nine
+  // MFMAs of a chunk are issued after the barrier and after the next chunk's first operand reads, so the
+  // matrix pipe has work while those reads are in flight (with the boundary exposed — LDS stores, barrier,
+  // read latency, then the first MFMA — the pipe idled ≈600 cycles per chunk of 2300)
+  float a[2][3], b[2][3];
+  auto read_ops = [&](int set, int buf, int kk) {
+    const float* as = &lds[buf][0][(kk * 4 + lk) * T16_LD + wm * 48 + lc];
+    const float* bs = &lds[buf][1][(kk * 4 + lk) * T16_LD + wn * 48 + lc];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (MI_GEMM_ABL & 8) {  // timing only: no LDS operand reads
+        a[set][i] = (float)(kk + i);
+        b[set][i] = (float)(set + i);
+        continue;
+      }
+      a[set][i] = as[16 * i];
+      b[set][i] = bs[16 * i];
+    }
+  };
+  auto mfma9 = [&](int set) {
+    if (MI_GEMM_ABL & 2) return;
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+      for (int mb = 0; mb < 3; ++mb)
+        acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[set][nb], a[set][mb], acc[nb][mb], 0, 0, 0);
+  };
+  // one chunk: steps 0 … 6 from LDS buffer `buf`, then the hand-over to the other buffer, then step 7
+  auto half = [&](int buf, int next_chunk_to_load, int set_load, int set_store) {
+    load_chunk(set_load, next_chunk_to_load);
+    __builtin_amdgcn_sched_barrier(0);  // left alone, hipcc sinks the loads behind the MFMAs, in front of the waits on them
+#pragma unroll
+    for (int kk = 0; kk < T16_KC / 4 - 1; ++kk) {
+      read_ops((kk + 1) & 1, buf, kk + 1);
+      mfma9(kk & 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    store_chunk(set_store, buf ^ 1);  // the next chunk (past the end: a copy of the last one that nobody multiplies)
+    __syncthreads();                  // it is in LDS; every wave is past its reads of this buffer
+    read_ops(0, buf ^ 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma9(1);  // step 7 of this chunk
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  load_chunk(0, 0);
+  store_chunk(0, 0);
+  load_chunk(1, 1);
+  __syncthreads();
+  read_ops(0, 0, 0);
+  for (int c = 0; c < chunks; c += 2) {  // an even number of chunks: one straight-line body (an exit between the
+    half(0, c + 2, 0, 1);                // halves lets the compiler sink the first half's loads past it)
+    half(1, c + 3, 1, 0);
+  }
+  if (MI_GEMM_ABL & 1) return;
+  float* Cp = C + item * strideC + ((long)tile_m * T16_TILE + wm * 48 + lc) * ldc + (long)tile_n * T16_TILE + wn * 48 + 4 * lk;
+#pragma unroll
+  for (int mb = 0; mb < 3; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+      __builtin_nontemporal_store(acc[nb][mb], reinterpret_cast<f32x4*>(Cp + (long)(16 * mb) * ldc + 16 * nb));
+}
+
 std::atomic<unsigned> g_launch_counter{0};  // one counter for every instantiation of launch()
 
 template <int BM, int BN, bool TA, bool TB>
@@ -727,6 +859,21 @@ int pick_tile(const float* A, const float* B, float* C, int m, int n, int k, lon
   // than leave CUs idle — the k order per element is the same for every tile shape.
   auto blocks_for = [&](int bm, int bn) { return (long)((m + bm - 1) / bm) * ((n + bn - 1) / bn) * batch; };
   const long want = 2L * 256;
+#ifndef MI_GEMM_NO_T16
+  if (TA && !TB && bias == nullptr && vecA && vecB && vecC && m % T16_TILE == 0 && n % T16_TILE == 0 &&
+      k % (2 * T16_KC) == 0 && k >= 16 * T16_KC && blocks_for(128, 128) < want) {
+    // few output tiles, long k: 96×96 tiles of 16×16 MFMA blocks when they fill the CUs better than any
+    // tile of 32×32 blocks does (see gemm_f32_t16_tn_kernel)
+    const long t96 = blocks_for(T16_TILE, T16_TILE);
+    const long rounds = (t96 + 255) / 256;
+    if (t96 <= 0x7fffffffL && 4 * t96 >= 3 * rounds * 256) {
+      const int rev = (int)(g_launch_counter.fetch_add(1, std::memory_order_relaxed) & 1u);
+      hipLaunchKernelGGL(gemm_f32_t16_tn_kernel, dim3((unsigned)t96), dim3(256), 0, s, A, B, C, k, lda, ldb, ldc, sA, sB,
+                         sC, n / T16_TILE, (m / T16_TILE) * (n / T16_TILE), rev);
+      return mi::check_launch();
+    }
+  }
+#endif
 #define MI_TILE(BM_, BN_) \
   return launch<BM_, BN_, TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, vecC, bias, s)
 #ifdef MI_GEMM_FORCE_TILE  // developer probes only

@@ -431,6 +431,26 @@ def test_gemm_bit_exact_vs_oracle(cmm, dev, oracle_mod, ta, tb, m, n, k):
     assert np.array_equal(C.cpu().numpy(), gemm_ref(oracle_mod, a, b, ta, tb))
 
 
+def test_gemm_few_tiles_long_k_96_tile_kernel_bit_exact(cmm, dev, oracle_mod):
+    """Aᵀ·B with few output tiles and a long k (an FC layer's weight gradient dYᵀ·x) runs on 96×96 tiles of
+    16×16 MFMA blocks — 256 workgroups at m = 3072, n = 768 instead of 144 — and stays the k-ordered chain:
+    bit-identical to the oracle, plain and batched (strided items)."""
+    g = np.random.Generator(np.random.PCG64(96))
+    dy = g.random((512, 3072), dtype=np.float32) - 0.5   # [k, m]
+    x = g.random((512, 768), dtype=np.float32) - 0.5     # [k, n]
+    C = torch.full((3072, 768), float("nan"), device=dev)
+    cmm.cublas_mmul(t(dy, dev), t(x, dev), C, True, False)
+    assert np.array_equal(C.cpu().numpy(), gemm_ref(oracle_mod, dy, x, True, False))
+    C2 = torch.full((768, 3072), float("nan"), device=dev)
+    cmm.cublas_mmul(t(x, dev), t(dy, dev), C2, True, False)
+    assert np.array_equal(C2.cpu().numpy(), gemm_ref(oracle_mod, x, dy, True, False))
+    a = g.random((4, 576, 768), dtype=np.float32) - 0.5  # four items, k = 576 = 18 chunks
+    b = g.random((4, 576, 768), dtype=np.float32) - 0.5
+    Cb = torch.full((4, 768, 768), float("nan"), device=dev)
+    cmm.cublas_bmm(t(a, dev), t(b, dev), Cb, 3, True, False)
+    assert np.array_equal(Cb.cpu().numpy(), gemm_ref(oracle_mod, a, b, True, False))
+
+
 def test_gemm_golden_and_batched(cmm, dev, golden, oracle_mod):
     for name in golden.cases("gemm"):
         c = golden.case(name)
