@@ -756,7 +756,9 @@ __global__ __launch_bounds__(256) void gemm_f32_t16_tn_kernel(
 #pragma unroll
     for (int kk = 0; kk < T16_KC / 4 - 1; ++kk) {
       read_ops((kk + 1) & 1, buf, kk + 1);
-      mfma9(kk & 1);
+      __builtin_amdgcn_sched_barrier(0);  // reads first: the scheduler otherwise moves them down to just before
+      mfma9(kk & 1);                      // their use, and the wave then waits out the LDS latency every step
+      __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
     store_chunk(set_store, buf ^ 1);  // the next chunk (past the end: a copy of the last one that nobody multiplies)
