@@ -177,7 +177,8 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()),
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--workload", args.workload, "--chunks", str(args.chunks), "--split", args.split]
+           "--workload", args.workload, "--chunks", str(args.chunks), "--split", args.split,
+           "--exchange", args.exchange]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
     env = dict(os.environ)
@@ -260,6 +261,9 @@ def main():
     ap.add_argument("--split", choices=["rows", "nnz"], default="rows",
                     help="N > 1: equal-row blocks (one all_gather_into_tensor per step) or nnz-balanced split "
                          "points (one in-place broadcast per owner and step)")
+    ap.add_argument("--exchange", choices=["auto", "allgather", "p2p"], default="auto",
+                    help="N > 1: how a step's blocks reach the other ranks — one RCCL collective, or direct sends to "
+                         "every peer (one xGMI link each); auto = both are tried before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -332,30 +336,35 @@ def main():
         local_bytes_alg = bytes_alg
     else:
         rp_t, col_t, val_t = torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val)
-        if auto_chunks:
+        auto_exchange = args.exchange == "auto"
+        if auto_chunks or auto_exchange:
             # Before anything is timed: how finely to cut a rank's rows is a trade between starting the
-            # first all-gather early (many chunks) and RCCL's efficiency on larger messages (few chunks); it
-            # depends on the node's fabric, so try the candidates for a few steps each and keep the fastest
-            # (max over ranks, so every rank decides alike).  Setup, like the warm-up: not in the timed region.
+            # first exchange early (many chunks) and RCCL's efficiency on larger messages (few chunks), and
+            # whether the collective or direct sends to every peer move the blocks faster depends on the
+            # node's fabric — so try the candidates for a few steps each and keep the fastest (max over
+            # ranks, so every rank decides alike).  Setup, like the warm-up: not in the timed region.
             chunk_trials = {}
-            for cand in ((2, 4) if world <= 2 else (2, 4, 8)):
-                trial = sharded.ShardedSpMM(rp_t, col_t, val_t, M, K, dev, chunks=cand, split=args.split)
-                Ct = trial.alloc_output(N)
-                for _ in range(2):
-                    trial.forward(B, out=Ct)
-                dist.barrier()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(3):
-                    trial.forward(B, out=Ct)
-                torch.cuda.synchronize()
-                tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                chunk_trials[cand] = float(tt) / 3 * 1e3
-                del trial, Ct
-            args.chunks = min(chunk_trials, key=chunk_trials.get)
+            chunk_cands = ((2, 4) if world <= 2 else (2, 4, 8)) if auto_chunks else (args.chunks,)
+            exch_cands = ("allgather", "p2p") if auto_exchange else (args.exchange,)
+            for exch in exch_cands:
+                for cand in chunk_cands:
+                    trial = sharded.ShardedSpMM(rp_t, col_t, val_t, M, K, dev, chunks=cand, split=args.split, exchange=exch)
+                    Ct = trial.alloc_output(N)
+                    for _ in range(2):
+                        trial.forward(B, out=Ct)
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        trial.forward(B, out=Ct)
+                    torch.cuda.synchronize()
+                    tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    chunk_trials[(exch, cand)] = float(tt) / 3 * 1e3
+                    del trial, Ct
+            args.exchange, args.chunks = min(chunk_trials, key=chunk_trials.get)
             torch.cuda.empty_cache()
-        op = sharded.ShardedSpMM(rp_t, col_t, val_t, M, K, dev, chunks=args.chunks, split=args.split)
+        op = sharded.ShardedSpMM(rp_t, col_t, val_t, M, K, dev, chunks=args.chunks, split=args.split, exchange=args.exchange)
         C = op.alloc_output(N)
 
         def step():
@@ -438,10 +447,12 @@ def main():
                 "sha256_rowptr_col_val": hashlib.sha256(rowptr.tobytes() + col.tobytes() + val.tobytes()).hexdigest()[:16],
                 "parallelism": "single GPU" if world == 1 else
                                f"A row-sharded over {world} GPUs ({args.split}-balanced blocks), block-cyclic "
-                               f"x{args.chunks}, RCCL all-gather of C",
+                               f"x{args.chunks}, " + ("RCCL all-gather of C" if args.exchange == "allgather" else
+                                                      "C exchanged by direct RCCL sends to every peer"),
                 "rccl_ranks": world if world > 1 else None,
                 "chunks": None if world == 1 else args.chunks,
-                "chunk_trials_ms_per_step": None if not chunk_trials else {str(c): round(v, 4) for c, v in chunk_trials.items()},
+                "exchange": None if world == 1 else args.exchange,
+                "chunk_trials_ms_per_step": None if not chunk_trials else {f"{e}/{c}": round(v, 4) for (e, c), v in chunk_trials.items()},
                 "collective_backend": None if world == 1 else ("gloo (rehearsal)" if rehearse else
                                                                 "rccl " + ".".join(str(x) for x in torch.cuda.nccl.version())),
                 "flops_per_step": flops, "algorithmic_bytes_per_step": bytes_alg,

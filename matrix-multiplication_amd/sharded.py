@@ -31,6 +31,15 @@ Two ways to cut the rows:
     [lower_bound(rowptr, i*nnz/nblocks), lower_bound(rowptr, (i+1)*nnz/nblocks)) —
     for skewed matrices; blocks have different heights, so a step's exchange is one
     in-place broadcast per owner (RCCL runs them back to back on its stream).
+
+Two ways to exchange a step's blocks:
+  * exchange="allgather": the collective above (RCCL picks its rings / trees);
+  * exchange="p2p": every rank sends its block straight to every peer and receives each peer's block
+    straight into its final position (one grouped batch of isend / irecv per step).  On a fully connected
+    xGMI node that uses each of the 7 peer links for exactly one shard at a time — the pattern SURVEY.md
+    §8e prices at a third of a ring's time; which one is faster on a given node is decided by timing
+    (bench.py tries both before its timed region).  Either split works: blocks of different heights
+    are just messages of different sizes.
 '''
 
 import numpy as np
@@ -77,14 +86,18 @@ class ShardedSpMM:
     :param rowptr, col, val: the FULL CSR of A (int32 / int32 / float32) on any
         device; only this rank's row blocks are kept (on `device`).
     :param split: "rows" (equal row counts) or "nnz" (nnz-balanced split points).
+    :param exchange: "allgather" (one collective per step) or "p2p" (direct sends to every peer).
     :param mm_op: 2-d kernel with the signature of ``custom_mm.naive_spmm`` (tests);
         default: ``custom_mm.naive_spmm_ex`` with the long-row rule of the whole problem.
     '''
 
     def __init__(self, rowptr, col, val, M, K, device, group=None, chunks=4, mm_op=None, split="rows",
-                 layout=None):
+                 layout=None, exchange="allgather"):
         if split not in ("rows", "nnz"):
             raise ValueError("split must be 'rows' or 'nnz'")
+        if exchange not in ("allgather", "p2p"):
+            raise ValueError("exchange must be 'allgather' or 'p2p'")
+        self.exchange = exchange
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -201,7 +214,19 @@ class ShardedSpMM:
             if not collective:
                 return
             first = j * self.world
-            if self.split == "rows":
+            if self.exchange == "p2p":
+                ops = []
+                for r in range(self.world):
+                    if r == self.rank:
+                        continue
+                    s0, s1 = int(self.bounds[first + r]), int(self.bounds[first + r + 1])
+                    if s1 > s0:
+                        ops.append(dist.P2POp(dist.irecv, out[s0:s1], self._src(r), group=self.group))
+                    if r1 > r0:
+                        ops.append(dist.P2POp(dist.isend, mine, self._src(r), group=self.group))
+                if ops:  # one group: the sends and receives of a step run side by side, one peer link each
+                    works.extend(dist.batch_isend_irecv(ops))
+            elif self.split == "rows":
                 span = out[int(self.bounds[first]):int(self.bounds[first + self.world])]
                 # in place: `mine` is span[rank*br : (rank+1)*br]; the collective is ordered after
                 # the kernel above (same stream) and runs beside the next step's kernel

@@ -89,7 +89,8 @@ def test_self_launch_builds_a_torchrun_child_and_relays_rank0(monkeypatch, capsy
 
     monkeypatch.setattr(bench.subprocess, "run", fake_run)
     monkeypatch.delitem(sys.modules, "torch", raising=False)
-    args = argparse.Namespace(gpus=4, steps=7, warmup=2, workload="c3", chunks=0, split="rows", no_cpu_baseline=True)
+    args = argparse.Namespace(gpus=4, steps=7, warmup=2, workload="c3", chunks=0, split="rows", exchange="auto",
+                              no_cpu_baseline=True)
     assert bench.self_launch(args) == 0
     cmd = seen["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]

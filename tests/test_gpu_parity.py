@@ -1541,12 +1541,21 @@ def test_bench_multi_gpu_path_rehearsal(dev):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and "REHEARSAL" in rec["data"]
     cfg = rec["config"]
-    assert cfg["rccl_ranks"] == 2 and cfg["chunks"] in (2, 4) and set(cfg["chunk_trials_ms_per_step"]) == {"2", "4"}
+    assert cfg["rccl_ranks"] == 2 and cfg["chunks"] in (2, 4) and cfg["exchange"] in ("allgather", "p2p")
+    assert set(cfg["chunk_trials_ms_per_step"]) == {"allgather/2", "allgather/4", "p2p/2", "p2p/4"}
     assert cfg["compute_only_ms_per_step"] > 0 and rec["value"] > 0 and "cpu_baseline" not in rec
     # and the nnz-balanced split (in-place broadcasts) through the same driver
     proc = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-                           "--workload", "c2", "--split", "nnz", "--chunks", "3"], capture_output=True, text=True,
-                          timeout=600, env=env)
+                           "--workload", "c2", "--split", "nnz", "--chunks", "3", "--exchange", "allgather"],
+                          capture_output=True, text=True, timeout=600, env=env)
     assert proc.returncode == 0, proc.stderr[-3000:]
     rec = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')][0])
     assert rec["config"]["chunks"] == 3 and "nnz-balanced" in rec["config"]["parallelism"]
+    assert rec["config"]["exchange"] == "allgather" and rec["config"]["chunk_trials_ms_per_step"] is None
+    # … and with direct sends to every peer
+    proc = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                           "--workload", "c2", "--split", "nnz", "--chunks", "2", "--exchange", "p2p"],
+                          capture_output=True, text=True, timeout=600, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    rec = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')][0])
+    assert rec["config"]["exchange"] == "p2p" and "direct RCCL sends" in rec["config"]["parallelism"]
