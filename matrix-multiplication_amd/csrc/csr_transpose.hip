@@ -433,9 +433,10 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_kernel(TrArgs a) {
       row_lo = a.tile_row[t];
       row_hi = a.tile_row[t + 1];
       const int r = row_lo + lane * TR_WAVES + wave;
-      if (r <= row_hi) {
+      if (r <= row_hi) {  // the last slot (row_hi of the last tile) has no successor: it holds no entry either
+        const int last_slot = a.batch * (a.M + 1) - 1;
         rp0 = a.rowptr[r];
-        rp1 = a.rowptr[r + 1];
+        rp1 = a.rowptr[r < last_slot ? r + 1 : last_slot];
       }
 #pragma unroll
       for (int c = 0; c < TR_PER; ++c) {
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_kernel(TrArgs a) {
         for (int k = 0; k < 64 && k * TR_WAVES + wave < span; ++k)
           fill(row_lo + k * TR_WAVES + wave, __builtin_amdgcn_readlane(rp0, k), __builtin_amdgcn_readlane(rp1, k));
         for (int r = row_lo + 64 * TR_WAVES + wave; r <= row_hi; r += TR_WAVES)  // tiles spanning > 1024 rows
-          fill(r, a.rowptr[r], a.rowptr[r + 1]);
+          fill(r, a.rowptr[r], a.rowptr[r < a.batch * (a.M + 1) - 1 ? r + 1 : r]);
       }
       __syncthreads();  // counters zeroed (rows known); the previous tile's LDS reads are complete
       if (FIRST) {
