@@ -496,15 +496,24 @@ bool spmm_dense_impl(const torch::Tensor& A, const torch::Tensor& B, const torch
     bias_ptr = bias_keep.data_ptr<float>();
   }
   if (batch == 0 || M == 0 || N == 0) return true;
-  if (!mi_spmm_dense_skip_supported((int32_t)N, K, N, N, Ac.data_ptr<float>(), Bc.data_ptr<float>(),
-                                    C.data_ptr<float>()) ||
-      (M * N) % 4 != 0 || (bias_ptr && (reinterpret_cast<uintptr_t>(bias_ptr) & 15u)))
+  // The kernel covers up to 256 columns; wider products (up to 1024 columns) run as column tiles of
+  // 256 — every column of C is its own chain, so the bits are the same — at the price of scanning A once
+  // per tile.  That keeps them free of the CSR route's host read-back (nnz sizes the CSR arrays), i.e.
+  // stream-ordered and graph-capturable; beyond 1024 columns the L2-blocked CSR plans are the better tool.
+  constexpr int64_t kTile = 256, kMaxN = 1024;
+  if (N > kMaxN || N % 4 != 0 || (M * N) % 4 != 0 || (bias_ptr && (reinterpret_cast<uintptr_t>(bias_ptr) & 15u)))
     return false;
+  for (int64_t n0 = 0; n0 < N; n0 += kTile)
+    if (!mi_spmm_dense_skip_supported((int32_t)std::min(kTile, N - n0), K, N, N, Ac.data_ptr<float>(),
+                                      Bc.data_ptr<float>() + n0, C.data_ptr<float>() + n0))
+      return false;
   c10::hip::HIPGuard guard(C.device().index());
-  check_status(mi_spmm_dense_skip_f32(Ac.data_ptr<float>(), std::max<int64_t>(K, 1), M * K, (int32_t)batch,
-                                      (int32_t)M, (int32_t)K, (int32_t)N, Bc.data_ptr<float>(), N, strideB, bias_ptr,
-                                      C.data_ptr<float>(), N, M * N, stream_of(C)),
-               what);
+  for (int64_t n0 = 0; n0 < N; n0 += kTile)
+    check_status(mi_spmm_dense_skip_f32(Ac.data_ptr<float>(), std::max<int64_t>(K, 1), M * K, (int32_t)batch,
+                                        (int32_t)M, (int32_t)K, (int32_t)std::min(kTile, N - n0),
+                                        Bc.data_ptr<float>() + n0, N, strideB, bias_ptr ? bias_ptr + n0 : nullptr,
+                                        C.data_ptr<float>() + n0, N, M * N, stream_of(C)),
+                 what);
   return true;
 }
 

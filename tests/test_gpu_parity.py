@@ -1185,6 +1185,7 @@ def test_fc_layer_modules_on_device(mm, dev):
     ((6, 512, 512), (6, 512, 64), 0.1),      # BERT-shaped: B[item] = 128 KiB → staged in LDS
     ((3, 100, 96), (96, 128), 0.2),          # one B shared by every item, LDS-staged
     ((2, 3, 64, 200), (2, 3, 200, 256), 1.0), ((4, 64, 0), (4, 0, 8), 0.5), ((1, 1), (1, 4), 1.0),
+    ((90, 300), (300, 512), 0.2), ((3, 70, 128), (3, 128, 300), 0.3), ((33, 65), (65, 1024), 0.5),   # column tiles of 256
 ])
 def test_fused_dense_skip_is_bit_identical_to_the_csr_route(cmm, dev, oracle_mod, shape_a, shape_b, density):
     g = np.random.Generator(np.random.PCG64(sum(shape_a) + sum(shape_b)))
@@ -1201,7 +1202,7 @@ def test_fused_dense_skip_is_bit_identical_to_the_csr_route(cmm, dev, oracle_mod
     expect = oracle_mod.spmm_csr_batched(rp, col, val, batch, M, K, bb).reshape(C.shape)
     assert np.array_equal(C.cpu().numpy(), expect)
     # widths the fused kernel does not cover are declined, not mis-computed
-    for n_bad in (7, 512):
+    for n_bad in (7, 1028):
         C2 = torch.empty(tuple(shape_a[:-1]) + (n_bad,), device=dev)
         assert cmm.naive_spmm_dense(t(a, dev), t(g.random(shape_b[:-1] + (n_bad,), dtype=np.float32), dev), C2) is False
 

@@ -299,3 +299,29 @@ def test_fc_layer_modules_host_logic(mm):
     fc_layers.sparse_forward_pays = _model
     names = [c[0] for c in fake.calls]
     assert "cublas_mmul_bias" in names and "naive_spmm_bias" in names and "dense_to_csr_fill" in names
+
+
+def test_dense_inputs_are_routed_by_shape(mm, monkeypatch):
+    """A dense A with zeros goes to the in-kernel zero-skipping product only where it beats dense→CSR + the CSR
+    kernels (one small matrix, batches of small / medium matrices) and to the CSR route for one large matrix
+    (the FC-layer call shape flattens to that) and for very long rows — tools/bench_skipwide.py."""
+    matmuls, fake = mm
+    assert matmuls.fused_skip_pays(1, 512, 512) and matmuls.fused_skip_pays(1, 1024, 1024)
+    assert not matmuls.fused_skip_pays(1, 2048, 2048) and not matmuls.fused_skip_pays(1, 16384, 768)
+    assert matmuls.fused_skip_pays(384, 512, 512) and matmuls.fused_skip_pays(16, 2048, 2048)
+    assert not matmuls.fused_skip_pays(4, 4096, 4096)
+    monkeypatch.setattr(fake, "fused_dense", True)
+    g = torch.Generator().manual_seed(3)
+
+    def route(a, b):
+        fake.calls.clear()
+        out = matmuls.naiveSpMM.apply(a, b)
+        assert torch.allclose(out, torch.matmul(a, b), rtol=1e-5, atol=1e-6)
+        return [c[0] for c in fake.calls if c[0].startswith("naive_spmm") or c[0] == "dense_to_csr"]
+
+    assert route(sparsify(g, 40, 30), rand(g, 30, 8)) == ["naive_spmm_dense"]                # one small matrix
+    monkeypatch.setattr(matmuls, "fused_skip_pays", lambda items, rows, cols: items > 1 and cols <= 16)
+    assert route(sparsify(g, 40, 30), rand(g, 30, 8)) == ["dense_to_csr", "naive_spmm"]      # "large": CSR route
+    assert route(sparsify(g, 3, 20, 30), rand(g, 30, 8)) == ["dense_to_csr", "naive_spmm"]   # FC call shape: flattened
+    assert route(sparsify(g, 3, 8, 12), rand(g, 3, 12, 4)) == ["naive_spmm_dense"]           # batch of small matrices
+    assert route(sparsify(g, 3, 8, 20), rand(g, 3, 20, 4)) == ["dense_to_csr", "naive_spmm_batched"]  # rows "too long"
