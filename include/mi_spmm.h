@@ -117,7 +117,8 @@ enum {
   MI_SPMM_GROUP_SCALAR = 5, /* any N / alignment: one float per lane                */
   MI_SPMM_WAVE_ROW_VL = 6,  /* wave per row, col/val via vector load + readlane     */
   MI_SPMM_PANELS_2 = 7,     /* N = 256: K cut into 2 column panels, one launch per   */
-  MI_SPMM_PANELS_3 = 8,     /*   panel (Infinity-Cache blocking of B); … 3 panels.   */
+  MI_SPMM_PANELS_3 = 8,     /*   panel (Infinity-Cache blocking of B ≥ 768 MiB; L2   */
+                            /*   blocking of 6 MiB < B ≤ 128 MiB with P ≈ |B| / 4 MiB); … 3 panels. */
                             /*   Rows whose columns descend somewhere are detected   */
                             /*   and summed in plain CSR order, so the result equals */
                             /*   the one-pass kernels' for every legal CSR input     */

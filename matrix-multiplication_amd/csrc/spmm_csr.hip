@@ -871,6 +871,26 @@ int coltile_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
   return tiles * 5 >= rounds * 8 * 4 ? panels : 0;
 }
 
+// L2-level panel blocking for N = 256 (one wave per row): when B is too large for the L2s (> 6 MiB) every
+// gathered row comes from the Infinity Cache or HBM and the one-pass kernels drop from ≈13 to ≈5 TFLOP/s.
+// Cutting K into P panels of ≈4 MiB (one launch per panel, all CUs on the same panel, C carried through
+// memory) keeps the gathers in L2 — the same mechanism as the two Infinity-Cache panels of config C3, one
+// level down.  Measured (tools/bench_plans.py, profiles/r02_plan_choice.log): 16384² × 256 at 10 %: 1.02 ms
+// with 4 panels vs 1.77 one-pass (slab 1.46); 8192 × 32768 × 256 at 10 %: 1.14 vs 1.83; 8192 × 65536 × 256
+// at 5 %: 1.50 (8 panels) vs 2.43; 8192 × 131072 × 256 at 1 %: 1.04 vs 1.27; at 0.5 % (82 non-zeros per row):
+// 0.091 vs 0.141; B = 4 MiB: one pass stays ahead.  N = 512 is left to the XCD-aware column tiles, which need
+// no second pass over C (16384² × 512 at 0.5 %: 0.150 ms vs 0.206 with panels) and to the slab plan.
+// Returns the number of panels (2, 3, 4, 5, 6 or 8), or 0 when the plan does not apply.
+int l2_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
+  if (N != 256) return 0;
+  const double b_bytes = (double)K * (double)ldb * 4.0;
+  if (b_bytes <= 6.0 * 1024 * 1024 || b_bytes > 128.0 * 1024 * 1024) return 0;
+  int p = (int)((b_bytes + (4 << 20) - 1) / (4 << 20));
+  p = p > 6 ? 8 : p;
+  while (p >= 2 && nnz < 8L * p * M) p = p > 6 ? 6 : p - 1;  // each pass carries C once: it needs work to pay for that
+  return p >= 2 ? p : 0;
+}
+
 struct Shape {
   bool vec4_ok, vec2_ok, wave_ok;
 };
@@ -901,6 +921,7 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
       nnz * (long)N >= 8 * b_elems)
     return MI_SPMM_PANELS_2;
   if (N < 4) return MI_SPMM_NARROW;
+  const int lp = (sh.wave_ok && batch == 1) ? l2_panels(M, K, N, ldb, nnz) : 0;
   // Moderate density: stage B through LDS (spmm_slab.hip) when its cost model beats the L2-blocked
   // row-split plans.  Fitted on MI355X (tools/bench_density.py, tools/bench_plans.py): a slab
   // workgroup (128 rows × 256 columns) spends ≈2.35 µs + 34 µs × density per 64-row slab of B, one
@@ -912,9 +933,20 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
     const double density = (double)nnz / ((double)M * (double)K);
     const double rounds = wgs <= 256.0 ? 1.0 : wgs / 256.0;  // beyond one wave of workgroups the tail averages out
     const double t_slab = rounds * (double)(((long)K + 63) / 64) * (2.35e-6 + 34e-6 * density);
-    const double t_rows = 2.0 * (double)nnz * (double)N / (N >= 512 ? 13e12 : 5e12);
+    // … and as much for narrower N while B (≤ 8 MiB) stays in the L2s: 16384 × 4096 × 256 at 10 %: row-split
+    // 0.25 ms (13.7 TFLOP/s) vs slab 0.38; 16384 × 768 × 128 at 30 %: 0.082 vs 0.164; the 5 TFLOP/s figure
+    // holds once B streams from the Infinity Cache or HBM (profiles/r02_plan_choice.log)
+    const bool b_in_l2 = (double)K * (double)ldb * 4.0 <= 8.0 * 1024 * 1024;
+    // with L2 panels the row-split plan gathers at the L2 rate and carries C (2·lp − 1) times
+    const double t_rows = lp > 0 ? 2.0 * (double)nnz * (double)N / 13e12 + (2.0 * lp - 1.0) * (double)M * (double)N * 4.0 / 4e12
+                                 : 2.0 * (double)nnz * (double)N / ((N >= 512 || b_in_l2) ? 13e12 : 5e12);
     // below ≈100 workgroups too few CUs have work for the model to hold
     if (wgs >= 96.0 && t_slab < t_rows) return MI_SPMM_SLAB;
+  }
+  if (lp > 0) {
+    static const int kVariantOf[9] = {0, 0, MI_SPMM_PANELS_2, MI_SPMM_PANELS_3, MI_SPMM_PANELS_4, MI_SPMM_PANELS_5,
+                                      MI_SPMM_PANELS_6, 0, MI_SPMM_PANELS_8};
+    return kVariantOf[lp];
   }
   if (sh.vec4_ok && batch == 1 && coltile_panels(M, K, N, ldb, nnz) > 0) return MI_SPMM_COLTILE_PANELS;
   if (sh.vec4_ok && batch == 1 && coltile_width(M, K, N, ldb) > 0) return MI_SPMM_COLTILE;

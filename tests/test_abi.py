@@ -137,7 +137,11 @@ def test_every_variant_id_has_a_kernel_name_and_the_plan_query_needs_no_gpu(lib)
     assert plan(100, 64, 64, 1) == 16                       # SpMV-like: narrow kernel
     assert plan(int(0.1 * 8192 * 8192), 8192, 8192, 8192) == 17   # pruned-weight density: LDS slabs
     assert plan(int(0.01 * 8192 * 8192), 8192, 8192, 8192) == 15  # 1 %: column tiles x row panels
-    assert plan(int(0.1 * 8192 * 8192), 8192, 8192, 256) == 2     # too few 128 x 256 blocks for the slab kernel
+    assert plan(int(0.1 * 8192 * 4096), 8192, 4096, 256) == 2     # too few 128 x 256 blocks for the slab kernel; B (4 MiB) in L2
+    assert plan(int(0.1 * 8192 * 8192), 8192, 8192, 256) == 7     # B = 8 MiB: two L2 panels
+    assert plan(int(0.1 * 16384 * 16384), 16384, 16384, 256) == 9  # B = 16 MiB: four L2 panels beat the slab plan
+    assert plan(40 * 16384, 16384, 16384, 256) == 9 and plan(20 * 16384, 16384, 16384, 256) == 7  # short rows: fewer passes
+    assert plan(8 * 16384, 16384, 16384, 256) == 2                 # too short to carry C at all
 
 
 def test_host_inspector_coo_to_csr(lib, golden, oracle_mod):

@@ -101,6 +101,28 @@ def test_spmm_every_variant_is_bit_identical(capi, dev, oracle_mod, M, K, N, den
     assert ran >= 2  # AUTO plus the generic kernel at least
 
 
+@pytest.mark.parametrize("M,K,N,density,panels", [(3000, 16384, 256, 0.01, 4), (2048, 24576, 256, 0.01, 6),
+                                                  (1500, 40000, 256, 0.004, 8), (4000, 8192, 256, 0.02, 2)])
+def test_spmm_auto_takes_l2_panels_for_mid_size_b(cmm, dev, oracle_mod, M, K, N, density, panels):
+    """B beyond the L2s (> 8 MiB) but far from the Infinity-Cache regime: AUTO cuts K into panels of about
+    4 MiB (one launch per panel, C carried) for N = 256 — still the CSR-order chain for every row,
+    rows whose columns do not ascend included (detected in the kernel and recomputed in plain order)."""
+    g = np.random.Generator(np.random.PCG64(M + K))
+    rowptr, col, val = oracle_mod.make_csr(M, K, density, seed=N)
+    col, val = col.copy(), val.copy() - 0.5
+    for r in (0, 9, M // 2, M - 1):
+        s0, e0 = rowptr[r], rowptr[r + 1]
+        perm = g.permutation(e0 - s0)
+        col[s0:e0], val[s0:e0] = col[s0:e0][perm], val[s0:e0][perm]
+    B = g.random((K, N), dtype=np.float32) - 0.5
+    d_B = t(B, dev)
+    C = torch.full((M, N), float("nan"), device=dev)
+    variant, name, launches, splits = cmm.spmm_plan(len(val), M, K, d_B, C)
+    assert name == "spmm_wave_row_panel_kernel" and launches == panels, (variant, name, launches)
+    cmm.naive_spmm(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, d_B, C)
+    assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr(rowptr, col, val, M, K, B))
+
+
 def test_spmm_edge_cases(cmm, dev, oracle_mod):
     # nnz = 0, empty rows at both ends, a row much longer than a wave, inf/nan must not leak from unused B rows
     M, K, N = 9, 70, 256
@@ -677,7 +699,7 @@ def test_inspect_handles_amortise_transpose_and_long_rows(cmm, dev, oracle_mod):
 
 
 @pytest.mark.parametrize("M,K,N,density,native", [(1024, 256, 4096, 0.5, True), (1100, 300, 4100, 0.6, True),
-                                                  (12301, 1030, 260, 0.25, False)])
+                                                  (12301, 1030, 516, 0.25, False)])
 def test_column_major_executor_native_slab_form(cmm, capi, dev, oracle_mod, M, K, N, density, native):
     """Where the LDS-slab plan serves the product, the column-major executor reads the activations
     X = Bᵀ [N, K] and writes Y = Cᵀ [N, M] directly (transposing slab loads, transposed tile store, no
