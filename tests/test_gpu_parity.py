@@ -433,6 +433,22 @@ def test_sddmm_bit_exact(cmm, dev, oracle_mod, N):
                                                                    Bw[:, N:].cpu().numpy()))
 
 
+@pytest.mark.parametrize("M,K,N,density", [(1500, 16384, 256, 0.02), (900, 40000, 256, 0.01), (700, 9000, 256, 0.05)])
+def test_sddmm_mid_size_b_runs_in_l2_panels_bit_exact(cmm, dev, oracle_mod, M, K, N, density):
+    """B beyond the L2s (6 MiB < |B| ≤ 128 MiB): SDDMM runs as up to 8 column-panel launches, every pattern
+    entry computed in exactly one of them by the same dot + tree — bit-exact against the oracle, rows out of
+    column order and empty rows included, every entry written."""
+    g = np.random.Generator(np.random.PCG64(M + N))
+    rowptr, col, val = oracle_mod.make_csr(M, K, density, seed=K % 97)
+    col = col.copy()
+    for r in (0, 5, M - 1):
+        s0, e0 = rowptr[r], rowptr[r + 1]
+        col[s0:e0] = g.permutation(col[s0:e0])
+    dC, B = g.random((M, N), dtype=np.float32) - 0.5, g.random((K, N), dtype=np.float32) - 0.5
+    got = cmm.sddmm(t(col, dev), t(rowptr, dev), len(col), M, K, t(dC, dev), t(B, dev))
+    assert np.array_equal(got.cpu().numpy(), oracle_mod.sddmm(rowptr, col, M, dC, B))
+
+
 # ------------------------------------------------------------------ GEMM ----
 
 def gemm_ref(oracle_mod, a, b, ta, tb):
