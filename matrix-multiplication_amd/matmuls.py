@@ -246,16 +246,19 @@ def _csr_of(a: torch.Tensor):
     return values, columns, offsets.view(-1), values.numel(), a.shape[-2], a.shape[-1]
 
 
-def fused_skip_pays(items: int, rows: int, cols: int) -> bool:
-    '''Dense A with zeros: the kernel that skips them in place (no CSR, no host read-back, one launch) against
-    dense→CSR + the CSR kernels.  Measured on MI355X (tools/bench_skipwide.py): the in-place kernel gives a wave
-    one row to scan, so it wins where launches and the read-back dominate or where the batched CSR kernel is the
-    alternative — one small matrix (512² 0.013 vs 0.054 ms, 1024² 0.043 vs 0.058), batches of small and medium
-    matrices (BERT's 384 × 512² 0.20 vs 0.32 ms, 16 × 2048² 0.19 vs 0.28) — and loses where one large matrix meets
-    the single-matrix CSR plans (2048² 0.145 vs 0.067 ms, 16384 × 768 0.39 vs 0.13, 4096² 0.50 vs 0.13) or the rows
-    are very long (4 × 4096² 0.59 vs 0.39).'''
+def fused_skip_pays(items: int, rows: int, cols: int, width: int = 256) -> bool:
+    '''Dense A with zeros: the kernel that skips them in place (no CSR, no host read-back, one launch per 256
+    output columns) against dense→CSR + the CSR kernels.  Measured on MI355X (tools/bench_skipwide.py,
+    benchmarks/random_tensor_benchmark.py): the in-place kernel gives a wave one row to scan, so it wins where
+    launches and the read-back dominate or where the batched CSR kernel is the alternative — one small matrix
+    (512² at 10 %: 0.013 vs 0.054 ms), batches of small and medium matrices (BERT's 384 × 512²: 0.20 vs 0.32 ms at
+    10 % kept, 0.91 vs 1.35 fully dense; 16 × 2048²: 0.19 vs 0.28) — and loses where one large matrix meets the
+    single-matrix CSR plans (2048² 0.145 vs 0.067 ms, 16384 × 768 0.39 vs 0.13, 4096² 0.50 vs 0.13), where the rows
+    are very long (4 × 4096²: 0.59 vs 0.39), and on a single matrix the denser and wider it gets: what it can win
+    there is a launch and a read-back (≈40 µs), what it can lose is unbounded (1024² fully dense × 1024 columns:
+    1.2 vs 0.25 ms) — so a single matrix takes it only when tiny.'''
     if items <= 1:
-        return rows * cols <= 1536 * 1024
+        return rows * cols * -(-width // 256) <= 512 * 512
     return cols <= 3072
 
 
@@ -285,7 +288,7 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch
 
     if a.dim() == 2 and b.dim() == 2:
         c = torch.empty((c_rows, c_cols), device=dev, dtype=torch.float32)
-        if fused and fused_skip_pays(1, c_rows, a_shape[-1]) and custom_mm.naive_spmm_dense(a, b, c):
+        if fused and fused_skip_pays(1, c_rows, a_shape[-1], c_cols) and custom_mm.naive_spmm_dense(a, b, c):
             return c
         return mm_op(*_csr_of(a), b, c)
 
@@ -304,7 +307,7 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch
         # batch of A × one B (the FC-layer call shape): flatten A's rows
         _a = a.reshape(-1, a_shape[-1])
         c = torch.empty((_a.shape[0], c_cols), device=dev, dtype=torch.float32)
-        if not (fused and fused_skip_pays(1, _a.shape[0], _a.shape[1]) and custom_mm.naive_spmm_dense(_a, b, c)):
+        if not (fused and fused_skip_pays(1, _a.shape[0], _a.shape[1], c_cols) and custom_mm.naive_spmm_dense(_a, b, c)):
             c = mm_op(*_csr_of(_a), b, c)
         return c.view(tuple(a_shape[:-1]) + (c_cols,))
 
@@ -314,7 +317,7 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch
     _b = b.expand(batch + tuple(b_shape[-2:])).reshape((-1,) + tuple(b_shape[-2:]))
     nb = _a.shape[0]
     c = torch.empty((nb, c_rows, c_cols), device=dev, dtype=torch.float32)
-    if fused and fused_skip_pays(nb, c_rows, a_shape[-1]) and custom_mm.naive_spmm_dense(_a, _b, c):
+    if fused and fused_skip_pays(nb, c_rows, a_shape[-1], c_cols) and custom_mm.naive_spmm_dense(_a, _b, c):
         pass  # one launch, A read once, no CSR materialised
     elif mm_op is default_op:
         # one dense→CSR conversion and one launch for the whole batch

@@ -306,7 +306,8 @@ def test_dense_inputs_are_routed_by_shape(mm, monkeypatch):
     kernels (one small matrix, batches of small / medium matrices) and to the CSR route for one large matrix
     (the FC-layer call shape flattens to that) and for very long rows — tools/bench_skipwide.py."""
     matmuls, fake = mm
-    assert matmuls.fused_skip_pays(1, 512, 512) and matmuls.fused_skip_pays(1, 1024, 1024)
+    assert matmuls.fused_skip_pays(1, 512, 512, 64) and matmuls.fused_skip_pays(1, 512, 512, 256)
+    assert not matmuls.fused_skip_pays(1, 1024, 1024, 1024) and not matmuls.fused_skip_pays(1, 512, 512, 512)
     assert not matmuls.fused_skip_pays(1, 2048, 2048) and not matmuls.fused_skip_pays(1, 16384, 768)
     assert matmuls.fused_skip_pays(384, 512, 512) and matmuls.fused_skip_pays(16, 2048, 2048)
     assert not matmuls.fused_skip_pays(4, 4096, 4096)
@@ -320,7 +321,7 @@ def test_dense_inputs_are_routed_by_shape(mm, monkeypatch):
         return [c[0] for c in fake.calls if c[0].startswith("naive_spmm") or c[0] == "dense_to_csr"]
 
     assert route(sparsify(g, 40, 30), rand(g, 30, 8)) == ["naive_spmm_dense"]                # one small matrix
-    monkeypatch.setattr(matmuls, "fused_skip_pays", lambda items, rows, cols: items > 1 and cols <= 16)
+    monkeypatch.setattr(matmuls, "fused_skip_pays", lambda items, rows, cols, width=256: items > 1 and cols <= 16)
     assert route(sparsify(g, 40, 30), rand(g, 30, 8)) == ["dense_to_csr", "naive_spmm"]      # "large": CSR route
     assert route(sparsify(g, 3, 20, 30), rand(g, 30, 8)) == ["dense_to_csr", "naive_spmm"]   # FC call shape: flattened
     assert route(sparsify(g, 3, 8, 12), rand(g, 3, 12, 4)) == ["naive_spmm_dense"]           # batch of small matrices

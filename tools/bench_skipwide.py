@@ -22,7 +22,7 @@ def timeit(fn, iters=10):
 
 
 g = torch.Generator(device=dev).manual_seed(0)
-for (shape_a, shape_b, kept) in [((512, 512), (512, 64), 0.1), ((1024, 1024), (1024, 256), 0.1), ((2048, 2048), (2048, 256), 0.1),
+for (shape_a, shape_b, kept) in [((512, 512), (512, 64), 0.1), ((1024, 1024), (1024, 256), 0.1), ((1024, 1024), (1024, 1024), 1.0), ((512, 512), (512, 256), 1.0), ((2048, 2048), (2048, 256), 0.1),
                                  ((2048, 2048), (2048, 64), 0.5), ((4096, 4096), (4096, 256), 0.1), ((4096, 4096), (4096, 64), 0.1),
                                  ((16384, 768), (768, 256), 0.5), ((16384, 768), (768, 256), 0.1), ((16384, 768), (768, 768), 0.1),
                                  ((16384, 3072), (3072, 512), 0.1), ((4096, 4096), (4096, 1024), 0.01),
@@ -48,6 +48,6 @@ for (shape_a, shape_b, kept) in [((512, 512), (512, 64), 0.1), ((1024, 1024), (1
     t_csr = timeit(csr_route)
     import matmuls  # noqa: E402
     items = 1 if a.dim() == 2 else a.shape[0]
-    pick = "in-kernel" if matmuls.fused_skip_pays(items, a.shape[-2], a.shape[-1]) else "CSR"
+    pick = "in-kernel" if matmuls.fused_skip_pays(items, a.shape[-2], a.shape[-1], b.shape[-1]) else "CSR"
     print(f"A {tuple(shape_a)} kept {kept} x B {tuple(shape_b)}: zeros skipped in the kernel {t_fused:.3f} ms; dense->CSR + CSR kernels "
           f"{t_csr:.3f} ms; matmuls takes the {pick} route", flush=True)
