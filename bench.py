@@ -346,22 +346,35 @@ def main():
             chunk_trials = {}
             chunk_cands = ((2, 4) if world <= 2 else (2, 4, 8)) if auto_chunks else (args.chunks,)
             exch_cands = ("allgather", "p2p") if auto_exchange else (args.exchange,)
-            for exch in exch_cands:
+            def try_candidate(exch, cand):
+                trial = sharded.ShardedSpMM(rp_t, col_t, val_t, M, K, dev, chunks=cand, split=args.split, exchange=exch)
+                Ct = trial.alloc_output(N)
+                for _ in range(2):
+                    trial.forward(B, out=Ct)
+                dist.barrier()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    trial.forward(B, out=Ct)
+                torch.cuda.synchronize()
+                return time.perf_counter() - t1
+
+            for exch in exch_cands:  # the collective first: it is the exchange every torch / RCCL build has
                 for cand in chunk_cands:
-                    trial = sharded.ShardedSpMM(rp_t, col_t, val_t, M, K, dev, chunks=cand, split=args.split, exchange=exch)
-                    Ct = trial.alloc_output(N)
-                    for _ in range(2):
-                        trial.forward(B, out=Ct)
-                    dist.barrier()
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    for _ in range(3):
-                        trial.forward(B, out=Ct)
-                    torch.cuda.synchronize()
-                    tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+                    seconds, failed = float("inf"), 0.0
+                    try:
+                        seconds = try_candidate(exch, cand)
+                    except Exception as e:  # an exchange this torch / RCCL build refuses is dropped, not fatal
+                        if not (auto_exchange and exch == "p2p"):
+                            raise
+                        failed = 1.0
+                        if rank == 0:
+                            print(f"bench: exchange '{exch}' dropped from the trial ({type(e).__name__}: {e})", file=sys.stderr)
+                    tt = torch.tensor([seconds if not failed else 0.0, failed], device=dev, dtype=torch.float64)
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    chunk_trials[(exch, cand)] = float(tt) / 3 * 1e3
-                    del trial, Ct
+                    if float(tt[1]) > 0:
+                        break  # some rank could not run it: every rank drops the remaining candidates of this exchange
+                    chunk_trials[(exch, cand)] = float(tt[0]) / 3 * 1e3
             args.exchange, args.chunks = min(chunk_trials, key=chunk_trials.get)
             torch.cuda.empty_cache()
         op = sharded.ShardedSpMM(rp_t, col_t, val_t, M, K, dev, chunks=args.chunks, split=args.split, exchange=args.exchange)
