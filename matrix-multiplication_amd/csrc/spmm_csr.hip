@@ -939,7 +939,9 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
     const bool b_in_l2 = (double)K * (double)ldb * 4.0 <= 8.0 * 1024 * 1024;
     // with L2 panels the row-split plan gathers at the L2 rate and carries C (2·lp − 1) times
     const double t_rows = lp > 0 ? 2.0 * (double)nnz * (double)N / 13e12 + (2.0 * lp - 1.0) * (double)M * (double)N * 4.0 / 4e12
-                                 : 2.0 * (double)nnz * (double)N / ((N >= 512 || b_in_l2) ? 13e12 : 5e12);
+                                 : 2.0 * (double)nnz * (double)N /
+                                       ((double)K * (double)ldb * 4.0 <= 2.0 * 1024 * 1024 ? 15e12  // B in every L2 at once
+                                        : (N >= 512 || b_in_l2) ? 13e12 : 5e12);
     // below ≈100 workgroups too few CUs have work for the model to hold
     if (wgs >= 96.0 && t_slab < t_rows) return MI_SPMM_SLAB;
   }
