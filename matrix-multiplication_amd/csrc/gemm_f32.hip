@@ -667,14 +667,32 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
 // (D = Bᵀ-block × A-block), so a lane's four accumulator registers are four consecutive n: 16-byte stores.
 // Whole tiles only (m, n multiples of 96, k of 64, 16-byte aligned rows): pick_tile() checks.
 // ---------------------------------------------------------------------------------------------
-constexpr int T16_TILE = 96, T16_KC = 32, T16_LD = 112;
+#ifndef MI_GEMM_T16_KC
+#define MI_GEMM_T16_KC 32
+#endif
+constexpr int T16_TILE = 96, T16_KC = MI_GEMM_T16_KC, T16_LD = 112;
+#ifndef MI_GEMM_T16_WAVES
+#define MI_GEMM_T16_WAVES 12
+#endif
 
-__global__ __launch_bounds__(256) void gemm_f32_t16_tn_kernel(
+// WAVES = 4: each wave owns 48×48 (3×3 blocks); one wave per SIMD — every non-MFMA instruction the wave
+// issues is a gap in its own MFMA stream (a 16×16×4 MFMA is 32 cycles): 0.75 ms at the BERT-base shape.
+// WAVES = 12: each wave owns 16×48 (1×3 blocks: one A-side and three B-side operand reads per three MFMAs),
+// three waves per SIMD fill each other's gaps.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemm_f32_t16_tn_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int k, long lda, long ldb,
     long ldc, long strideA, long strideB, long strideC, int tiles_n, int tiles_per_item, int reverse) {
-  __shared__ __attribute__((aligned(16))) float lds[2][2][T16_KC * T16_LD];  // [buffer][operand][k][m or n]
+  static_assert(WAVES == 4 || WAVES == 12, "36 blocks of 16x16: nine or three per wave");
+  constexpr int THREADS = WAVES * 64;
+  constexpr int MB = WAVES == 4 ? 3 : 1;        // m blocks per wave (n blocks: 3)
+  constexpr int VECS = T16_KC * 24 / THREADS;   // float4 per thread, operand and chunk (T16_KC rows × 24 float4)
+  extern __shared__ __attribute__((aligned(16))) float t16_lds[];
+  float (*lds)[2][T16_KC * T16_LD] = reinterpret_cast<float (*)[2][T16_KC * T16_LD]>(t16_lds);  // [buffer][operand][k][m or n]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  // first m / n column of the wave's sub-tile
+  const int m_w = WAVES == 4 ? (wave >> 1) * 48 : (wave % 6) * 16;
+  const int n_w = WAVES == 4 ? (wave & 1) * 48 : (wave / 6) * 48;
   // XCD-contiguous work ids, 8-tile column groups: as gemm_f32_kernel
   const unsigned total = gridDim.x, bid = blockIdx.x;
   const unsigned q = total / 8, rem = total % 8, xcd = bid % 8, pos = bid / 8;
@@ -687,24 +705,24 @@ __global__ __launch_bounds__(256) void gemm_f32_t16_tn_kernel(
   const float* Ap = A + item * strideA + (long)tile_m * T16_TILE;  // A stored [k][m]
   const float* Bp = B + item * strideB + (long)tile_n * T16_TILE;  // B stored [k][n]
 
-  f32x4 acc[3][3];  // [n block][m block]: register r ↔ n = 16·nb + 4·(lane>>4) + r, m = 16·mb + (lane&15)
+  f32x4 acc[3][MB];  // [n block][m block]: register r ↔ n = 16·nb + 4·(lane>>4) + r, m = 16·mb + (lane&15)
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // a chunk of an operand: 32 rows × 24 float4; thread t takes float4 t, t + 256, t + 512.  Two register
+  // a chunk of an operand: 32 rows × 24 float4; thread t takes float4 t, t + THREADS, ….  Two register
   // sets: chunk c+2 is loaded while chunk c is multiplied and goes to LDS after chunk c+1's MFMAs, so a
   // load has two chunks' time (≈2 µs) to land; with one set (one chunk ahead) the kernel waited on memory
   // a third of the time.  The loads carry no predicate (past the end: the last chunk again), so the
-  // compiler's wait before a store to LDS is vmcnt(6), not vmcnt(0).
-  f32x4 ra[2][3], rb[2][3];
+  // compiler's wait before a store to LDS counts the younger loads instead of being vmcnt(0).
+  f32x4 ra[2][VECS], rb[2][VECS];
   const int chunks = k / T16_KC;
   auto load_chunk = [&](int set, int c) {
     const int k0 = (c < chunks ? c : chunks - 1) * T16_KC;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int j = tid + 256 * i, row = j / 24, c4 = j % 24;
+    for (int i = 0; i < VECS; ++i) {
+      const int j = tid + THREADS * i, row = j / 24, c4 = j % 24;
       if (MI_GEMM_ABL & 4) {
         ra[set][i] = rb[set][i] = f32x4{1.f, 2.f, 3.f, (float)k0};
         continue;
@@ -715,38 +733,37 @@ __global__ __launch_bounds__(256) void gemm_f32_t16_tn_kernel(
   };
   auto store_chunk = [&](int set, int buf) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int j = tid + 256 * i, row = j / 24, c4 = j % 24;
+    for (int i = 0; i < VECS; ++i) {
+      const int j = tid + THREADS * i, row = j / 24, c4 = j % 24;
       *reinterpret_cast<f32x4*>(&lds[buf][0][row * T16_LD + 4 * c4]) = ra[set][i];
       *reinterpret_cast<f32x4*>(&lds[buf][1][row * T16_LD + 4 * c4]) = rb[set][i];
     }
   };
   const int lk = lane >> 4, lc = lane & 15;
-  // operand reads run one k-step (4 k) ahead of the MFMAs, ACROSS the chunk boundary: the last step's nine
+  // operand reads run one k-step (4 k) ahead of the MFMAs, ACROSS the chunk boundary: the last step's
   // MFMAs of a chunk are issued after the barrier and after the next chunk's first operand reads, so the
-  // matrix pipe has work while those reads are in flight (with the boundary exposed — LDS stores, barrier,
-  // read latency, then the first MFMA — the pipe idled ≈600 cycles per chunk of 2300)
-  float a[2][3], b[2][3];
+  // matrix pipe has work while those reads are in flight
+  float a[2][MB], b[2][3];
   auto read_ops = [&](int set, int buf, int kk) {
-    const float* as = &lds[buf][0][(kk * 4 + lk) * T16_LD + wm * 48 + lc];
-    const float* bs = &lds[buf][1][(kk * 4 + lk) * T16_LD + wn * 48 + lc];
+    const float* as = &lds[buf][0][(kk * 4 + lk) * T16_LD + m_w + lc];
+    const float* bs = &lds[buf][1][(kk * 4 + lk) * T16_LD + n_w + lc];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       if (MI_GEMM_ABL & 8) {  // timing only: no LDS operand reads
-        a[set][i] = (float)(kk + i);
+        if (i < MB) a[set][i] = (float)(kk + i);
         b[set][i] = (float)(set + i);
         continue;
       }
-      a[set][i] = as[16 * i];
+      if (i < MB) a[set][i] = as[16 * i];
       b[set][i] = bs[16 * i];
     }
   };
-  auto mfma9 = [&](int set) {
+  auto mfmas = [&](int set) {
     if (MI_GEMM_ABL & 2) return;
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
-      for (int mb = 0; mb < 3; ++mb)
+      for (int mb = 0; mb < MB; ++mb)
         acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[set][nb], a[set][mb], acc[nb][mb], 0, 0, 0);
   };
   // one chunk: steps 0 … 6 from LDS buffer `buf`, then the hand-over to the other buffer, then step 7
@@ -757,7 +774,7 @@ __global__ __launch_bounds__(256) void gemm_f32_t16_tn_kernel(
     for (int kk = 0; kk < T16_KC / 4 - 1; ++kk) {
       read_ops((kk + 1) & 1, buf, kk + 1);
       __builtin_amdgcn_sched_barrier(0);  // reads first: the scheduler otherwise moves them down to just before
-      mfma9(kk & 1);                      // their use, and the wave then waits out the LDS latency every step
+      mfmas(kk & 1);                      // their use, and the wave then waits out the LDS latency every step
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -765,7 +782,7 @@ __global__ __launch_bounds__(256) void gemm_f32_t16_tn_kernel(
     __syncthreads();                  // it is in LDS; every wave is past its reads of this buffer
     read_ops(0, buf ^ 1, 0);
     __builtin_amdgcn_sched_barrier(0);
-    mfma9(1);  // step 7 of this chunk
+    mfmas(1);  // step 7 of this chunk
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -779,9 +796,9 @@ __global__ __launch_bounds__(256) void gemm_f32_t16_tn_kernel(
     half(1, c + 3, 1, 0);
   }
   if (MI_GEMM_ABL & 1) return;
-  float* Cp = C + item * strideC + ((long)tile_m * T16_TILE + wm * 48 + lc) * ldc + (long)tile_n * T16_TILE + wn * 48 + 4 * lk;
+  float* Cp = C + item * strideC + ((long)tile_m * T16_TILE + m_w + lc) * ldc + (long)tile_n * T16_TILE + n_w + 4 * lk;
 #pragma unroll
-  for (int mb = 0; mb < 3; ++mb)
+  for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb)
       __builtin_nontemporal_store(acc[nb][mb], reinterpret_cast<f32x4*>(Cp + (long)(16 * mb) * ldc + 16 * nb));
@@ -870,8 +887,12 @@ int pick_tile(const float* A, const float* B, float* C, int m, int n, int k, lon
     const long rounds = (t96 + 255) / 256;
     if (t96 <= 0x7fffffffL && 4 * t96 >= 3 * rounds * 256) {
       const int rev = (int)(g_launch_counter.fetch_add(1, std::memory_order_relaxed) & 1u);
-      hipLaunchKernelGGL(gemm_f32_t16_tn_kernel, dim3((unsigned)t96), dim3(256), 0, s, A, B, C, k, lda, ldb, ldc, sA, sB,
-                         sC, n / T16_TILE, (m / T16_TILE) * (n / T16_TILE), rev);
+      constexpr int lds_bytes = 2 * 2 * T16_KC * T16_LD * (int)sizeof(float);
+      auto kern = gemm_f32_t16_tn_kernel<MI_GEMM_T16_WAVES>;
+      if (lds_bytes > 64 * 1024)
+        MI_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+      hipLaunchKernelGGL(kern, dim3((unsigned)t96), dim3(MI_GEMM_T16_WAVES * 64), lds_bytes, s,
+                         A, B, C, k, lda, ldb, ldc, sA, sB, sC, n / T16_TILE, (m / T16_TILE) * (n / T16_TILE), rev);
       return mi::check_launch();
     }
   }
