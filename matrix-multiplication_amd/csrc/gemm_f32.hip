@@ -670,29 +670,36 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
 #ifndef MI_GEMM_T16_KC
 #define MI_GEMM_T16_KC 32
 #endif
-constexpr int T16_TILE = 96, T16_KC = MI_GEMM_T16_KC, T16_LD = 112;
+constexpr int T16_KC = MI_GEMM_T16_KC;
 #ifndef MI_GEMM_T16_WAVES
-#define MI_GEMM_T16_WAVES 12
+#define MI_GEMM_T16_WAVES 12  // waves per workgroup of the 96×96 tile (4: one wave per SIMD, 0.75 ms at the BERT-base shape)
 #endif
 
-// WAVES = 4: each wave owns 48×48 (3×3 blocks); one wave per SIMD — every non-MFMA instruction the wave
-// issues is a gap in its own MFMA stream (a 16×16×4 MFMA is 32 cycles): 0.75 ms at the BERT-base shape.
-// WAVES = 12: each wave owns 16×48 (1×3 blocks: one A-side and three B-side operand reads per three MFMAs),
-// three waves per SIMD fill each other's gaps.
-template <int WAVES>
+// TILE × TILE outputs per workgroup, 16×16 MFMA blocks dealt to WAVES waves so that every SIMD holds 2–4 waves:
+//   TILE 128, 16 waves: 32×32 (2×2 blocks) per wave — level with the 32×32-block kernels at 4096 × 1024 / 2048²
+//                       outputs (1.12 vs 1.16 ms, 0.55 vs 0.54): instantiable, not dispatched
+//   TILE  96, 12 waves: 16×48 (1×3)          per wave — 256 workgroups at 3072 × 768 (BERT-base FFN)
+//   TILE  96,  4 waves: 48×48 (3×3), one wave per SIMD: every non-MFMA instruction the wave issues is a gap in its
+//                       own MFMA stream (a 16×16×4 MFMA is 32 cycles) — kept for comparison
+//   TILE  64,  8 waves: 16×32 (1×2)          per wave — 256 workgroups at 1024² or 2048 × 512 (0.155 vs 0.164 ms)
+template <int TILE, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gemm_f32_t16_tn_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int k, long lda, long ldb,
     long ldc, long strideA, long strideB, long strideC, int tiles_n, int tiles_per_item, int reverse) {
-  static_assert(WAVES == 4 || WAVES == 12, "36 blocks of 16x16: nine or three per wave");
+  static_assert((TILE == 128 && WAVES == 16) || (TILE == 96 && (WAVES == 12 || WAVES == 4)) || (TILE == 64 && WAVES == 8),
+                "see the table above");
   constexpr int THREADS = WAVES * 64;
-  constexpr int MB = WAVES == 4 ? 3 : 1;        // m blocks per wave (n blocks: 3)
-  constexpr int VECS = T16_KC * 24 / THREADS;   // float4 per thread, operand and chunk (T16_KC rows × 24 float4)
+  constexpr int LD = TILE + 16;                 // LDS row stride: the four k-rows an operand read touches sit 16 banks apart
+  constexpr int ROWV = TILE / 4;                // float4 per operand row
+  constexpr int MB = TILE == 128 ? 2 : (WAVES == 4 ? 3 : 1);  // m blocks per wave
+  constexpr int NB = TILE == 96 ? 3 : 2;                      // n blocks per wave
+  constexpr int WM = TILE / 16 / MB;                           // waves along m
+  constexpr int VECS = T16_KC * ROWV / THREADS;                // float4 per thread, operand and chunk
+  static_assert(VECS * THREADS == T16_KC * ROWV && WM * (TILE / 16 / NB) == WAVES, "tile / wave layout");
   extern __shared__ __attribute__((aligned(16))) float t16_lds[];
-  float (*lds)[2][T16_KC * T16_LD] = reinterpret_cast<float (*)[2][T16_KC * T16_LD]>(t16_lds);  // [buffer][operand][k][m or n]
+  float (*lds)[2][T16_KC * LD] = reinterpret_cast<float (*)[2][T16_KC * LD]>(t16_lds);  // [buffer][operand][k][m or n]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // first m / n column of the wave's sub-tile
-  const int m_w = WAVES == 4 ? (wave >> 1) * 48 : (wave % 6) * 16;
-  const int n_w = WAVES == 4 ? (wave & 1) * 48 : (wave / 6) * 48;
+  const int m_w = (wave % WM) * (MB * 16), n_w = (wave / WM) * (NB * 16);  // first m / n column of the wave's sub-tile
   // XCD-contiguous work ids, 8-tile column groups: as gemm_f32_kernel
   const unsigned total = gridDim.x, bid = blockIdx.x;
   const unsigned q = total / 8, rem = total % 8, xcd = bid % 8, pos = bid / 8;
@@ -702,16 +709,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_f32_t16_tn_kernel(
   const int tile = work % tiles_per_item;
   int tile_m, tile_n;
   tile_coords(tile, tiles_n, tiles_per_item / tiles_n, tile_m, tile_n);
-  const float* Ap = A + item * strideA + (long)tile_m * T16_TILE;  // A stored [k][m]
-  const float* Bp = B + item * strideB + (long)tile_n * T16_TILE;  // B stored [k][n]
+  const float* Ap = A + item * strideA + (long)tile_m * TILE;  // A stored [k][m]
+  const float* Bp = B + item * strideB + (long)tile_n * TILE;  // B stored [k][n]
 
-  f32x4 acc[3][MB];  // [n block][m block]: register r ↔ n = 16·nb + 4·(lane>>4) + r, m = 16·mb + (lane&15)
+  f32x4 acc[NB][MB];  // [n block][m block]: register r ↔ n = 16·nb + 4·(lane>>4) + r, m = 16·mb + (lane&15)
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int i = 0; i < NB; ++i)
 #pragma unroll
     for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // a chunk of an operand: 32 rows × 24 float4; thread t takes float4 t, t + THREADS, ….  Two register
+  // a chunk of an operand: T16_KC rows × ROWV float4; thread t takes float4 t, t + THREADS, ….  Two register
   // sets: chunk c+2 is loaded while chunk c is multiplied and goes to LDS after chunk c+1's MFMAs, so a
   // load has two chunks' time (≈2 µs) to land; with one set (one chunk ahead) the kernel waited on memory
   // a third of the time.  The loads carry no predicate (past the end: the last chunk again), so the
@@ -722,7 +729,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_f32_t16_tn_kernel(
     const int k0 = (c < chunks ? c : chunks - 1) * T16_KC;
 #pragma unroll
     for (int i = 0; i < VECS; ++i) {
-      const int j = tid + THREADS * i, row = j / 24, c4 = j % 24;
+      const int j = tid + THREADS * i, row = j / ROWV, c4 = j % ROWV;
       if (MI_GEMM_ABL & 4) {
         ra[set][i] = rb[set][i] = f32x4{1.f, 2.f, 3.f, (float)k0};
         continue;
@@ -734,34 +741,35 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_f32_t16_tn_kernel(
   auto store_chunk = [&](int set, int buf) {
 #pragma unroll
     for (int i = 0; i < VECS; ++i) {
-      const int j = tid + THREADS * i, row = j / 24, c4 = j % 24;
-      *reinterpret_cast<f32x4*>(&lds[buf][0][row * T16_LD + 4 * c4]) = ra[set][i];
-      *reinterpret_cast<f32x4*>(&lds[buf][1][row * T16_LD + 4 * c4]) = rb[set][i];
+      const int j = tid + THREADS * i, row = j / ROWV, c4 = j % ROWV;
+      *reinterpret_cast<f32x4*>(&lds[buf][0][row * LD + 4 * c4]) = ra[set][i];
+      *reinterpret_cast<f32x4*>(&lds[buf][1][row * LD + 4 * c4]) = rb[set][i];
     }
   };
   const int lk = lane >> 4, lc = lane & 15;
   // operand reads run one k-step (4 k) ahead of the MFMAs, ACROSS the chunk boundary: the last step's
   // MFMAs of a chunk are issued after the barrier and after the next chunk's first operand reads, so the
   // matrix pipe has work while those reads are in flight
-  float a[2][MB], b[2][3];
+  float a[2][MB], b[2][NB];
   auto read_ops = [&](int set, int buf, int kk) {
-    const float* as = &lds[buf][0][(kk * 4 + lk) * T16_LD + m_w + lc];
-    const float* bs = &lds[buf][1][(kk * 4 + lk) * T16_LD + n_w + lc];
+    const float* as = &lds[buf][0][(kk * 4 + lk) * LD + m_w + lc];
+    const float* bs = &lds[buf][1][(kk * 4 + lk) * LD + n_w + lc];
+    if (MI_GEMM_ABL & 8) {  // timing only: no LDS operand reads
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      if (MI_GEMM_ABL & 8) {  // timing only: no LDS operand reads
-        if (i < MB) a[set][i] = (float)(kk + i);
-        b[set][i] = (float)(set + i);
-        continue;
-      }
-      if (i < MB) a[set][i] = as[16 * i];
-      b[set][i] = bs[16 * i];
+      for (int i = 0; i < MB; ++i) a[set][i] = (float)(kk + i);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) b[set][i] = (float)(set + i);
+      return;
     }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) a[set][i] = as[16 * i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b[set][i] = bs[16 * i];
   };
   auto mfmas = [&](int set) {
     if (MI_GEMM_ABL & 2) return;
 #pragma unroll
-    for (int nb = 0; nb < 3; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
         acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[set][nb], a[set][mb], acc[nb][mb], 0, 0, 0);
@@ -796,12 +804,25 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_f32_t16_tn_kernel(
     half(1, c + 3, 1, 0);
   }
   if (MI_GEMM_ABL & 1) return;
-  float* Cp = C + item * strideC + ((long)tile_m * T16_TILE + m_w + lc) * ldc + (long)tile_n * T16_TILE + n_w + 4 * lk;
+  float* Cp = C + item * strideC + ((long)tile_m * TILE + m_w + lc) * ldc + (long)tile_n * TILE + n_w + 4 * lk;
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < 3; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
       __builtin_nontemporal_store(acc[nb][mb], reinterpret_cast<f32x4*>(Cp + (long)(16 * mb) * ldc + 16 * nb));
+}
+
+template <int TILE, int WAVES>
+int launch_t16(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb, long ldc, long sA,
+               long sB, long sC, int batch, int rev, hipStream_t s) {
+  constexpr int lds_bytes = 2 * 2 * T16_KC * (TILE + 16) * (int)sizeof(float);
+  auto kern = gemm_f32_t16_tn_kernel<TILE, WAVES>;
+  if (lds_bytes > 64 * 1024)
+    MI_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  const long tiles = (long)(m / TILE) * (n / TILE);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * batch)), dim3(WAVES * 64), lds_bytes, s, A, B, C, k, lda, ldb, ldc,
+                     sA, sB, sC, n / TILE, (int)tiles, rev);
+  return mi::check_launch();
 }
 
 std::atomic<unsigned> g_launch_counter{0};  // one counter for every instantiation of launch()
@@ -879,21 +900,24 @@ int pick_tile(const float* A, const float* B, float* C, int m, int n, int k, lon
   auto blocks_for = [&](int bm, int bn) { return (long)((m + bm - 1) / bm) * ((n + bn - 1) / bn) * batch; };
   const long want = 2L * 256;
 #ifndef MI_GEMM_NO_T16
-  if (TA && !TB && bias == nullptr && vecA && vecB && vecC && m % T16_TILE == 0 && n % T16_TILE == 0 &&
-      k % (2 * T16_KC) == 0 && k >= 16 * T16_KC && blocks_for(128, 128) < want) {
-    // few output tiles, long k: 96×96 tiles of 16×16 MFMA blocks when they fill the CUs better than any
-    // tile of 32×32 blocks does (see gemm_f32_t16_tn_kernel)
-    const long t96 = blocks_for(T16_TILE, T16_TILE);
-    const long rounds = (t96 + 255) / 256;
-    if (t96 <= 0x7fffffffL && 4 * t96 >= 3 * rounds * 256) {
+  if (TA && !TB && bias == nullptr && vecA && vecB && vecC && k % (2 * T16_KC) == 0 && k >= 16 * T16_KC &&
+      blocks_for(128, 128) < want) {
+    // Aᵀ·B with few output tiles and a long k (weight gradients): tiles of 16×16 MFMA blocks, one workgroup per CU
+    // with 2–4 waves per SIMD, in the tile size that fills the CUs' rounds best (the larger tile on a tie: fewer
+    // operand bytes per flop) — see gemm_f32_t16_tn_kernel
+    int best = 0;
+    double best_eff = 0.0;
+    for (int tile : {96, 64}) {  // 128×128 (16 waves of 2×2 blocks) measured level with the 32×32-block kernels: not taken
+      if (m % tile != 0 || n % tile != 0) continue;
+      const long t = blocks_for(tile, tile);
+      if (t > 0x7fffffffL) continue;
+      const double eff = (double)t / (double)(((t + 255) / 256) * 256);
+      if (eff > best_eff + 1e-9) best_eff = eff, best = tile;
+    }
+    if (best_eff >= 0.75) {
       const int rev = (int)(g_launch_counter.fetch_add(1, std::memory_order_relaxed) & 1u);
-      constexpr int lds_bytes = 2 * 2 * T16_KC * T16_LD * (int)sizeof(float);
-      auto kern = gemm_f32_t16_tn_kernel<MI_GEMM_T16_WAVES>;
-      if (lds_bytes > 64 * 1024)
-        MI_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-      hipLaunchKernelGGL(kern, dim3((unsigned)t96), dim3(MI_GEMM_T16_WAVES * 64), lds_bytes, s,
-                         A, B, C, k, lda, ldb, ldc, sA, sB, sC, n / T16_TILE, (m / T16_TILE) * (n / T16_TILE), rev);
-      return mi::check_launch();
+      if (best == 96) return launch_t16<96, MI_GEMM_T16_WAVES>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, rev, s);
+      return launch_t16<64, 8>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, rev, s);
     }
   }
 #endif

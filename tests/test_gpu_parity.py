@@ -482,6 +482,12 @@ def test_gemm_few_tiles_long_k_96_tile_kernel_bit_exact(cmm, dev, oracle_mod):
     C2 = torch.full((768, 3072), float("nan"), device=dev)
     cmm.cublas_mmul(t(x, dev), t(dy, dev), C2, True, False)
     assert np.array_equal(C2.cpu().numpy(), gemm_ref(oracle_mod, x, dy, True, False))
+    # the same kernel on 64×64 tiles (1024² outputs: 256 workgroups)
+    for mn in (1024,):
+        a2, b2 = g.random((512, mn), dtype=np.float32) - 0.5, g.random((512, mn), dtype=np.float32) - 0.5
+        C3 = torch.full((mn, mn), float("nan"), device=dev)
+        cmm.cublas_mmul(t(a2, dev), t(b2, dev), C3, True, False)
+        assert np.array_equal(C3.cpu().numpy(), gemm_ref(oracle_mod, a2, b2, True, False)), mn
     a = g.random((4, 576, 768), dtype=np.float32) - 0.5  # four items, k = 576 = 18 chunks
     b = g.random((4, 576, 768), dtype=np.float32) - 0.5
     Cb = torch.full((4, 768, 768), float("nan"), device=dev)

@@ -25,7 +25,7 @@ g = torch.Generator(device=dev).manual_seed(0)
 SHAPES = [(16384, 3072, 768, 0, 1), (16384, 768, 3072, 0, 1), (16384, 768, 3072, 0, 0), (3072, 768, 16384, 1, 0), (768, 3072, 16384, 1, 0),
           (4096, 4096, 4096, 0, 0), (4096, 4096, 4096, 0, 1), (4096, 4096, 4096, 1, 0), (1024, 1024, 1024, 0, 1), (2048, 512, 8192, 1, 0),
           (768, 768, 16384, 1, 0), (1536, 768, 8192, 1, 0), (1152, 1152, 8192, 1, 0), (256, 256, 65536, 1, 0), (8192, 128, 8192, 0, 0),
-          (128, 8192, 8192, 0, 0), (16384, 64, 768, 0, 1), (1000, 1000, 1000, 0, 0), (16384, 256, 3072, 0, 1), (2048, 2048, 256, 0, 1)]
+          (128, 8192, 8192, 0, 0), (16384, 64, 768, 0, 1), (1000, 1000, 1000, 0, 0), (4096, 1024, 16384, 1, 0), (1024, 4096, 16384, 1, 0), (2048, 2048, 8192, 1, 0), (1024, 1024, 8192, 1, 0), (16384, 256, 3072, 0, 1), (2048, 2048, 256, 0, 1)]
 for (m, n, k, ta, tb) in SHAPES:
     a = torch.rand((k, m) if ta else (m, k), device=dev, generator=g)
     b = torch.rand((n, k) if tb else (k, n), device=dev, generator=g)
