@@ -399,6 +399,48 @@ def test_sddmm_config_c3_two_panel_launches_bit_exact(cmm, dev, oracle_mod):
     assert np.array_equal(got[idx], want)
 
 
+@pytest.mark.parametrize("batch,M,K,nnz,skew", [(1, 200000, 300000, 6_000_000, 0.3), (1, 50000, 900, 5_000_000, 1.0),
+                                                 (1, 3000, 3_000_000, 4_000_000, 0.5), (6, 20000, 70000, 5_000_000, 0.2)])
+def test_csr_transpose_many_tiles_per_workgroup_skewed(cmm, dev, batch, M, K, nnz, skew):
+    """Several tiles per persistent workgroup (the software-pipelined scatter: previous tile streaming out, next
+    tile loading while one is ranked) on SKEWED data — Dirichlet row lengths with runs of empty rows, a hub
+    column holding 5 % of the entries (every lane of a ranking step with the same digit), duplicates, some rows
+    out of column order — in the one-, two- and three-pass plans and the batched form: offsets, row indices and
+    values equal numpy's stable sort of the keys."""
+    rng = np.random.Generator(np.random.PCG64(M + K))
+    lens = rng.multinomial(nnz, rng.dirichlet(np.full(batch * M, skew)))
+    col = rng.integers(0, K, size=nnz).astype(np.int32)
+    col[rng.random(nnz) < 0.05] = K // 3                       # the hub column
+    off = np.zeros(batch * M + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    rows_flat = np.repeat(np.arange(batch * M, dtype=np.int64), lens)
+    # ascending columns inside every row … except in every 7th row
+    order = np.lexsort((col, rows_flat))
+    unsorted = (rows_flat % 7) == 3
+    col = np.where(unsorted, col, col[order]).astype(np.int32)
+    val = rng.random(nnz, dtype=np.float32) - 0.5
+    offs = np.zeros((batch, M + 1), np.int64)
+    offs[:, 1:] = off[1:].reshape(batch, M)
+    offs[1:, 0] = offs[:-1, M]
+    offs = offs.astype(np.int32)
+    if batch == 1:
+        t_val, t_col, t_off = cmm.csr_transpose(t(val, dev), t(col, dev), t(offs[0], dev), nnz, M, K)
+        t_off = t_off.view(1, -1)
+    else:
+        t_val, t_col, t_off = cmm.csr_transpose_batched(t(val, dev), t(col, dev), t(offs, dev), nnz, batch, M, K)
+    torch.cuda.synchronize()
+    item = rows_flat // M
+    key = item * K + col
+    order = np.argsort(key, kind="stable")
+    assert np.array_equal(t_col.cpu().numpy(), (rows_flat - item * M).astype(np.int32)[order])
+    assert np.array_equal(t_val.cpu().numpy(), val[order])
+    counts = np.bincount(key, minlength=batch * K).reshape(batch, K)
+    want_off = np.zeros((batch, K + 1), np.int64)
+    want_off[:, 1:] = np.cumsum(counts, axis=1)
+    want_off += np.concatenate([[0], np.cumsum(counts.sum(1))[:-1]])[:, None]
+    assert np.array_equal(t_off.cpu().numpy().astype(np.int64), want_off)
+
+
 def test_csr_transpose_config_c3_shape(cmm, dev, oracle_mod):
     """The transpose at BASELINE config C3's matrix (1M x 1M, 110 M non-zeros): integer artefacts
     (offsets, row indices) and values bit-exact against numpy's stable argsort of the columns."""
