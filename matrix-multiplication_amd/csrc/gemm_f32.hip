@@ -682,17 +682,20 @@ constexpr int T16_KC = MI_GEMM_T16_KC;
 //   TILE  96,  4 waves: 48×48 (3×3), one wave per SIMD: every non-MFMA instruction the wave issues is a gap in its
 //                       own MFMA stream (a 16×16×4 MFMA is 32 cycles) — kept for comparison
 //   TILE  64,  8 waves: 16×32 (1×2)          per wave — 256 workgroups at 1024² or 2048 × 512 (0.155 vs 0.164 ms)
+//   TILE  32,  4 waves: 16×16 (one block)    per wave — tiny outputs (256² with k = 65536: 64 workgroups instead of the
+//                       16 of 64×64 tiles; every wave is one dependent MFMA chain, ≈40 cycles per 4 k)
 template <int TILE, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gemm_f32_t16_tn_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int k, long lda, long ldb,
     long ldc, long strideA, long strideB, long strideC, int tiles_n, int tiles_per_item, int reverse) {
-  static_assert((TILE == 128 && WAVES == 16) || (TILE == 96 && (WAVES == 12 || WAVES == 4)) || (TILE == 64 && WAVES == 8),
+  static_assert((TILE == 128 && WAVES == 16) || (TILE == 96 && (WAVES == 12 || WAVES == 4)) || (TILE == 64 && WAVES == 8) ||
+                    (TILE == 32 && WAVES == 4),
                 "see the table above");
   constexpr int THREADS = WAVES * 64;
   constexpr int LD = TILE + 16;                 // LDS row stride: the four k-rows an operand read touches sit 16 banks apart
   constexpr int ROWV = TILE / 4;                // float4 per operand row
-  constexpr int MB = TILE == 128 ? 2 : (WAVES == 4 ? 3 : 1);  // m blocks per wave
-  constexpr int NB = TILE == 96 ? 3 : 2;                      // n blocks per wave
+  constexpr int MB = TILE == 128 ? 2 : ((TILE == 96 && WAVES == 4) ? 3 : 1);  // m blocks per wave
+  constexpr int NB = TILE == 96 ? 3 : (TILE == 32 ? 1 : 2);   // n blocks per wave
   constexpr int WM = TILE / 16 / MB;                           // waves along m
   constexpr int VECS = T16_KC * ROWV / THREADS;                // float4 per thread, operand and chunk
   static_assert(VECS * THREADS == T16_KC * ROWV && WM * (TILE / 16 / NB) == WAVES, "tile / wave layout");
@@ -914,9 +917,11 @@ int pick_tile(const float* A, const float* B, float* C, int m, int n, int k, lon
       const double eff = (double)t / (double)(((t + 255) / 256) * 256);
       if (eff > best_eff + 1e-9) best_eff = eff, best = tile;
     }
+    if (m % 32 == 0 && n % 32 == 0 && blocks_for(64, 64) <= 64) best = 32, best_eff = 1.0;  // a tiny output: most workgroups win
     if (best_eff >= 0.75) {
       const int rev = (int)(g_launch_counter.fetch_add(1, std::memory_order_relaxed) & 1u);
       if (best == 96) return launch_t16<96, MI_GEMM_T16_WAVES>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, rev, s);
+      if (best == 32) return launch_t16<32, 4>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, rev, s);
       return launch_t16<64, 8>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, rev, s);
     }
   }

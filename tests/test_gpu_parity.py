@@ -500,7 +500,9 @@ def gemm_ref(oracle_mod, a, b, ta, tb):
 @pytest.mark.parametrize("ta", [False, True])
 @pytest.mark.parametrize("tb", [False, True])
 @pytest.mark.parametrize("m,n,k", [(1, 1, 1), (37, 45, 53), (64, 64, 32), (65, 129, 33), (128, 128, 64), (200, 70, 130),
-                                   (130, 260, 7), (3, 300, 257)])
+                                   (130, 260, 7), (3, 300, 257),
+                                   (37, 45, 1030), (256, 256, 4099), (16, 16, 1024), (100, 7, 3000), (1, 300, 2048), (512, 512, 1025),
+                                   (256, 256, 4096), (64, 96, 2048)])   # tiny aligned outputs, long k: 32×32 tiles under Aᵀ·B
 def test_gemm_bit_exact_vs_oracle(cmm, dev, oracle_mod, ta, tb, m, n, k):
     g = np.random.Generator(np.random.PCG64(m * 7 + n * 3 + k))
     a = g.random((k, m) if ta else (m, k), dtype=np.float32)
@@ -535,6 +537,16 @@ def test_gemm_few_tiles_long_k_96_tile_kernel_bit_exact(cmm, dev, oracle_mod):
     Cb = torch.full((4, 768, 768), float("nan"), device=dev)
     cmm.cublas_bmm(t(a, dev), t(b, dev), Cb, 3, True, False)
     assert np.array_equal(Cb.cpu().numpy(), gemm_ref(oracle_mod, a, b, True, False))
+
+
+def test_gemm_tiny_output_long_k_batched(cmm, dev, oracle_mod):
+    """Aᵀ·B with a tiny output and a long k runs on 32×32 tiles of 16×16 MFMA blocks (one block per wave) — batched."""
+    g = np.random.Generator(np.random.PCG64(16))
+    a = g.random((3, 2176, 64), dtype=np.float32) - 0.5    # [k, m] per item, k = 34 chunks
+    b = g.random((3, 2176, 96), dtype=np.float32) - 0.5    # [k, n]
+    C = torch.full((3, 64, 96), float("nan"), device=dev)
+    cmm.cublas_bmm(t(a, dev), t(b, dev), C, 3, True, False)
+    assert np.array_equal(C.cpu().numpy(), gemm_ref(oracle_mod, a, b, True, False))
 
 
 def test_gemm_golden_and_batched(cmm, dev, golden, oracle_mod):
