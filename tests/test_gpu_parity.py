@@ -1348,12 +1348,13 @@ def test_entry_points_are_graph_capturable(cmm, dev, oracle_mod):
 
 def test_inspector_products_and_round2_entries_are_graph_capturable(cmm, dev, oracle_mod):
     """An inspector handle owns its buffers, so `cusparse_mmul_opt` / `_opt_t` neither allocate nor
-    synchronise and can be captured in a hipGraph — both forms of the executor (transposes around the
-    row-split kernel; native LDS-slab) — as can `naive_spmm_ex` (one launch, no workspace) and the chained
+    synchronise and can be captured in a hipGraph — every form of the executor (transposes around the
+    row-split kernel; native LDS-slab; transpose in + column-major output fused into the kernel) — as can `naive_spmm_ex` (one launch, no workspace) and the chained
     short-k GEMM; the graph replays on new activations."""
     g = np.random.Generator(np.random.PCG64(21))
     cases = []
-    for tag, (M, K, N, density) in {"rows": (900, 700, 64, 0.02), "slab": (1024, 256, 4096, 0.5)}.items():
+    for tag, (M, K, N, density) in {"rows": (900, 700, 64, 0.02), "slab": (1024, 256, 4096, 0.5),
+                                    "fused-out": (700, 900, 1024, 0.02)}.items():  # 1024 columns: > 64 KiB of LDS per workgroup
         rowptr, col, val = oracle_mod.make_csr(M, K, density, seed=len(tag))
         cmm.cusparse_inspect(t(rowptr, dev), t(col, dev), t(val, dev), len(val), M, N, K, tag)
         cases.append((tag, M, K, N, rowptr, col, val, torch.zeros(N, K, device=dev), torch.empty(N, M, device=dev),
