@@ -918,7 +918,10 @@ int pick_tile(const float* A, const float* B, float* C, int m, int n, int k, lon
       if (eff > best_eff + 1e-9) best_eff = eff, best = tile;
     }
     if (m % 32 == 0 && n % 32 == 0 && blocks_for(64, 64) <= 64) best = 32, best_eff = 1.0;  // a tiny output: most workgroups win
-    if (best_eff >= 0.75) {
+#ifndef MI_GEMM_T16_MIN_EFF
+#define MI_GEMM_T16_MIN_EFF 0.75
+#endif
+    if (best_eff >= MI_GEMM_T16_MIN_EFF) {
       const int rev = (int)(g_launch_counter.fetch_add(1, std::memory_order_relaxed) & 1u);
       if (best == 96) return launch_t16<96, MI_GEMM_T16_WAVES>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, rev, s);
       if (best == 32) return launch_t16<32, 4>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, rev, s);
