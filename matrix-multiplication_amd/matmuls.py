@@ -238,12 +238,49 @@ def get_sparse_tensor_properties(a: torch.Tensor):
         a.shape[-2], a.shape[-1]
 
 
+def _csr_key(a: torch.Tensor):
+    vals, crow, ccol = torch.Tensor.values(a), torch.Tensor.crow_indices(a), torch.Tensor.col_indices(a)
+    return (vals.data_ptr(), crow.data_ptr(), ccol.data_ptr(), vals._version, crow._version, ccol._version,
+            tuple(a.shape), vals.numel())
+
+
+def _csr_props_cached(a: torch.Tensor):
+    '''((values, columns i32, offsets i32, nnz, rows, cols), longest row) of a CSR tensor, kept ON the tensor
+    object between calls (keyed on the component tensors' storage and version counters; it dies with the
+    tensor): a static sparse operand is narrowed to int32 once instead of on every product (two passes over
+    the indices: 0.3 ms at the 1M × 1M config), and its longest row — one read-back, once — tells the product
+    whether the long-row machinery (a workspace and three helper launches per call) is needed at all.'''
+    key = _csr_key(a)
+    hit = getattr(a, '_mi_csr_props', None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    props = get_sparse_tensor_properties(a)
+    offsets = props[2]
+    longest = int((offsets[1:] - offsets[:-1]).max()) if offsets.numel() > 1 else 0
+    try:
+        a._mi_csr_props = (key, props, longest)
+    except (AttributeError, RuntimeError):
+        pass  # a tensor type that takes no attributes: just no caching
+    return props, longest
+
+
 def _csr_of(a: torch.Tensor):
     '''(values, columns, offsets, nnz, rows, cols) of a 2-d dense or CSR tensor.'''
     if a.is_sparse_csr:
-        return get_sparse_tensor_properties(a)
+        return _csr_props_cached(a)[0]
     values, columns, offsets = custom_mm.dense_to_csr(a)
     return values, columns, offsets.view(-1), values.numel(), a.shape[-2], a.shape[-1]
+
+
+def _csr_product(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, mm_op, default_op):
+    '''c = a·b for a 2-d CSR (or dense, converted) a through mm_op; the stock kernel on a CSR tensor without
+    over-long rows runs as ONE launch (custom_mm.naive_spmm_ex, rule 0: same bits — the long-row rule only
+    concerns rows beyond custom_mm.long_row_threshold() non-zeros).'''
+    if a.is_sparse_csr and mm_op is default_op and hasattr(custom_mm, 'naive_spmm_ex'):
+        props, longest = _csr_props_cached(a)
+        if longest <= custom_mm.long_row_threshold():
+            return custom_mm.naive_spmm_ex(*props, b, c, 0)
+    return mm_op(*_csr_of(a), b, c)
 
 
 def fused_skip_pays(items: int, rows: int, cols: int, width: int = 256) -> bool:
@@ -290,14 +327,14 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch
         c = torch.empty((c_rows, c_cols), device=dev, dtype=torch.float32)
         if fused and fused_skip_pays(1, c_rows, a_shape[-1], c_cols) and custom_mm.naive_spmm_dense(a, b, c):
             return c
-        return mm_op(*_csr_of(a), b, c)
+        return _csr_product(a, b, c, mm_op, default_op)
 
     if a.dim() == 2:
         # one CSR × a batch of B: C[i] = A·B[i]  ==  A · [K, batch·N]
         batch = tuple(b_shape[:-2])
         _b = b.reshape((-1,) + tuple(b_shape[-2:])).permute(1, 0, 2).reshape(b_shape[-2], -1)
         c = torch.empty((c_rows, _b.shape[1]), device=dev, dtype=torch.float32)
-        c = mm_op(*_csr_of(a), _b, c)
+        c = _csr_product(a, _b, c, mm_op, default_op)
         return c.view(c_rows, -1, c_cols).permute(1, 0, 2).reshape(batch + (c_rows, c_cols))
 
     if a.is_sparse_csr:
@@ -368,13 +405,11 @@ def _csr_cached(m1: torch.Tensor):
     transpose (≈2.5 ms at the 1M × 1M config) would otherwise be paid on every backward.  The entry is
     keyed on the component tensors' storage and version counters, so an in-place update of the values
     (or a different tensor) rebuilds it; it dies with the tensor.'''
-    vals, crow, ccol = torch.Tensor.values(m1), torch.Tensor.crow_indices(m1), torch.Tensor.col_indices(m1)
-    key = (vals.data_ptr(), crow.data_ptr(), ccol.data_ptr(), vals._version, crow._version, ccol._version,
-           tuple(m1.shape), vals.numel())
+    key = _csr_key(m1)
     hit = getattr(m1, '_mi_csr_cache', None)
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
-    props = get_sparse_tensor_properties(m1)
+    props = _csr_props_cached(m1)[0]
     values, columns, offsets, nnz, rows, cols = props
     transposed = custom_mm.csr_transpose(values, columns, offsets, nnz, rows, cols)
     try:

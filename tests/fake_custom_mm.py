@@ -47,6 +47,14 @@ def naive_spmm(vals, cols, offs, nnz, rows, kcols, B, C):
     return _spmm("naive_spmm", vals, cols, offs, nnz, rows, kcols, B, C)
 
 
+def naive_spmm_ex(vals, cols, offs, nnz, rows, kcols, B, C, long_rows):
+    return _spmm("naive_spmm_ex", vals, cols, offs, nnz, rows, kcols, B, C)
+
+
+def long_row_threshold():
+    return 8192
+
+
 def cusparse_mmul(vals, cols, offs, nnz, rows, kcols, B, C):
     return _spmm("cusparse_mmul", vals, cols, offs, nnz, rows, kcols, B, C)
 

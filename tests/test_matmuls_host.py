@@ -326,3 +326,29 @@ def test_dense_inputs_are_routed_by_shape(mm, monkeypatch):
     assert route(sparsify(g, 3, 20, 30), rand(g, 30, 8)) == ["dense_to_csr", "naive_spmm"]   # FC call shape: flattened
     assert route(sparsify(g, 3, 8, 12), rand(g, 3, 12, 4)) == ["naive_spmm_dense"]           # batch of small matrices
     assert route(sparsify(g, 3, 8, 20), rand(g, 3, 20, 4)) == ["dense_to_csr", "naive_spmm_batched"]  # rows "too long"
+
+
+def test_csr_operand_is_narrowed_once_and_skips_the_long_row_machinery(mm, monkeypatch):
+    """A CSR tensor's int32 arrays and its longest row are kept on the tensor between products (rebuilt when the
+    values change in place); without over-long rows the stock kernel is called as naive_spmm_ex(rule 0): one
+    launch, no workspace."""
+    matmuls, fake = mm
+    g = torch.Generator().manual_seed(8)
+    a = sparsify(g, 12, 20).to_sparse_csr()
+    b = rand(g, 20, 6)
+    seen = []
+    real = matmuls.get_sparse_tensor_properties
+    monkeypatch.setattr(matmuls, "get_sparse_tensor_properties", lambda t: (seen.append(1), real(t))[1])
+    fake.calls.clear()
+    out1 = matmuls.naiveSpMM.apply(a, b)
+    out2 = matmuls.cusparseMM.apply(a, b)
+    assert len(seen) == 1                                     # narrowed once
+    assert [c[0] for c in fake.calls if c[0].startswith("naive_spmm") or c[0] == "cusparse_mmul"] == ["naive_spmm_ex", "naive_spmm_ex"]
+    assert torch.allclose(out1, a.to_dense() @ b, rtol=1e-5, atol=1e-6) and torch.equal(out1, out2)
+    torch.Tensor.values(a).mul_(2.0)                          # in-place update: the entry is rebuilt
+    out3 = matmuls.naiveSpMM.apply(a, b)
+    assert len(seen) == 2 and torch.allclose(out3, 2 * out1, rtol=1e-5, atol=1e-6)
+    monkeypatch.setattr(fake, "long_row_threshold", lambda: 3)   # "long" rows present: the stock entry with its workspace
+    fake.calls.clear()
+    matmuls.naiveSpMM.apply(a, b)
+    assert [c[0] for c in fake.calls if c[0].startswith("naive_spmm")] == ["naive_spmm"]
