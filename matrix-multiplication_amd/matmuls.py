@@ -276,10 +276,14 @@ def _csr_product(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, mm_op, defau
     '''c = a·b for a 2-d CSR (or dense, converted) a through mm_op; the stock kernel on a CSR tensor without
     over-long rows runs as ONE launch (custom_mm.naive_spmm_ex, rule 0: same bits — the long-row rule only
     concerns rows beyond custom_mm.long_row_threshold() non-zeros).'''
-    if a.is_sparse_csr and mm_op is default_op and hasattr(custom_mm, 'naive_spmm_ex'):
-        props, longest = _csr_props_cached(a)
+    if mm_op is default_op and hasattr(custom_mm, 'naive_spmm_ex'):
+        if a.is_sparse_csr:
+            props, longest = _csr_props_cached(a)
+        else:  # a dense matrix converts without duplicate columns: no row is longer than it is wide
+            props, longest = _csr_of(a), a.shape[-1]
         if longest <= custom_mm.long_row_threshold():
             return custom_mm.naive_spmm_ex(*props, b, c, 0)
+        return mm_op(*props, b, c)
     return mm_op(*_csr_of(a), b, c)
 
 
@@ -345,7 +349,7 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch
         _a = a.reshape(-1, a_shape[-1])
         c = torch.empty((_a.shape[0], c_cols), device=dev, dtype=torch.float32)
         if not (fused and fused_skip_pays(1, _a.shape[0], _a.shape[1], c_cols) and custom_mm.naive_spmm_dense(_a, b, c)):
-            c = mm_op(*_csr_of(_a), b, c)
+            c = _csr_product(_a, b, c, mm_op, default_op)
         return c.view(tuple(a_shape[:-1]) + (c_cols,))
 
     # batch × batch

@@ -57,7 +57,7 @@ def check_fwd_bwd(fn, ref_fn, a, b, grad_a=True, grad_b=True):
         assert b1.grad is None
 
 
-def test_c1_plumbing_config(mm):
+def test_c1_plumbing_config(mm, monkeypatch):
     """BASELINE.json configs[0]: dense 8×64 @ 64×8 via the wrappers, fwd + bwd, equals torch.mm."""
     matmuls, fake = mm
     torch.manual_seed(0)
@@ -68,6 +68,17 @@ def test_c1_plumbing_config(mm):
     names = [c[0] for c in fake.calls]
     assert "cublas_mmul" in names and "naive_spmm_dense" in names
     fake.fused_dense = False  # and through the CSR kernels proper
+    try:
+        check_fwd_bwd(matmuls.naiveSpMM.apply, torch.mm, a, b)
+        check_fwd_bwd(matmuls.cusparseMM.apply, torch.mm, a, b)
+    finally:
+        fake.fused_dense = True
+    names = [c[0] for c in fake.calls]
+    assert "naive_spmm_ex" in names   # the stock kernels' one-launch entry: a dense 8 × 64 matrix has no over-long row
+    fake.calls.clear()
+    monkeypatch.delattr(fake, "naive_spmm_ex")   # a custom_mm with the reference's names only
+    check_fwd_bwd(matmuls.naiveSpMM.apply, torch.mm, sparsify(torch.Generator().manual_seed(1), 30, 40), torch.rand(40, 8))
+    fake.fused_dense = False
     try:
         check_fwd_bwd(matmuls.naiveSpMM.apply, torch.mm, a, b)
         check_fwd_bwd(matmuls.cusparseMM.apply, torch.mm, a, b)
@@ -322,8 +333,8 @@ def test_dense_inputs_are_routed_by_shape(mm, monkeypatch):
 
     assert route(sparsify(g, 40, 30), rand(g, 30, 8)) == ["naive_spmm_dense"]                # one small matrix
     monkeypatch.setattr(matmuls, "fused_skip_pays", lambda items, rows, cols, width=256: items > 1 and cols <= 16)
-    assert route(sparsify(g, 40, 30), rand(g, 30, 8)) == ["dense_to_csr", "naive_spmm"]      # "large": CSR route
-    assert route(sparsify(g, 3, 20, 30), rand(g, 30, 8)) == ["dense_to_csr", "naive_spmm"]   # FC call shape: flattened
+    assert route(sparsify(g, 40, 30), rand(g, 30, 8)) == ["dense_to_csr", "naive_spmm_ex"]      # "large": CSR route
+    assert route(sparsify(g, 3, 20, 30), rand(g, 30, 8)) == ["dense_to_csr", "naive_spmm_ex"]   # FC call shape: flattened
     assert route(sparsify(g, 3, 8, 12), rand(g, 3, 12, 4)) == ["naive_spmm_dense"]           # batch of small matrices
     assert route(sparsify(g, 3, 8, 20), rand(g, 3, 20, 4)) == ["dense_to_csr", "naive_spmm_batched"]  # rows "too long"
 
