@@ -282,6 +282,16 @@ torch::Tensor naive_spmm_ex(torch::Tensor A_values, torch::Tensor A_columns, tor
   return spmm_impl(A_values, A_columns, A_offsets, nnzA, A_rows, A_cols, B, C, "naive_spmm_ex", nullptr, long_rows);
 }
 
+// … and with the fused bias (fc_layers: activations converted from a dense matrix have no row longer than
+// the layer is wide, so a layer of ≤ long_row_threshold() inputs needs neither workspace nor helper launches).
+torch::Tensor naive_spmm_bias_ex(torch::Tensor A_values, torch::Tensor A_columns, torch::Tensor A_offsets,
+                                 int64_t nnzA, int64_t A_rows, int64_t A_cols, torch::Tensor B, torch::Tensor bias,
+                                 torch::Tensor C, int long_rows) {
+  if (long_rows < MI_LONG_ROWS_AUTO || long_rows > MI_LONG_ROWS_SPLIT)
+    throw std::invalid_argument("naive_spmm_bias_ex: long_rows must be -1, 0 or 1");
+  return spmm_impl(A_values, A_columns, A_offsets, nnzA, A_rows, A_cols, B, C, "naive_spmm_bias_ex", &bias, long_rows);
+}
+
 // (variant id, kernel name, launches per product, splits_long_rows) of the AUTO plan for
 // C[M,N] = A[M,K]·B with nnz non-zeros and these operand buffers — no GPU work.
 std::tuple<int, std::string, int, bool> spmm_plan(int64_t nnz, int64_t M, int64_t K, torch::Tensor B, torch::Tensor C) {
@@ -975,6 +985,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("column_sums", &column_sums, "sum over rows of a 2-d tensor (bias gradient)");
   m.def("naive_spmm_bias", &naive_spmm_bias, "CSR x dense + bias, fused epilogue");
   m.def("naive_spmm_ex", &naive_spmm_ex, "naive_spmm with the long-row rule pinned (-1 auto, 0 none, 1 split)");
+  m.def("naive_spmm_bias_ex", &naive_spmm_bias_ex, "naive_spmm_bias with the long-row rule pinned (-1 auto, 0 none, 1 split)");
   m.def("spmm_plan", &spmm_plan, "(variant, kernel name, launches, splits_long_rows) of the AUTO plan");
   m.def("validate_csr", &validate_csr, "opt-in check of CSR contents (offsets monotone, columns in range); raises");
   m.def("long_row_threshold", &long_row_threshold, "rows with more non-zeros are 'long' (split rule)");

@@ -118,10 +118,13 @@ class _SparseLinearBias(InplaceFunction):
                     csr = (values, columns, offsets.view(-1))
         if csr is not None:
             wt = weight.t().contiguous()                                 # [in, out] row-major B operand
+            # rows of x have at most `fin` non-zeros (no duplicate columns): a layer no wider than the long-row
+            # threshold runs as ONE launch, without the workspace and the helper kernels of the long-row rule
+            rule = 0 if fin <= custom_mm.long_row_threshold() else -1
             if bias is not None:
-                custom_mm.naive_spmm_bias(csr[0], csr[1], csr[2], csr[0].numel(), tokens, fin, wt, bias, out)
+                custom_mm.naive_spmm_bias_ex(csr[0], csr[1], csr[2], csr[0].numel(), tokens, fin, wt, bias, out, rule)
             else:
-                custom_mm.naive_spmm(csr[0], csr[1], csr[2], csr[0].numel(), tokens, fin, wt, out)
+                custom_mm.naive_spmm_ex(csr[0], csr[1], csr[2], csr[0].numel(), tokens, fin, wt, out, rule)
         elif bias is not None:
             custom_mm.cublas_mmul_bias(x2, weight, bias, out, False, True)
         else:

@@ -120,6 +120,13 @@ def naive_spmm_bias(vals, cols, offs, nnz, rows, kcols, B, bias, C):
     return _write(C, oracle.spmm_csr(_np(offs), _np(cols)[:nnz], _np(vals)[:nnz], rows, kcols, _np(B)) + _np(bias)[None, :])
 
 
+def naive_spmm_bias_ex(vals, cols, offs, nnz, rows, kcols, B, bias, C, long_rows):
+    calls.append(("naive_spmm_bias_ex", (rows, kcols)))
+    _spmm_into = naive_spmm_bias(vals, cols, offs, nnz, rows, kcols, B, bias, C)
+    calls.pop()   # the inner naive_spmm_bias record
+    return _spmm_into
+
+
 def column_sums(src):
     calls.append(("column_sums", tuple(src.shape)))
     return torch.from_numpy(_np(src).astype(np.float64).sum(axis=0).astype(np.float32))

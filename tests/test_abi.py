@@ -174,7 +174,7 @@ def test_custom_mm_surface(custom_mm):
     for name in REFERENCE_NAMES:
         assert callable(getattr(custom_mm, name)), name
     for extra in ("dense_to_csr", "naive_spmm_batched", "csr_transpose", "sddmm", "naive_spmm_dense",
-                  "naive_spmm_dense_bias", "cublas_mmul_bias", "naive_spmm_bias", "column_sums"):
+                  "naive_spmm_dense_bias", "cublas_mmul_bias", "naive_spmm_bias", "naive_spmm_bias_ex", "column_sums"):
         assert callable(getattr(custom_mm, extra)), extra
     # positional-only, like the reference's m.def without py::arg
     with pytest.raises(TypeError):

@@ -309,7 +309,7 @@ def test_fc_layer_modules_host_logic(mm):
         assert layer(torch.rand(2, 5)) == 0  # wrong width: prints and returns 0, like the reference
     fc_layers.sparse_forward_pays = _model
     names = [c[0] for c in fake.calls]
-    assert "cublas_mmul_bias" in names and "naive_spmm_bias" in names and "dense_to_csr_fill" in names
+    assert "cublas_mmul_bias" in names and "naive_spmm_bias_ex" in names and "dense_to_csr_fill" in names
 
 
 def test_dense_inputs_are_routed_by_shape(mm, monkeypatch):
