@@ -882,9 +882,11 @@ int coltile_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
 // no second pass over C (16384² × 512 at 0.5 %: 0.150 ms vs 0.206 with panels) and to the slab plan.
 // Returns the number of panels (2, 3, 4, 5, 6 or 8), or 0 when the plan does not apply.
 int l2_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
-  if (N != 256) return 0;
+  // N = 512 / 1024 only where no column-tile width keeps an XCD's slice of B in its L2 (K too tall): 32768² × 512 at
+  // 0.3 %: 0.64 ms with 8 panels vs 0.86 one-pass
+  if (N != 256 && !((N == 512 || N == 1024) && coltile_width(M, K, N, ldb) == 0)) return 0;
   const double b_bytes = (double)K * (double)ldb * 4.0;
-  if (b_bytes <= 6.0 * 1024 * 1024 || b_bytes > 128.0 * 1024 * 1024) return 0;
+  if (b_bytes <= (N == 256 ? 6.0 : 8.0) * 1024 * 1024 || b_bytes > 128.0 * 1024 * 1024) return 0;
   int p = (int)((b_bytes + (4 << 20) - 1) / (4 << 20));
   p = p > 6 ? 8 : p;
   while (p >= 2 && nnz < 8L * p * M) p = p > 6 ? 6 : p - 1;  // each pass carries C once: it needs work to pay for that
