@@ -21,7 +21,7 @@
 // whole 128-B row segments with non-temporal 16-B stores.  Work ids are dealt XCD-contiguously and
 // in 8-tile column groups, so the workgroups an XCD runs together share operand panels in its L2.
 //
-// Two kernels share loader, layouts and epilogue (same k order per element → same bits):
+// Two kernels share loader, layouts and epilogue (same k order per element → same bits), a third covers one regime:
 //  * gemm_f32_kernel (k < 256): one LDS buffer, two barriers per k-tile, the next tile's global
 //    loads issued before the MFMAs; 3–4 workgroups per CU overlap each other's phases.  BERT's
 //    q·kᵀ (k = 64) is bound by writing the 403 MB of scores and runs here.
@@ -30,6 +30,10 @@
 //    MFMA) and the loads of tile t+3 are issued (1 per MFMA; two register sets, so a load has
 //    almost two k-tiles to land); operand reads run one 8-MFMA batch ahead.  The issue order is pinned with sched_group_barrier/sched_barrier: left alone, hipcc
 //    sinks the loads to the end of the tile, directly in front of the waits on them.
+//  * gemm_f32_t16_tn_kernel (Aᵀ·B with few output tiles and a long k — weight gradients): tiles of 16×16 MFMA
+//    blocks (v_mfma_f32_16x16x4_f32, the same k-ordered chain) sized to fill the 256 CUs in whole rounds — 96×96
+//    with twelve waves, 64×64 with eight, 32×32 with four — both operands streamed through LDS as they lie in
+//    memory; its own section below.
 // Measured (MI355X, fp32 MFMA peak 157 TFLOP/s; tools/gemm_square_probe.py, tools/bench_misc.py):
 // 8192³ A·Bᵀ 7.64 ms = 144 TFLOP/s (single-buffer kernel 8.37, rocBLAS 7.15), A·B 7.90,
 // Aᵀ·B 8.10; 4096³ 0.97–1.02 ms (rocBLAS 0.91); 1024³ 0.026 ms (was 0.034; rocBLAS 0.022);
