@@ -221,6 +221,16 @@ int mi_gemm_f32(int transa, int transb, int32_t m, int32_t n, int32_t k,
                 int64_t ldb, int64_t strideB, float* C, int64_t ldc,
                 int64_t strideC, int32_t batch, mi_stream_t stream);
 
+/* Which kernel family mi_gemm_f32 / mi_gemm_bias_f32 take (process-wide; every
+ * plan produces the same bits — tests pin one to compare it with another):
+ * AUTO picks; TILES = one output tile (or a short chain) per 4-wave workgroup;
+ * DUO = the persistent 8-wave kernel whose halves run in anti-phase (whole
+ * 128-row tiles only: MI_EINVAL when pinned on a shape it cannot take). */
+#define MI_GEMM_PLAN_AUTO 0
+#define MI_GEMM_PLAN_TILES 1
+#define MI_GEMM_PLAN_DUO 2
+int mi_gemm_set_plan(int plan);
+
 /* ------------------------------------------------------------------------ *
  * Fused "sparsify on the fly" form: A is given DENSE (batch × M×K, leading
  * dimension lda, item stride strideA) and its exact zeros are skipped inside the

@@ -121,16 +121,26 @@ struct TileLoader {
     }
   }
 
-  // Interior tile (every element in range, 16-B aligned rows): unconditional vector loads.
-  static __device__ __forceinline__ void load_fast(f32x4 (&r)[VECS], const float* src, long ld, int e0, int k0,
-                                                   int tid) {
+  // Interior tile (every element in range, 16-B aligned rows): unconditional buffer loads whose address is a scalar
+  // descriptor (the tile's origin: uniform) + a scalar row step + ONE loop-invariant lane offset — no vector address
+  // arithmetic in the k-loop.  On gfx950 the fp32 MFMA runs at the vector-ALU rate and a co-resident wave's VALU
+  // instruction waits for a gap in the multiplying wave's stream (≈50 cycles each, tools/probes/duo_probe.cpp), so
+  // the ≈3.5 address instructions per flat global_load of the first version were not free.
+  static constexpr int ROWV = KCONTIG ? BK / 4 : EXT / 4;  // float4 per source row
+  static constexpr int RPV = 256 / ROWV;                    // source rows per float4-per-thread pass
+  static __device__ __forceinline__ unsigned lane_offset(long ld, int tid) {  // bytes, loop-invariant
+    return (unsigned)((tid / ROWV) * (int)ld + (tid % ROWV) * 4) * 4u;
+  }
+  static __device__ __forceinline__ const float* origin(const float* src, long ld, int e0, int k0) {  // uniform
+    return KCONTIG ? src + (long)e0 * ld + k0 : src + (long)k0 * ld + e0;
+  }
+  static __device__ __forceinline__ void load_fast(f32x4 (&r)[VECS], const float* tile, long ld, unsigned lane_off) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tile), 0, 0x7fffffff, 0x00020000);
+    const unsigned step = (unsigned)(RPV * (int)ld) * 4u;
 #pragma unroll
-    for (int v = 0; v < VECS; ++v) {
-      int e, k;
-      coords(v, tid, e, k);
-      const float* p = KCONTIG ? src + (long)(e0 + e) * ld + (k0 + k) : src + (long)(k0 + k) * ld + (e0 + e);
-      r[v] = *reinterpret_cast<const f32x4*>(p);
-    }
+    for (int v = 0; v < VECS; ++v)
+      r[v] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)(v * step), 0));
   }
 
   // Registers → LDS.
@@ -169,69 +179,64 @@ __device__ __forceinline__ void tile_coords(int tile, int tiles_n, int tiles_m, 
   tile_n = g * G + r % width;
 }
 
-// Epilogue shared by both kernels.  D' = Cᵀ tile: lane&31 = row m inside the tile, register r
-// holds column n = (r&3) + 8·(r>>2) + 4·(lane>>5).
-template <int BM, int BN, int TM, int TN, bool ALIGNED = false>
-__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds, float* __restrict__ C, int m, int n,
-                                              long ldc, int m0, int n0, int wm, int wn, int wave, int lane, bool vecC,
-                                              const float* __restrict__ bias) {
+// Epilogue shared by the one-tile kernels.  The accumulators hold C blocks with lane ↔ column: register r of a
+// 32×32 block is row (r&3) + 8·(r>>2) + 4·(lane>>5), column lane&31, so one store instruction of one register
+// writes two whole 128-byte row segments.  16 dword stores per block, no LDS staging, no waits; on whole tiles
+// (ALIGNED) they are buffer stores — scalar descriptor of the block + scalar row offset + one loop-invariant lane
+// offset — so the epilogue costs no vector-ALU instruction either (+ bias[n], fused, when given).  The first
+// version kept Cᵀ in the accumulators and staged every block through an LDS patch to store 16 B per lane: the
+// streaming-store ceiling is the same for dword and dwordx4 stores (tools/probes/store_bw_probe.cpp: 5.1–5.5 TB/s
+// either way), and the patch cost 8 LDS instructions, two waits and ≈20 address instructions per block.
+template <int BM, int BN, int TM, int TN, bool ALIGNED, bool HAS_BIAS>
+__device__ __forceinline__ void gemm_epilogue_b(f32x16 (&acc)[TM][TN], float* __restrict__ C, int m, int n, long ldc,
+                                                int m0, int n0, int wm, int wn, int lane, const float* __restrict__ bias) {
   const int l31 = lane & 31, lhi = lane >> 5;
-  // Epilogue.  D' = Cᵀ tile: lane&31 = row m inside the tile, register r holds column
-  // n = (r&3) + 8·(r>>2) + 4·(lane>>5).  Each wave stages one 32×32 tile at a time in its own
-  // LDS patch ([32][36] floats, conflict-free b128 writes), reads it back row-major and stores
-  // whole 128-B row segments with non-temporal 16-B stores (+ bias[n], fused epilogue).
-  constexpr int PLD = 36;
-  float* patch = lds + wave * (32 * PLD);  // the k-loop ended with a barrier: LDS is free
+  const unsigned c_lane = (unsigned)(4 * lhi * (int)ldc + l31) * 4u, c_row = (unsigned)ldc * 4u;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
+      const int row0 = m0 + wm * (BM / 2) + i * 32, col0 = n0 + wn * (BN / 2) + j * 32;  // uniform
+      const int col = col0 + l31;
+      float bv = 0.f;
+      if (HAS_BIAS && (ALIGNED || col < n)) bv = bias[col];
+      if (ALIGNED) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(C + (long)row0 * ldc + col0, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 v = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-        *reinterpret_cast<f32x4*>(patch + l31 * PLD + 8 * g + 4 * lhi) = v;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      const int tile_row0 = m0 + wm * (BM / 2) + i * 32;
-      const int tile_col0 = n0 + wn * (BN / 2) + j * 32;
-      const int c4 = (lane & 7) * 4;
-      const int col = tile_col0 + c4;
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r];
+          if (HAS_BIAS) v += bv;  // after the chain: one extra rounding, like `output += bias` (never x + 0: keeps −0)
+          const unsigned soff = (unsigned)((r & 3) + 8 * (r >> 2)) * c_row;
+          if (MI_GEMM_ABL & 1) {
+            if (v == 12345.678f) C[(long)row0 * ldc + col0 + (soff + c_lane) / 4] = v;  // keeps the accumulators live
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)c_lane, (int)soff, 2 /* nt */);
+          }
+        }
+      } else {
 #pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int rr = (lane >> 3) + 8 * pass;
-        const int row = tile_row0 + rr;
-        f32x4 v = *reinterpret_cast<const f32x4*>(patch + rr * PLD + c4);
-        if (ALIGNED) {  // every tile whole, C rows 16-B aligned: no bounds, no scalar tail
-          if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
-          if (MI_GEMM_ABL & 1) {
-            if (v.x == 12345.678f) C[(long)row * ldc + col] = v.x;
-          } else {
-            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(C + (long)row * ldc + col));
-          }
-        } else if (row < m && col < n) {
-          float* dst = C + (long)row * ldc + col;
-          if (bias) {
-            if (col + 0 < n) v.x += bias[col + 0];
-            if (col + 1 < n) v.y += bias[col + 1];
-            if (col + 2 < n) v.z += bias[col + 2];
-            if (col + 3 < n) v.w += bias[col + 3];
-          }
-          if (MI_GEMM_ABL & 1) {
-            if (v.x == 12345.678f) dst[0] = v.x;  // keeps the accumulators live
-          } else if (vecC && col + 3 < n) {
-            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
-          } else {
-            if (col + 0 < n) __builtin_nontemporal_store(v.x, dst + 0);
-            if (col + 1 < n) __builtin_nontemporal_store(v.y, dst + 1);
-            if (col + 2 < n) __builtin_nontemporal_store(v.z, dst + 2);
-            if (col + 3 < n) __builtin_nontemporal_store(v.w, dst + 3);
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          float v = acc[i][j][r];
+          if (HAS_BIAS) v += bv;
+          if (row < m && col < n) {
+            if (MI_GEMM_ABL & 1) {
+              if (v == 12345.678f) C[(long)row * ldc + col] = v;
+            } else {
+              __builtin_nontemporal_store(v, C + (long)row * ldc + col);
+            }
           }
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
     }
+}
+
+template <int BM, int BN, int TM, int TN, bool ALIGNED = false>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* __restrict__ C, int m, int n, long ldc,
+                                              int m0, int n0, int wm, int wn, int lane, const float* __restrict__ bias) {
+  if (bias) gemm_epilogue_b<BM, BN, TM, TN, ALIGNED, true>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
+  else gemm_epilogue_b<BM, BN, TM, TN, ALIGNED, false>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
 }
 
 #ifdef MI_GEMM_TIMING
@@ -254,14 +259,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI_GEMM_SHO
   typedef TileLoader<BM, !TA> LA;  // A not transposed → contiguous along k
   typedef TileLoader<BN, TB> LB;   // B transposed     → contiguous along k
   constexpr int kOperandFloats = LA::LDS_FLOATS + LB::LDS_FLOATS;
-  constexpr int kEpilogueFloats = 4 * 32 * 36;  // one [32][36] staging patch per wave
-  __shared__ __attribute__((aligned(16))) float lds[kOperandFloats > kEpilogueFloats ? kOperandFloats : kEpilogueFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kOperandFloats];
   float* As = lds;
   float* Bs = lds + LA::LDS_FLOATS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: the epilogue's descriptors stay scalar
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware work order: workgroups are dealt round-robin over the 8 XCDs (block b runs on XCD
   // b % 8, each with a private L2), so give every XCD a CONTIGUOUS range of work ids: the tiles
@@ -313,15 +317,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI_GEMM_SHO
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          // operands swapped: the accumulator tile is Cᵀ (lane ↔ row m of C, registers ↔ 4-column
-          // groups of n), so the epilogue can move 16 B per lane; a·b = b·a keeps every bit.
-          if (!(MI_GEMM_ABL & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
+          // accumulator block = C block: lane ↔ column n, registers ↔ rows (see gemm_epilogue)
+          if (!(MI_GEMM_ABL & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   };
   if (interior) {
+    const unsigned a_lane = LA::lane_offset(lda, tid), b_lane = LB::lane_offset(ldb, tid);
     if (!(MI_GEMM_ABL & 4)) {
-      LA::load_fast(ra, A, lda, m0, 0, tid);
-      LB::load_fast(rb, B, ldb, n0, 0, tid);
+      LA::load_fast(ra, LA::origin(A, lda, m0, 0), lda, a_lane);
+      LB::load_fast(rb, LB::origin(B, ldb, n0, 0), ldb, b_lane);
     }
     for (int k0 = 0; k0 < k; k0 += BK) {
       LA::store(ra, As, tid);
@@ -330,8 +334,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI_GEMM_SHO
       __syncthreads();
       GEMM_STAMP(1);
       if (k0 + BK < k && !(MI_GEMM_ABL & 4)) {
-        LA::load_fast(ra, A, lda, m0, k0 + BK, tid);
-        LB::load_fast(rb, B, ldb, n0, k0 + BK, tid);
+        LA::load_fast(ra, LA::origin(A, lda, m0, k0 + BK), lda, a_lane);
+        LB::load_fast(rb, LB::origin(B, ldb, n0, k0 + BK), ldb, b_lane);
       }
       mfma_tile();
       GEMM_STAMP(2);  // MFMAs of the tile issued
@@ -354,7 +358,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI_GEMM_SHO
     }
   }
 
-  gemm_epilogue<BM, BN, TM, TN, ALIGNED>(acc, lds, C, m, n, ldc, m0, n0, wm, wn, wave, lane, vecC, bias);
+  if (interior) gemm_epilogue<BM, BN, TM, TN, true>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
+  else if (!ALIGNED) gemm_epilogue<BM, BN, TM, TN, false>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
   GEMM_STAMP(4);  // epilogue issued
 }
 
@@ -372,12 +377,11 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
   typedef TileLoader<BM, !TA> LA;
   typedef TileLoader<BN, TB> LB;
   constexpr int kStage = LA::LDS_FLOATS + LB::LDS_FLOATS;
-  constexpr int kEpilogueFloats = 4 * 32 * 36;
-  __shared__ __attribute__((aligned(16))) float lds[2 * kStage > kEpilogueFloats ? 2 * kStage : kEpilogueFloats];
+  __shared__ __attribute__((aligned(16))) float lds[2 * kStage];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: the epilogue's descriptors stay scalar
   const int wm = wave >> 1, wn = wave & 1;
   const unsigned total = gridDim.x, bid = blockIdx.x;
   const unsigned q = total / 8, rem = total % 8, xcd = bid % 8, pos = bid / 8;
@@ -410,11 +414,12 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
     // MFMA phase of a 128×64 tile is only ≈0.85 µs, shorter than an HBM round trip.
     f32x4 ra0[LA::VECS], rb0[LB::VECS], ra1[LA::VECS], rb1[LB::VECS];
     const int k_last = k - BK;  // start of the last tile: later "prefetches" re-read it (never used)
+    const unsigned a_lane = LA::lane_offset(lda, tid), b_lane = LB::lane_offset(ldb, tid);
     auto load_tile = [&](f32x4 (&ra)[LA::VECS], f32x4 (&rb)[LB::VECS], int k0) {
       const int kk = k0 < k_last ? k0 : k_last;
       if (MI_GEMM_ABL & 4) return;
-      LA::load_fast(ra, A, lda, m0, kk, tid);
-      LB::load_fast(rb, B, ldb, n0, kk, tid);
+      LA::load_fast(ra, LA::origin(A, lda, m0, kk), lda, a_lane);
+      LB::load_fast(rb, LB::origin(B, ldb, n0, kk), ldb, b_lane);
     };
     load_tile(ra0, rb0, 0);
     LA::store(ra0, lds, tid);
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              if (!(MI_GEMM_ABL & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s & 1][h][j], a[s & 1][h][i], acc[i][j], 0, 0, 0);
+              if (!(MI_GEMM_ABL & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][h][i], b[s & 1][h][j], acc[i][j], 0, 0, 0);
         // Fence the scheduler per batch: hipcc otherwise sinks the operand reads next to their
         // use and the global loads to the end of the tile (right in front of the waits on them).
         if (s == 0) {
@@ -511,12 +516,13 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
       }
       __syncthreads();
     }
   }
-  gemm_epilogue<BM, BN, TM, TN>(acc, lds, C, m, n, ldc, m0, n0, wm, wn, wave, lane, vecC, bias);
+  if (interior) gemm_epilogue<BM, BN, TM, TN, true>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
+  else gemm_epilogue<BM, BN, TM, TN, false>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -542,25 +548,22 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int BM, int BN, bool TA, bool TB, int NK, int CHAIN>
 __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int m, int n, int k, long lda,
-    long ldb, long ldc, long strideA, long strideB, long strideC, int groups_n, int groups_per_item,
-    const float* __restrict__ bias, int reverse) {
+    long ldb, long ldc, long strideA, long strideB, long strideC, int groups_n, int groups_per_item, int reverse) {
   constexpr int TM = BM / 64, TN = BN / 64, NT = TM * TN;
-  constexpr int PHASES = 2 * NT;            // per tile: write the patch, then read it back and store
+  constexpr int PHASES = 2 * NT;            // per tile: each 32×32 block leaves in two phases of 8 dword stores
   static_assert(PHASES % NK == 0 && (BK / 2) % (PHASES / NK) == 0, "phases must divide the MFMA steps of a stage");
   constexpr int PPS = PHASES / NK;          // phases per stage
   constexpr int GAP = (BK / 2) / PPS;       // MFMA k-steps between two phases
   typedef TileLoader<BM, !TA> LA;
   typedef TileLoader<BN, TB> LB;
   constexpr int kOperandFloats = LA::LDS_FLOATS + LB::LDS_FLOATS;
-  constexpr int PLD = 36;
-  __shared__ __attribute__((aligned(16))) float lds[kOperandFloats + 4 * 32 * PLD];
+  __shared__ __attribute__((aligned(16))) float lds[kOperandFloats];
   float* As = lds;
   float* Bs = lds + LA::LDS_FLOATS;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lhi = lane >> 5;
-  float* patch = lds + kOperandFloats + wave * (32 * PLD);
   const unsigned total = gridDim.x, bid = blockIdx.x;
   const unsigned q8 = total / 8, rem = total % 8, xcd = bid % 8, pos = bid / 8;
   const unsigned work0 = xcd * q8 + (xcd < rem ? xcd : rem) + pos;
@@ -575,41 +578,35 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
   C += item * strideC;
 
   f32x16 acc[2][TM][TN];  // tile T of the chain accumulates in set T % 2
+  const unsigned c_lane = (unsigned)(4 * lhi * (int)ldc + l31) * 4u, c_row = (unsigned)ldc * 4u;
 
-  // one epilogue phase of chain tile T: phase 2q writes 32×32 tile q of its accumulators to the patch,
-  // phase 2q+1 reads it back row-major and stores four 128-byte row segments per lane group (+ bias)
+  // one epilogue phase of chain tile T: phase 2q + h stores registers 8h … 8h+7 of 32×32 block q of its accumulators
+  // (lane ↔ column, register ↔ row: each store instruction writes two whole 128-byte row segments) as buffer
+  // stores — scalar descriptor of the block + scalar row offset + the lane's loop-invariant offset: no LDS, no
+  // waits, no vector-ALU instruction (products with a bias take the one-tile kernel).  Spread over the next tile's MFMAs, one store per two MFMAs: the
+  // 403 MB of q·kᵀ scores leave as a steady stream instead of in bursts.
   auto phase = [&](auto T_, auto P_) {
     constexpr int T = decltype(T_)::value, P = decltype(P_)::value;
-    constexpr int q = P / 2, i = q / TN, j = q % TN, SET = T % 2;
-    const int n0 = (CHAIN * group_n + T) * BN;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    if constexpr (P % 2 == 0) {
+    constexpr int q = P / 2, h = P % 2, i = q / TN, j = q % TN, SET = T % 2;
+    const int col0 = (CHAIN * group_n + T) * BN + wn * (BN / 2) + j * 32;  // uniform
+    const int row0 = m0 + wm * (BM / 2) + i * 32;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(C + (long)row0 * ldc + col0, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 v = f32x4{acc[SET][i][j][4 * g], acc[SET][i][j][4 * g + 1], acc[SET][i][j][4 * g + 2], acc[SET][i][j][4 * g + 3]};
-        *reinterpret_cast<f32x4*>(patch + l31 * PLD + 8 * g + 4 * lhi) = v;
-      }
-    } else {
-      const int tile_row0 = m0 + wm * (BM / 2) + i * 32;
-      const int col = n0 + wn * (BN / 2) + j * 32 + (lane & 7) * 4;
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int rr = (lane >> 3) + 8 * pass;
-        f32x4 v = *reinterpret_cast<const f32x4*>(patch + rr * PLD + (lane & 7) * 4);
-        if (bias) v += *reinterpret_cast<const f32x4*>(bias + col);
-        if (MI_GEMM_ABL & 1) {
-          if (v.x == 12345.678f) C[(long)(tile_row0 + rr) * ldc + col] = v.x;
-        } else {
-          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(C + (long)(tile_row0 + rr) * ldc + col));
-        }
+    for (int r = 8 * h; r < 8 * h + 8; ++r) {
+      const float v = acc[SET][i][j][r];
+      const unsigned soff = (unsigned)((r & 3) + 8 * (r >> 2)) * c_row;
+      if (MI_GEMM_ABL & 1) {
+        if (v == 12345.678f) C[(long)row0 * ldc + col0 + (soff + c_lane) / 4] = v;
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)c_lane, (int)soff, 2 /* nt */);
       }
     }
   };
 
   f32x4 ra[LA::VECS], rb[LB::VECS];
-  LA::load_fast(ra, A, lda, m0, 0, tid);
-  LB::load_fast(rb, B, ldb, CHAIN * group_n * BN, 0, tid);
+  const unsigned a_lane = LA::lane_offset(lda, tid), b_lane = LB::lane_offset(ldb, tid);
+  LA::load_fast(ra, LA::origin(A, lda, m0, 0), lda, a_lane);
+  LB::load_fast(rb, LB::origin(B, ldb, CHAIN * group_n * BN, 0), ldb, b_lane);
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   static_for<CHAIN>([&](auto T_) {
@@ -621,11 +618,11 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
       __syncthreads();
       // the next stage's operands: the next k-tile of this output tile, or the first of the next one
       if constexpr (KT + 1 < NK) {
-        LA::load_fast(ra, A, lda, m0, (KT + 1) * BK, tid);
-        LB::load_fast(rb, B, ldb, (CHAIN * group_n + T) * BN, (KT + 1) * BK, tid);
+        LA::load_fast(ra, LA::origin(A, lda, m0, (KT + 1) * BK), lda, a_lane);
+        LB::load_fast(rb, LB::origin(B, ldb, (CHAIN * group_n + T) * BN, (KT + 1) * BK), ldb, b_lane);
       } else if constexpr (T + 1 < CHAIN) {
-        LA::load_fast(ra, A, lda, m0, 0, tid);
-        LB::load_fast(rb, B, ldb, (CHAIN * group_n + T + 1) * BN, 0, tid);
+        LA::load_fast(ra, LA::origin(A, lda, m0, 0), lda, a_lane);
+        LB::load_fast(rb, LB::origin(B, ldb, (CHAIN * group_n + T + 1) * BN, 0), ldb, b_lane);
       }
       static_for<BK / 2>([&](auto S_) {
         constexpr int S = decltype(S_)::value;  // MFMA k-step of this stage
@@ -644,9 +641,9 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
               if (KT == 0 && S == 0) acc[SET][i][j] = zero16;
             } else if constexpr (KT == 0 && S == 0) {
               // a tile's first product starts its accumulators (set reused from tile T − 2) from zero
-              acc[SET][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], zero16, 0, 0, 0);
+              acc[SET][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], zero16, 0, 0, 0);
             } else {
-              acc[SET][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[SET][i][j], 0, 0, 0);
+              acc[SET][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[SET][i][j], 0, 0, 0);
             }
           }
       });
@@ -732,17 +729,25 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_f32_t16_tn_kernel(
   // compiler's wait before a store to LDS counts the younger loads instead of being vmcnt(0).
   f32x4 ra[2][VECS], rb[2][VECS];
   const int chunks = k / T16_KC;
+  // buffer loads: scalar descriptor of the chunk + scalar row step (THREADS / ROWV rows per pass) + one loop-invariant
+  // lane offset per operand — no vector address arithmetic between the MFMAs (see TileLoader::load_fast)
+  static_assert(THREADS % ROWV == 0, "a pass of float4-per-thread loads covers whole rows");
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned a_lane = (unsigned)((tid / ROWV) * (int)lda + 4 * (tid % ROWV)) * 4u;
+  const unsigned b_lane = (unsigned)((tid / ROWV) * (int)ldb + 4 * (tid % ROWV)) * 4u;
+  const unsigned a_step = (unsigned)((THREADS / ROWV) * (int)lda) * 4u, b_step = (unsigned)((THREADS / ROWV) * (int)ldb) * 4u;
   auto load_chunk = [&](int set, int c) {
     const int k0 = (c < chunks ? c : chunks - 1) * T16_KC;
+    const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ap + (long)k0 * lda), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bp + (long)k0 * ldb), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int i = 0; i < VECS; ++i) {
-      const int j = tid + THREADS * i, row = j / ROWV, c4 = j % ROWV;
       if (MI_GEMM_ABL & 4) {
         ra[set][i] = rb[set][i] = f32x4{1.f, 2.f, 3.f, (float)k0};
         continue;
       }
-      ra[set][i] = *reinterpret_cast<const f32x4*>(Ap + (long)(k0 + row) * lda + 4 * c4);
-      rb[set][i] = *reinterpret_cast<const f32x4*>(Bp + (long)(k0 + row) * ldb + 4 * c4);
+      ra[set][i] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(ra_src, (int)a_lane, (int)(i * a_step), 0));
+      rb[set][i] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rb_src, (int)b_lane, (int)(i * b_step), 0));
     }
   };
   auto store_chunk = [&](int set, int buf) {
@@ -833,6 +838,7 @@ int launch_t16(const float* A, const float* B, float* C, int m, int n, int k, lo
 }
 
 std::atomic<unsigned> g_launch_counter{0};  // one counter for every instantiation of launch()
+std::atomic<int> g_gemm_plan{MI_GEMM_PLAN_AUTO};
 
 template <int BM, int BN, bool TA, bool TB>
 int launch(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb,
@@ -865,15 +871,14 @@ int launch(const float* A, const float* B, float* C, int m, int n, int k, long l
 #ifndef MI_GEMM_CHAIN_MAX
 #define MI_GEMM_CHAIN_MAX 4
 #endif
-    if (BM == 128 && BN == 128 && tiles_n % 2 == 0 && (k == BK || k == 2 * BK || k == 4 * BK) &&
-        (bias == nullptr || mi::aligned16(bias))) {
+    if (BM == 128 && BN == 128 && tiles_n % 2 == 0 && (k == BK || k == 2 * BK || k == 4 * BK) && bias == nullptr) {
       // CHAIN output tiles of one tile row per workgroup, each tile's epilogue inside the next one's MFMAs
       const int chain = (tiles_n % 4 == 0 && MI_GEMM_CHAIN_MAX >= 4) ? 4 : 2;
       const unsigned gblocks = (unsigned)(blocks / chain);
       const int gn = (int)(tiles_n / chain), gpi = (int)(tiles_m * tiles_n / chain);
 #define MI_PAIR(NK_, CH_)                                                                                         \
   hipLaunchKernelGGL((gemm_f32_pair_kernel<128, 128, TA, TB, NK_, CH_>), dim3(gblocks), dim3(256), 0, s, A, B, C, m, n, \
-                     k, lda, ldb, ldc, sA, sB, sC, gn, gpi, bias, rev)
+                     k, lda, ldb, ldc, sA, sB, sC, gn, gpi, rev)
       if (chain == 4) {
         if (k == BK) MI_PAIR(1, 4);
         else if (k == 2 * BK) MI_PAIR(2, 4);
@@ -977,9 +982,18 @@ extern "C" int mi_gemm_bias_f32(int transa, int transb, int32_t m, int32_t n, in
   if (!A || !B) return MI_EINVAL;
   if (lda < (transa ? m : k) || ldb < (transb ? k : n)) return MI_EINVAL;
   if (strideA < 0 || strideB < 0 || strideC < 0) return MI_EINVAL;
-  const bool vecA = (lda % 4 == 0) && (strideA % 4 == 0) && mi::aligned16(A);
-  const bool vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && mi::aligned16(B);
+  // (the interior loaders address a tile with 32-bit byte offsets: leading dimensions below 2^21 elements)
+  const bool vecA = (lda % 4 == 0) && (strideA % 4 == 0) && mi::aligned16(A) && lda < (1 << 21) && ldc < (1 << 24);
+  const bool vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && mi::aligned16(B) && ldb < (1 << 21);
   const bool vecC = (ldc % 4 == 0) && (strideC % 4 == 0) && mi::aligned16(C);
+  // whole 128-row tiles and enough of them: the persistent two-halves kernel (gemm_f32_duo.hip); same bits
+  const int plan = g_gemm_plan.load(std::memory_order_relaxed);
+  if (plan != MI_GEMM_PLAN_TILES) {
+    const int st = mi::launch_gemm_duo(transa, transb, m, n, k, A, lda, strideA, B, ldb, strideB, bias, C, ldc, strideC,
+                                       batch, plan == MI_GEMM_PLAN_DUO, s);
+    if (st != 1) return st;
+    if (plan == MI_GEMM_PLAN_DUO) return MI_EINVAL;  // pinned, but the shape is not made of whole tiles
+  }
 #define MI_GEMM(TA_, TB_)                                                                       \
   return pick_tile<TA_, TB_>(A, B, C, m, n, k, lda, ldb, ldc, strideA, strideB, strideC, batch, \
                              vecA, vecB, vecC, bias, s)
@@ -988,6 +1002,12 @@ extern "C" int mi_gemm_bias_f32(int transa, int transb, int32_t m, int32_t n, in
   if (transa && !transb) MI_GEMM(true, false);
   MI_GEMM(true, true);
 #undef MI_GEMM
+}
+
+extern "C" int mi_gemm_set_plan(int plan) {
+  if (plan != MI_GEMM_PLAN_AUTO && plan != MI_GEMM_PLAN_TILES && plan != MI_GEMM_PLAN_DUO) return MI_EINVAL;
+  g_gemm_plan.store(plan, std::memory_order_relaxed);
+  return MI_OK;
 }
 
 extern "C" int mi_gemm_f32(int transa, int transb, int32_t m, int32_t n, int32_t k, const float* A,

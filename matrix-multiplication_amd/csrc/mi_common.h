@@ -45,6 +45,13 @@ int launch_spmm_wave_row_colmajor_out(const int32_t* rowptr, const int32_t* col,
                                       int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb, float* Ccm,
                                       int64_t ldc, bool launch, hipStream_t s);
 
+// gemm_f32_duo.hip — the persistent two-halves-in-anti-phase form of the dense fp32 product.  MI_OK = launched;
+// 1 = the shape is not made of whole tiles (or, unless `force`, of too few of them): the caller takes gemm_f32.hip's
+// tile kernels; negative = error.  Same bits either way.
+int launch_gemm_duo(int transa, int transb, int32_t m, int32_t n, int32_t k, const float* A, int64_t lda,
+                    int64_t strideA, const float* B, int64_t ldb, int64_t strideB, const float* bias, float* C,
+                    int64_t ldc, int64_t strideC, int32_t batch, bool force, hipStream_t s);
+
 }  // namespace mi
 
 #define MI_HIP_TRY(expr)                                  \
