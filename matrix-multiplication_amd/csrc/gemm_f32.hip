@@ -986,9 +986,11 @@ extern "C" int mi_gemm_bias_f32(int transa, int transb, int32_t m, int32_t n, in
   const bool vecA = (lda % 4 == 0) && (strideA % 4 == 0) && mi::aligned16(A) && lda < (1 << 21) && ldc < (1 << 24);
   const bool vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && mi::aligned16(B) && ldb < (1 << 21);
   const bool vecC = (ldc % 4 == 0) && (strideC % 4 == 0) && mi::aligned16(C);
-  // whole 128-row tiles and enough of them: the persistent two-halves kernel (gemm_f32_duo.hip); same bits
+  // The persistent two-halves kernel (gemm_f32_duo.hip; same bits) only when pinned: with their k-loops free of
+  // vector-ALU work the tile kernels below are level with it or ahead on every shape measured
+  // (tools/probes/duo_probe.cpp; profiles/r03_gemm_duo_vs_tiles.log), so AUTO = TILES.
   const int plan = g_gemm_plan.load(std::memory_order_relaxed);
-  if (plan != MI_GEMM_PLAN_TILES) {
+  if (plan == MI_GEMM_PLAN_DUO) {
     const int st = mi::launch_gemm_duo(transa, transb, m, n, k, A, lda, strideA, B, ldb, strideB, bias, C, ldc, strideC,
                                        batch, plan == MI_GEMM_PLAN_DUO, s);
     if (st != 1) return st;
