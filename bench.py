@@ -56,17 +56,31 @@ def algorithmic_bytes(nnz, M, N):
     return nnz * (4 * N + 8) + 4 * (M + 1) + 4 * M * N
 
 
-def committed_traffic(workload):
-    """HBM bytes per product (= per step at N = 1) from the committed PMC passes of this same
-    command (profiles/pmc_traffic.json, written by tools/collect_profiles.py), or None."""
+def source_fingerprint():
+    """sha256 (16 hex digits) of bench.py and of the SpMM kernel sources: what a committed PMC figure is tied to."""
+    h = hashlib.sha256()
+    for f in [REPO / "bench.py"] + sorted((REPO / "matrix-multiplication_amd" / "csrc").glob("spmm_*.hip")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(workload, kernel_name=None):
+    """HBM-side bytes per product from the committed PMC passes of this same command (profiles/pmc_traffic.json,
+    written by tools/collect_profiles.py) as (fabric_bytes, dram_bytes_or_None) — or (None, None) when the record
+    was taken with other sources (bench.py or the SpMM kernels changed since: fingerprint) or another kernel."""
     p = REPO / "profiles" / "pmc_traffic.json"
     if not p.exists():
-        return None
+        return None, None
     try:
-        rec = json.loads(p.read_text())
-        return rec.get(workload, {}).get("hbm_bytes_per_product")
+        rec = json.loads(p.read_text()).get(workload, {})
     except (ValueError, OSError):
-        return None
+        return None, None
+    if rec.get("source_fingerprint") != source_fingerprint():
+        return None, None
+    if kernel_name is not None and kernel_name not in " ".join(rec.get("kernels", {}).get("FETCH_SIZE", {})):
+        return None, None
+    return rec.get("hbm_bytes_per_product"), rec.get("dram_bytes_per_product")
 
 
 def spmm_plan(nnz, M, K, B, C):
@@ -221,16 +235,17 @@ def bench_c5(args):
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
+    ev[0].record()
+    for i in range(args.steps):
         step()
-    e1.record()
+        ev[i + 1].record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     flops = 6 * 2.0 * Bz * H * S * S * D
-    kern_ms = e0.elapsed_time(e1) / args.steps
+    step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+    kern_ms = ev[0].elapsed_time(ev[-1]) / args.steps
     # light parity check against torch autograd of matmul on one head
     qq, kk2 = q.detach()[:1, :1].clone().requires_grad_(True), k.detach()[:1, :1].clone().requires_grad_(True)
     torch.matmul(qq, kk2.transpose(-1, -2)).backward(d_scores[:1, :1])
@@ -242,8 +257,13 @@ def bench_c5(args):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BERT-base attention B=32 H=12 S=512 D=64 via cublasTransbMM / cublasMM .apply, fwd+bwd "
                                "(BASELINE.json configs[4])", "flops_per_step": flops},
-        "roofline": {"bound": "mfma", "kernel": "gemm_f32_pipe_kernel ×4 (k = 512) + gemm_f32_kernel ×2 (k = 64) per step", "achieved": round(flops / kern_ms / 1e9, 2),
+        "roofline": {"bound": "mfma",
+                     "kernel": "per step: gemm_f32_pipe_kernel<128,64,false,false> ×2 (probs·V, dS·K) + gemm_f32_pipe_kernel<128,64,true,false> ×2 "
+                               "(dSᵀ·Q, Pᵀ·dC), k = 512; gemm_f32_pair_kernel<128,128,false,true,2,4> ×2 (q·kᵀ, dC·Vᵀ), k = 64",
+                     "achieved": round(flops / kern_ms / 1e9, 2),
                      "peak": 157.3, "unit": "TFLOP/s", "frac": round(flops / kern_ms / 1e9 / 157.3, 4), "traffic": None,
+                     "kernel_ms_per_step": round(kern_ms, 4), "kernel_ms_per_step_median": round(float(np.median(step_ms)), 4),
+                     "kernel_ms_per_step_min": round(float(np.min(step_ms)), 4),
                      "note": "fp32-input MFMA peak (MI355X_MICROARCH.md); the q.kT product is also bound by writing "
                              "403 MB of scores"},
     }), flush=True)
@@ -440,6 +460,7 @@ def main():
         if compute_only_ms is not None:  # N > 1: the event interval also spans the gather wait; use the compute-only loop
             kernels_ms_per_step = compute_only_ms
         achieved = local_bytes_alg / (kernels_ms_per_step * 1e-3) / 1e9
+        traffic, traffic_dram = committed_traffic(args.workload, kernel_name) if world == 1 else (None, None)
         cache_resident = 4 * K * N <= (256 << 20)
         peak = CACHE_GATHER_PEAK_GBS if cache_resident else HBM_PEAK_GBS
         rec = {
@@ -486,13 +507,19 @@ def main():
                                 ("fabric-side gather rate: ~25-50 % of the B-row gathers hit the Infinity Cache "
                                  "(FETCH_SIZE counts those hits), priced against the 8 TB/s HBM spec peak; the guide's "
                                  "pure-HBM random-row gather ceiling is 5.5-5.8 TB/s, streaming 6.29 TB/s"),
-                "traffic": committed_traffic(args.workload) if world == 1 else None,
+                "traffic": traffic, "traffic_dram": traffic_dram,
+                "frac_dram_only": None if not traffic_dram else round(traffic_dram / (kernels_ms_per_step * 1e-3) / 1e9 / peak, 4),
                 "kernel_ms_per_step": round(kernels_ms_per_step, 4),
+                "kernel_ms_per_step_median": round(float(np.median(step_ms)), 4),
+                "kernel_ms_per_step_min": round(float(np.min(step_ms)), 4),
                 "avg_launch_ms": round(kernels_ms_per_step / launches_per_step, 4),
                 "algorithmic_bytes_per_step": local_bytes_alg,
                 "note": "achieved = algorithmic bytes of one product / summed duration of its "
                         f"{launches_per_step} back-to-back launch(es) (HIP events on the launch stream); "
-                        "traffic = PMC bytes per product from profiles/pmc_traffic.json",
+                        "traffic = fabric-side PMC bytes per product (Infinity-Cache hits included), traffic_dram = the "
+                        "DRAM-side share, both from profiles/pmc_traffic.json and null unless that record was taken "
+                        "with these very sources (fingerprint of bench.py + csrc/spmm_*.hip) and this kernel; "
+                        "frac_dram_only = traffic_dram / time / peak",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

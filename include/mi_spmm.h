@@ -89,7 +89,12 @@ int mi_spmm_csr_ws_f32(const int32_t* rowptr, const int32_t* col, const float* v
 /* MI_LONG_ROWS_PREPARED: as SPLIT, and the list of long rows in `workspace` was already built by
  * mi_spmm_long_rows_prepare for this matrix (same nnz and N): the per-call memset + list-building
  * launch are skipped — the inspector–executor form (custom_mm.cusparse_inspect / tiledspmm_inspect_*). */
-enum { MI_LONG_ROWS_AUTO = -1, MI_LONG_ROWS_NONE = 0, MI_LONG_ROWS_SPLIT = 1, MI_LONG_ROWS_PREPARED = 2 };
+/* MI_LONG_ROWS_AUTO_ZEROED: as AUTO, and the caller keeps the first 16 bytes of `workspace` ZERO between products:
+ * they are zero on entry and zero again once the product's kernels have run (one workspace per stream, reused —
+ * what custom_mm.naive_spmm / cusparse_mmul do).  Saves the per-product memset: a product is then exactly two
+ * launches — the main kernel, which lists the rows it skips, and one follow-up that sums them (or finds none). */
+enum { MI_LONG_ROWS_AUTO = -1, MI_LONG_ROWS_NONE = 0, MI_LONG_ROWS_SPLIT = 1, MI_LONG_ROWS_PREPARED = 2,
+       MI_LONG_ROWS_AUTO_ZEROED = 3 };
 /* Inspector step for MI_LONG_ROWS_PREPARED: lists the rows beyond the threshold once.  workspace ≥
  * mi_spmm_csr_workspace_bytes(nnz, N); it must stay untouched between the products that use it,
  * and products sharing one workspace must be ordered on one stream (the partial-row area is reused).

@@ -27,6 +27,7 @@
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 
+#include <map>
 #include <mutex>
 #include <string>
 #include <tuple>
@@ -192,6 +193,41 @@ torch::Tensor cublas_bmm(torch::Tensor A, torch::Tensor B, torch::Tensor C, int 
 
 // ---- CSR × dense, row-major (reference custom_mm.cpp:166-179, :203-217) -----
 
+// One long-row workspace per (device, stream), reused by every plain naive_spmm / cusparse_mmul on that stream
+// (products on one stream are ordered, so they can share it).  Invariant (MI_LONG_ROWS_AUTO_ZEROED, include/mi_spmm.h):
+// its first 16 bytes are zero whenever no product is in flight — zeroed once here, restored by each product's
+// follow-up kernel.  Not used under stream capture (the buffer would belong to the graph's pool).
+struct StreamWorkspace {
+  torch::Tensor buf;
+};
+std::mutex g_stream_ws_mutex;
+std::map<std::pair<int, mi_stream_t>, StreamWorkspace> g_stream_ws;
+
+bool stream_is_capturing(mi_stream_t stream) {
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &status) != hipSuccess) {
+    (void)hipGetLastError();
+    return true;  // be conservative: the per-call path is always valid
+  }
+  return status != hipStreamCaptureStatusNone;
+}
+
+torch::Tensor zeroed_stream_workspace(const torch::Device& dev, mi_stream_t stream, size_t bytes) {
+  std::lock_guard<std::mutex> lock(g_stream_ws_mutex);
+  StreamWorkspace& w = g_stream_ws[std::make_pair((int)dev.index(), stream)];
+  if (!w.buf.defined() || (size_t)w.buf.numel() < bytes) {
+    const int64_t cap = (int64_t)(bytes + bytes / 2 + 4096);
+    w.buf = torch::empty({cap}, torch::dtype(torch::kUInt8).device(dev));
+    w.buf.narrow(0, 0, 16).zero_();  // once per (re)allocation, on the current stream
+  }
+  return w.buf;
+}
+
+void drop_stream_workspace(const torch::Device& dev, mi_stream_t stream) {
+  std::lock_guard<std::mutex> lock(g_stream_ws_mutex);
+  g_stream_ws.erase(std::make_pair((int)dev.index(), stream));
+}
+
 torch::Tensor spmm_impl(const torch::Tensor& A_values, const torch::Tensor& A_columns,
                         const torch::Tensor& A_offsets, int64_t nnzA, int64_t A_rows,
                         int64_t A_cols, const torch::Tensor& B, torch::Tensor C, const char* what,
@@ -232,16 +268,28 @@ torch::Tensor spmm_impl(const torch::Tensor& A_values, const torch::Tensor& A_co
     bias_ptr = bias_keep.data_ptr<float>();
   }
   c10::hip::HIPGuard guard(C.device().index());
-  // workspace for the over-long rows (list + partial rows of the split ones; caching allocator);
+  // workspace for the over-long rows (list + partial rows of the split ones);
   // none when the caller pins "no row is split" (MI_LONG_ROWS_NONE: one launch, nothing else)
   const size_t ws_bytes = long_rows == MI_LONG_ROWS_NONE ? 0 : mi_spmm_csr_workspace_bytes(nnzA, (int32_t)N);
   torch::Tensor ws;
-  if (ws_bytes > 0) ws = torch::empty({(int64_t)ws_bytes}, torch::dtype(torch::kUInt8).device(C.device()));
+  int mode = long_rows;
+  const mi_stream_t stream = stream_of(C);
+  if (ws_bytes > 0) {
+    if (long_rows == MI_LONG_ROWS_AUTO && !stream_is_capturing(stream)) {
+      // the plain entry points: one workspace per (device, stream), kept with a zero header between products, so a
+      // product is the main kernel (which lists the rows it skips) + one follow-up launch — no memset, no scan
+      ws = zeroed_stream_workspace(C.device(), stream, ws_bytes);
+      mode = MI_LONG_ROWS_AUTO_ZEROED;
+    } else {
+      ws = torch::empty({(int64_t)ws_bytes}, torch::dtype(torch::kUInt8).device(C.device()));  // caching allocator
+    }
+  }
   const int st = mi_spmm_csr_ex_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
                                     A_values.data_ptr<float>(), nnzA, (int32_t)A_rows, (int32_t)A_cols,
                                     (int32_t)N, Bc.data_ptr<float>(), ldb, bias_ptr, C.data_ptr<float>(),
-                                    std::max<int64_t>(N, 1), long_rows, ws_bytes > 0 ? ws.data_ptr() : nullptr,
-                                    ws_bytes, stream_of(C));
+                                    std::max<int64_t>(N, 1), mode, ws_bytes > 0 ? ws.data_ptr() : nullptr,
+                                    ws_bytes > 0 ? (size_t)ws.numel() : 0, stream);
+  if (st != MI_OK && mode == MI_LONG_ROWS_AUTO_ZEROED) drop_stream_workspace(C.device(), stream);  // its header may be dirty
   check_status(st, what);
   return C;
 }

@@ -38,6 +38,52 @@ __device__ __forceinline__ f32x4 fma4(float a, f32x4 x, f32x4 acc) {
 }
 
 // ---------------------------------------------------------------------------
+// Rows beyond the long-row threshold (see "Skewed matrices" below) are skipped by the kernels of this file and
+// LISTED by them on the way: the wave (or lane group) that meets such a row appends it to the list in the
+// caller's workspace, so a product costs no separate scan of rowptr — main kernel + one follow-up launch that
+// sums the listed rows (or finds the list empty and exits).
+// Workspace (ints): [0] rows listed, [1] workgroup slots handed out, [2] partial-row slots handed out,
+// [3] follow-up workgroups done; then cap_e entries of 8 ints {row, slot base, S, partial base, arrivals, –, –, –};
+// then cap_s slot → entry indices; then (16-B aligned) cap_p × N floats of partial rows.
+// ---------------------------------------------------------------------------
+constexpr int kLongRow = 8192;
+constexpr int kLongChunk = 1024;
+constexpr int kLongWaves = 16;
+constexpr int kLongSplitShift = 15;  // one workgroup per 32768 non-zeros of a row …
+constexpr int kLongSplitMax = 128;   // … up to 128 workgroups
+constexpr int kLongEnt = 8;          // ints per list entry
+
+struct LongArg {
+  int thresh;               // rows with more non-zeros are left to spmm_long_rows_kernel
+  int cap_e, cap_s, cap_p;  // list capacities (hold for any rowptr consistent with nnz)
+  int* ws;                  // the list; nullptr: skip only (the list was prepared beforehand) or nothing is skipped
+};
+
+// One lane per long row.  The order of the list does not matter: every slot is a fixed function of (row, g).
+__device__ __forceinline__ void long_list_append(const LongArg& la, int row, int len) {
+  int* ws = la.ws;
+  if (ws == nullptr) return;
+  int S = len >> kLongSplitShift;
+  S = S < 1 ? 1 : (S > kLongSplitMax ? kLongSplitMax : S);
+  const int e = atomicAdd(&ws[0], 1);
+  const int sb = atomicAdd(&ws[1], S);
+  const int pb = S > 1 ? atomicAdd(&ws[2], S) : 0;
+  // the caps hold for any rowptr consistent with nnz; a lying rowptr must not write out of bounds, and an
+  // entry below the count must never hold garbage (its S = 0 makes every slot that points at it a no-op)
+  if (e >= la.cap_e) return;
+  const bool fits = sb + S <= la.cap_s && (S <= 1 || pb + S <= la.cap_p);
+  int* ent = ws + 4 + kLongEnt * (long)e;
+  ent[0] = row;
+  ent[1] = sb;
+  ent[2] = fits ? S : 0;
+  ent[3] = pb;
+  ent[4] = 0;  // workgroups of this row that have delivered their partial sums
+  if (!fits) return;
+  int* owner = ws + 4 + kLongEnt * (long)la.cap_e;
+  for (int g = 0; g < S; ++g) owner[sb + g] = e;
+}
+
+// ---------------------------------------------------------------------------
 // One wave per row, N == 256·T exactly.  col/val through the scalar unit.
 // grid = (⌈M/4⌉, batch), block = 256 (4 waves = 4 rows).
 // ---------------------------------------------------------------------------
@@ -46,7 +92,7 @@ __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
     int M, long ldb, long ldc, long strideB, long strideC, const float* __restrict__ bias,
-    int long_thresh) {
+    LongArg la) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long row = (long)blockIdx.x * 4 + wave;
@@ -58,7 +104,10 @@ __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
 
   int p = rp[row];
   const int end = rp[row + 1];
-  if (end - p > long_thresh) return;  // left to spmm_long_rows_kernel
+  if (end - p > la.thresh) {  // left to spmm_long_rows_kernel
+    if (lane == 0) long_list_append(la, (int)row, end - p);
+    return;
+  }
 
   f32x4 acc[T];
 #pragma unroll
@@ -187,7 +236,7 @@ __global__ __launch_bounds__(256) void spmm_wave_row_vl_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
     int M, long ldb, long ldc, long strideB, long strideC, const float* __restrict__ bias,
-    int long_thresh) {
+    LongArg la) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long row = (long)blockIdx.x * 4 + wave;
@@ -199,7 +248,10 @@ __global__ __launch_bounds__(256) void spmm_wave_row_vl_kernel(
 
   const int start = rp[row];
   const int end = rp[row + 1];
-  if (end - start > long_thresh) return;  // left to spmm_long_rows_kernel
+  if (end - start > la.thresh) {  // left to spmm_long_rows_kernel
+    if (lane == 0) long_list_append(la, (int)row, end - start);
+    return;
+  }
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int p = start; p < end; p += 64) {
@@ -254,16 +306,18 @@ __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
     int M, long ldb, long ldc, int c_lo, int c_hi, const float* __restrict__ bias, int last_pass, int ctiles,
-    unsigned row_blocks, int long_thresh) {
+    unsigned row_blocks, LongArg la) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned rb = blockIdx.x;
+  bool lists = FIRST;  // the first pass over the first column tile lists the long rows it skips
   if (ctiles > 1) {
     // wide N: column tiles of 256·T columns dealt XCD-aware exactly as in spmm_group_kernel, so the
     // (row panel × column tile) slice of B this pass gathers from stays in the XCD's L2
     const unsigned xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
     const int tile = (int)(xcd + 8 * (idx / row_blocks));
     if (tile >= ctiles) return;
+    lists = FIRST && tile == 0;
     rb = idx % row_blocks;
     B += (long)tile * (256 * T);
     C += (long)tile * (256 * T);
@@ -275,7 +329,10 @@ __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
   float* Cl = C + row * ldc + lane * 4;
   const int start = rowptr[row];
   const int end = rowptr[row + 1];
-  if (end - start > long_thresh) return;  // left to spmm_long_rows_kernel (in every pass)
+  if (end - start > la.thresh) {  // left to spmm_long_rows_kernel (in every pass)
+    if (lists && lane == 0) long_list_append(la, (int)row, end - start);
+    return;
+  }
   f32x4 acc[T];
 #pragma unroll
   for (int t = 0; t < T; ++t)
@@ -375,7 +432,7 @@ __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
 
 template <int T, int U>
 int launch_panels_t(int panels, const int* rowptr, const int* col, const float* val, const float* B,
-                    float* C, int M, int K, long ldb, long ldc, const float* bias, int long_thresh,
+                    float* C, int M, int K, long ldb, long ldc, const float* bias, LongArg la,
                     hipStream_t s, int ctiles = 1) {
   const long row_blocks = ((long)M + 3) / 4;
   const long blocks = ctiles > 1 ? 8L * ((ctiles + 7) / 8) * row_blocks : row_blocks;
@@ -387,21 +444,21 @@ int launch_panels_t(int panels, const int* rowptr, const int* col, const float* 
     if (q == 0)
       hipLaunchKernelGGL((spmm_wave_row_panel_kernel<true, T, U>), dim3((unsigned)blocks), dim3(256), 0,
                          s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi, bias, q == panels - 1 ? 1 : 0, ctiles,
-                         (unsigned)row_blocks, long_thresh);
+                         (unsigned)row_blocks, la);
     else
       hipLaunchKernelGGL((spmm_wave_row_panel_kernel<false, T, U>), dim3((unsigned)blocks), dim3(256), 0,
                          s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi, bias, q == panels - 1 ? 1 : 0, ctiles,
-                         (unsigned)row_blocks, long_thresh);
+                         (unsigned)row_blocks, la);
   }
   return mi::check_launch();
 }
 
 int launch_panels(int panels, const int* rowptr, const int* col, const float* val, const float* B,
-                  float* C, int M, int K, int N, long ldb, long ldc, const float* bias, int long_thresh,
+                  float* C, int M, int K, int N, long ldb, long ldc, const float* bias, LongArg la,
                   hipStream_t s) {
-  if (N == 256) return launch_panels_t<1, 8>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, long_thresh, s);
-  if (N == 512) return launch_panels_t<2, 4>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, long_thresh, s);
-  return launch_panels_t<4, 2>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, long_thresh, s);
+  if (N == 256) return launch_panels_t<1, 8>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, la, s);
+  if (N == 512) return launch_panels_t<2, 4>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, la, s);
+  return launch_panels_t<4, 2>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, la, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -450,7 +507,7 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
     int M, int N, long ldb, long ldc, long strideB, long strideC, const float* __restrict__ bias,
-    int ctiles, int tile_cols, unsigned row_blocks, int long_thresh) {
+    int ctiles, int tile_cols, unsigned row_blocks, LongArg la) {
   typedef Vec<VEC> V;
   typedef typename V::type vec_t;
   constexpr int RPW = 64 / G;  // rows per wave
@@ -462,6 +519,7 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
   const float* Bi = B + item * strideB;
   float* Ci = C + item * strideC;
   unsigned rb = blockIdx.x;
+  bool lists = true;  // the first column tile lists the long rows it skips
   if (ctiles > 1) {
     // XCD-aware column tiling (wide N): workgroup b runs on XCD b % 8, whose private 4 MiB L2
     // should hold the K × tile_cols slice of B it gathers from.  XCD x takes column tiles
@@ -471,6 +529,7 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
     const unsigned xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
     const int tile = (int)(xcd + 8 * (idx / row_blocks));
     if (tile >= ctiles) return;
+    lists = tile == 0;
     rb = idx % row_blocks;
     const int c0 = tile * tile_cols;
     Bi += c0;
@@ -485,8 +544,11 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
     start = rp[row];
     end = rp[row + 1];
   }
-  const bool skipped = end - start > long_thresh;  // left to spmm_long_rows_kernel
-  if (skipped) end = start;
+  const bool skipped = end - start > la.thresh;  // left to spmm_long_rows_kernel
+  if (skipped) {
+    if (lists && gl == 0 && item == 0) long_list_append(la, (int)row, end - start);
+    end = start;
+  }
 
   for (int n0 = 0; n0 < N; n0 += G * VEC * T) {  // wave-uniform pass loop
     vec_t acc[T];
@@ -578,20 +640,20 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
 template <int G, int VEC, int T>
 int launch_group(const int* rowptr, const int* col, const float* val, const float* B,
                  float* C, int M, int N, long ldb, long ldc, long strideB, long strideC,
-                 int batch, const float* bias, int long_thresh, hipStream_t s) {
+                 int batch, const float* bias, LongArg la, hipStream_t s) {
   constexpr int rows_per_block = 4 * (64 / G);
   const long blocks = ((long)M + rows_per_block - 1) / rows_per_block;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   hipLaunchKernelGGL((spmm_group_kernel<G, VEC, T>), dim3((unsigned)blocks, (unsigned)batch),
                      dim3(256), 0, s, rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, bias, 1, N,
-                     (unsigned)blocks, long_thresh);
+                     (unsigned)blocks, la);
   return mi::check_launch();
 }
 
 // Column-tiled launch of the float4 group kernel: tile_cols = 4·G columns per tile.
 template <int G>
 int launch_coltile(const int* rowptr, const int* col, const float* val, const float* B, float* C, int M,
-                   int N, long ldb, long ldc, const float* bias, int long_thresh, hipStream_t s) {
+                   int N, long ldb, long ldc, const float* bias, LongArg la, hipStream_t s) {
   constexpr int rows_per_block = 4 * (64 / G);
   constexpr int tile_cols = 4 * G;
   const long row_blocks = ((long)M + rows_per_block - 1) / rows_per_block;
@@ -599,7 +661,7 @@ int launch_coltile(const int* rowptr, const int* col, const float* val, const fl
   const long blocks = 8L * ((ctiles + 7) / 8) * row_blocks;  // every XCD gets the same count; extras exit
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   hipLaunchKernelGGL((spmm_group_kernel<G, 4, 1>), dim3((unsigned)blocks, 1u), dim3(256), 0, s, rowptr, col, val,
-                     B, C, M, N, ldb, ldc, 0L, 0L, bias, ctiles, tile_cols, (unsigned)row_blocks, long_thresh);
+                     B, C, M, N, ldb, ldc, 0L, 0L, bias, ctiles, tile_cols, (unsigned)row_blocks, la);
   return mi::check_launch();
 }
 
@@ -622,12 +684,12 @@ int coltile_width(int32_t M, int32_t K, int32_t N, int64_t ldb) {
 template <int VEC>
 int dispatch_group(const int* rowptr, const int* col, const float* val, const float* B,
                    float* C, int M, int N, long ldb, long ldc, long strideB, long strideC,
-                   int batch, const float* bias, int long_thresh, hipStream_t s) {
+                   int batch, const float* bias, LongArg la, hipStream_t s) {
   const int nv = (N + VEC - 1) / VEC;  // vector columns
   const int G = nv >= 64 ? 64 : mi::pow2_ceil(nv);
 #define MI_GROUP(G_, T_) \
   return launch_group<G_, VEC, T_>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, \
-                                   long_thresh, s)
+                                   la, s)
   switch (G) {
     case 1: MI_GROUP(1, 1);
     case 2: MI_GROUP(2, 1);
@@ -647,22 +709,22 @@ int dispatch_group(const int* rowptr, const int* col, const float* val, const fl
 template <int T, int U>
 int launch_wave_row(const int* rowptr, const int* col, const float* val, const float* B,
                     float* C, int M, long ldb, long ldc, long strideB, long strideC,
-                    int batch, const float* bias, int long_thresh, hipStream_t s) {
+                    int batch, const float* bias, LongArg la, hipStream_t s) {
   const long blocks = ((long)M + 3) / 4;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   hipLaunchKernelGGL((spmm_wave_row_kernel<T, U>), dim3((unsigned)blocks, (unsigned)batch),
-                     dim3(256), 0, s, rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, bias, long_thresh);
+                     dim3(256), 0, s, rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, bias, la);
   return mi::check_launch();
 }
 
 template <int U>
 int launch_wave_row_vl(const int* rowptr, const int* col, const float* val, const float* B,
                        float* C, int M, long ldb, long ldc, long strideB, long strideC,
-                       int batch, const float* bias, int long_thresh, hipStream_t s) {
+                       int batch, const float* bias, LongArg la, hipStream_t s) {
   const long blocks = ((long)M + 3) / 4;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   hipLaunchKernelGGL((spmm_wave_row_vl_kernel<U>), dim3((unsigned)blocks, (unsigned)batch),
-                     dim3(256), 0, s, rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, bias, long_thresh);
+                     dim3(256), 0, s, rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, bias, la);
   return mi::check_launch();
 }
 
@@ -709,25 +771,18 @@ __global__ __launch_bounds__(256) void spmm_narrow_kernel(
 // Skewed matrices.  A row is owned by one wave, which sustains only a few GB/s of gathers, so
 // a row with 10⁵–10⁶ non-zeros would be a serial tail of tens of milliseconds.  When the caller
 // supplies a workspace (custom_mm always does), rows with more than kLongRow non-zeros are
-// skipped by the kernels above (`long_thresh`), collected by find_long_rows_kernel, and summed
+// skipped AND listed by the kernels above (`la`: long_list_append; find_long_rows_kernel builds the same
+// list for plans whose kernel lives elsewhere, and for prepared lists), and summed
 // here by S = clamp(len / 32768, 1, 128) 16-wave workgroups: the row's 1024-non-zero chunks are
 // dealt round-robin to 16·S chains (chain q runs the fmaf chain over chunks q, q+16S, q+32S, …
 // in increasing position), workgroup g owns chains 16g … 16g+15 and adds them in that order,
-// and the S workgroup sums are added in order g = 0 … S-1 (by the same workgroup when S = 1,
-// else through the workspace by combine_long_rows_kernel).  That is a different — fixed,
-// launch-independent, a function of the row length only — summation order for those rows;
-// oracle_spmm_csr_long_f32 restates it, so results stay bit-identical to the oracle.
-//
-// Workspace (ints): [0] rows listed, [1] workgroup slots handed out, [2] partial-row slots
-// handed out, then cap_e entries {row, slot base, S, partial base}, then cap_s slot → entry
-// indices, then (16-B aligned) cap_p × N floats of partial rows.
+// and the S workgroup sums are added in order g = 0 … S-1 — by the same workgroup when S = 1,
+// else through the workspace by whichever of the S workgroups delivers its partial row LAST
+// (an arrival counter per row; agent-scope release by every deliverer, acquire by the last: the sum
+// itself is always taken in the order g = 0 … S-1, so it does not depend on who arrives when).
+// That is a different — fixed, launch-independent, a function of the row length only — summation
+// order for those rows; oracle_spmm_csr_long_f32 restates it, so results stay bit-identical to the oracle.
 // ---------------------------------------------------------------------------
-constexpr int kLongRow = 8192;
-constexpr int kLongChunk = 1024;
-constexpr int kLongWaves = 16;
-constexpr int kLongSplitShift = 15;  // one workgroup per 32768 non-zeros of a row …
-constexpr int kLongSplitMax = 128;   // … up to 128 workgroups
-
 struct LongWs {
   long cap_e, cap_s, cap_p;
   size_t owner_off, partial_off, bytes;  // offsets in ints / bytes
@@ -738,55 +793,46 @@ LongWs long_ws_layout(int64_t nnz, int32_t N) {
   w.cap_e = nnz / kLongRow + 1;
   w.cap_p = nnz >> kLongSplitShift;
   w.cap_s = w.cap_e + w.cap_p;
-  w.owner_off = 4 + 4 * (size_t)w.cap_e;
+  w.owner_off = 4 + (size_t)kLongEnt * (size_t)w.cap_e;
   const size_t ints = w.owner_off + (size_t)w.cap_s;
   w.partial_off = (ints * sizeof(int) + 15) / 16 * 16;
   w.bytes = w.partial_off + (size_t)w.cap_p * (size_t)N * sizeof(float);
   return w;
 }
 
-__global__ void find_long_rows_kernel(const int* __restrict__ rowptr, int M, int* __restrict__ ws, int cap_e,
-                                      int cap_s, int cap_p) {
+__global__ void find_long_rows_kernel(const int* __restrict__ rowptr, int M, LongArg la) {
   const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= M) return;
   const int len = rowptr[r + 1] - rowptr[r];
-  if (len <= kLongRow) return;
-  int S = len >> kLongSplitShift;
-  S = S < 1 ? 1 : (S > kLongSplitMax ? kLongSplitMax : S);
-  // the order of the lists does not matter: every slot is a fixed function of (row, g)
-  const int e = atomicAdd(&ws[0], 1);
-  const int sb = atomicAdd(&ws[1], S);
-  const int pb = S > 1 ? atomicAdd(&ws[2], S) : 0;
-  // the caps hold for any rowptr consistent with nnz; a lying rowptr must not write out of bounds
-  if (e >= cap_e || sb + S > cap_s || (S > 1 && pb + S > cap_p)) return;
-  int* ent = ws + 4 + 4 * e;
-  ent[0] = (int)r;
-  ent[1] = sb;
-  ent[2] = S;
-  ent[3] = pb;
-  int* owner = ws + 4 + 4 * (long)cap_e;
-  for (int g = 0; g < S; ++g) owner[sb + g] = e;
+  if (len > kLongRow) long_list_append(la, (int)r, len);
 }
 
+// reset != 0: the list was built for this product only — the workgroup that finishes last zeroes the four
+// counters, so a workspace that entered with a zero header leaves with one (MI_LONG_ROWS_AUTO_ZEROED: no memset
+// per product).  reset == 0: a prepared list, used again by the next product (only the arrival counters are reset).
 template <int VEC>
 __global__ __launch_bounds__(kLongWaves * 64) void spmm_long_rows_kernel(
-    const int* __restrict__ ws, int cap_e, int cap_s, float* __restrict__ partial, const int* __restrict__ rowptr,
+    int* __restrict__ ws, int cap_e, int cap_s, float* __restrict__ partial, const int* __restrict__ rowptr,
     const int* __restrict__ col, const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
-    int N, long ldb, long ldc, const float* __restrict__ bias) {
+    int N, long ldb, long ldc, const float* __restrict__ bias, int reset) {
   typedef Vec<VEC> V;
   typedef typename V::type vec_t;
   __shared__ vec_t part[kLongWaves][64];
+  __shared__ int last_flag;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int slots = ws[1] < cap_s ? ws[1] : cap_s;
-  const int* owner = ws + 4 + 4 * (long)cap_e;
+  const int listed = ws[0], handed = ws[1], handed_p = ws[2];
+  if (listed == 0 && handed == 0 && handed_p == 0) return;  // no long row: nothing to sum, nothing to reset
+  const int count = listed < cap_e ? listed : cap_e;
+  const int slots = handed < cap_s ? handed : cap_s;
+  const int* owner = ws + 4 + kLongEnt * (long)cap_e;
   for (int t = blockIdx.x; t < slots; t += gridDim.x) {
     const int e = owner[t];
-    if ((unsigned)e >= (unsigned)cap_e) continue;
-    const int* ent = ws + 4 + 4 * e;
+    if ((unsigned)e >= (unsigned)count) continue;  // slot of a dropped entry
+    int* ent = ws + 4 + kLongEnt * (long)e;
     const int row = ent[0], S = ent[2], pb = ent[3];
     const int g = t - ent[1];
-    if ((unsigned)g >= (unsigned)S) continue;  // slot of a dropped entry
+    if ((unsigned)g >= (unsigned)S) continue;  // not a slot of that entry
     const long start = rowptr[row], end = rowptr[row + 1];
     const long stride = (long)kLongWaves * S * kLongChunk;
     for (int n0 = 0; n0 < N; n0 += 64 * VEC) {  // 64·VEC output columns per pass
@@ -836,24 +882,50 @@ __global__ __launch_bounds__(kLongWaves * 64) void spmm_long_rows_kernel(
       }
       __syncthreads();
     }
+    if (S > 1) {
+      // Deliver: wave 0 is the only wave that stored partial sums.  Its stores are drained, written back at
+      // agent scope, and only then does one lane take an arrival ticket (cdna_hip_programming.md Guideline 16:
+      // fence before the ticket, with the explicit wait hipcc may drop).  The workgroup that draws the last
+      // ticket acquires and adds the S partial rows in order g = 0 … S-1, then the bias.
+      if (wave == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+          const int ticket = __hip_atomic_fetch_add(&ent[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          last_flag = ticket == S - 1;
+          if (ticket == S - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+        }
+      }
+      __syncthreads();
+      if (last_flag) {
+        for (int c = threadIdx.x; c < N; c += blockDim.x) {
+          // sc1 loads: served by L2 / memory, never by a line this CU cached before the other workgroups wrote
+          float tot = __hip_atomic_load(partial + (long)pb * N + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int gg = 1; gg < S; ++gg)
+            tot += __hip_atomic_load(partial + (long)(pb + gg) * N + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (bias) tot += bias[c];
+          C[(long)row * ldc + c] = tot;
+        }
+        if (threadIdx.x == 0) ent[4] = 0;  // a prepared list serves the next product too
+      }
+      __syncthreads();  // last_flag is rewritten by the next slot
+    }
   }
-}
-
-// Rows summed by S > 1 workgroups: add the S partial rows in order g = 0 … S-1, then the bias.
-__global__ __launch_bounds__(256) void combine_long_rows_kernel(const int* __restrict__ ws, int cap_e,
-                                                               const float* __restrict__ partial,
-                                                               float* __restrict__ C, int N, long ldc,
-                                                               const float* __restrict__ bias) {
-  const int count = ws[0] < cap_e ? ws[0] : cap_e;
-  for (int e = blockIdx.x; e < count; e += gridDim.x) {
-    const int* ent = ws + 4 + 4 * e;
-    const int row = ent[0], S = ent[2], pb = ent[3];
-    if (S <= 1) continue;
-    for (int c = threadIdx.x; c < N; c += blockDim.x) {
-      float tot = partial[(long)pb * N + c];
-      for (int g = 1; g < S; ++g) tot += partial[(long)(pb + g) * N + c];
-      if (bias) tot += bias[c];
-      C[(long)row * ldc + c] = tot;
+  if (reset) {
+    // every read of the counters by this workgroup is done (they were read into registers at the top)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int done = __hip_atomic_fetch_add(&ws[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (done == (int)gridDim.x - 1) {
+        __hip_atomic_store(&ws[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws[3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }
@@ -963,11 +1035,11 @@ size_t long_rows_workspace_bytes(int64_t nnz, int32_t N) { return long_ws_layout
 int launch_variant(int variant, const Shape& sh, const int32_t* rowptr, const int32_t* col, const float* val,
                    int64_t nnz, int32_t batch, int32_t M, int32_t K, int32_t N, const float* B,
                    int64_t ldb, int64_t strideB, float* C, int64_t ldc, int64_t strideC,
-                   const float* bias, int long_thresh, hipStream_t s) {
+                   const float* bias, LongArg la, hipStream_t s) {
   const bool vec4_ok = sh.vec4_ok, vec2_ok = sh.vec2_ok, wave_ok = sh.wave_ok;
 
 #define MI_WAVE(T_, U_) \
-  return launch_wave_row<T_, U_>(rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, batch, bias, long_thresh, s)
+  return launch_wave_row<T_, U_>(rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, batch, bias, la, s)
   switch (variant) {
     case MI_SPMM_WAVE_ROW_U4:
       if (!wave_ok) return MI_EINVAL;
@@ -986,38 +1058,38 @@ int launch_variant(int variant, const Shape& sh, const int32_t* rowptr, const in
       MI_WAVE(4, 4);
     case MI_SPMM_WAVE_ROW_VL:
       if (!(vec4_ok && N == 256)) return MI_EINVAL;
-      return launch_wave_row_vl<8>(rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, batch, bias, long_thresh, s);
+      return launch_wave_row_vl<8>(rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, batch, bias, la, s);
     case MI_SPMM_PANELS_2: case MI_SPMM_PANELS_3: case MI_SPMM_PANELS_4: case MI_SPMM_PANELS_5:
     case MI_SPMM_PANELS_6: case MI_SPMM_PANELS_8: {
       if (!(wave_ok && batch == 1)) return MI_EINVAL;
       static const int kPanels[] = {2, 3, 4, 5, 6, 8};
-      return launch_panels(kPanels[variant - MI_SPMM_PANELS_2], rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, long_thresh, s);
+      return launch_panels(kPanels[variant - MI_SPMM_PANELS_2], rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
     }
     case MI_SPMM_COLTILE_PANELS: {
       if (!(vec4_ok && batch == 1 && N % 256 == 0 && N >= 256)) return MI_EINVAL;
       int panels = coltile_panels(M, K, N, ldb, nnz);
       if (panels == 0) panels = 3;  // forced by the caller
-      return launch_panels_t<1, 8>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, long_thresh, s, N / 256);
+      return launch_panels_t<1, 8>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, la, s, N / 256);
     }
     case MI_SPMM_COLTILE: {
       if (!(vec4_ok && batch == 1)) return MI_EINVAL;
       int w = coltile_width(M, K, N, ldb);
       if (w == 0) w = N >= 256 ? 256 : (N >= 128 ? 128 : 64);  // forced by the caller: any width works
-      if (w == 256) return launch_coltile<64>(rowptr, col, val, B, C, M, N, ldb, ldc, bias, long_thresh, s);
-      if (w == 128) return launch_coltile<32>(rowptr, col, val, B, C, M, N, ldb, ldc, bias, long_thresh, s);
-      return launch_coltile<16>(rowptr, col, val, B, C, M, N, ldb, ldc, bias, long_thresh, s);
+      if (w == 256) return launch_coltile<64>(rowptr, col, val, B, C, M, N, ldb, ldc, bias, la, s);
+      if (w == 128) return launch_coltile<32>(rowptr, col, val, B, C, M, N, ldb, ldc, bias, la, s);
+      return launch_coltile<16>(rowptr, col, val, B, C, M, N, ldb, ldc, bias, la, s);
     }
     case MI_SPMM_GROUP_VEC4:
       if (!vec4_ok) return MI_EINVAL;
-      return dispatch_group<4>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, long_thresh, s);
+      return dispatch_group<4>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, la, s);
     case MI_SPMM_GROUP_VEC2:
       if (!vec2_ok) return MI_EINVAL;
-      return dispatch_group<2>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, long_thresh, s);
+      return dispatch_group<2>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, la, s);
     case MI_SPMM_GROUP_SCALAR:
-      return dispatch_group<1>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, long_thresh, s);
+      return dispatch_group<1>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, la, s);
     case MI_SPMM_SLAB:
       if (!(vec4_ok && batch == 1 && K > 0)) return MI_EINVAL;
-      return mi::launch_spmm_slab(rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, long_thresh, s);
+      return mi::launch_spmm_slab(rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la.thresh, s);
     case MI_SPMM_NARROW: {
       if (N >= 4) return MI_EINVAL;
       const long blocks = ((long)M + 3) / 4;
@@ -1039,7 +1111,7 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
                   int long_mode = MI_LONG_ROWS_AUTO) {
   if (M < 0 || K < 0 || N < 0 || nnz < 0 || batch < 0) return MI_EINVAL;
   if (variant < 0 || variant >= MI_SPMM_VARIANT_COUNT) return MI_EINVAL;
-  if (long_mode < MI_LONG_ROWS_AUTO || long_mode > MI_LONG_ROWS_PREPARED) return MI_EINVAL;
+  if (long_mode < MI_LONG_ROWS_AUTO || long_mode > MI_LONG_ROWS_AUTO_ZEROED) return MI_EINVAL;
   if (nnz > 0x7fffffffLL) return MI_ERANGE;  // int32 rowptr entries
   if (batch > 65535) return MI_ERANGE;       // grid.y
   if (M == 0 || N == 0 || batch == 0) return MI_OK;
@@ -1059,36 +1131,44 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
   // one-workgroup-per-row kernel; its rows all keep the plain CSR order)
   // MI_LONG_ROWS_SPLIT / _NONE pin the rule whatever the plan (a row shard must sum its rows the way
   // the whole matrix would: sharded.py); N < 4 keeps the narrow kernel's own order in every mode.
+  const bool pinned_split = long_mode == MI_LONG_ROWS_SPLIT || long_mode == MI_LONG_ROWS_PREPARED;
   const bool split = workspace != nullptr && batch == 1 && nnz > kLongRow && variant != MI_SPMM_NARROW &&
-                     long_mode != MI_LONG_ROWS_NONE && (variant != MI_SPMM_SLAB || long_mode >= MI_LONG_ROWS_SPLIT);
+                     long_mode != MI_LONG_ROWS_NONE && (variant != MI_SPMM_SLAB || pinned_split);
   int* ws = static_cast<int*>(workspace);
   const LongWs lw = long_ws_layout(nnz, N);
+  LongArg la = {0x7fffffff, 0, 0, 0, nullptr};
+  const bool prepared = long_mode == MI_LONG_ROWS_PREPARED;
   if (split) {
     if (workspace_bytes < lw.bytes) return MI_ENOMEM;
     if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return MI_EINVAL;
-    if (long_mode != MI_LONG_ROWS_PREPARED) {  // else: the list was built once by mi_spmm_long_rows_prepare
-      // counters, entries and the slot → entry map (a few KB per 10⁶ non-zeros)
-      MI_HIP_TRY(hipMemsetAsync(ws, 0, lw.partial_off, s));
-      hipLaunchKernelGGL(find_long_rows_kernel, dim3((unsigned)(((long)M + 255) / 256)), dim3(256), 0, s, rowptr, M,
-                         ws, (int)lw.cap_e, (int)lw.cap_s, (int)lw.cap_p);
+    la.thresh = kLongRow;
+    la.cap_e = (int)lw.cap_e, la.cap_s = (int)lw.cap_s, la.cap_p = (int)lw.cap_p;
+    if (!prepared) {  // else: the list was built once by mi_spmm_long_rows_prepare
+      // the four counters start from zero; entries and the slot → entry map are written before they are read.
+      // MI_LONG_ROWS_AUTO_ZEROED: the caller's workspace enters with a zero header (and leaves with one)
+      if (long_mode != MI_LONG_ROWS_AUTO_ZEROED) MI_HIP_TRY(hipMemsetAsync(ws, 0, 16, s));
+      if (variant == MI_SPMM_SLAB) {  // that kernel lives in spmm_slab.hip and only skips: list here
+        LongArg fl = la;
+        fl.ws = ws;
+        hipLaunchKernelGGL(find_long_rows_kernel, dim3((unsigned)(((long)M + 255) / 256)), dim3(256), 0, s, rowptr, M, fl);
+      } else {
+        la.ws = ws;  // the main kernel lists the rows it skips
+      }
     }
   }
   int st = launch_variant(variant, sh, rowptr, col, val, nnz, batch, M, K, N, B, ldb, strideB, C, ldc, strideC,
-                          bias, split ? kLongRow : 0x7fffffff, s);
+                          bias, la, s);
   if (st != MI_OK || !split) return st;
+  // One follow-up launch: the listed rows, their combination (by the last workgroup of each row) and, for a list
+  // built by this product, the reset of the counters.  With no long row every workgroup reads three zeros and exits.
   float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + lw.partial_off);
-  const unsigned grid = lw.cap_s < 2048 ? (unsigned)lw.cap_s : 2048u;
+  const unsigned grid = lw.cap_s < 256 ? (unsigned)lw.cap_s : 256u;  // one 16-wave workgroup per CU (grid-stride over the slots)
   if (sh.vec4_ok)
     hipLaunchKernelGGL(spmm_long_rows_kernel<4>, dim3(grid), dim3(kLongWaves * 64), 0, s, ws, (int)lw.cap_e,
-                       (int)lw.cap_s, partial, rowptr, col, val, B, C, N, ldb, ldc, bias);
+                       (int)lw.cap_s, partial, rowptr, col, val, B, C, N, ldb, ldc, bias, prepared ? 0 : 1);
   else
     hipLaunchKernelGGL(spmm_long_rows_kernel<1>, dim3(grid), dim3(kLongWaves * 64), 0, s, ws, (int)lw.cap_e,
-                       (int)lw.cap_s, partial, rowptr, col, val, B, C, N, ldb, ldc, bias);
-  if (lw.cap_p >= 2) {  // a row can be split only when the matrix has ≥ 65536 non-zeros
-    const unsigned cgrid = lw.cap_e < 1024 ? (unsigned)lw.cap_e : 1024u;
-    hipLaunchKernelGGL(combine_long_rows_kernel, dim3(cgrid), dim3(256), 0, s, ws, (int)lw.cap_e, partial, C, N, ldc,
-                       bias);
-  }
+                       (int)lw.cap_s, partial, rowptr, col, val, B, C, N, ldb, ldc, bias, prepared ? 0 : 1);
   return mi::check_launch();
 }
 
@@ -1169,9 +1249,9 @@ int mi_spmm_long_rows_prepare(const int32_t* rowptr, int32_t M, int64_t nnz, int
   const LongWs lw = long_ws_layout(nnz, N);
   if (workspace_bytes < lw.bytes) return MI_ENOMEM;
   int* ws = static_cast<int*>(workspace);
-  MI_HIP_TRY(hipMemsetAsync(ws, 0, lw.partial_off, s));
-  hipLaunchKernelGGL(find_long_rows_kernel, dim3((unsigned)(((long)M + 255) / 256)), dim3(256), 0, s, rowptr, M, ws,
-                     (int)lw.cap_e, (int)lw.cap_s, (int)lw.cap_p);
+  MI_HIP_TRY(hipMemsetAsync(ws, 0, 16, s));
+  const LongArg la = {kLongRow, (int)lw.cap_e, (int)lw.cap_s, (int)lw.cap_p, ws};
+  hipLaunchKernelGGL(find_long_rows_kernel, dim3((unsigned)(((long)M + 255) / 256)), dim3(256), 0, s, rowptr, M, la);
   return mi::check_launch();
 }
 

@@ -138,9 +138,18 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_slab_kernel(
         // wave w, lane l, piece v: row n = 16·w + (l & 15) of X (column of B), k quad = 4·v + (l >> 4)
         int n = c0 + wave * 16 + (lane & 15);
         n = n < N ? n : N - 1;                 // columns past N belong to lanes that are off
-        int kk = s * kSlab + (4 * v + (lane >> 4)) * 4;
-        kk = kk + 3 < K ? kk : (K >= 4 ? K - 4 : 0);  // k past K is never referenced: any valid address will do
-        st[v] = *reinterpret_cast<const f32x4*>(B + (long)n * ldb + kk);
+        const int k0 = s * kSlab + (4 * v + (lane >> 4)) * 4;
+        // a quad wholly past K is never referenced (any valid address will do); the PARTIAL last quad (K % 4 != 0) is
+        // read as X[n][K-4 … K-1] — the padding behind the last row of X need not exist — and shifted so that
+        // component j still holds k0 + j, which is where store_slab puts it (round 2 stored the clamped quad at the
+        // rows of k0: wrong B values for the last K % 4 columns of A whenever ldb was padded beyond K)
+        const int kk = k0 + 3 < K ? k0 : (K >= 4 ? K - 4 : 0);
+        f32x4 x = *reinterpret_cast<const f32x4*>(B + (long)n * ldb + kk);
+        if (k0 < K && k0 + 3 >= K && K >= 4) {
+          const int d = k0 - kk;  // 1 … 3: component j of the wanted quad is component j + d of the loaded one
+          x = d == 1 ? f32x4{x.y, x.z, x.w, 0.f} : d == 2 ? f32x4{x.z, x.w, 0.f, 0.f} : f32x4{x.w, 0.f, 0.f, 0.f};
+        }
+        st[v] = x;
       } else {
         int kr = s * kSlab + wave + kWaves * v;
         kr = kr < K ? kr : K - 1;  // rows past K are never referenced: any valid address will do

@@ -245,46 +245,42 @@ def _csr_key(a: torch.Tensor):
 
 
 def _csr_props_cached(a: torch.Tensor):
-    '''((values, columns i32, offsets i32, nnz, rows, cols), longest row) of a CSR tensor, kept ON the tensor
-    object between calls (keyed on the component tensors' storage and version counters; it dies with the
-    tensor): a static sparse operand is narrowed to int32 once instead of on every product (two passes over
-    the indices: 0.3 ms at the 1M × 1M config), and its longest row — one read-back, once — tells the product
-    whether the long-row machinery (a workspace and three helper launches per call) is needed at all.'''
+    '''(values, columns i32, offsets i32, nnz, rows, cols) of a CSR tensor, kept ON the tensor object between
+    calls (keyed on the component tensors' storage and version counters; it dies with the tensor): a static sparse
+    operand is narrowed to int32 once instead of on every product (two passes over the indices: 0.3 ms at the
+    1M × 1M config).  Nothing is read back to the host (round 2 read the longest row back to decide whether the
+    long-row helpers were needed: since round 3 the plain entry points cost the main kernel + one empty follow-up
+    launch, so the question no longer pays for a synchronisation — and the call stays graph-capturable).'''
     key = _csr_key(a)
     hit = getattr(a, '_mi_csr_props', None)
     if hit is not None and hit[0] == key:
-        return hit[1], hit[2]
+        return hit[1]
     props = get_sparse_tensor_properties(a)
-    offsets = props[2]
-    longest = int((offsets[1:] - offsets[:-1]).max()) if offsets.numel() > 1 else 0
     try:
-        a._mi_csr_props = (key, props, longest)
+        a._mi_csr_props = (key, props)
     except (AttributeError, RuntimeError):
         pass  # a tensor type that takes no attributes: just no caching
-    return props, longest
+    return props
 
 
 def _csr_of(a: torch.Tensor):
     '''(values, columns, offsets, nnz, rows, cols) of a 2-d dense or CSR tensor.'''
     if a.is_sparse_csr:
-        return _csr_props_cached(a)[0]
+        return _csr_props_cached(a)
     values, columns, offsets = custom_mm.dense_to_csr(a)
     return values, columns, offsets.view(-1), values.numel(), a.shape[-2], a.shape[-1]
 
 
 def _csr_product(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, mm_op, default_op):
-    '''c = a·b for a 2-d CSR (or dense, converted) a through mm_op; the stock kernel on a CSR tensor without
-    over-long rows runs as ONE launch (custom_mm.naive_spmm_ex, rule 0: same bits — the long-row rule only
-    concerns rows beyond custom_mm.long_row_threshold() non-zeros).'''
-    if mm_op is default_op and hasattr(custom_mm, 'naive_spmm_ex'):
-        if a.is_sparse_csr:
-            props, longest = _csr_props_cached(a)
-        else:  # a dense matrix converts without duplicate columns: no row is longer than it is wide
-            props, longest = _csr_of(a), a.shape[-1]
-        if longest <= custom_mm.long_row_threshold():
-            return custom_mm.naive_spmm_ex(*props, b, c, 0)
-        return mm_op(*props, b, c)
-    return mm_op(*_csr_of(a), b, c)
+    '''c = a·b for a 2-d CSR (or dense, converted) a through mm_op.  A matrix no wider than
+    custom_mm.long_row_threshold() columns cannot hold an over-long row (columns are not repeated inside a row of a
+    torch CSR or of a converted dense matrix), so the stock kernel then runs as ONE launch
+    (custom_mm.naive_spmm_ex, rule 0: same bits); wider ones take the plain entry, which is the main kernel plus
+    one follow-up launch that finds its list of long rows empty.  No host read-back either way.'''
+    props = _csr_of(a)
+    if mm_op is default_op and hasattr(custom_mm, 'naive_spmm_ex') and a.shape[-1] <= custom_mm.long_row_threshold():
+        return custom_mm.naive_spmm_ex(*props, b, c, 0)
+    return mm_op(*props, b, c)
 
 
 def fused_skip_pays(items: int, rows: int, cols: int, width: int = 256) -> bool:
@@ -301,6 +297,84 @@ def fused_skip_pays(items: int, rows: int, cols: int, width: int = 256) -> bool:
     if items <= 1:
         return rows * cols * -(-width // 256) <= 512 * 512
     return cols <= 3072
+
+
+def _batched_csr_product(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch.Tensor:
+    '''A batched CSR tensor ([..., M, K], every item with the same number of non-zeros — what torch builds) as the
+    sparse operand: the reference recurses over the leading dimension (matmuls.py:289-293); here the whole batch is
+    ONE launch of the batched kernel — the items' compressed row offsets get their base offset added, which is the
+    "rowptr of rowptrs" layout of custom_mm.naive_spmm_batched.  b: [K, N] (shared) or [..., K, N] (same batch).'''
+    a_shape, b_shape = a.shape, b.shape
+    rows, cols, n = a_shape[-2], a_shape[-1], b_shape[-1]
+    batch = tuple(a_shape[:-2])
+    if b.dim() > 2 and tuple(b_shape[:-2]) != batch:
+        raise RuntimeError('sparse matmul: a batched CSR tensor needs b of shape [K, N] or with the same batch dimensions')
+    crow = torch.Tensor.crow_indices(a).reshape(-1, rows + 1)
+    col = torch.Tensor.col_indices(a)
+    val = torch.Tensor.values(a)
+    nb = crow.shape[0]
+    per_item = col.shape[-1]
+    total = nb * per_item
+    if total >= 2 ** 31:
+        raise ValueError('sparse matmul: the batch holds too many non-zeros for int32 indices')
+    dev = val.device if val.is_cuda else b.device
+    _b = (b.reshape(nb, cols, n) if b.dim() > 2 else b).to(dev)  # a 2-d b is shared by every item
+    c = torch.empty((nb, rows, n), device=dev, dtype=torch.float32)
+    if mm_op is default_op:
+        base = torch.arange(nb, device=crow.device, dtype=crow.dtype).unsqueeze(1) * per_item
+        offsets = (crow + base).to(device=dev, dtype=torch.int32).contiguous()
+        values = val.reshape(-1).to(dev).contiguous()
+        columns = col.reshape(-1).to(device=dev, dtype=torch.int32).contiguous()
+        for lo in range(0, nb, 65535):
+            hi = min(nb, lo + 65535)
+            custom_mm.naive_spmm_batched(values, columns, offsets[lo:hi].contiguous(), total, hi - lo, rows, cols,
+                                         _b[lo:hi].contiguous() if _b.dim() > 2 else _b.contiguous(), c[lo:hi])
+    else:
+        # a caller-supplied 2-d kernel: slice by slice, as the reference does
+        for i in range(nb):
+            mm_op(val.reshape(nb, -1)[i].to(dev).contiguous(), col.reshape(nb, -1)[i].to(device=dev, dtype=torch.int32).contiguous(),
+                  crow[i].to(device=dev, dtype=torch.int32).contiguous(), per_item, rows, cols,
+                  (_b[i] if _b.dim() > 2 else _b).contiguous(), c[i])
+    return c.view(batch + (rows, n))
+
+
+_DENSE_SAMPLE_ROWS = 512
+
+
+def dense_route_pays(density: float, items: int, rows: int, cols: int, width: int) -> bool:
+    '''Dense-with-zeros A: the exact-fp32 MFMA product (custom_mm.cublas_mmul / cublas_bmm) against the routes that
+    skip the zeros.  Fitted on MI355X (tools/bench_skipwide.py, tools/bench_attn_sparse.py,
+    profiles/r03_dense_input_routing.log): the MFMA product sustains ≈110 TFLOP/s on batches of attention-sized
+    matrices and ≈140 on large ones; the zero-skipping routes ≈12–15 TFLOP/s of useful flops plus one pass over A
+    per 256 output columns (≈4 TB/s).  BERT-base probs·V (384 × 512² × 64): dense 0.115 ms whatever the density,
+    skipping 0.91 ms at 100 % kept, 0.20 at 10 %, level at ≈2 %.'''
+    flops = 2.0 * items * rows * cols * width
+    t_dense = flops / (140e12 if rows * cols >= 2048 * 2048 else 110e12) + 4e-6
+    t_skip = density * flops / 14e12 + items * rows * cols * 4.0 * -(-width // 256) / 4e12
+    return t_dense < t_skip
+
+
+def _dense_route(a: torch.Tensor, b: torch.Tensor, items: int, rows: int, cols: int, width: int) -> bool:
+    '''Whether a dense-with-zeros `a` should take the dense MFMA product: decided from an evenly spaced sample of
+    ≤ 512 rows of `a` (one small count kernel) and — because the dense product multiplies the zeros of `a` with the
+    facing entries of `b` where the sparse routes skip them — only when every entry of `b` is finite (0·finite adds
+    an exact zero: same value; 0·inf or 0·nan would turn a finite result into nan).  Both facts come back in ONE
+    host read-back (the reference converts with `to_sparse_csr()` per call, which synchronises as well,
+    matmuls.py:295-296).  Under stream capture nothing may be read back: the question is not asked.
+    Products whose dense form takes under ≈20 µs are not worth the question either.'''
+    if not a.is_cuda or torch.cuda.is_current_stream_capturing() or a.numel() == 0 or b.numel() == 0:
+        return False
+    if 2.0 * items * rows * cols * width / 110e12 < 20e-6:
+        return False
+    flat = a.reshape(-1, cols)
+    step = max(1, flat.shape[0] // _DENSE_SAMPLE_ROWS)
+    sample = flat[::step][:_DENSE_SAMPLE_ROWS]
+    kept = custom_mm.dense_row_offsets(sample).view(-1)[-1].to(torch.float32)
+    # a sum is finite only if every term is (an overflow of finite terms reads as "not finite": the skipping route)
+    kept, total = torch.stack((kept, b.sum(dtype=torch.float32))).tolist()
+    if total != total or total in (float('inf'), float('-inf')):
+        return False
+    return dense_route_pays(kept / sample.numel(), items, rows, cols, width)
 
 
 def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch.Tensor:
@@ -326,10 +400,24 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch
     dev = b.device if b.is_cuda else a.device
 
     fused = mm_op is default_op and not a.is_sparse_csr  # dense A + stock kernel: skip zeros in the kernel
+    capturing = b.is_cuda and torch.cuda.is_current_stream_capturing()
+    if fused:
+        # A dense matrix that is not sparse enough belongs on the matrix cores: same result (see _dense_route),
+        # 6× faster on the reference's own naive test shapes (tests/naive_kernel_test.py:48-49 feeds torch.rand).
+        items = 1
+        for d in torch.broadcast_shapes(tuple(a_shape[:-2]), tuple(b_shape[:-2])):
+            items *= d
+        if a.dim() > 2 and b.dim() == 2:
+            items, rows_eff = 1, a.numel() // a_shape[-1]
+        else:
+            rows_eff = c_rows
+        if _dense_route(a, b, items, rows_eff, a_shape[-1], c_cols):
+            return custom_matmul(a.contiguous(), b.contiguous())
 
     if a.dim() == 2 and b.dim() == 2:
         c = torch.empty((c_rows, c_cols), device=dev, dtype=torch.float32)
-        if fused and fused_skip_pays(1, c_rows, a_shape[-1], c_cols) and custom_mm.naive_spmm_dense(a, b, c):
+        # (under capture the conversion's read-back of nnz is not possible: the in-kernel route whenever it applies)
+        if fused and (capturing or fused_skip_pays(1, c_rows, a_shape[-1], c_cols)) and custom_mm.naive_spmm_dense(a, b, c):
             return c
         return _csr_product(a, b, c, mm_op, default_op)
 
@@ -342,13 +430,14 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch
         return c.view(c_rows, -1, c_cols).permute(1, 0, 2).reshape(batch + (c_rows, c_cols))
 
     if a.is_sparse_csr:
-        raise RuntimeError('sparse matmul: batched CSR tensors are not supported; pass a dense batch')
+        return _batched_csr_product(a, b, mm_op, default_op)
 
     if b.dim() == 2:
         # batch of A × one B (the FC-layer call shape): flatten A's rows
         _a = a.reshape(-1, a_shape[-1])
         c = torch.empty((_a.shape[0], c_cols), device=dev, dtype=torch.float32)
-        if not (fused and fused_skip_pays(1, _a.shape[0], _a.shape[1], c_cols) and custom_mm.naive_spmm_dense(_a, b, c)):
+        if not (fused and (capturing or fused_skip_pays(1, _a.shape[0], _a.shape[1], c_cols))
+                and custom_mm.naive_spmm_dense(_a, b, c)):
             c = _csr_product(_a, b, c, mm_op, default_op)
         return c.view(tuple(a_shape[:-1]) + (c_cols,))
 
@@ -358,7 +447,7 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch
     _b = b.expand(batch + tuple(b_shape[-2:])).reshape((-1,) + tuple(b_shape[-2:]))
     nb = _a.shape[0]
     c = torch.empty((nb, c_rows, c_cols), device=dev, dtype=torch.float32)
-    if fused and fused_skip_pays(nb, c_rows, a_shape[-1], c_cols) and custom_mm.naive_spmm_dense(_a, _b, c):
+    if fused and (capturing or fused_skip_pays(nb, c_rows, a_shape[-1], c_cols)) and custom_mm.naive_spmm_dense(_a, _b, c):
         pass  # one launch, A read once, no CSR materialised
     elif mm_op is default_op:
         # one dense→CSR conversion and one launch for the whole batch
@@ -404,23 +493,27 @@ def naive_matmul(a: torch.Tensor,
 
 
 def _csr_cached(m1: torch.Tensor):
-    '''(values, columns i32, offsets i32, nnz, rows, cols) and the CSR of m1ᵀ for a CSR tensor, kept
-    ON the tensor object between calls: in a training loop A's pattern is static, and the device
-    transpose (≈2.5 ms at the 1M × 1M config) would otherwise be paid on every backward.  The entry is
-    keyed on the component tensors' storage and version counters, so an in-place update of the values
-    (or a different tensor) rebuilds it; it dies with the tensor.'''
-    key = _csr_key(m1)
-    hit = getattr(m1, '_mi_csr_cache', None)
-    if hit is not None and hit[0] == key:
-        return hit[1], hit[2]
-    props = _csr_props_cached(m1)[0]
+    '''(values, columns i32, offsets i32, nnz, rows, cols) and the CSR of m1ᵀ for a CSR tensor.  What is kept ON the
+    tensor object between calls is the PATTERN of the transpose — its columns, its offsets and the permutation that
+    carries m1's values into it — because in a training loop the pattern is static and the device transpose (1.3 ms
+    at the 1M × 1M config) would otherwise be paid on every backward.  The VALUES of m1ᵀ are gathered through the
+    permutation on every call (one pass over nnz), so a write to m1's values that no version counter sees
+    (`a.values().data.mul_(3)`, a kernel writing through data_ptr) can never leave a stale copy behind.  The entry is
+    keyed on the index tensors' storage and version counters; it dies with the tensor.'''
+    key = _csr_key(m1)[1:3] + _csr_key(m1)[4:]
+    props = _csr_props_cached(m1)
     values, columns, offsets, nnz, rows, cols = props
-    transposed = custom_mm.csr_transpose(values, columns, offsets, nnz, rows, cols)
-    try:
-        m1._mi_csr_cache = (key, props, transposed)
-    except (AttributeError, RuntimeError):
-        pass  # a tensor type that takes no attributes: just no caching
-    return props, transposed
+    hit = getattr(m1, '_mi_csr_cache', None)
+    if hit is None or hit[0] != key:
+        # the transpose moves 4-byte values untouched: transposing 0, 1, 2, … gives the permutation
+        iota = torch.arange(nnz, device=values.device, dtype=torch.int32).view(torch.float32)
+        t_perm, t_col, t_off = custom_mm.csr_transpose(iota, columns, offsets, nnz, rows, cols)
+        hit = (key, t_perm.view(torch.int32).to(torch.int64), t_col, t_off)
+        try:
+            m1._mi_csr_cache = hit
+        except (AttributeError, RuntimeError):
+            pass  # a tensor type that takes no attributes: just no caching
+    return props, (values[hit[1]], hit[2], hit[3])
 
 
 def _sparse_backward(ctx, grad_output):
@@ -437,6 +530,9 @@ def _sparse_backward(ctx, grad_output):
     grad_m1 = grad_m2 = None
 
     if m1.is_sparse_csr:
+        if m1.dim() > 2:
+            raise NotImplementedError('backward through a batched CSR tensor is not supported (the reference has none '
+                                      'either, matmuls.py:250-254); differentiate item by item')
         (values, columns, offsets, nnz, rows, cols), (t_val, t_col, t_off) = _csr_cached(m1)
         if m2.dim() == 1:
             g, b = grad_output.reshape(rows, 1), m2.unsqueeze(-1)

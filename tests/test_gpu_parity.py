@@ -1659,3 +1659,249 @@ def test_bench_multi_gpu_path_rehearsal(dev):
     assert proc.returncode == 0, proc.stderr[-3000:]
     rec = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')][0])
     assert rec["config"]["exchange"] == "p2p" and "direct RCCL sends" in rec["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_long_rows_listed_by_the_main_kernel_and_zero_header_contract(capi, cmm, dev, oracle_mod):
+    """Round 3: the kernels list the rows they skip (no separate scan of rowptr), one follow-up launch sums them,
+    combines the split ones (last workgroup of a row) and resets the counters.  MI_LONG_ROWS_AUTO_ZEROED (3): a
+    workspace that enters with a zero 16-byte header leaves with one, product after product, and gives the bits of
+    the memset-per-call mode (-1) and of the oracle; custom_mm.naive_spmm keeps such a workspace per stream, so
+    matrices with and without hub rows can alternate on it.  Reference entry: src/custom_mm.cpp:166-179."""
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_spmm_csr_ex_f32.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, i64, vp, vp, i64, ctypes.c_int, vp,
+                                        ctypes.c_size_t, vp]
+    capi.mi_spmm_csr_workspace_bytes.restype = ctypes.c_size_t
+    capi.mi_spmm_csr_workspace_bytes.argtypes = [i64, i32]
+    g = np.random.Generator(np.random.PCG64(77))
+    K = 200000
+
+    def skewed(M, hubs, N):
+        lens = g.integers(0, 200, size=M)
+        for r, n in hubs:
+            lens[r] = n
+        cols = [np.sort(g.choice(K, size=int(n), replace=False)).astype(np.int32) for n in lens]
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        col = np.concatenate(cols)
+        val = g.random(len(col), dtype=np.float32) - 0.5
+        B = g.random((K, N), dtype=np.float32)
+        return rowptr, col, val, B
+
+    stream = torch.cuda.current_stream().cuda_stream
+    for N in (256, 128, 36):  # one wave per row, lane groups, scalar lanes
+        M = 64
+        with_hubs = skewed(M, [(0, 70000), (5, 9000), (33, 140000), (63, 8193)], N)
+        without = skewed(M, [], N)
+        nnz_max = max(len(with_hubs[1]), len(without[1]))
+        nbytes = capi.mi_spmm_csr_workspace_bytes(nnz_max, N)
+        ws = torch.full((nbytes,), 0x5A, dtype=torch.uint8, device=dev)  # garbage beyond the header …
+        ws[:16] = 0                                                        # … and the contract's zero header
+        for rowptr, col, val, B in (with_hubs, without, with_hubs):
+            want = oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B)
+            d = [t(x, dev) for x in (rowptr, col, val, B)]
+            for mode in (3, -1):
+                C = torch.full((M, N), float("nan"), device=dev)
+                wsm = ws if mode == 3 else torch.full((nbytes,), 0xA5, dtype=torch.uint8, device=dev)
+                assert capi.mi_spmm_csr_ex_f32(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(val), M, K, N,
+                                               d[3].data_ptr(), N, None, C.data_ptr(), N, mode, wsm.data_ptr(), nbytes,
+                                               stream) == 0
+                assert np.array_equal(C.cpu().numpy(), want), (N, mode)
+                if mode == 3:
+                    assert int(wsm[:16].to(torch.int32).sum()) == 0, "the counters are zero again after the product"
+            # the reference-named entry on its persistent per-stream workspace
+            assert np.array_equal(run_spmm(cmm, dev, rowptr, col, val, M, K, B, "naive_spmm"), want)
+            assert np.array_equal(run_spmm(cmm, dev, rowptr, col, val, M, K, B, "cusparse_mmul"), want)
+    # a side stream gets a workspace of its own
+    side = torch.cuda.Stream()
+    rowptr, col, val, B = with_hubs
+    want = oracle_mod.spmm_csr_long(rowptr, col, val, 64, K, B)
+    with torch.cuda.stream(side):
+        got = run_spmm(cmm, dev, rowptr, col, val, 64, K, B, "naive_spmm")
+    side.synchronize()
+    assert np.array_equal(got, want)
+
+
+def test_dense_inputs_of_the_sparse_classes_take_the_matrix_cores_above_the_crossover(mm, cmm, dev, monkeypatch):
+    """Round 3: naiveSpMM / cusparseMM on a DENSE tensor that is not sparse enough run the exact-fp32 MFMA product
+    (the reference's own naive test feeds torch.rand, tests/naive_kernel_test.py:48-49,62-68).  Same values as the
+    zero-skipping routes: the skipped terms are exact zeros times FINITE entries of b.  With a non-finite entry in b
+    the question is not even asked the dense way: a zero of a facing it is skipped, as `to_sparse_csr()` would."""
+    g = torch.Generator(device=dev).manual_seed(5)
+    calls = []
+    real = mm.custom_matmul  # (its kernels are default arguments bound at import: spy on the wrapper itself)
+    monkeypatch.setattr(mm, "custom_matmul", lambda *a, **k: (calls.append("dense"), real(*a, **k))[1])
+    for kept, expect_dense in ((1.0, True), (0.1, True), (0.005, False)):
+        probs = torch.rand(8, 12, 512, 512, device=dev, generator=g)
+        probs = probs * (torch.rand(probs.shape, device=dev, generator=g) < kept)
+        v = torch.rand(8, 12, 512, 64, device=dev, generator=g) - 0.5
+        del calls[:]
+        out = mm.naiveSpMM.apply(probs, v)
+        assert bool(calls) == expect_dense, (kept, calls)
+        assert torch.allclose(out, torch.matmul(probs, v), rtol=RTOL, atol=1e-4)
+        # the CSR route on the same data, bit for bit
+        values, columns, offsets = cmm.dense_to_csr(probs.reshape(-1, 512, 512))
+        c = torch.empty(96, 512, 64, device=dev)
+        cmm.naive_spmm_batched(values, columns, offsets, values.numel(), 96, 512, 512, v.reshape(96, 512, 64), c)
+        assert torch.equal(out.reshape(96, 512, 64), c), kept
+    # one large matrix (the FC-layer call shape), dense → one MFMA launch
+    x, w = torch.rand(4, 1024, 768, device=dev, generator=g), torch.rand(768, 512, device=dev, generator=g)
+    del calls[:]
+    out = mm.cusparseMM.apply(x, w)
+    assert calls and torch.allclose(out, x @ w, rtol=RTOL, atol=1e-4)
+    # a non-finite entry of b facing zeros of a: skipped, never multiplied
+    a = torch.rand(2048, 512, device=dev, generator=g)
+    a[:, 7] = 0.0
+    b = torch.rand(512, 128, device=dev, generator=g)
+    b[7, 3] = float("inf")
+    b[7, 5] = float("nan")
+    del calls[:]
+    out = mm.naiveSpMM.apply(a, b)
+    assert not calls and bool(torch.isfinite(out).all())
+    b0 = b.clone()
+    b0[7] = 0.0
+    assert torch.equal(out, mm.naiveSpMM.apply(a, b0))
+
+
+def test_naive_matmul_of_a_dense_matrix_is_graph_capturable(mm, dev):
+    """Advisor (round 2): under stream capture nothing may be read back — dense inputs take the in-kernel
+    zero-skipping route whenever it covers the shape, whatever the regime model says; replay follows new data."""
+    g = torch.Generator(device=dev).manual_seed(6)
+    a = torch.rand(2048, 1024, device=dev, generator=g) * (torch.rand(2048, 1024, device=dev, generator=g) < 0.05)
+    b = torch.rand(1024, 256, device=dev, generator=g)
+    mm.naive_matmul(a, b)  # warm-up outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = mm.naive_matmul(a, b)
+    a.copy_(torch.rand(2048, 1024, device=dev, generator=g) * (torch.rand(2048, 1024, device=dev, generator=g) < 0.05))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.allclose(out, a @ b, rtol=RTOL, atol=1e-4)
+
+
+def test_batched_csr_tensor_as_the_sparse_operand(mm, dev):
+    """Reference matmuls.py:289-293 recurses over the leading dimension of `a`; here a batched CSR tensor runs as one
+    launch of the batched kernel (shared or per-item b), for both classes."""
+    g = torch.Generator().manual_seed(8)
+    dense = torch.rand(6, 40, 50, generator=g)
+    keep = torch.zeros(6, 40, 50, dtype=torch.bool)
+    for i in range(6):  # torch's batched CSR wants the same number of non-zeros in every item
+        idx = torch.randperm(2000, generator=g)[:300]
+        keep[i].view(-1)[idx] = True
+    dense = dense * keep
+    a = dense.to(dev).to_sparse_csr()
+    assert a.dim() == 3 and a.is_sparse_csr
+    for b in (torch.rand(50, 36, generator=g), torch.rand(6, 50, 64, generator=g)):
+        exp = torch.matmul(dense, b)
+        for cls in (mm.naiveSpMM, mm.cusparseMM):
+            out = cls.apply(a, b.to(dev))
+            assert out.shape == exp.shape and torch.allclose(exp, out.cpu(), rtol=RTOL, atol=1e-5)
+    a4 = (dense.reshape(2, 3, 40, 50)).to(dev).to_sparse_csr()
+    out = mm.naiveSpMM.apply(a4, torch.rand(2, 3, 50, 8, generator=g).to(dev))
+    assert out.shape == (2, 3, 40, 8)
+    with pytest.raises(RuntimeError):
+        mm.naive_matmul(a, torch.rand(5, 50, 8).to(dev))  # batch dimensions differ
+
+
+def test_transpose_cache_keeps_the_pattern_not_the_values(mm, dev):
+    """Advisor (round 2): a write to the values that bypasses the version counter must not meet a stale copy — the
+    cache on the CSR tensor holds the transposed pattern and a permutation; values are gathered per backward."""
+    g = torch.Generator().manual_seed(9)
+    a = torch.rand(60, 80, generator=g) * (torch.rand(60, 80, generator=g) < 0.15)
+    b = torch.rand(80, 32, generator=g)
+    dc = torch.rand(60, 32, generator=g)
+    a_csr = a.to(dev).to_sparse_csr().requires_grad_(True)
+    b1 = b.to(dev).requires_grad_(True)
+    mm.naiveSpMM.apply(a_csr, b1).backward(dc.to(dev))
+    assert torch.allclose((a.t() @ dc), b1.grad.cpu(), rtol=RTOL, atol=1e-5)
+    a_csr.values().data.mul_(3.0)  # no version bump
+    b1.grad = None
+    mm.naiveSpMM.apply(a_csr, b1).backward(dc.to(dev))
+    assert torch.allclose(3.0 * (a.t() @ dc), b1.grad.cpu(), rtol=RTOL, atol=1e-4)
+
+
+def test_reference_test_shapes_at_full_size(mm, cmm, dev):
+    """reference tests/naive_kernel_test.py:67-68 and tests/cublas_kernel_test.py:68-69 at their own size:
+    (256,16,512,512) × (256,16,512,64) through cublasMM, cublasTransbMM and naiveSpMM against torch.matmul at the
+    reference's tolerance, and the CSR route on the fully dense "sparse" input — 1.07 × 10⁹ non-zeros in one batched
+    CSR: the int32 index guard and the 64-bit offsets meet a shape the reference holds."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs ≈ 30 GB of device memory")
+    g = torch.Generator(device=dev).manual_seed(11)
+    a = torch.rand(256, 16, 512, 512, device=dev, generator=g)
+    b = torch.rand(256, 16, 512, 64, device=dev, generator=g)
+    exp = torch.matmul(a, b)
+    assert torch.allclose(exp, mm.cublasMM.apply(a, b), rtol=RTOL, atol=ATOL)
+    out = mm.naiveSpMM.apply(a, b)  # dense input: the matrix cores
+    assert torch.allclose(exp, out, rtol=RTOL, atol=ATOL)
+    # the CSR route at 2³⁰ non-zeros, in chunks of ≤ 65535 items as matmuls does
+    values, columns, offsets = cmm.dense_to_csr(a.reshape(-1, 512, 512))
+    # (torch.rand draws an exact 0 about once in 2²⁴ samples: a few dozen of the 2³⁰ entries)
+    assert values.numel() == int(torch.count_nonzero(a)) > 2 ** 30 - 4096 and int(offsets.view(-1)[-1]) == values.numel()
+    c = torch.empty(4096, 512, 64, device=dev)
+    cmm.naive_spmm_batched(values, columns, offsets, values.numel(), 4096, 512, 512, b.reshape(4096, 512, 64), c)
+    assert torch.equal(c.view_as(out), out)  # same chain either way
+    del values, columns, offsets, c, out
+    q = torch.rand(256, 16, 512, 64, device=dev, generator=g)
+    scores = mm.cublasTransbMM.apply(q, b)
+    ref = torch.matmul(q, b.transpose(-1, -2))
+    assert torch.allclose(ref, scores, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("K", [301, 302, 303])
+def test_column_major_native_form_with_a_padded_leading_dimension(capi, cmm, dev, oracle_mod, K):
+    """Advisor (round 2, medium): through the C-ABI the activations may come with ldb > K; with K % 4 != 0 the
+    native LDS-slab form read its partial last k-quad at the wrong rows.  K % 4 = 1, 2, 3 with ldb = K rounded up,
+    on a slab-plan shape: bit-identical to the oracle (executor of reference src/baseline_mm.cu:272-321)."""
+    M, N, density = 1100, 4100, 0.6
+    ldb = (K + 3) // 4 * 4
+    g = np.random.Generator(np.random.PCG64(K))
+    rowptr, col, val = oracle_mod.make_csr(M, K, density, seed=K)
+    val = val - 0.5
+    x = g.random((N, K), dtype=np.float32) - 0.5
+    xp = np.full((N, ldb), np.float32(777.0))   # the padding must never reach a result
+    xp[:, :K] = x
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_spmm_colmajor_native_form.argtypes = [i64, i32, i32, i32, vp, i64, vp, i64]
+    capi.mi_spmm_colmajor_workspace_bytes.restype = ctypes.c_size_t
+    capi.mi_spmm_colmajor_workspace_bytes.argtypes = [i32, i32, i32]
+    capi.mi_spmm_csr_colmajor_f32.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, i64, vp, i64, vp, ctypes.c_size_t, vp]
+    d = [t(a, dev) for a in (rowptr, col, val, xp)]
+    y = torch.full((N, M), float("nan"), device=dev)
+    assert capi.mi_spmm_colmajor_native_form(len(val), M, K, N, d[3].data_ptr(), ldb, y.data_ptr(), M) == 1
+    nbytes = capi.mi_spmm_colmajor_workspace_bytes(M, K, N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    assert capi.mi_spmm_csr_colmajor_f32(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(val), M, K, N,
+                                         d[3].data_ptr(), ldb, y.data_ptr(), M, ws.data_ptr(), nbytes,
+                                         torch.cuda.current_stream().cuda_stream) == 0
+    want = oracle_mod.spmm_csr_colmajor(rowptr, col, val, M, K, N, x).reshape(N, M)
+    assert np.array_equal(y.cpu().numpy(), want)
+
+
+def test_validate_csr_rejects_bad_contents_for_every_plan(cmm, dev, oracle_mod):
+    """The per-product entry points trust CSR contents as the reference does (src/naive_sparse_mm.cu:60-92) and an
+    out-of-range column fails differently under different plans; custom_mm.validate_csr is the opt-in check — it
+    must catch an out-of-range column, a negative column and non-monotone offsets on inputs that would take the
+    row-split, the L2-panel and the LDS-slab plan alike (the check does not depend on the plan: asserted per shape)."""
+    shapes = [("spmm_wave_row_kernel", 2000, 3000, 256, 0.01), ("spmm_wave_row_panel_kernel", 16384, 16384, 256, 0.01),
+              ("spmm_slab_kernel", 4096, 4096, 2048, 0.2), ("spmm_group_kernel", 500, 700, 64, 0.05)]
+    for plan, M, K, N, density in shapes:
+        rowptr, col, val = oracle_mod.make_csr(M, K, density, seed=M)
+        nnz = len(val)
+        b, c = torch.empty(K, N, device=dev), torch.empty(M, N, device=dev)
+        assert cmm.spmm_plan(nnz, M, K, b, c)[1] == plan, (plan, cmm.spmm_plan(nnz, M, K, b, c))
+        d_val = t(val, dev)
+        cmm.validate_csr(d_val, t(col, dev), t(rowptr, dev), nnz, M, K)  # the good matrix passes
+        bad = col.copy(); bad[nnz // 2] = K
+        with pytest.raises(RuntimeError):
+            cmm.validate_csr(d_val, t(bad, dev), t(rowptr, dev), nnz, M, K)
+        bad = col.copy(); bad[7] = -1
+        with pytest.raises(RuntimeError):
+            cmm.validate_csr(d_val, t(bad, dev), t(rowptr, dev), nnz, M, K)
+        rp = rowptr.copy(); rp[M // 2] = rp[M // 2 + 1] + 1
+        with pytest.raises(RuntimeError):
+            cmm.validate_csr(d_val, t(col, dev), t(rp, dev), nnz, M, K)
+        rp = rowptr.copy(); rp[-1] = nnz - 1
+        with pytest.raises(RuntimeError):
+            cmm.validate_csr(d_val, t(col, dev), t(rp, dev), nnz, M, K)

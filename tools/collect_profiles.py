@@ -41,6 +41,22 @@ write_kb = sum(per_counter["WRITE_SIZE"].values())
 # the µs-scale helper launches (find_long_rows / spmm_long_rows with an empty list) ride along
 main = [k for k in per_counter["FETCH_SIZE"] if "long_rows" not in k]
 assert len(main) == launches or launches == 1, (per_counter, launches)
+# optional third pass (tools/profile_bench.sh): the DRAM-side share of the reads — requests the L2s sent to HBM
+# (TCC_EA0_RDREQ_DRAM: 32-byte and 64-byte requests, the latter counted apart) as opposed to all fabric reads
+dram = None
+dram_files = glob.glob(str(src / "pmc_dram" / "**" / "*_counter_collection.csv"), recursive=True)
+if dram_files:
+    by = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(max(dram_files, key=os.path.getmtime))):
+        if "spmm" in r["Kernel_Name"]:
+            k = r["Kernel_Name"].split("(int const")[0].replace("void (anonymous namespace)::", "")
+            by[r["Counter_Name"]][k].append(float(r["Counter_Value"]))
+    dram = {c: {k: sum(v) / len(v) for k, v in d.items()} for c, d in by.items()}
+    shutil.copy(max(dram_files, key=os.path.getmtime), dst / f"{prefix}_{workload}_pmc_dram_counter_collection.csv")
+
+sys.path.insert(0, str(REPO))
+import bench as _bench  # noqa: E402  (fingerprint of the sources these counters were taken with)
+
 rec_path = dst / "pmc_traffic.json"
 rec = json.loads(rec_path.read_text()) if rec_path.exists() else {}
 rec[workload] = {
@@ -55,6 +71,20 @@ rec[workload] = {
     "hbm_bytes_per_product": (fetch_kb * 2 + write_kb) * 1024,
     "algorithmic_bytes_per_product": bench["config"]["algorithmic_bytes_per_step"],
     "note": "fabric-side (L2-miss) bytes: Infinity-Cache hits are included in FETCH_SIZE",
+    "source_fingerprint": _bench.source_fingerprint(),
+    "dram_counters": dram,
 }
+if dram and "TCC_EA0_RDREQ_DRAM_sum" in dram and "TCC_EA0_RDREQ_sum" in dram:
+    # share of the fabric read REQUESTS that went to DRAM, applied to the (width-corrected) fabric read bytes
+    rd = sum(dram["TCC_EA0_RDREQ_sum"].values())
+    rd_dram = sum(dram["TCC_EA0_RDREQ_DRAM_sum"].values())
+    share = rd_dram / rd if rd else None
+    rec[workload]["dram_read_request_share"] = share
+    if share is not None:
+        wr_share = 1.0
+        if "TCC_EA0_WRREQ_DRAM_sum" in dram and "TCC_EA0_WRREQ_sum" in dram and sum(dram["TCC_EA0_WRREQ_sum"].values()):
+            wr_share = sum(dram["TCC_EA0_WRREQ_DRAM_sum"].values()) / sum(dram["TCC_EA0_WRREQ_sum"].values())
+        rec[workload]["dram_write_request_share"] = wr_share
+        rec[workload]["dram_bytes_per_product"] = fetch_kb * 2 * 1024 * share + write_kb * 1024 * wr_share
 rec_path.write_text(json.dumps(rec, indent=1))
 print(json.dumps(rec[workload], indent=1))
