@@ -281,9 +281,12 @@ def main():
     ap.add_argument("--split", choices=["rows", "nnz"], default="rows",
                     help="N > 1: equal-row blocks (one all_gather_into_tensor per step) or nnz-balanced split "
                          "points (one in-place broadcast per owner and step)")
-    ap.add_argument("--exchange", choices=["auto", "allgather", "p2p"], default="auto",
-                    help="N > 1: how a step's blocks reach the other ranks — one RCCL collective, or direct sends to "
-                         "every peer (one xGMI link each); auto = both are tried before the timed region")
+    ap.add_argument("--exchange", choices=["auto", "allgather", "allgather_copy", "p2p", "try-p2p"], default="auto",
+                    help="N > 1: how a step's blocks reach the other ranks.  auto / allgather: one in-place RCCL "
+                         "collective per step (falling back by itself to gather + copy if the build refuses the in-place "
+                         "form); allgather_copy pins that fallback; p2p: direct sends to every peer (one xGMI link each); "
+                         "try-p2p: the collective and the direct sends are both timed before the timed region (a p2p "
+                         "exchange that fails ends the run: a process group is not reused after a failed exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -323,9 +326,16 @@ def main():
             # "nccl" is RCCL on ROCm.  Its kernels go on a HIGH-PRIORITY stream: the all-gather of block j runs
             # beside the SpMM of block j+1, which fills every CU — at normal priority the collective's
             # workgroups would queue behind it and the overlap the layout is built for would be lost
+            os.environ.setdefault("NCCL_DEBUG", "VERSION")  # RCCL prints its version line once (stderr of the ranks)
             opts = dist.ProcessGroupNCCL.Options()
             opts.is_high_priority_stream = True
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=opts)
+    rank_devices = None
+    if world > 1:
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
+                "name": torch.cuda.get_device_name(dev), "pid": os.getpid()}
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, mine)
 
     import custom_mm
     import sharded
@@ -356,16 +366,24 @@ def main():
         local_bytes_alg = bytes_alg
     else:
         rp_t, col_t, val_t = torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val)
-        auto_exchange = args.exchange == "auto"
-        if auto_chunks or auto_exchange:
+        try_p2p = args.exchange == "try-p2p"
+        if args.exchange in ("auto", "try-p2p"):
+            args.exchange = "allgather"
+        if auto_chunks or try_p2p:
             # Before anything is timed: how finely to cut a rank's rows is a trade between starting the
-            # first exchange early (many chunks) and RCCL's efficiency on larger messages (few chunks), and
-            # whether the collective or direct sends to every peer move the blocks faster depends on the
-            # node's fabric — so try the candidates for a few steps each and keep the fastest (max over
-            # ranks, so every rank decides alike).  Setup, like the warm-up: not in the timed region.
+            # first exchange early (many chunks) and RCCL's efficiency on larger messages (few chunks) — and, on
+            # request (--exchange try-p2p), whether direct sends to every peer beat the collective on this node's
+            # fabric — so try the candidates for a few steps each and keep the fastest (max over ranks, so every
+            # rank decides alike).  Setup, like the warm-up: not in the timed region.
+            # The collective cannot half-fail: the only refusal seen in the wild (the aliased in-place form) is an
+            # argument check that every rank hits alike before anything is sent, and ShardedSpMM then gathers out
+            # of place by itself.  A p2p exchange CAN fail on some ranks only, which would leave the others inside
+            # their sends: it is therefore never part of the default trial, and an exception in it ends this rank
+            # (and with it the job) instead of reusing the group.
             chunk_trials = {}
             chunk_cands = ((2, 4) if world <= 2 else (2, 4, 8)) if auto_chunks else (args.chunks,)
-            exch_cands = ("allgather", "p2p") if auto_exchange else (args.exchange,)
+            exch_cands = (args.exchange, "p2p") if try_p2p else (args.exchange,)
+
             def try_candidate(exch, cand):
                 trial = sharded.ShardedSpMM(rp_t, col_t, val_t, M, K, dev, chunks=cand, split=args.split, exchange=exch)
                 Ct = trial.alloc_output(N)
@@ -377,24 +395,19 @@ def main():
                 for _ in range(3):
                     trial.forward(B, out=Ct)
                 torch.cuda.synchronize()
-                return time.perf_counter() - t1
+                return time.perf_counter() - t1, trial.exchange
 
-            for exch in exch_cands:  # the collective first: it is the exchange every torch / RCCL build has
+            for exch in exch_cands:
                 for cand in chunk_cands:
-                    seconds, failed = float("inf"), 0.0
                     try:
-                        seconds = try_candidate(exch, cand)
-                    except Exception as e:  # an exchange this torch / RCCL build refuses is dropped, not fatal
-                        if not (auto_exchange and exch == "p2p"):
-                            raise
-                        failed = 1.0
-                        if rank == 0:
-                            print(f"bench: exchange '{exch}' dropped from the trial ({type(e).__name__}: {e})", file=sys.stderr)
-                    tt = torch.tensor([seconds if not failed else 0.0, failed], device=dev, dtype=torch.float64)
+                        seconds, used = try_candidate(exch, cand)
+                    except Exception as e:
+                        print(f"bench: rank {rank}: exchange '{exch}' with {cand} chunks failed ({type(e).__name__}: {e}); "
+                              "the process group is not reused after a failed exchange", file=sys.stderr, flush=True)
+                        os._exit(3)
+                    tt = torch.tensor([seconds], device=dev, dtype=torch.float64)
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    if float(tt[1]) > 0:
-                        break  # some rank could not run it: every rank drops the remaining candidates of this exchange
-                    chunk_trials[(exch, cand)] = float(tt[0]) / 3 * 1e3
+                    chunk_trials[(used, cand)] = float(tt[0]) / 3 * 1e3
             args.exchange, args.chunks = min(chunk_trials, key=chunk_trials.get)
             torch.cuda.empty_cache()
         op = sharded.ShardedSpMM(rp_t, col_t, val_t, M, K, dev, chunks=args.chunks, split=args.split, exchange=args.exchange)
@@ -481,11 +494,15 @@ def main():
                 "sha256_rowptr_col_val": hashlib.sha256(rowptr.tobytes() + col.tobytes() + val.tobytes()).hexdigest()[:16],
                 "parallelism": "single GPU" if world == 1 else
                                f"A row-sharded over {world} GPUs ({args.split}-balanced blocks), block-cyclic "
-                               f"x{args.chunks}, " + ("RCCL all-gather of C" if args.exchange == "allgather" else
-                                                      "C exchanged by direct RCCL sends to every peer"),
+                               f"x{args.chunks}, " + {"allgather": "RCCL all-gather of C, in place",
+                                                      "allgather_copy": "RCCL all-gather of C into a scratch span + copy",
+                                                      "p2p": "C exchanged by direct RCCL sends to every peer"}[op.exchange if world > 1 else "allgather"],
                 "rccl_ranks": world if world > 1 else None,
                 "chunks": None if world == 1 else args.chunks,
-                "exchange": None if world == 1 else args.exchange,
+                "exchange": None if world == 1 else op.exchange,
+                "exchange_fallbacks": None if world == 1 else op.fallbacks,
+                "rank_devices": rank_devices,
+                "nccl_debug_env": os.environ.get("NCCL_DEBUG"),
                 "chunk_trials_ms_per_step": None if not chunk_trials else {f"{e}/{c}": round(v, 4) for (e, c), v in chunk_trials.items()},
                 "collective_backend": None if world == 1 else ("gloo (rehearsal)" if rehearse else
                                                                 "rccl " + ".".join(str(x) for x in torch.cuda.nccl.version())),

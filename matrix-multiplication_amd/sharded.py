@@ -32,8 +32,11 @@ Two ways to cut the rows:
     for skewed matrices; blocks have different heights, so a step's exchange is one
     in-place broadcast per owner (RCCL runs them back to back on its stream).
 
-Two ways to exchange a step's blocks:
-  * exchange="allgather": the collective above (RCCL picks its rings / trees);
+Ways to exchange a step's blocks:
+  * exchange="allgather": the collective above (RCCL picks its rings / trees), IN PLACE.  Should a torch / RCCL
+    build refuse the aliased in-place form — an argument check, raised on every rank alike before anything is
+    sent — the operator falls back for good to exchange="allgather_copy": the same collective into a scratch span
+    followed by one device copy into C (an extra M·N·4/chunks bytes of traffic per step; same bits);
   * exchange="p2p": every rank sends its block straight to every peer and receives each peer's block
     straight into its final position (one grouped batch of isend / irecv per step).  On a fully connected
     xGMI node that uses each of the 7 peer links for exactly one shard at a time — the pattern SURVEY.md
@@ -95,8 +98,8 @@ class ShardedSpMM:
                  layout=None, exchange="allgather"):
         if split not in ("rows", "nnz"):
             raise ValueError("split must be 'rows' or 'nnz'")
-        if exchange not in ("allgather", "p2p"):
-            raise ValueError("exchange must be 'allgather' or 'p2p'")
+        if exchange not in ("allgather", "allgather_copy", "p2p"):
+            raise ValueError("exchange must be 'allgather', 'allgather_copy' or 'p2p'")
         self.exchange = exchange
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -141,6 +144,8 @@ class ShardedSpMM:
         self._rule = {}  # N -> does the whole problem split long rows
         self._two_streams = {}  # N -> alternate the blocks over two streams?
         self._side = None
+        self._scratch = {}     # (step, shape) -> out-of-place gather target (exchange="allgather_copy")
+        self.fallbacks = []    # what was refused and replaced: reported by bench.py
 
     def alloc_output(self, N: int) -> torch.Tensor:
         return torch.empty((self.padded_rows, N), device=self.device, dtype=torch.float32)
@@ -195,7 +200,7 @@ class ShardedSpMM:
         if out is None:
             out = self.alloc_output(N)
         assert out.shape == (self.padded_rows, N) and out.is_contiguous()
-        works = []
+        works, copies = [], []
         collective = gather and (self.world > 1 or force_collective)
         if collective and self.modelled:
             raise RuntimeError("a modelled layout has no process group: call forward(..., gather=False)")
@@ -228,9 +233,24 @@ class ShardedSpMM:
                     works.extend(dist.batch_isend_irecv(ops))
             elif self.split == "rows":
                 span = out[int(self.bounds[first]):int(self.bounds[first + self.world])]
-                # in place: `mine` is span[rank*br : (rank+1)*br]; the collective is ordered after
-                # the kernel above (same stream) and runs beside the next step's kernel
-                works.append(dist.all_gather_into_tensor(span, mine, group=self.group, async_op=True))
+                if self.exchange == "allgather":
+                    # in place: `mine` is span[rank*br : (rank+1)*br]; the collective is ordered after
+                    # the kernel above (same stream) and runs beside the next step's kernel
+                    try:
+                        works.append(dist.all_gather_into_tensor(span, mine, group=self.group, async_op=True))
+                    except (RuntimeError, ValueError, TypeError) as err:
+                        # refused at call time (argument validation: identical on every rank, nothing was sent)
+                        self.fallbacks.append(f"in-place all_gather_into_tensor refused ({type(err).__name__}: "
+                                              f"{str(err)[:120]}): out-of-place gather + copy from now on")
+                        self.exchange = "allgather_copy"
+                if self.exchange == "allgather_copy":
+                    # one scratch span per step (together: a second C), copied into place after the waits
+                    key = (j, tuple(span.shape))
+                    if key not in self._scratch:
+                        self._scratch[key] = torch.empty_like(span)
+                    works.append(dist.all_gather_into_tensor(self._scratch[key], mine.contiguous(), group=self.group,
+                                                             async_op=True))
+                    copies.append((span, self._scratch[key]))
             else:
                 for r in range(self.world):  # blocks of different heights: one in-place broadcast per owner
                     s0, s1 = int(self.bounds[first + r]), int(self.bounds[first + r + 1])
@@ -247,4 +267,6 @@ class ShardedSpMM:
             streams[0].wait_stream(streams[1])
         for w in works:
             w.wait()
+        for span, scratch in copies:
+            span.copy_(scratch)
         return out[:self.M]

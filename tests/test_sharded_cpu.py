@@ -40,7 +40,8 @@ def _skewed_csr(M, K):
     return rowptr, col, val
 
 
-def _worker(rank, world, port, M, K, N, chunks, out_dir, split="rows", skew=False, exchange="allgather"):
+def _worker(rank, world, port, M, K, N, chunks, out_dir, split="rows", skew=False, exchange="allgather",
+            refuse_in_place=False):
     for p in (str(REPO), str(REPO / "matrix-multiplication_amd")):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -48,6 +49,17 @@ def _worker(rank, world, port, M, K, N, chunks, out_dir, split="rows", skew=Fals
     try:
         import oracle
         import sharded
+        if refuse_in_place:
+            # a torch / RCCL build that refuses the aliased in-place form: an argument check, raised on every rank
+            # alike before anything is sent
+            real = dist.all_gather_into_tensor
+
+            def picky(output, input, *a, **k):
+                lo, hi = output.data_ptr(), output.data_ptr() + output.numel() * output.element_size()
+                if lo <= input.data_ptr() < hi:
+                    raise RuntimeError("all_gather_into_tensor: input aliases output (refused by this build)")
+                return real(output, input, *a, **k)
+            dist.all_gather_into_tensor = picky
         rowptr, col, val = _skewed_csr(M, K) if skew else oracle.make_csr(M, K, 0.05, seed=0)
         B = torch.from_numpy(np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32))
         op = sharded.ShardedSpMM(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), M, K, "cpu",
@@ -67,6 +79,10 @@ def _worker(rank, world, port, M, K, N, chunks, out_dir, split="rows", skew=Fals
         assert int(total) == len(val)
         C = op.forward(B)
         np.save(os.path.join(out_dir, f"c_{rank}.npy"), C.numpy())
+        if refuse_in_place:
+            assert op.exchange == "allgather_copy" and len(op.fallbacks) == 1 and "refused" in op.fallbacks[0]
+            C2 = op.forward(B)  # stays on the fallback without a second refusal
+            assert len(op.fallbacks) == 1 and torch.equal(C, C2)
     finally:
         dist.destroy_process_group()
 
@@ -106,6 +122,22 @@ def test_direct_p2p_exchange_equals_single_rank(tmp_path, oracle_mod, M, chunks,
     K, N = 64, 24
     mp.spawn(_worker, args=(world, _free_port(), M, K, N, chunks, str(tmp_path), split, skew, "p2p"), nprocs=world, join=True)
     rowptr, col, val = _skewed_csr(M, K) if skew else oracle_mod.make_csr(M, K, 0.05, seed=0)
+    B = np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32)
+    single = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    for r in range(world):
+        got = np.load(tmp_path / f"c_{r}.npy")
+        assert got.shape == (M, N) and np.array_equal(got, single), f"rank {r}"
+
+
+@pytest.mark.parametrize("M,chunks,refuse", [(96, 2, True), (101, 3, True), (101, 3, False)])
+def test_refused_in_place_gather_falls_back_to_gather_plus_copy(tmp_path, oracle_mod, M, chunks, refuse):
+    """Round 3 (first contact with a multi-GPU node): if the in-place all_gather_into_tensor is what a torch / RCCL
+    build refuses, the operator switches — on every rank alike, nothing having been sent — to the out-of-place
+    collective + one copy per step and still returns the single-rank bits; exchange="allgather_copy" pins that form."""
+    K, N, world = 64, 24, 2
+    mp.spawn(_worker, args=(world, _free_port(), M, K, N, chunks, str(tmp_path), "rows", False,
+                            "allgather" if refuse else "allgather_copy", refuse), nprocs=world, join=True)
+    rowptr, col, val = oracle_mod.make_csr(M, K, 0.05, seed=0)
     B = np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32)
     single = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
     for r in range(world):
