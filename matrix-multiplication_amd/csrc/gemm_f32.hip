@@ -337,6 +337,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI_GEMM_SHO
         LA::load_fast(ra, LA::origin(A, lda, m0, k0 + BK), lda, a_lane);
         LB::load_fast(rb, LB::origin(B, ldb, n0, k0 + BK), ldb, b_lane);
       }
+      // the loads stay in front of the MFMAs: hipcc otherwise sinks them (they feed nothing until the next
+      // iteration) to the end of the tile, right in front of the waits on them — no prefetch left
+      __builtin_amdgcn_sched_barrier(0);
       mfma_tile();
       GEMM_STAMP(2);  // MFMAs of the tile issued
       __syncthreads();
@@ -624,15 +627,25 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
         LA::load_fast(ra, LA::origin(A, lda, m0, 0), lda, a_lane);
         LB::load_fast(rb, LB::origin(B, ldb, (CHAIN * group_n + T + 1) * BN, 0), ldb, b_lane);
       }
+      // the next stage's loads stay in front of this stage's MFMAs (hipcc otherwise sinks them to the end of the
+      // stage, right in front of the waits on them: the ISA of the first round-3 build showed exactly that)
+      __builtin_amdgcn_sched_barrier(0);
+      // operand reads run one k-step ahead of the MFMAs (two register slots): left to itself the compiler reads
+      // each step's operands immediately before its MFMAs and the wave waits out the LDS latency every four MFMAs
+      float a[2][TM], b[2][TN];
+      auto read_step = [&](int step, int slot) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[slot][i] = LA::at(As, wm * (BM / 2) + i * 32 + l31, 2 * step + lhi);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[slot][j] = LB::at(Bs, wn * (BN / 2) + j * 32 + l31, 2 * step + lhi);
+      };
+      read_step(0, 0);
       static_for<BK / 2>([&](auto S_) {
         constexpr int S = decltype(S_)::value;  // MFMA k-step of this stage
+        if constexpr (S + 1 < BK / 2) read_step(S + 1, (S + 1) & 1);
         // the previous tile's epilogue rides here (its accumulators are the other set)
         if constexpr (T > 0 && S % GAP == 0) phase(std::integral_constant<int, T - 1>{}, std::integral_constant<int, KT * PPS + S / GAP>{});
-        float a[TM], b[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = LA::at(As, wm * (BM / 2) + i * 32 + l31, 2 * S + lhi);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = LB::at(Bs, wn * (BN / 2) + j * 32 + l31, 2 * S + lhi);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -641,11 +654,12 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
               if (KT == 0 && S == 0) acc[SET][i][j] = zero16;
             } else if constexpr (KT == 0 && S == 0) {
               // a tile's first product starts its accumulators (set reused from tile T − 2) from zero
-              acc[SET][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], zero16, 0, 0, 0);
+              acc[SET][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S & 1][i], b[S & 1][j], zero16, 0, 0, 0);
             } else {
-              acc[SET][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[SET][i][j], 0, 0, 0);
+              acc[SET][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S & 1][i], b[S & 1][j], acc[SET][i][j], 0, 0, 0);
             }
           }
+        __builtin_amdgcn_sched_barrier(0);
       });
       __syncthreads();
     });

@@ -338,16 +338,17 @@ def _batched_csr_product(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) ->
     return c.view(batch + (rows, n))
 
 
-_DENSE_SAMPLE_ROWS = 512
+_DENSE_SAMPLE_ROWS = 128
+_density_of_shape = {}  # (shape of a, shape of b, device) -> {'est', 'n', 'host', 'event'}: see _dense_route
 
 
 def dense_route_pays(density: float, items: int, rows: int, cols: int, width: int) -> bool:
     '''Dense-with-zeros A: the exact-fp32 MFMA product (custom_mm.cublas_mmul / cublas_bmm) against the routes that
-    skip the zeros.  Fitted on MI355X (tools/bench_skipwide.py, tools/bench_attn_sparse.py,
-    profiles/r03_dense_input_routing.log): the MFMA product sustains ≈110 TFLOP/s on batches of attention-sized
-    matrices and ≈140 on large ones; the zero-skipping routes ≈12–15 TFLOP/s of useful flops plus one pass over A
-    per 256 output columns (≈4 TB/s).  BERT-base probs·V (384 × 512² × 64): dense 0.115 ms whatever the density,
-    skipping 0.91 ms at 100 % kept, 0.20 at 10 %, level at ≈2 %.'''
+    skip the zeros.  Fitted on MI355X (tools/bench_dense_routing.py, profiles/r03_dense_input_routing.log): the MFMA
+    product sustains ≈110 TFLOP/s on batches of attention-sized matrices and ≈140 on large ones; the zero-skipping
+    routes ≈12–15 TFLOP/s of useful flops plus one pass over A per 256 output columns (≈4 TB/s).  BERT-base probs·V
+    (384 × 512² × 64): dense 0.10–0.12 ms whatever the density, skipping 0.96 ms at 100 % kept, 0.19 at 10 %, level
+    at ≈2 %; 16384 × 768 × 3072: dense 0.53, CSR route 2.56 / 0.49 / 0.18 ms at 100 / 10 / 2 %.'''
     flops = 2.0 * items * rows * cols * width
     t_dense = flops / (140e12 if rows * cols >= 2048 * 2048 else 110e12) + 4e-6
     t_skip = density * flops / 14e12 + items * rows * cols * 4.0 * -(-width // 256) / 4e12
@@ -355,26 +356,44 @@ def dense_route_pays(density: float, items: int, rows: int, cols: int, width: in
 
 
 def _dense_route(a: torch.Tensor, b: torch.Tensor, items: int, rows: int, cols: int, width: int) -> bool:
-    '''Whether a dense-with-zeros `a` should take the dense MFMA product: decided from an evenly spaced sample of
-    ≤ 512 rows of `a` (one small count kernel) and — because the dense product multiplies the zeros of `a` with the
-    facing entries of `b` where the sparse routes skip them — only when every entry of `b` is finite (0·finite adds
-    an exact zero: same value; 0·inf or 0·nan would turn a finite result into nan).  Both facts come back in ONE
-    host read-back (the reference converts with `to_sparse_csr()` per call, which synchronises as well,
-    matmuls.py:295-296).  Under stream capture nothing may be read back: the question is not asked.
-    Products whose dense form takes under ≈20 µs are not worth the question either.'''
+    '''Whether a dense-with-zeros `a` should take the dense MFMA product, decided from the density of an evenly
+    spaced sample of ≤ 128 rows of `a` (one small count kernel).  The count comes back WITHOUT stalling the stream:
+    it is copied to pinned memory behind an event, and a call decides from the most recent count that has landed for
+    operands of the same shapes — the previous call's, in a loop — so only the first call of a shape waits (the
+    reference converts with `to_sparse_csr()` on every call, which synchronises every time, matmuls.py:295-296).  A
+    stale estimate can only cost time: with finite operands every route returns the same bits (the skipped terms
+    are exact zeros).  The one semantic difference is pinned in
+    tests/test_gpu_parity.py::test_dense_inputs_of_the_sparse_classes_take_the_matrix_cores_above_the_crossover:
+    on the dense route a zero of `a` multiplies the entry of `b` it faces, so a NON-FINITE entry there gives nan,
+    exactly as `torch.matmul(a, b)` — the oracle of the reference's own tests, tests/naive_kernel_test.py:30-37 —
+    while the zero-skipping routes leave it out as `to_sparse_csr()` does.
+    Under stream capture nothing is read back: the question is not asked.  Products whose dense form takes under
+    ≈20 µs are not worth the question either.'''
     if not a.is_cuda or torch.cuda.is_current_stream_capturing() or a.numel() == 0 or b.numel() == 0:
         return False
     if 2.0 * items * rows * cols * width / 110e12 < 20e-6:
         return False
-    flat = a.reshape(-1, cols)
-    step = max(1, flat.shape[0] // _DENSE_SAMPLE_ROWS)
-    sample = flat[::step][:_DENSE_SAMPLE_ROWS]
-    kept = custom_mm.dense_row_offsets(sample).view(-1)[-1].to(torch.float32)
-    # a sum is finite only if every term is (an overflow of finite terms reads as "not finite": the skipping route)
-    kept, total = torch.stack((kept, b.sum(dtype=torch.float32))).tolist()
-    if total != total or total in (float('inf'), float('-inf')):
-        return False
-    return dense_route_pays(kept / sample.numel(), items, rows, cols, width)
+    key = (tuple(a.shape), tuple(b.shape), a.device.index)
+    ent = _density_of_shape.get(key)
+    if ent is None:
+        if len(_density_of_shape) >= 64:
+            _density_of_shape.clear()
+        ent = _density_of_shape[key] = {'est': None, 'n': 1, 'event': None,
+                                        'host': torch.empty((), dtype=torch.int64, pin_memory=True)}
+    if ent['event'] is not None and ent['event'].query():
+        ent['est'], ent['event'] = float(ent['host']) / ent['n'], None
+    if ent['event'] is None:  # no read-back in flight: start one on this call's operand
+        flat = a.reshape(-1, cols)
+        step = max(1, flat.shape[0] // _DENSE_SAMPLE_ROWS)
+        sample = flat[::step][:_DENSE_SAMPLE_ROWS]
+        ent['host'].copy_(torch.count_nonzero(sample), non_blocking=True)
+        ent['n'] = sample.numel()
+        ent['event'] = torch.cuda.Event()
+        ent['event'].record()
+    if ent['est'] is None:  # first call of this shape: wait for its own count
+        ent['event'].synchronize()
+        ent['est'], ent['event'] = float(ent['host']) / ent['n'], None
+    return dense_route_pays(ent['est'], items, rows, cols, width)
 
 
 def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch.Tensor:

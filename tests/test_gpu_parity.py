@@ -1723,20 +1723,27 @@ def test_long_rows_listed_by_the_main_kernel_and_zero_header_contract(capi, cmm,
 
 def test_dense_inputs_of_the_sparse_classes_take_the_matrix_cores_above_the_crossover(mm, cmm, dev, monkeypatch):
     """Round 3: naiveSpMM / cusparseMM on a DENSE tensor that is not sparse enough run the exact-fp32 MFMA product
-    (the reference's own naive test feeds torch.rand, tests/naive_kernel_test.py:48-49,62-68).  Same values as the
-    zero-skipping routes: the skipped terms are exact zeros times FINITE entries of b.  With a non-finite entry in b
-    the question is not even asked the dense way: a zero of a facing it is skipped, as `to_sparse_csr()` would."""
+    (the reference's own naive test feeds torch.rand, tests/naive_kernel_test.py:48-49,62-68).  With finite operands
+    every route returns the same bits: the skipped terms are exact zeros.  The route is decided from a sampled
+    density that comes back without stalling the stream (the most recent count that has landed for operands of the
+    same shapes).  THE RULE for non-finite operands: on the dense route a zero of `a` multiplies the entry of `b`
+    it faces — nan, exactly as torch.matmul (the reference tests' oracle) — while the zero-skipping routes leave
+    it out, as `to_sparse_csr()` does."""
     g = torch.Generator(device=dev).manual_seed(5)
     calls = []
     real = mm.custom_matmul  # (its kernels are default arguments bound at import: spy on the wrapper itself)
     monkeypatch.setattr(mm, "custom_matmul", lambda *a, **k: (calls.append("dense"), real(*a, **k))[1])
+    mm._density_of_shape.clear()
     for kept, expect_dense in ((1.0, True), (0.1, True), (0.005, False)):
         probs = torch.rand(8, 12, 512, 512, device=dev, generator=g)
         probs = probs * (torch.rand(probs.shape, device=dev, generator=g) < kept)
         v = torch.rand(8, 12, 512, 64, device=dev, generator=g) - 0.5
+        out = mm.naiveSpMM.apply(probs, v)   # may still run on the previous density's route …
+        torch.cuda.synchronize()
         del calls[:]
-        out = mm.naiveSpMM.apply(probs, v)
+        out2 = mm.naiveSpMM.apply(probs, v)  # … this one knows the operand's own density
         assert bool(calls) == expect_dense, (kept, calls)
+        assert torch.equal(out, out2), "the route must not change a bit"
         assert torch.allclose(out, torch.matmul(probs, v), rtol=RTOL, atol=1e-4)
         # the CSR route on the same data, bit for bit
         values, columns, offsets = cmm.dense_to_csr(probs.reshape(-1, 512, 512))
@@ -1748,18 +1755,27 @@ def test_dense_inputs_of_the_sparse_classes_take_the_matrix_cores_above_the_cros
     del calls[:]
     out = mm.cusparseMM.apply(x, w)
     assert calls and torch.allclose(out, x @ w, rtol=RTOL, atol=1e-4)
-    # a non-finite entry of b facing zeros of a: skipped, never multiplied
-    a = torch.rand(2048, 512, device=dev, generator=g)
-    a[:, 7] = 0.0
-    b = torch.rand(512, 128, device=dev, generator=g)
+    # the rule for a non-finite entry of b facing zeros of a
+    b = torch.rand(512, 256, device=dev, generator=g)
     b[7, 3] = float("inf")
     b[7, 5] = float("nan")
-    del calls[:]
-    out = mm.naiveSpMM.apply(a, b)
-    assert not calls and bool(torch.isfinite(out).all())
     b0 = b.clone()
     b0[7] = 0.0
-    assert torch.equal(out, mm.naiveSpMM.apply(a, b0))
+    a_dense = torch.rand(16384, 512, device=dev, generator=g)
+    a_dense[:, 7] = 0.0
+    a_sparse = a_dense * (torch.rand(16384, 512, device=dev, generator=g) < 0.004)
+    for a, dense in ((a_dense, True), (a_sparse, False)):
+        mm.naiveSpMM.apply(a, b)
+        torch.cuda.synchronize()
+        del calls[:]
+        out = mm.naiveSpMM.apply(a, b)
+        assert bool(calls) == dense
+        if dense:   # as torch.matmul: 0·inf = nan in columns 3 and 5, every other column untouched
+            ref = torch.matmul(a, b)
+            assert torch.equal(torch.isnan(out), torch.isnan(ref)) and bool(torch.isnan(out[:, 3]).all())
+            assert torch.equal(out[:, :3], mm.naiveSpMM.apply(a, b0)[:, :3])
+        else:       # as to_sparse_csr(): the zero is not a term of the sum
+            assert bool(torch.isfinite(out).all()) and torch.equal(out, mm.naiveSpMM.apply(a, b0))
 
 
 def test_naive_matmul_of_a_dense_matrix_is_graph_capturable(mm, dev):

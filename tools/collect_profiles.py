@@ -85,6 +85,15 @@ if dram and "TCC_EA0_RDREQ_DRAM_sum" in dram and "TCC_EA0_RDREQ_sum" in dram:
         if "TCC_EA0_WRREQ_DRAM_sum" in dram and "TCC_EA0_WRREQ_sum" in dram and sum(dram["TCC_EA0_WRREQ_sum"].values()):
             wr_share = sum(dram["TCC_EA0_WRREQ_DRAM_sum"].values()) / sum(dram["TCC_EA0_WRREQ_sum"].values())
         rec[workload]["dram_write_request_share"] = wr_share
-        rec[workload]["dram_bytes_per_product"] = fetch_kb * 2 * 1024 * share + write_kb * 1024 * wr_share
+        if share >= 0.999 and wr_share >= 0.999:
+            # what MI355X gives (round 3): every fabric request of the L2s is a "DRAM" request — the counters tell local
+            # HBM from remote (GMI) and IO targets, not an Infinity-Cache hit from a miss: the cache sits on the memory
+            # side of the fabric, behind the point where the TCC counts.  No DRAM-only figure can be derived from them.
+            rec[workload]["dram_bytes_per_product"] = None
+            rec[workload]["dram_note"] = ("TCC_EA0_RDREQ_DRAM == TCC_EA0_RDREQ and TCC_EA0_WRREQ_DRAM == TCC_EA0_WRREQ: the L2-side "
+                                          "counters classify a request by its TARGET (local HBM / GMI / IO), not by whether the "
+                                          "memory-side Infinity Cache served it; HBM-only traffic is not observable from rocprofv3")
+        else:
+            rec[workload]["dram_bytes_per_product"] = fetch_kb * 2 * 1024 * share + write_kb * 1024 * wr_share
 rec_path.write_text(json.dumps(rec, indent=1))
 print(json.dumps(rec[workload], indent=1))

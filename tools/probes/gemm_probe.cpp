@@ -2,6 +2,7 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DMI_GEMM_TIMING -Iinclude -Imatrix-multiplication_amd/csrc tools/probes/gemm_probe.cpp -o tools/probes/gemm_probe
 #include "../../matrix-multiplication_amd/csrc/mi_status.hip"
 #include "../../matrix-multiplication_amd/csrc/gemm_f32.hip"
+#include "../../matrix-multiplication_amd/csrc/gemm_f32_duo.hip"
 #include <cstdio>
 #include <vector>
 int main(int argc, char** argv) {
