@@ -13,7 +13,8 @@ REQUIRED = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "s
 
 
 @pytest.mark.parametrize("name", ["r01_bench_c3.json", "r01_bench_c2.json", "r01_bench_c5.json",
-                                  "r02_bench_c3.json", "r02_bench_c2.json", "r02_bench_c5.json"])
+                                  "r02_bench_c3.json", "r02_bench_c2.json", "r02_bench_c5.json",
+                                  "r03_bench_c3.json", "r03_bench_c2.json", "r03_bench_c5.json"])
 def test_recorded_bench_lines_follow_the_contract(name):
     rec = json.loads((PROFILES / name).read_text())
     for key, typ in REQUIRED.items():
@@ -26,13 +27,16 @@ def test_recorded_bench_lines_follow_the_contract(name):
         assert key in roof, (name, key)
     assert roof["bound"] in ("hbm", "mfma", "cache") and roof["unit"] in ("GB/s", "TFLOP/s")
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
-    if name.startswith("r02"):
+    if name.startswith("r03"):
+        # median and min per step beside the mean
+        assert roof["kernel_ms_per_step_min"] <= roof["kernel_ms_per_step_median"] and roof["kernel_ms_per_step"] > 0
+    if name[:3] in ("r02", "r03"):
         # a cache-resident B (C2) is priced against the cache-gather figure, never as an HBM fraction > 1
         assert roof["frac"] <= 1.0 and (roof["bound"] == "cache") == ("64k" in rec["config"]["workload"])
     if roof["bound"] in ("hbm", "cache"):
         assert roof["peak"] == (8000.0 if roof["bound"] == "hbm" else 8600.0)
         cpu = rec["cpu_baseline"]
-        if name.startswith("r02"):
+        if name[:3] in ("r02", "r03"):
             # every core the process may use, the whole matrix, 1 warm-up + best of 3
             assert cpu["cores"] == cpu["usable_cpus"] <= cpu["host_logical_cpus"] and "whole matrix" in cpu["sample"]
             assert "torch_cpu_csr_matmul_gflops" in cpu and "host_cpu" in cpu
@@ -47,7 +51,7 @@ def test_recorded_bench_lines_follow_the_contract(name):
         assert abs(roof["achieved"] - alg / (roof["kernel_ms_per_step"] * 1e-3) / 1e9) / roof["achieved"] < 0.01
 
 
-@pytest.mark.parametrize("rnd", ["r01", "r02"])
+@pytest.mark.parametrize("rnd", ["r01", "r02", "r03"])
 def test_c3_kernel_stats_agree_with_the_bench_line(rnd):
     """rocprofv3's average launch durations (same command) add up to bench.py's HIP-event time per product."""
     import csv
@@ -57,11 +61,33 @@ def test_c3_kernel_stats_agree_with_the_bench_line(rnd):
     assert len(main) == rec["roofline"]["launches_per_step"] == 2
     total_ms = sum(float(r["AverageNs"]) for r in main) / 1e6
     assert abs(total_ms - rec["roofline"]["kernel_ms_per_step"]) / total_ms < 0.03
-    traffic = json.loads((PROFILES / "pmc_traffic.json").read_text())["c3"]
-    # (the bench line quotes the PMC passes of the previous profile run: equal to within counter noise)
-    assert abs(traffic["hbm_bytes_per_product"] - rec["roofline"]["traffic"]) < 1e-3 * rec["roofline"]["traffic"]
-    assert rnd == "r01" or traffic["round"] == "r02"
-    assert 1.0 <= traffic["hbm_bytes_per_product"] / rec["config"]["algorithmic_bytes_per_step"] < 1.05
+    if rnd == "r03":
+        # the bench line quotes the committed PMC record only while it was taken with the very sources that print it
+        traffic = json.loads((PROFILES / "pmc_traffic.json").read_text())["c3"]
+        assert traffic["round"] == "r03" and len(traffic["source_fingerprint"]) == 16
+        assert abs(traffic["hbm_bytes_per_product"] - rec["roofline"]["traffic"]) < 1e-3 * rec["roofline"]["traffic"]
+        assert 1.0 <= traffic["hbm_bytes_per_product"] / rec["config"]["algorithmic_bytes_per_step"] < 1.05
+        assert rec["roofline"]["traffic_dram"] is None and "TARGET" in traffic["dram_note"]
+        # two dispatches per product at C2: the main kernel and the (empty) follow-up — no memset, no scan of rowptr
+        c2 = [r["Name"] for r in csv.DictReader(open(PROFILES / "r03_bench_c2_kernel_stats.csv"))]
+        spmm = [n for n in c2 if "spmm_" in n or "find_long" in n or "combine_long" in n]
+        assert len(spmm) == 2 and any("spmm_group_kernel" in n for n in spmm) and any("spmm_long_rows_kernel" in n for n in spmm)
+
+
+def test_committed_traffic_is_tied_to_the_sources(tmp_path, monkeypatch):
+    """bench.committed_traffic returns the committed PMC bytes only for the fingerprint (bench.py + csrc/spmm_*.hip) and
+    the kernel they were taken with; otherwise (None, None) — never a stale figure beside a fresh `achieved`."""
+    bench = _load_bench()
+    fp = bench.source_fingerprint()
+    assert len(fp) == 16 and fp == bench.source_fingerprint()
+    rec = json.loads((PROFILES / "pmc_traffic.json").read_text())["c3"]
+    got = bench.committed_traffic("c3", "spmm_wave_row_panel_kernel")
+    if rec.get("source_fingerprint") == fp:
+        assert got[0] == rec["hbm_bytes_per_product"]
+        assert bench.committed_traffic("c3", "some_other_kernel") == (None, None)
+    else:
+        assert got == (None, None)
+    assert bench.committed_traffic("no-such-workload") == (None, None)
 
 
 # --- `python bench.py --gpus N` started plainly: the parent spawns the ranks itself ------------------

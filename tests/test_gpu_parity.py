@@ -1641,9 +1641,17 @@ def test_bench_multi_gpu_path_rehearsal(dev):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and "REHEARSAL" in rec["data"]
     cfg = rec["config"]
-    assert cfg["rccl_ranks"] == 2 and cfg["chunks"] in (2, 4) and cfg["exchange"] in ("allgather", "p2p")
-    assert set(cfg["chunk_trials_ms_per_step"]) == {"allgather/2", "allgather/4", "p2p/2", "p2p/4"}
+    # the default trial times the collective only (direct sends can half-fail: they are tried on request)
+    assert cfg["rccl_ranks"] == 2 and cfg["chunks"] in (2, 4) and cfg["exchange"] == "allgather"
+    assert set(cfg["chunk_trials_ms_per_step"]) == {"allgather/2", "allgather/4"} and cfg["exchange_fallbacks"] == []
+    assert [d["rank"] for d in cfg["rank_devices"]] == [0, 1] and all("name" in d and "pid" in d for d in cfg["rank_devices"])
     assert cfg["compute_only_ms_per_step"] > 0 and rec["value"] > 0 and "cpu_baseline" not in rec
+    proc = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                           "--workload", "c2", "--exchange", "try-p2p"], capture_output=True, text=True, timeout=600, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    cfg = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')][0])["config"]
+    assert set(cfg["chunk_trials_ms_per_step"]) == {"allgather/2", "allgather/4", "p2p/2", "p2p/4"}
+    assert cfg["exchange"] in ("allgather", "p2p")
     # and the nnz-balanced split (in-place broadcasts) through the same driver
     proc = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
                            "--workload", "c2", "--split", "nnz", "--chunks", "3", "--exchange", "allgather"],
