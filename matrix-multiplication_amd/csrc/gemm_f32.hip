@@ -944,6 +944,12 @@ int pick_tile(const float* A, const float* B, float* C, int m, int n, int k, lon
 #ifndef MI_GEMM_T16_MIN_EFF
 #define MI_GEMM_T16_MIN_EFF 0.75
 #endif
+    // neither 96- nor 64-tiles fill the CUs' rounds (768², 1536 × 768, 1152² outputs: 0.56–0.63): 32×32 tiles give every
+    // SIMD two to five one-block waves instead (round 3, tools/probes/duo_probe.cpp gw*: 768² × 16384 0.287 → 0.261 ms,
+    // 1536 × 768 × 8192 0.264 → 0.216, 1152² × 8192 0.267 → 0.249; where 64-tiles give exactly one workgroup per CU they
+    // stay ahead: 2048 × 512 × 8192 0.164 vs 0.188)
+    if (best_eff < MI_GEMM_T16_MIN_EFF && m % 32 == 0 && n % 32 == 0 && blocks_for(32, 32) >= 256 && blocks_for(64, 64) <= 512)
+      best = 32, best_eff = 1.0;
     if (best_eff >= MI_GEMM_T16_MIN_EFF) {
       const int rev = (int)(g_launch_counter.fetch_add(1, std::memory_order_relaxed) & 1u);
       if (best == 96) return launch_t16<96, MI_GEMM_T16_WAVES>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, rev, s);

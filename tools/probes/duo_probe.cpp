@@ -10,13 +10,15 @@
 #include <cstring>
 #include <vector>
 
-struct Shape { const char* name; int ta, tb, batch, m, n, k; };
+struct Shape { const char* name; int ta, tb, batch, m, n, k; int share_a = 0; };  // share_a: every item reads the same A (stride 0: cache-resident)
 
 int main(int argc, char** argv) {
   const Shape shapes[] = {
       {"qk   NT 384x(512x64.64x512)", 0, 1, 384, 512, 512, 64},
       {"pv   NN 384x(512x512.512x64)", 0, 0, 384, 512, 64, 512},
       {"dv   TN 384x(512x512.512x64)", 1, 0, 384, 512, 64, 512},
+      {"pvsh NN same, A shared by all items (no HBM stream)", 0, 0, 384, 512, 64, 512, 1},
+      {"dvsh TN same, A shared by all items (no HBM stream)", 1, 0, 384, 512, 64, 512, 1},
       {"sq4k NN 4096^3", 0, 0, 1, 4096, 4096, 4096},
       {"sq4k NT 4096^3", 0, 1, 1, 4096, 4096, 4096},
       {"sq4k TN 4096^3", 1, 0, 1, 4096, 4096, 4096},
@@ -24,6 +26,13 @@ int main(int argc, char** argv) {
       {"sq8k NT 8192^3", 0, 1, 1, 8192, 8192, 8192},
       {"fc   NT 16384x768.768x3072", 0, 1, 1, 16384, 3072, 768},
       {"fcb  NN 16384x3072.3072x768", 0, 0, 1, 16384, 768, 3072},
+      {"gw1  TN 768x768 k16384", 1, 0, 1, 768, 768, 16384},
+      {"gw2  TN 1536x768 k8192", 1, 0, 1, 1536, 768, 8192},
+      {"gw3  TN 1152x1152 k8192", 1, 0, 1, 1152, 1152, 8192},
+      {"gw4  TN 2048x512 k8192", 1, 0, 1, 2048, 512, 8192},
+      {"gw5  TN 1024x1024 k8192", 1, 0, 1, 1024, 1024, 8192},
+      {"gw6  TN 256x256 k65536", 1, 0, 1, 256, 256, 65536},
+      {"gw7  TN 3072x768 k16384", 1, 0, 1, 3072, 768, 16384},
   };
   const char* only = argc > 1 ? argv[1] : nullptr;
   const bool check = MI_DUO_ABL == 0;
@@ -53,8 +62,8 @@ int main(int argc, char** argv) {
         mi_gemm_set_plan(plan);
         for (int r = 0; r < reps + 3; ++r) {
           if (r == 3) hipEventRecord(e0);
-          st[plan] = mi_gemm_f32(s.ta, s.tb, s.m, s.n, s.k, A, lda, (long)s.m * s.k, B, ldb, (long)s.n * s.k, plan == 1 ? C1 : C2, s.n,
-                                 (long)s.m * s.n, s.batch, nullptr);
+          st[plan] = mi_gemm_f32(s.ta, s.tb, s.m, s.n, s.k, A, lda, s.share_a ? 0 : (long)s.m * s.k, B, ldb, (long)s.n * s.k,
+                                 plan == 1 ? C1 : C2, s.n, (long)s.m * s.n, s.batch, nullptr);
         }
         hipEventRecord(e1);
         hipDeviceSynchronize();
