@@ -46,6 +46,9 @@
 
 #include "mi_common.h"
 
+#ifndef MI_GEMM_STORE_AUX
+#define MI_GEMM_STORE_AUX 2  // cache policy of the C stores: 2 = non-temporal, 0 = default (developer probes)
+#endif
 #ifndef MI_GEMM_ABL
 #define MI_GEMM_ABL 0  // developer probes only (tools/probes/gemm_probe.cpp): 1 no C stores, 2 no MFMAs, 4 no operand loads
 #endif
@@ -211,7 +214,7 @@ __device__ __forceinline__ void gemm_epilogue_b(f32x16 (&acc)[TM][TN], float* __
           if (MI_GEMM_ABL & 1) {
             if (v == 12345.678f) C[(long)row0 * ldc + col0 + (soff + c_lane) / 4] = v;  // keeps the accumulators live
           } else {
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)c_lane, (int)soff, 2 /* nt */);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)c_lane, (int)soff, MI_GEMM_STORE_AUX /* nt */);
           }
         }
       } else {
@@ -601,7 +604,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
       if (MI_GEMM_ABL & 1) {
         if (v == 12345.678f) C[(long)row0 * ldc + col0 + (soff + c_lane) / 4] = v;
       } else {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)c_lane, (int)soff, 2 /* nt */);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)c_lane, (int)soff, MI_GEMM_STORE_AUX /* nt */);
       }
     }
   };

@@ -1929,3 +1929,46 @@ def test_validate_csr_rejects_bad_contents_for_every_plan(cmm, dev, oracle_mod):
         rp = rowptr.copy(); rp[-1] = nnz - 1
         with pytest.raises(RuntimeError):
             cmm.validate_csr(d_val, t(col, dev), t(rp, dev), nnz, M, K)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm_duo_plan_bit_exact_vs_oracle_and_tiles(capi, cmm, dev, oracle_mod, ta, tb):
+    """The persistent two-halves kernel (gemm_f32_duo.hip, pinned with mi_gemm_set_plan(2); AUTO takes the tile
+    kernels) is the same k-ordered chain: bit-identical to the oracle and to the tile kernels for every transposition,
+    128- and 64-column tiles, several k-tiles, an odd number of tiles per workgroup, a batch, and the fused bias;
+    a shape that is not made of whole tiles is refused when pinned (reference entry: src/custom_mm.cpp:104-164)."""
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_gemm_bias_f32.argtypes = [ctypes.c_int, ctypes.c_int, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, vp, i64,
+                                      i64, i32, vp]
+    stream = torch.cuda.current_stream().cuda_stream
+    g = np.random.Generator(np.random.PCG64(int(ta) * 2 + int(tb)))
+    try:
+        for batch, m, n, k, with_bias in ((1, 384, 256, 192, False), (3, 128, 192, 64, True), (5, 256, 64, 320, False),
+                                          (1, 1152, 128, 128, True)):
+            a = g.random((batch, k, m) if ta else (batch, m, k), dtype=np.float32) - 0.5
+            b = g.random((batch, n, k) if tb else (batch, k, n), dtype=np.float32) - 0.5
+            bias = g.random(n, dtype=np.float32) if with_bias else None
+            want = gemm_ref(oracle_mod, a, b, ta, tb)
+            if with_bias:
+                want = want + bias[None, None, :]
+            d_a, d_b = t(a, dev), t(b, dev)
+            d_bias = t(bias, dev) if with_bias else None
+            outs = {}
+            for plan in (1, 2):
+                assert capi.mi_gemm_set_plan(plan) == 0
+                C = torch.full((batch, m, n), float("nan"), device=dev)
+                st = capi.mi_gemm_bias_f32(int(ta), int(tb), m, n, k, d_a.data_ptr(), m if ta else k, m * k, d_b.data_ptr(),
+                                           k if tb else n, n * k, d_bias.data_ptr() if with_bias else None, C.data_ptr(), n,
+                                           m * n, batch, stream)
+                assert st == 0, (plan, batch, m, n, k)
+                outs[plan] = C.cpu().numpy()
+            assert np.array_equal(outs[2], want), (batch, m, n, k)
+            assert np.array_equal(outs[1], outs[2])
+        # pinned, but 100 rows are not whole 128-row tiles
+        assert capi.mi_gemm_set_plan(2) == 0
+        a, b, C = torch.rand(100, 64, device=dev), torch.rand(64, 64, device=dev), torch.empty(100, 64, device=dev)
+        assert capi.mi_gemm_bias_f32(0, 0, 100, 64, 64, a.data_ptr(), 64, 0, b.data_ptr(), 64, 0, None, C.data_ptr(), 64, 0, 1,
+                                     stream) == -1
+        assert capi.mi_gemm_set_plan(7) == -1
+    finally:
+        capi.mi_gemm_set_plan(0)
