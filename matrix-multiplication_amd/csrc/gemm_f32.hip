@@ -50,7 +50,8 @@
 #define MI_GEMM_STORE_AUX 2  // cache policy of the C stores: 2 = non-temporal, 0 = default (developer probes)
 #endif
 #ifndef MI_GEMM_ABL
-#define MI_GEMM_ABL 0  // developer probes only (tools/probes/gemm_probe.cpp): 1 no C stores, 2 no MFMAs, 4 no operand loads
+#define MI_GEMM_ABL 0  // developer probes only (tools/probes/*): 1 no C stores, 2 no MFMAs, 4 no operand loads; pipelined kernel also
+                       // 8 no LDS operand reads, 16 no LDS writes, 32 no barriers (timing only: wrong results)
 #endif
 
 namespace {
@@ -448,9 +449,9 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) a[slot][h][i] = LA::at(As, wm * (BM / 2) + i * 32 + l31, 4 * s + 2 * h + lhi);
+          for (int i = 0; i < TM; ++i) a[slot][h][i] = (MI_GEMM_ABL & 8) ? (float)(s + i) : LA::at(As, wm * (BM / 2) + i * 32 + l31, 4 * s + 2 * h + lhi);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) b[slot][h][j] = LB::at(Bs, wn * (BN / 2) + j * 32 + l31, 4 * s + 2 * h + lhi);
+          for (int j = 0; j < TN; ++j) b[slot][h][j] = (MI_GEMM_ABL & 8) ? (float)(h + j) : LB::at(Bs, wn * (BN / 2) + j * 32 + l31, 4 * s + 2 * h + lhi);
         }
       };
       read_batch(0, 0);
@@ -460,8 +461,12 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
         if (s == 0) {
           // tile t+1: registers → the other buffer, whose last readers passed the previous
           // barrier.  After the last tile this writes a buffer nobody reads.
-          LA::store(ra, An, tid);
-          LB::store(rb, Bn, tid);
+          if (!(MI_GEMM_ABL & 16)) {
+            LA::store(ra, An, tid);
+            LB::store(rb, Bn, tid);
+          } else {
+            asm volatile("" :: "v"(ra[0]), "v"(rb[0]));  // keeps the loads live
+          }
         }
         if (s == 1) load_tile(ra, rb, k0 + 3 * BK);
 #pragma unroll
@@ -491,7 +496,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      __syncthreads();
+      if (!(MI_GEMM_ABL & 32)) __syncthreads();
     };
     for (int k0 = 0; k0 < k; k0 += 2 * BK) {
       k_tile(k0, 0, ra1, rb1);                        // even tile: tile t+1 is odd → set 1
