@@ -214,7 +214,10 @@ bool stream_is_capturing(mi_stream_t stream) {
 
 torch::Tensor zeroed_stream_workspace(const torch::Device& dev, mi_stream_t stream, size_t bytes) {
   std::lock_guard<std::mutex> lock(g_stream_ws_mutex);
-  StreamWorkspace& w = g_stream_ws[std::make_pair((int)dev.index(), stream)];
+  const auto key = std::make_pair((int)dev.index(), stream);
+  if (g_stream_ws.size() >= 64 && g_stream_ws.find(key) == g_stream_ws.end())
+    g_stream_ws.clear();  // a program that keeps creating streams: start over (the allocator keeps freed blocks stream-ordered)
+  StreamWorkspace& w = g_stream_ws[key];
   if (!w.buf.defined() || (size_t)w.buf.numel() < bytes) {
     const int64_t cap = (int64_t)(bytes + bytes / 2 + 4096);
     w.buf = torch::empty({cap}, torch::dtype(torch::kUInt8).device(dev));

@@ -324,11 +324,8 @@ int launch_duo_b(const float* A, const float* B, float* C, int m, int n, int k, 
 #endif
   static_assert(lds_bytes <= 160 * 1024, "two halves' operand buffers must fit one CU's LDS");
   auto kern = gemm_f32_duo_kernel<BN, AK, BKC, HAS_BIAS>;
-  static bool attr_set = false;  // per instantiation
-  if (!attr_set) {
-    MI_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    attr_set = true;
-  }
+  // (per device and cheap: set on every launch rather than remembered per process)
+  MI_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
   const int tiles_n = n / BN, tiles_per_item = (m / DBM) * tiles_n;
   const long total = (long)tiles_per_item * batch;
   const long grid = total / 2 < g_cu_count ? total / 2 : g_cu_count;
@@ -355,8 +352,8 @@ int launch_gemm_duo(int transa, int transb, int32_t m, int32_t n, int32_t k, con
   if (m % DBM != 0 || n % 64 != 0 || k % DBK != 0 || k == 0) return 1;
   if (lda % 4 != 0 || ldb % 4 != 0 || strideA % 4 != 0 || strideB % 4 != 0 || !aligned16(A) || !aligned16(B)) return 1;
   if (lda >= (1 << 21) || ldb >= (1 << 21) || ldc >= (1 << 21)) return 1;  // a tile's byte offsets stay below 2^31
-  if (g_cu_count == 0) {
-    int dev = 0, cus = 0;
+  {
+    int dev = 0, cus = 0;  // the current device's CU count (devices of one node are alike, but ask anyway)
     MI_HIP_TRY(hipGetDevice(&dev));
     MI_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     g_cu_count = cus > 0 ? cus : 256;
