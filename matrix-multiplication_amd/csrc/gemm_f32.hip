@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
     auto load_tile = [&](f32x4 (&ra)[LA::VECS], f32x4 (&rb)[LB::VECS], int k0) {
       const int kk = k0 < k_last ? k0 : k_last;
       if (MI_GEMM_ABL & 4) return;
-      LA::load_fast(ra, LA::origin(A, lda, m0, kk), lda, a_lane);
+      LA::load_fast(ra, LA::origin(A, lda, m0, kk), lda, a_lane);  // default cache policy: nt / sc loads measured 3-5 % slower here
       LB::load_fast(rb, LB::origin(B, ldb, n0, kk), ldb, b_lane);
     };
     load_tile(ra0, rb0, 0);
