@@ -326,7 +326,8 @@ def main():
             # "nccl" is RCCL on ROCm.  Its kernels go on a HIGH-PRIORITY stream: the all-gather of block j runs
             # beside the SpMM of block j+1, which fills every CU — at normal priority the collective's
             # workgroups would queue behind it and the overlap the layout is built for would be lost
-            os.environ.setdefault("NCCL_DEBUG", "VERSION")  # RCCL prints its version line once (stderr of the ranks)
+            # (NCCL_DEBUG is left as the environment has it: RCCL's own VERSION line would go to the ranks' stdout,
+            # beside the one JSON line the driver reads; the RCCL version is in config.collective_backend instead)
             opts = dist.ProcessGroupNCCL.Options()
             opts.is_high_priority_stream = True
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=opts)
