@@ -1,6 +1,6 @@
 """BASELINE config C4 on a one-GPU box: MEASURED per-rank compute of the row-sharded product (one rank's
 block-cyclic share of the C3 matrix, timed on one MI355X for G = 2, 4, 8) + an explicitly labelled MODEL of
-the all-gather leg from link rates.  Writes profiles/r02_c4_model.json.  Nothing here is a multi-GPU
+the all-gather leg from link rates.  Writes profiles/r03_c4_model.json.  Nothing here is a multi-GPU
 measurement; the driver's 8-GPU node gives those (bench.py --gpus N).
 
     python tools/c4_model.py [--steps 20]
@@ -84,8 +84,8 @@ for G in (2, 4, 8):
 rec["label"] = ("compute figures are MEASURED on one MI355X (one rank's share at a time); every *MODEL* figure is an "
                 "estimate from assumed link rates, not a measurement — RCCL kernels also take CUs and HBM bandwidth "
                 "from the concurrent SpMM, which this model ignores")
-out = REPO / "profiles" / "r02_c4_model.json"
+out = REPO / "profiles" / "r03_c4_model.json"
 (REPO / "gpurun_out").mkdir(exist_ok=True)
-(REPO / "gpurun_out" / "r02_c4_model.json").write_text(json.dumps(rec, indent=1))
+(REPO / "gpurun_out" / "r03_c4_model.json").write_text(json.dumps(rec, indent=1))
 out.write_text(json.dumps(rec, indent=1))
 print(json.dumps(rec, indent=1))
