@@ -514,7 +514,7 @@ def naive_matmul(a: torch.Tensor,
 def _csr_cached(m1: torch.Tensor):
     '''(values, columns i32, offsets i32, nnz, rows, cols) and the CSR of m1ᵀ for a CSR tensor.  What is kept ON the
     tensor object between calls is the PATTERN of the transpose — its columns, its offsets and the permutation that
-    carries m1's values into it — because in a training loop the pattern is static and the device transpose (1.3 ms
+    carries m1's values into it — because in a training loop the pattern is static and the device transpose (1.7 ms
     at the 1M × 1M config) would otherwise be paid on every backward.  The VALUES of m1ᵀ are gathered through the
     permutation on every call (one pass over nnz), so a write to m1's values that no version counter sees
     (`a.values().data.mul_(3)`, a kernel writing through data_ptr) can never leave a stale copy behind.  The entry is
@@ -527,12 +527,12 @@ def _csr_cached(m1: torch.Tensor):
         # the transpose moves 4-byte values untouched: transposing 0, 1, 2, … gives the permutation
         iota = torch.arange(nnz, device=values.device, dtype=torch.int32).view(torch.float32)
         t_perm, t_col, t_off = custom_mm.csr_transpose(iota, columns, offsets, nnz, rows, cols)
-        hit = (key, t_perm.view(torch.int32).to(torch.int64), t_col, t_off)
+        hit = (key, t_perm.view(torch.int32), t_col, t_off)  # int32 permutation: 4 B per non-zero
         try:
             m1._mi_csr_cache = hit
         except (AttributeError, RuntimeError):
             pass  # a tensor type that takes no attributes: just no caching
-    return props, (values[hit[1]], hit[2], hit[3])
+    return props, (values.index_select(0, hit[1]), hit[2], hit[3])
 
 
 def _sparse_backward(ctx, grad_output):
