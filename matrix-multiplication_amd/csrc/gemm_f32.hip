@@ -165,6 +165,24 @@ struct TileLoader {
     }
   }
 
+  // one of the thread's float4 (the pair kernel spreads a stage's LDS writes over the MFMA steps of the previous one)
+  template <int V>
+  static __device__ __forceinline__ void store_one(const f32x4 (&r)[VECS], float* lds, int tid) {
+    if constexpr (V < VECS) {
+      int e, k;
+      coords(V, tid, e, k);
+      if (KCONTIG) {
+        float* p = lds + e * LDS_LD + k;
+        p[0] = r[V].x;
+        p[1] = r[V].y;
+        p[2] = r[V].z;
+        p[3] = r[V].w;
+      } else {
+        *reinterpret_cast<f32x4*>(lds + k * LDS_LD + e) = r[V];
+      }
+    }
+  }
+
   // MFMA operand element (e, k) from LDS.
   static __device__ __forceinline__ float at(const float* lds, int e, int k) {
     return KCONTIG ? lds[e * LDS_LD + k] : lds[k * LDS_LD + e];
@@ -537,16 +555,15 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Short k, whole tiles: TWO output tiles per workgroup (the pair (tile_m, 2j), (tile_m, 2j+1)), so
-// that the first tile's epilogue — accumulators → LDS patch → 128-byte row segments → global — is
-// issued between the MFMAs of the second tile instead of after its own.  With k = 64 a wave has
-// only 128 MFMAs per tile; in the one-tile kernel their 0.082 ms of matrix-pipe time and the 0.030 ms
-// staging + epilogue skeleton simply add up (tools/probes/gemm_probe.cpp), because co-resident
-// workgroups run in step.  Here the skeleton of tile 0 rides inside tile 1's MFMA stream of the SAME
-// wave (two accumulator sets, the patch beside the operand buffer), and the pair's stages form one
-// prefetch chain (tile 1's first operands are requested during tile 0's last MFMAs).  Same k order
-// per element as every other kernel here → same bits.  NK = k / 32 is a template parameter so that
-// the epilogue phases land at fixed places of the unrolled MFMA stream.
+// Short k, whole tiles: a CHAIN of two or four output tiles of one tile row per workgroup, (tile_m, CHAIN·g …
+// CHAIN·g + CHAIN − 1), so that a tile's epilogue — 16 dword buffer stores per 32×32 block, straight from the
+// accumulator registers — is issued between the MFMAs of the NEXT tile instead of after its own.  With k = 64 a
+// wave has only 128 MFMAs per tile; in the one-tile kernel their 0.082 ms of matrix-pipe time and the staging +
+// epilogue skeleton simply add up (tools/probes/gemm_probe.cpp), because co-resident workgroups run in step.
+// Here the skeleton of tile T rides inside tile T + 1's MFMA stream of the SAME wave (two accumulator sets), and
+// the chain's stages form one prefetch chain through two LDS buffers (the next tile's first operands are
+// requested during this tile's last MFMAs).  Same k order per element as every other kernel here → same bits.
+// NK = k / 32 is a template parameter so that the epilogue phases land at fixed places of the unrolled MFMA stream.
 // ---------------------------------------------------------------------------------------------
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -568,9 +585,8 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
   typedef TileLoader<BM, !TA> LA;
   typedef TileLoader<BN, TB> LB;
   constexpr int kOperandFloats = LA::LDS_FLOATS + LB::LDS_FLOATS;
-  __shared__ __attribute__((aligned(16))) float lds[kOperandFloats];
-  float* As = lds;
-  float* Bs = lds + LA::LDS_FLOATS;
+  constexpr int STAGES = CHAIN * NK;        // stage G = k-tile G % NK of chain tile G / NK, in LDS buffer G % 2
+  __shared__ __attribute__((aligned(16))) float lds[2 * kOperandFloats];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -615,61 +631,71 @@ __global__ __launch_bounds__(256) void gemm_f32_pair_kernel(
 
   f32x4 ra[LA::VECS], rb[LB::VECS];
   const unsigned a_lane = LA::lane_offset(lda, tid), b_lane = LB::lane_offset(ldb, tid);
-  LA::load_fast(ra, LA::origin(A, lda, m0, 0), lda, a_lane);
-  LB::load_fast(rb, LB::origin(B, ldb, CHAIN * group_n * BN, 0), ldb, b_lane);
+  auto load_stage = [&](auto G_) {  // global → registers: the operands of stage G
+    constexpr int T = decltype(G_)::value / NK, KT = decltype(G_)::value % NK;
+    LA::load_fast(ra, LA::origin(A, lda, m0, KT * BK), lda, a_lane);
+    LB::load_fast(rb, LB::origin(B, ldb, (CHAIN * group_n + T) * BN, KT * BK), ldb, b_lane);
+  };
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  constexpr int WV = LA::VECS > LB::VECS ? LA::VECS : LB::VECS;  // MFMA steps that carry one float4 of each operand to LDS
+  static_assert(WV + 2 <= BK / 2, "a stage's LDS writes and the next loads must fit its MFMA steps");
 
-  static_for<CHAIN>([&](auto T_) {
-    constexpr int T = decltype(T_)::value, SET = T % 2;
-    static_for<NK>([&](auto KT_) {
-      constexpr int KT = decltype(KT_)::value;
-      LA::store(ra, As, tid);
-      LB::store(rb, Bs, tid);
-      __syncthreads();
-      // the next stage's operands: the next k-tile of this output tile, or the first of the next one
-      if constexpr (KT + 1 < NK) {
-        LA::load_fast(ra, LA::origin(A, lda, m0, (KT + 1) * BK), lda, a_lane);
-        LB::load_fast(rb, LB::origin(B, ldb, (CHAIN * group_n + T) * BN, (KT + 1) * BK), ldb, b_lane);
-      } else if constexpr (T + 1 < CHAIN) {
-        LA::load_fast(ra, LA::origin(A, lda, m0, 0), lda, a_lane);
-        LB::load_fast(rb, LB::origin(B, ldb, (CHAIN * group_n + T + 1) * BN, 0), ldb, b_lane);
+  // Two LDS buffers, ONE barrier per stage: stage G's MFMAs read buffer G % 2 while the registers holding stage G + 1
+  // (requested one stage earlier) are written to the other buffer, one float4 per operand per MFMA step, and stage
+  // G + 2's loads are issued into the freed registers right after.  (The first round-3 build had one buffer and two
+  // barriers per stage: every wave stood still while the workgroup's LDS writes drained — with the epilogue's LDS
+  // patch gone, 2 × 33 KB per workgroup fit twice per CU beside the registers' own limit of two.)
+  load_stage(std::integral_constant<int, 0>{});
+  LA::store(ra, lds, tid);
+  LB::store(rb, lds + LA::LDS_FLOATS, tid);
+  if constexpr (STAGES > 1) load_stage(std::integral_constant<int, 1>{});
+  __syncthreads();
+
+  static_for<STAGES>([&](auto G_) {
+    constexpr int G = decltype(G_)::value, T = G / NK, KT = G % NK, SET = T % 2;
+    const float* As = lds + (G % 2) * kOperandFloats;
+    const float* Bs = As + LA::LDS_FLOATS;
+    float* An = lds + ((G + 1) % 2) * kOperandFloats;
+    float* Bn = An + LA::LDS_FLOATS;
+    // operand reads run one k-step ahead of the MFMAs (two register slots): left to itself the compiler reads
+    // each step's operands immediately before its MFMAs and the wave waits out the LDS latency every four MFMAs
+    float a[2][TM], b[2][TN];
+    auto read_step = [&](int step, int slot) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[slot][i] = LA::at(As, wm * (BM / 2) + i * 32 + l31, 2 * step + lhi);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[slot][j] = LB::at(Bs, wn * (BN / 2) + j * 32 + l31, 2 * step + lhi);
+    };
+    read_step(0, 0);
+    static_for<BK / 2>([&](auto S_) {
+      constexpr int S = decltype(S_)::value;  // MFMA k-step of this stage
+      if constexpr (S + 1 < BK / 2) read_step(S + 1, (S + 1) & 1);
+      if constexpr (G + 1 < STAGES && S >= 1 && S <= WV) {
+        LA::template store_one<S - 1>(ra, An, tid);
+        LB::template store_one<S - 1>(rb, Bn, tid);
       }
-      // the next stage's loads stay in front of this stage's MFMAs (hipcc otherwise sinks them to the end of the
-      // stage, right in front of the waits on them: the ISA of the first round-3 build showed exactly that)
+      if constexpr (G + 2 < STAGES && S == WV + 1) load_stage(std::integral_constant<int, G + 2>{});
+      // the previous tile's epilogue rides here (its accumulators are the other set)
+      if constexpr (T > 0 && S % GAP == 0) phase(std::integral_constant<int, T - 1>{}, std::integral_constant<int, KT * PPS + S / GAP>{});
+      // (the issue order above is the order wanted: hipcc otherwise sinks the loads to the end of the stage, right
+      // in front of the waits on them — the ISA of the first round-3 build showed exactly that)
       __builtin_amdgcn_sched_barrier(0);
-      // operand reads run one k-step ahead of the MFMAs (two register slots): left to itself the compiler reads
-      // each step's operands immediately before its MFMAs and the wave waits out the LDS latency every four MFMAs
-      float a[2][TM], b[2][TN];
-      auto read_step = [&](int step, int slot) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[slot][i] = LA::at(As, wm * (BM / 2) + i * 32 + l31, 2 * step + lhi);
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[slot][j] = LB::at(Bs, wn * (BN / 2) + j * 32 + l31, 2 * step + lhi);
-      };
-      read_step(0, 0);
-      static_for<BK / 2>([&](auto S_) {
-        constexpr int S = decltype(S_)::value;  // MFMA k-step of this stage
-        if constexpr (S + 1 < BK / 2) read_step(S + 1, (S + 1) & 1);
-        // the previous tile's epilogue rides here (its accumulators are the other set)
-        if constexpr (T > 0 && S % GAP == 0) phase(std::integral_constant<int, T - 1>{}, std::integral_constant<int, KT * PPS + S / GAP>{});
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            if (MI_GEMM_ABL & 2) {
-              if (KT == 0 && S == 0) acc[SET][i][j] = zero16;
-            } else if constexpr (KT == 0 && S == 0) {
-              // a tile's first product starts its accumulators (set reused from tile T − 2) from zero
-              acc[SET][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S & 1][i], b[S & 1][j], zero16, 0, 0, 0);
-            } else {
-              acc[SET][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S & 1][i], b[S & 1][j], acc[SET][i][j], 0, 0, 0);
-            }
+        for (int j = 0; j < TN; ++j) {
+          if (MI_GEMM_ABL & 2) {
+            if (KT == 0 && S == 0) acc[SET][i][j] = zero16;
+          } else if constexpr (KT == 0 && S == 0) {
+            // a tile's first product starts its accumulators (set reused from tile T − 2) from zero
+            acc[SET][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S & 1][i], b[S & 1][j], zero16, 0, 0, 0);
+          } else {
+            acc[SET][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[S & 1][i], b[S & 1][j], acc[SET][i][j], 0, 0, 0);
           }
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      __syncthreads();
+        }
+      __builtin_amdgcn_sched_barrier(0);
     });
+    if constexpr (G + 1 < STAGES) __syncthreads();
   });
   // the last tile's own epilogue (nothing left to hide it behind)
   static_for<PHASES>([&](auto P_) { phase(std::integral_constant<int, CHAIN - 1>{}, P_); });

@@ -17,6 +17,9 @@ int main(int argc, char** argv) {
       {"qk   NT 384x(512x64.64x512)", 0, 1, 384, 512, 512, 64},
       {"pv   NN 384x(512x512.512x64)", 0, 0, 384, 512, 64, 512},
       {"dv   TN 384x(512x512.512x64)", 1, 0, 384, 512, 64, 512},
+      {"pvh  NN 192x(512x512.512x64): one round of workgroups", 0, 0, 192, 512, 64, 512},
+      {"pvq  NN 96x(512x512.512x64): half a round", 0, 0, 96, 512, 64, 512},
+      {"pvd  NN 768x(512x512.512x64): four rounds", 0, 0, 768, 512, 64, 512},
       {"pvsh NN same, A shared by all items (no HBM stream)", 0, 0, 384, 512, 64, 512, 1},
       {"dvsh TN same, A shared by all items (no HBM stream)", 1, 0, 384, 512, 64, 512, 1},
       {"sq4k NN 4096^3", 0, 0, 1, 4096, 4096, 4096},
