@@ -1972,3 +1972,64 @@ def test_gemm_duo_plan_bit_exact_vs_oracle_and_tiles(capi, cmm, dev, oracle_mod,
         assert capi.mi_gemm_set_plan(7) == -1
     finally:
         capi.mi_gemm_set_plan(0)
+
+
+def test_gemm_shape_and_stride_fuzz_against_oracle(capi, dev, oracle_mod):
+    """Random products through the C-ABI (`mi_gemm_bias_f32`, the entry behind `cublas_mmul` / `cublas_bmm`,
+    reference src/custom_mm.cpp:104-164): extents around the tile sizes the dispatcher chooses between (32 / 64 / 96 /
+    128, ± a few), every transposition, padded leading dimensions, batches with padded item strides, a broadcast
+    (stride-0) operand, the fused bias.  Each case: bit-identical to the oracle, and not one element of the padding
+    of C is written.  MI_FUZZ_CASES (default 80) / MI_FUZZ_SEED set the number of cases and the seed."""
+    import os
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_gemm_bias_f32.argtypes = [ctypes.c_int, ctypes.c_int, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, vp, i64,
+                                      i64, i32, vp]
+    stream = torch.cuda.current_stream().cuda_stream
+    g = np.random.Generator(np.random.PCG64(int(os.environ.get("MI_FUZZ_SEED", "2026"))))
+    cases = int(os.environ.get("MI_FUZZ_CASES", "80"))
+
+    def extent(limit):
+        base = int(g.choice([0, 32, 64, 96, 128, 192, 256, 384, 512]))
+        return int(min(limit, max(1, base + int(g.integers(-3, 4)) * int(g.integers(0, 2)) + (int(g.integers(1, 40)) if base == 0 else 0))))
+
+    for case in range(cases):
+        ta, tb = bool(g.integers(0, 2)), bool(g.integers(0, 2))
+        batch = int(g.choice([1, 1, 2, 3, 5]))
+        m, n = extent(520), extent(520)
+        k = int(g.choice([1, 7, 32, 64, 96, 128, 256, 320, 1024, 2048])) + int(g.integers(0, 3)) * int(g.integers(0, 2))
+        if g.integers(0, 4) == 0:  # whole tiles only: the chained short-k kernel, the 16×16-block kernel
+            m, n, k = int(g.choice([128, 256, 384])), int(g.choice([64, 128, 256, 512])), int(g.choice([32, 64, 128, 512, 2048]))
+        while batch * m * n * k > 40_000_000:  # the oracle's scalar chain stays under a second
+            k = max(1, k // 2)
+        pad = lambda: int(g.choice([0, 0, 1, 4, 12]))
+        rows_a, cols_a = (k, m) if ta else (m, k)
+        rows_b, cols_b = (n, k) if tb else (k, n)
+        lda, ldb, ldc = cols_a + pad(), cols_b + pad(), n + pad()
+        share_b = batch > 1 and g.integers(0, 4) == 0
+        sa = rows_a * lda + pad()
+        sb = 0 if share_b else rows_b * ldb + pad()
+        sc = m * ldc + pad()
+        a_buf = g.random(batch * sa + 16, dtype=np.float32) - 0.5
+        b_buf = g.random((1 if share_b else batch) * max(sb, rows_b * ldb) + 16, dtype=np.float32) - 0.5
+        with_bias = bool(g.integers(0, 3) == 0)
+        bias = (g.random(n, dtype=np.float32) - 0.5) if with_bias else None
+        view = lambda buf, i, stride, rows, cols, ld: np.lib.stride_tricks.as_strided(
+            buf[i * stride:], shape=(rows, cols), strides=(ld * 4, 4))
+        want = np.empty((batch, m, n), dtype=np.float32)
+        for i in range(batch):
+            w = gemm_ref(oracle_mod, np.ascontiguousarray(view(a_buf, i, sa, rows_a, cols_a, lda)),
+                         np.ascontiguousarray(view(b_buf, i, sb, rows_b, cols_b, ldb)), ta, tb)
+            want[i] = w + bias[None, :] if with_bias else w
+        d_a, d_b = t(a_buf, dev), t(b_buf, dev)
+        d_bias = t(bias, dev) if with_bias else None
+        C = torch.full((batch * sc + 16,), float("nan"), device=dev)
+        st = capi.mi_gemm_bias_f32(int(ta), int(tb), m, n, k, d_a.data_ptr(), lda, sa, d_b.data_ptr(), ldb, sb,
+                                   d_bias.data_ptr() if with_bias else None, C.data_ptr(), ldc, sc, batch, stream)
+        what = (case, ta, tb, batch, m, n, k, lda, ldb, ldc, sa, sb, sc, with_bias)
+        assert st == 0, what
+        got = C.cpu().numpy()
+        written = np.zeros(got.shape, dtype=bool)
+        for i in range(batch):
+            assert np.array_equal(view(got, i, sc, m, n, ldc), want[i]), what
+            written[(i * sc + np.arange(m)[:, None] * ldc + np.arange(n)[None, :]).ravel()] = True
+        assert np.isnan(got[~written]).all(), what
