@@ -2033,3 +2033,81 @@ def test_gemm_shape_and_stride_fuzz_against_oracle(capi, dev, oracle_mod):
             assert np.array_equal(view(got, i, sc, m, n, ldc), want[i]), what
             written[(i * sc + np.arange(m)[:, None] * ldc + np.arange(n)[None, :]).ravel()] = True
         assert np.isnan(got[~written]).all(), what
+
+
+def test_long_row_machinery_fuzz_against_oracle(capi, cmm, dev, oracle_mod):
+    """Random skewed matrices — mostly short rows plus 0–4 rows around and far beyond the 8192 threshold (lengths at
+    the split points 65535 / 65536, up to a fully dense row), sorted or shuffled columns, widths for every kernel
+    family, padded ldb / ldc, the fused bias — through every long-row mode of the C-ABI (`mi_spmm_csr_ex_f32`:
+    memset-per-call AUTO, SPLIT, PREPARED after `mi_spmm_long_rows_prepare`, AUTO_ZEROED on one workspace reused
+    across all cases) and through `custom_mm.naive_spmm` (reference entry src/custom_mm.cpp:166-179): bit-identical to
+    the oracle's statement of the long-row order, padding of C untouched.  MI_FUZZ_CASES / MI_FUZZ_SEED as above."""
+    import os
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_spmm_csr_ex_f32.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, i64, vp, vp, i64, ctypes.c_int, vp,
+                                        ctypes.c_size_t, vp]
+    capi.mi_spmm_long_rows_prepare.argtypes = [vp, i32, i64, i32, vp, ctypes.c_size_t, vp]
+    capi.mi_spmm_csr_workspace_bytes.restype = ctypes.c_size_t
+    capi.mi_spmm_csr_workspace_bytes.argtypes = [i64, i32]
+    g = np.random.Generator(np.random.PCG64(int(os.environ.get("MI_FUZZ_SEED", "303"))))
+    cases = int(os.environ.get("MI_FUZZ_CASES", "24"))
+    stream = torch.cuda.current_stream().cuda_stream
+    thr = capi.mi_spmm_long_row_threshold()
+    assert thr == 8192
+    zeroed_bytes = capi.mi_spmm_csr_workspace_bytes(4_000_000, 1024)
+    zeroed = torch.full((zeroed_bytes,), 0x5A, dtype=torch.uint8, device=dev)
+    zeroed[:16] = 0
+    for case in range(cases):
+        M = int(g.integers(1, 200))
+        K = int(g.choice([20000, 70000, 140000, 300000]))
+        N = int(g.choice([4, 8, 30, 36, 64, 100, 128, 192, 256, 260, 512]))
+        lens = g.integers(0, 150, size=M)
+        hubs = int(g.integers(0, 5))
+        for _ in range(hubs):
+            kind = int(g.integers(0, 5))
+            n = (thr + int(g.integers(-2, 3)), int(g.integers(thr, 4 * thr)), int(g.choice([65535, 65536, 65537, 98304])),
+                 int(g.integers(thr, K + 1)), K)[kind]
+            lens[int(g.integers(0, M))] = min(n, K)
+        while int(lens.sum()) * N > 150_000_000:  # the oracle stays around a second
+            lens[int(np.argmax(lens))] //= 2
+        shuffled = bool(g.integers(0, 2))
+        cols = []
+        for n in lens:
+            c = g.choice(K, size=int(n), replace=False).astype(np.int32)
+            cols.append(c if shuffled else np.sort(c))
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        col = np.concatenate(cols) if len(cols) else np.zeros(0, np.int32)
+        nnz = len(col)
+        val = g.random(nnz, dtype=np.float32) - 0.5
+        ldb, ldc = N + int(g.choice([0, 0, 4, 7])), N + int(g.choice([0, 0, 4, 9]))
+        Bp = g.random((K, ldb), dtype=np.float32)
+        B = np.ascontiguousarray(Bp[:, :N])
+        with_bias = bool(g.integers(0, 3) == 0)
+        bias = g.random(N, dtype=np.float32) if with_bias else None
+        want = oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B)
+        if with_bias:
+            want = want + bias[None, :]
+        d_rp, d_col, d_val, d_B = t(rowptr, dev), t(col, dev), t(val, dev), t(Bp, dev)
+        d_bias = t(bias, dev) if with_bias else None
+        nbytes = capi.mi_spmm_csr_workspace_bytes(nnz, N)
+        assert nbytes <= zeroed_bytes
+        what = (case, M, K, N, nnz, sorted(int(x) for x in lens if x > thr - 3), shuffled, ldb, ldc, with_bias)
+        # AUTO follows the plan: SLAB / NARROW plans keep their own order — not reachable here (N ≥ 4, K ≥ 20000 at
+        # < 1 % density), asserted rather than assumed
+        assert capi.mi_spmm_auto_splits_long_rows(nnz, M, K, N, d_B.data_ptr(), ldb, None, ldc) == (1 if nnz > thr else 0), what
+        for mode in (-1, 1, 2, 3):
+            ws = zeroed if mode == 3 else torch.full((max(nbytes, 16),), 0xA5, dtype=torch.uint8, device=dev)
+            if mode == 2:
+                assert capi.mi_spmm_long_rows_prepare(d_rp.data_ptr(), M, nnz, N, ws.data_ptr(), ws.numel(), stream) == 0
+            C = torch.full((M, ldc), float("nan"), device=dev)
+            st = capi.mi_spmm_csr_ex_f32(d_rp.data_ptr(), d_col.data_ptr(), d_val.data_ptr(), nnz, M, K, N, d_B.data_ptr(),
+                                         ldb, d_bias.data_ptr() if with_bias else None, C.data_ptr(), ldc, mode,
+                                         ws.data_ptr(), ws.numel(), stream)
+            assert st == 0, (mode,) + what
+            got = C.cpu().numpy()
+            assert np.array_equal(got[:, :N], want), (mode,) + what
+            assert np.isnan(got[:, N:]).all(), (mode,) + what
+            if mode == 3:
+                assert int(zeroed[:16].to(torch.int32).sum()) == 0, what
+        if not with_bias:
+            assert np.array_equal(run_spmm(cmm, dev, rowptr, col, val, M, K, B, "naive_spmm"), want), what
