@@ -2111,3 +2111,53 @@ def test_long_row_machinery_fuzz_against_oracle(capi, cmm, dev, oracle_mod):
                 assert int(zeroed[:16].to(torch.int32).sum()) == 0, what
         if not with_bias:
             assert np.array_equal(run_spmm(cmm, dev, rowptr, col, val, M, K, B, "naive_spmm"), want), what
+
+
+def test_matmuls_broadcasting_fuzz_forward_and_backward(mm, dev):
+    """Random operand ranks and batch shapes as torch.matmul broadcasts them (dims of size 1, missing leading dims,
+    rank-1 operands for the dense classes, transposed and sliced views) through every autograd class of matmuls.py
+    (reference matmuls.py:75-327): forward and both gradients against torch.matmul and its autograd at the reference
+    tests' tolerance (rtol 1e-5)."""
+    import os
+    g = torch.Generator().manual_seed(int(os.environ.get("MI_FUZZ_SEED", "404")))
+    cases = int(os.environ.get("MI_FUZZ_CASES", "60"))
+    ri = lambda lo, hi: int(torch.randint(lo, hi, (1,), generator=g))
+    classes = [("cublasMM", 0, 0, False), ("cublasTransaMM", 1, 0, False), ("cublasTransbMM", 0, 1, False),
+               ("cublasTransabMM", 1, 1, False), ("naiveSpMM", 0, 0, True), ("cusparseMM", 0, 0, True)]
+
+    def operand(batch, rows, cols, density):
+        kind = ri(0, 3)
+        if kind == 0:
+            x = torch.rand(*batch, rows, cols, generator=g)
+        elif kind == 1:   # a transposed view
+            x = torch.rand(*batch, cols, rows, generator=g).transpose(-1, -2)
+        else:             # a slice of a wider tensor
+            x = torch.rand(*batch, rows, cols + 5, generator=g)[..., 2:cols + 2]
+        if density < 1.0:
+            x = x * (torch.rand(*batch, rows, cols, generator=g) < density)
+        return x
+
+    for case in range(cases):
+        name, ta, tb, sparse = classes[ri(0, len(classes))]
+        common = tuple(ri(1, 4) for _ in range(ri(0, 4)))
+        def batch_of():
+            keep = ri(0, len(common) + 1)
+            b = list(common[len(common) - keep:])
+            return tuple(1 if ri(0, 4) == 0 else d for d in b)
+        ba, bb = batch_of(), batch_of()
+        m, n, k = ri(1, 70), ri(1, 70), ri(1, 65)
+        density = (0.0, 0.1, 0.5, 1.0)[ri(0, 4)] if sparse else 1.0
+        a = operand(ba, *((k, m) if ta else (m, k)), density)
+        b = operand(bb, *((n, k) if tb else (k, n)), 1.0)
+        if not sparse and not ta and not tb and ri(0, 6) == 0:   # rank-1 operands
+            if ri(0, 2):
+                a = torch.rand(k, generator=g)
+            else:
+                b = torch.rand(k, generator=g)
+        ref = lambda x, y: torch.matmul(x.transpose(-1, -2) if ta and x.dim() > 1 else x,
+                                        y.transpose(-1, -2) if tb and y.dim() > 1 else y)
+        try:
+            fwd_bwd_device(getattr(mm, name).apply, ref, a, b, dev)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: {name} a{tuple(a.shape)} (strides {a.stride()}) b{tuple(b.shape)} "
+                                 f"(strides {b.stride()}) density {density}") from e
