@@ -147,6 +147,38 @@ struct TileLoader {
       r[v] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)(v * step), 0));
   }
 
+  // The same loads on a tile that may reach beyond the operand (an edge tile of C): one loop-invariant byte offset
+  // per float4 instead of one per lane + a scalar step, each CLAMPED to the operand — a row of the tile beyond the
+  // last row re-reads the last row, a float4 beyond the end of a k-row (operands contiguous along ext) re-reads the
+  // row's last float4.  The duplicates only reach rows / columns of C that are never stored; nothing outside the
+  // operand is touched (but the ≤ 3 floats of row padding behind a ragged extent: ld ≥ ext rounded up to 4).  Still
+  // no vector-ALU instruction in the k-loop.  `left` = extent of the operand from the tile's origin (≥ 1).  The k
+  // extent must be whole tiles.  (Clamping through the descriptor's range check instead — num_records up to the
+  // operand's end — cost the 4096³ product 2 %: ten scalar instructions per tile and operand.)
+  static __device__ __forceinline__ void lane_offsets(unsigned (&off)[VECS], long ld, int tid, int left) {
+#pragma unroll
+    for (int v = 0; v < VECS; ++v) {
+      const int idx = v * 256 + tid;
+      if (KCONTIG) {
+        int e = idx / (BK / 4);
+        e = e < left ? e : left - 1;
+        off[v] = (unsigned)(e * (int)ld + (idx % (BK / 4)) * 4) * 4u;
+      } else {
+        const int quads = (left + 3) / 4;
+        int q = idx % (EXT / 4);
+        q = q < quads ? q : quads - 1;
+        off[v] = (unsigned)((idx / (EXT / 4)) * (int)ld + q * 4) * 4u;
+      }
+    }
+  }
+  static __device__ __forceinline__ void load_clamped(f32x4 (&r)[VECS], const float* tile, const unsigned (&off)[VECS]) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tile), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int v = 0; v < VECS; ++v)
+      r[v] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off[v], 0, 0));
+  }
+
   // Registers → LDS.
   static __device__ __forceinline__ void store(const f32x4 (&r)[VECS], float* lds, int tid) {
 #pragma unroll
@@ -209,7 +241,10 @@ __device__ __forceinline__ void tile_coords(int tile, int tiles_n, int tiles_m, 
 // version kept Cᵀ in the accumulators and staged every block through an LDS patch to store 16 B per lane: the
 // streaming-store ceiling is the same for dword and dwordx4 stores (tools/probes/store_bw_probe.cpp: 5.1–5.5 TB/s
 // either way), and the patch cost 8 LDS instructions, two waits and ≈20 address instructions per block.
-template <int BM, int BN, int TM, int TN, bool ALIGNED, bool HAS_BIAS>
+// MODE 0: whole tile.  MODE 1: edge tile of a product whose rows are 16-byte aligned (ldc < 2²⁴): the same buffer
+// stores, rows beyond m dropped by the descriptor's range check (records end with row m − 1), columns beyond n by the
+// lane mask.  MODE 2: anything else — bounds-checked scalar stores with 64-bit addresses.
+template <int BM, int BN, int TM, int TN, int MODE, bool HAS_BIAS>
 __device__ __forceinline__ void gemm_epilogue_b(f32x16 (&acc)[TM][TN], float* __restrict__ C, int m, int n, long ldc,
                                                 int m0, int n0, int wm, int wn, int lane, const float* __restrict__ bias) {
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -221,18 +256,22 @@ __device__ __forceinline__ void gemm_epilogue_b(f32x16 (&acc)[TM][TN], float* __
       const int row0 = m0 + wm * (BM / 2) + i * 32, col0 = n0 + wn * (BN / 2) + j * 32;  // uniform
       const int col = col0 + l31;
       float bv = 0.f;
-      if (HAS_BIAS && (ALIGNED || col < n)) bv = bias[col];
-      if (ALIGNED) {
+      if (HAS_BIAS && (MODE == 0 || col < n)) bv = bias[col];
+      if (MODE < 2) {
+        int recs = 0x7fffffff;
+        if (MODE == 1) {
+          const long bytes = ((long)(m - row0 - 1) * ldc + (n - col0)) * 4;  // up to the last stored element of the block
+          recs = (row0 >= m || col0 >= n) ? 0 : (bytes > 0x7fffffffL ? 0x7fffffff : (int)bytes);
+        }
+        if ((MI_GEMM_ABL & 1) && MODE == 0) recs = 0;  // timing only: every store dropped by the range check
         const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(C + (long)row0 * ldc + col0, 0, 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc(C + (long)row0 * ldc + col0, 0, recs, 0x00020000);
+        if (MODE == 0 || col < n) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[i][j][r];
-          if (HAS_BIAS) v += bv;  // after the chain: one extra rounding, like `output += bias` (never x + 0: keeps −0)
-          const unsigned soff = (unsigned)((r & 3) + 8 * (r >> 2)) * c_row;
-          if (MI_GEMM_ABL & 1) {
-            if (v == 12345.678f) C[(long)row0 * ldc + col0 + (soff + c_lane) / 4] = v;  // keeps the accumulators live
-          } else {
+          for (int r = 0; r < 16; ++r) {
+            float v = acc[i][j][r];
+            if (HAS_BIAS) v += bv;  // after the chain: one extra rounding, like `output += bias` (never x + 0: keeps −0)
+            const unsigned soff = (unsigned)((r & 3) + 8 * (r >> 2)) * c_row;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, (int)c_lane, (int)soff, MI_GEMM_STORE_AUX /* nt */);
           }
         }
@@ -242,23 +281,17 @@ __device__ __forceinline__ void gemm_epilogue_b(f32x16 (&acc)[TM][TN], float* __
           const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
           float v = acc[i][j][r];
           if (HAS_BIAS) v += bv;
-          if (row < m && col < n) {
-            if (MI_GEMM_ABL & 1) {
-              if (v == 12345.678f) C[(long)row * ldc + col] = v;
-            } else {
-              __builtin_nontemporal_store(v, C + (long)row * ldc + col);
-            }
-          }
+          if (row < m && col < n) __builtin_nontemporal_store(v, C + (long)row * ldc + col);
         }
       }
     }
 }
 
-template <int BM, int BN, int TM, int TN, bool ALIGNED = false>
+template <int BM, int BN, int TM, int TN, int MODE>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* __restrict__ C, int m, int n, long ldc,
                                               int m0, int n0, int wm, int wn, int lane, const float* __restrict__ bias) {
-  if (bias) gemm_epilogue_b<BM, BN, TM, TN, ALIGNED, true>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
-  else gemm_epilogue_b<BM, BN, TM, TN, ALIGNED, false>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
+  if (bias) gemm_epilogue_b<BM, BN, TM, TN, MODE, true>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
+  else gemm_epilogue_b<BM, BN, TM, TN, MODE, false>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
 }
 
 #ifdef MI_GEMM_TIMING
@@ -319,11 +352,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI_GEMM_SHO
 #endif
   f32x4 ra[LA::VECS], rb[LB::VECS];
   const int l31 = lane & 31, lhi = lane >> 5;
-  // block-uniform: whole tiles (inside C, k a multiple of BK, 16-B loads) take unconditional vector
-  // loads; the bounds-checked loader (≈50 scalar / branch instructions per float4) only at the edges
-  // ALIGNED: the launcher saw that EVERY tile is interior, and the edge code is compiled out (it is
-  // what sets the kernel's register count otherwise)
-  const bool interior = ALIGNED || (vecA && vecB && m0 + BM <= m && n0 + BN <= n && k % BK == 0);
+  // Launch-uniform: operands whose rows are 16-byte aligned take unconditional buffer loads — on edge tiles too,
+  // with lane offsets clamped to the operand (TileLoader::lane_offsets) — for every WHOLE k-tile; only a ragged last
+  // k-tile goes through the bounds-checked loader (≈50 scalar / branch instructions per float4), as the prefetch of
+  // the last whole one.  Until round 3 every edge tile and every product with a ragged k took that loader for all
+  // of its k-tiles (ViT's 197-token attention: 3 of 4 output tiles).
+  // ALIGNED: the launcher saw that EVERY tile is whole, and the edge code is compiled out (it is what sets the
+  // kernel's register count otherwise)
+  const bool fast = ALIGNED || (vecA && vecB);
+  const bool whole = ALIGNED || (m0 + BM <= m && n0 + BN <= n);
 #ifndef MI_GEMM_KK_UNROLL
 #define MI_GEMM_KK_UNROLL 16
 #endif
@@ -343,22 +380,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI_GEMM_SHO
           if (!(MI_GEMM_ABL & 2)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   };
-  if (interior) {
+  if (fast) {
     const unsigned a_lane = LA::lane_offset(lda, tid), b_lane = LB::lane_offset(ldb, tid);
-    if (!(MI_GEMM_ABL & 4)) {
-      LA::load_fast(ra, LA::origin(A, lda, m0, 0), lda, a_lane);
-      LB::load_fast(rb, LB::origin(B, ldb, n0, 0), ldb, b_lane);
+    unsigned a_off[LA::VECS], b_off[LB::VECS];
+    if (!ALIGNED) {
+      LA::lane_offsets(a_off, lda, tid, m - m0);
+      LB::lane_offsets(b_off, ldb, tid, n - n0);
     }
+    auto load_tile = [&](int k0) {  // k-tile starting at k0 < k
+      if (MI_GEMM_ABL & 4) return;
+      if (ALIGNED) {
+        LA::load_fast(ra, LA::origin(A, lda, m0, k0), lda, a_lane);
+        LB::load_fast(rb, LB::origin(B, ldb, n0, k0), ldb, b_lane);
+      } else if (k0 + BK <= k) {
+        LA::load_clamped(ra, LA::origin(A, lda, m0, k0), a_off);
+        LB::load_clamped(rb, LB::origin(B, ldb, n0, k0), b_off);
+      } else {
+        LA::load(ra, A, lda, m0, k0, m, k, vecA, tid);
+        LB::load(rb, B, ldb, n0, k0, n, k, vecB, tid);
+      }
+    };
+    load_tile(0);
     for (int k0 = 0; k0 < k; k0 += BK) {
       LA::store(ra, As, tid);
       LB::store(rb, Bs, tid);
       GEMM_STAMP(0);  // operand tile landed and written to LDS
       __syncthreads();
       GEMM_STAMP(1);
-      if (k0 + BK < k && !(MI_GEMM_ABL & 4)) {
-        LA::load_fast(ra, LA::origin(A, lda, m0, k0 + BK), lda, a_lane);
-        LB::load_fast(rb, LB::origin(B, ldb, n0, k0 + BK), ldb, b_lane);
-      }
+      if (k0 + BK < k) load_tile(k0 + BK);
       // the loads stay in front of the MFMAs: hipcc otherwise sinks them (they feed nothing until the next
       // iteration) to the end of the tile, right in front of the waits on them — no prefetch left
       __builtin_amdgcn_sched_barrier(0);
@@ -383,8 +432,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI_GEMM_SHO
     }
   }
 
-  if (interior) gemm_epilogue<BM, BN, TM, TN, true>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
-  else if (!ALIGNED) gemm_epilogue<BM, BN, TM, TN, false>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
+  if (ALIGNED || (fast && whole)) gemm_epilogue<BM, BN, TM, TN, 0>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
+  else if (fast) gemm_epilogue<BM, BN, TM, TN, 1>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
+  else gemm_epilogue<BM, BN, TM, TN, 2>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
   GEMM_STAMP(4);  // epilogue issued
 }
 
@@ -430,21 +480,27 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int l31 = lane & 31, lhi = lane >> 5;
-  // block-uniform: whole tiles only (inside C, k a multiple of BK, 16-B loads) take the
-  // straight-line loop below; everything else the simple one with the bounds-checked loader
-  const bool interior = vecA && vecB && m0 + BM <= m && n0 + BN <= n && k % BK == 0;
-  if (interior) {
+  // launch-uniform: operands with 16-byte aligned rows and whole k-tiles take the pipelined loop below — edge tiles
+  // too (lane offsets clamped to the operands: TileLoader::lane_offsets); everything else the simple loop with the
+  // bounds-checked loader.  (A ragged last k-tile as one more, bounds-checked, stage of the pipeline was tried: the
+  // branch inside the stage costs the straight-line loop 6 % at 4096³.)
+  const bool fast = vecA && vecB && k % BK == 0;
+  const bool whole = m0 + BM <= m && n0 + BN <= n;
+  if (fast) {
     // Two register sets: tile t+1 and tile t+3 travel in one, tile t+2 in the other, so a tile's
     // global loads are issued almost two k-tiles (not one) before they are written to LDS — the
     // MFMA phase of a 128×64 tile is only ≈0.85 µs, shorter than an HBM round trip.
     f32x4 ra0[LA::VECS], rb0[LB::VECS], ra1[LA::VECS], rb1[LB::VECS];
     const int k_last = k - BK;  // start of the last tile: later "prefetches" re-read it (never used)
-    const unsigned a_lane = LA::lane_offset(lda, tid), b_lane = LB::lane_offset(ldb, tid);
+    unsigned a_off[LA::VECS], b_off[LB::VECS];  // loop-invariant, clamped to the operands: edge tiles need no other care
+    LA::lane_offsets(a_off, lda, tid, m - m0);
+    LB::lane_offsets(b_off, ldb, tid, n - n0);
     auto load_tile = [&](f32x4 (&ra)[LA::VECS], f32x4 (&rb)[LB::VECS], int k0) {
       const int kk = k0 < k_last ? k0 : k_last;
       if (MI_GEMM_ABL & 4) return;
-      LA::load_fast(ra, LA::origin(A, lda, m0, kk), lda, a_lane);  // default cache policy: nt / sc loads measured 3-5 % slower here
-      LB::load_fast(rb, LB::origin(B, ldb, n0, kk), ldb, b_lane);
+      // default cache policy: nt / sc loads measured 3-5 % slower here
+      LA::load_clamped(ra, LA::origin(A, lda, m0, kk), a_off);
+      LB::load_clamped(rb, LB::origin(B, ldb, n0, kk), b_off);
     };
     load_tile(ra0, rb0, 0);
     LA::store(ra0, lds, tid);
@@ -550,8 +606,9 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
       __syncthreads();
     }
   }
-  if (interior) gemm_epilogue<BM, BN, TM, TN, true>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
-  else gemm_epilogue<BM, BN, TM, TN, false>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
+  if (fast && whole) gemm_epilogue<BM, BN, TM, TN, 0>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
+  else if (fast) gemm_epilogue<BM, BN, TM, TN, 1>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
+  else gemm_epilogue<BM, BN, TM, TN, 2>(acc, C, m, n, ldc, m0, n0, wm, wn, lane, bias);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,49 @@
+"""Developer probe (round 3): the attention products of BERT-class models at other sequence lengths and head sizes
+than BASELINE.json configs[4] — q·kᵀ (cublasTransbMM's forward), probs·V (cublasMM's), and the two transposed products
+of their backward — `custom_mm.cublas_bmm` beside torch.matmul (rocBLAS / hipBLASLt, which may split k or reorder:
+not bit-compatible with the reference's fp32 chain, timing only).  -> profiles/r03_attention_shapes.log"""
+import sys
+from pathlib import Path
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "matrix-multiplication_amd"))
+import custom_mm  # noqa: E402
+dev = torch.device("cuda")
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters)
+    return best
+
+
+print("# tools/bench_attention_shapes.py on MI355X (ms per product, best of 3 blocks of 20; TFLOP/s of ours)")
+print("# items x S x D        product          ours     torch    ours/torch   TFLOP/s")
+for items, S, D in [(384, 128, 64), (384, 256, 64), (384, 384, 64), (384, 512, 64), (96, 1024, 64), (48, 2048, 64),
+                    (512, 512, 64), (256, 512, 128), (384, 512, 96), (384, 512, 80), (384, 197, 64), (192, 577, 64)]:
+    q = torch.rand(items, S, D, device=dev)
+    kk = torch.rand(items, S, D, device=dev)
+    v = torch.rand(items, S, D, device=dev)
+    p = torch.rand(items, S, S, device=dev)
+    dc = torch.rand(items, S, D, device=dev)
+    sc = torch.empty(items, S, S, device=dev)
+    ctx = torch.empty(items, S, D, device=dev)
+    flops = 2.0 * items * S * S * D
+    rows = [
+        ("q.kT   (NT, k=D)", lambda: custom_mm.cublas_bmm(q, kk, sc, 3, False, True), lambda: torch.matmul(q, kk.transpose(-1, -2), out=sc)),
+        ("P.V    (NN, k=S)", lambda: custom_mm.cublas_bmm(p, v, ctx, 3, False, False), lambda: torch.matmul(p, v, out=ctx)),
+        ("PT.dC  (TN, k=S)", lambda: custom_mm.cublas_bmm(p, dc, ctx, 3, True, False), lambda: torch.matmul(p.transpose(-1, -2), dc, out=ctx)),
+        ("dC.VT  (NT, k=D)", lambda: custom_mm.cublas_bmm(dc, v, sc, 3, False, True), lambda: torch.matmul(dc, v.transpose(-1, -2), out=sc)),
+    ]
+    for name, ours, ref in rows:
+        t0, t1 = timeit(ours), timeit(ref)
+        print(f"{items:4d} x {S:4d} x {D:3d}   {name}   {t0:7.4f}  {t1:7.4f}   {t0 / t1:6.2f}     {flops / t0 / 1e9:6.1f}", flush=True)
