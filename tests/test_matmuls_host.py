@@ -322,6 +322,13 @@ def test_dense_inputs_are_routed_by_shape(mm, monkeypatch):
     assert not matmuls.fused_skip_pays(1, 2048, 2048) and not matmuls.fused_skip_pays(1, 16384, 768)
     assert matmuls.fused_skip_pays(384, 512, 512) and matmuls.fused_skip_pays(16, 2048, 2048)
     assert not matmuls.fused_skip_pays(4, 4096, 4096)
+    # dense-with-zeros → the MFMA product above the crossover (profiles/r03_dense_input_routing.log): BERT-base
+    # probs·V pays at 100 % and 10 % kept, not at 1 %; the FC call shape pays at 100 % and 10 %, not at 2 %
+    assert matmuls.dense_route_pays(1.0, 384, 512, 512, 64) and matmuls.dense_route_pays(0.1, 384, 512, 512, 64)
+    assert not matmuls.dense_route_pays(0.01, 384, 512, 512, 64)
+    assert matmuls.dense_route_pays(1.0, 1, 16384, 768, 3072) and matmuls.dense_route_pays(0.1, 1, 16384, 768, 3072)
+    assert not matmuls.dense_route_pays(0.02, 1, 16384, 768, 3072)
+    assert not matmuls.dense_route_pays(0.0, 1, 4096, 4096, 4096)
     monkeypatch.setattr(fake, "fused_dense", True)
     g = torch.Generator().manual_seed(3)
 
