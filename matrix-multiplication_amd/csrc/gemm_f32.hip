@@ -975,9 +975,11 @@ int launch(const float* A, const float* B, float* C, int m, int n, int k, long l
 #ifndef MI_GEMM_CHAIN_MAX
 #define MI_GEMM_CHAIN_MAX 4
 #endif
-    if (BM == 128 && BN == 128 && tiles_n % 2 == 0 && (k == BK || k == 2 * BK || k == 4 * BK) && bias == nullptr) {
+    if (BM == 128 && BN == 128 && (tiles_n % 2 == 0 || tiles_n % 3 == 0) && (k == BK || k == 2 * BK || k == 4 * BK) &&
+        bias == nullptr) {
       // CHAIN output tiles of one tile row per workgroup, each tile's epilogue inside the next one's MFMAs
-      const int chain = (tiles_n % 4 == 0 && MI_GEMM_CHAIN_MAX >= 4) ? 4 : 2;
+      // (three for tile rows of 3, 9, 15 … tiles: 384 tokens, BERT's SQuAD length)
+      const int chain = (tiles_n % 4 == 0 && MI_GEMM_CHAIN_MAX >= 4) ? 4 : (tiles_n % 2 == 0 ? 2 : 3);
       const unsigned gblocks = (unsigned)(blocks / chain);
       const int gn = (int)(tiles_n / chain), gpi = (int)(tiles_m * tiles_n / chain);
 #define MI_PAIR(NK_, CH_)                                                                                         \
@@ -987,6 +989,10 @@ int launch(const float* A, const float* B, float* C, int m, int n, int k, long l
         if (k == BK) MI_PAIR(1, 4);
         else if (k == 2 * BK) MI_PAIR(2, 4);
         else MI_PAIR(4, 4);
+      } else if (chain == 3) {
+        if (k == BK) MI_PAIR(1, 3);
+        else if (k == 2 * BK) MI_PAIR(2, 3);
+        else MI_PAIR(4, 3);
       } else {
         if (k == BK) MI_PAIR(1, 2);
         else if (k == 2 * BK) MI_PAIR(2, 2);

@@ -2161,3 +2161,20 @@ def test_matmuls_broadcasting_fuzz_forward_and_backward(mm, dev):
         except AssertionError as e:
             raise AssertionError(f"case {case}: {name} a{tuple(a.shape)} (strides {a.stride()}) b{tuple(b.shape)} "
                                  f"(strides {b.stride()}) density {density}") from e
+
+
+@pytest.mark.parametrize("k", [32, 64, 128])
+def test_gemm_short_k_chains_of_two_three_and_four_tiles(cmm, dev, oracle_mod, k):
+    """Short-k products on whole 128×128 tiles run a CHAIN of output tiles per workgroup (each tile's epilogue inside
+    the next tile's MFMAs): four for tile rows of 4·j tiles, two for other even counts, three for 3, 9, 15 … (384
+    tokens).  Every chain length, every transposition, batched: bit-identical to the oracle
+    (reference entry: cublas_bmm, src/custom_mm.cpp:104-164)."""
+    g = np.random.Generator(np.random.PCG64(k))
+    for n in (256, 384, 512, 768, 1152):       # 2, 3, 4, 6 (→ 2), 9 (→ 3) tiles per tile row
+        for ta, tb in ((False, True), (False, False), (True, False), (True, True)):
+            m, batch = 256, 2
+            a = g.random((batch, k, m) if ta else (batch, m, k), dtype=np.float32) - 0.5
+            b = g.random((batch, n, k) if tb else (batch, k, n), dtype=np.float32) - 0.5
+            C = torch.full((batch, m, n), float("nan"), device=dev)
+            cmm.cublas_bmm(t(a, dev), t(b, dev), C, 3, ta, tb)
+            assert np.array_equal(C.cpu().numpy(), gemm_ref(oracle_mod, a, b, ta, tb)), (n, ta, tb)
