@@ -16,6 +16,7 @@ from __future__ import annotations
 import argparse
 import hashlib
 import os
+import re
 import shlex
 import subprocess
 import sys
@@ -74,14 +75,16 @@ def build_library(force=False, verbose=False) -> Path:
     def compile_one(src: Path):
         obj = OBJ_DIR / (src.stem + ".o")
         stamp = OBJ_DIR / (src.stem + ".stamp")
-        digest = _digest([src], hdr_digest)
+        # a unit that includes another .hip (gemm_f32_nn.hip → gemm_f32.hip) is stale when that file changes
+        included = [CSRC / m for m in re.findall(r'#include "([\w.]+\.hip)"', src.read_text()) if (CSRC / m).exists()]
+        digest = _digest([src, *included], hdr_digest)
         if force or _stale(obj, stamp, digest):
             _run([HIPCC, *flags, "-c", src, "-o", obj], verbose)
             stamp.write_text(digest)
             return obj, True
         return obj, False
 
-    with ThreadPoolExecutor(max_workers=min(4, len(sources))) as pool:
+    with ThreadPoolExecutor(max_workers=min(max(2, (os.cpu_count() or 4) - 2), len(sources))) as pool:
         results = list(pool.map(compile_one, sources))
     objs = [o for o, _ in results]
     if force or any(changed for _, changed in results) or not LIB_PATH.exists():

@@ -16,10 +16,10 @@
 // consecutive m or n at one k) bank-conflict free:
 //    source contiguous along k  → Xs[mn][BK+1]   (A not transposed, B transposed)
 //    source contiguous along mn → Xs[BK][BMN]    (A transposed, B not transposed)
-// The MFMA operands are swapped so the accumulators hold Cᵀ tiles (lane ↔ row, registers ↔
-// 4-column groups): the epilogue stages each 32×32 tile through LDS with b128 writes and stores
-// whole 128-B row segments with non-temporal 16-B stores.  Work ids are dealt XCD-contiguously and
-// in 8-tile column groups, so the workgroups an XCD runs together share operand panels in its L2.
+// The accumulators hold C blocks (lane ↔ column, register ↔ row): the epilogue is 16 dword buffer stores per 32×32
+// block straight from the accumulator registers, each writing two whole 128-byte row segments — no LDS staging, no
+// vector-ALU instruction (round 3; until then Cᵀ blocks went through an LDS patch).  Work ids are dealt XCD-contiguously
+// and in 8-tile column groups, so the workgroups an XCD runs together share operand panels in its L2.
 //
 // Two kernels share loader, layouts and epilogue (same k order per element → same bits), a third covers one regime:
 //  * gemm_f32_kernel (k < 256): one LDS buffer, two barriers per k-tile, the next tile's global
@@ -34,13 +34,16 @@
 //    blocks (v_mfma_f32_16x16x4_f32, the same k-ordered chain) sized to fill the 256 CUs in whole rounds — 96×96
 //    with twelve waves, 64×64 with eight, 32×32 with four — both operands streamed through LDS as they lie in
 //    memory; its own section below.
-// Measured (MI355X, fp32 MFMA peak 157 TFLOP/s; tools/gemm_square_probe.py, tools/bench_misc.py):
-// 8192³ A·Bᵀ 7.64 ms = 144 TFLOP/s (single-buffer kernel 8.37, rocBLAS 7.15), A·B 7.90,
-// Aᵀ·B 8.10; 4096³ 0.97–1.02 ms (rocBLAS 0.91); 1024³ 0.026 ms (was 0.034; rocBLAS 0.022);
-// BERT-base attention (B 32, H 12, S 512, D 64): q·kᵀ 0.164 ms (rocBLAS 0.184), probs·v
-// 0.144 ms (was 0.156; rocBLAS 0.131).  Ablation of the pipelined kernel at 8192³: MFMAs alone
-// 7.13 ms; + operand reads 7.34; + LDS writes 7.52; + global loads 7.80 (half of that is issue
-// cost, half L2-miss latency beyond the one-tile prefetch distance).
+//  * gemm_f32_pair_kernel (k = 32 / 64 / 128 on whole 128×128 tiles — q·kᵀ): a chain of 2–4 output tiles per workgroup,
+//    each tile's epilogue inside the next tile's MFMAs; its own section below.
+// Measured (MI355X, fp32 MFMA peak 157 TFLOP/s; tools/probes/duo_probe.cpp, profiles/r03_*): 8192³ A·Bᵀ 7.20 ms =
+// 152.6 TFLOP/s, 4096³ 0.91–0.92 ms (150), BERT-base attention (B 32, H 12, S 512, D 64) q·kᵀ 0.118 ms, probs·V
+// 0.115–0.120 ms; DESIGN.md §3.3 has the history and the ablations.
+//
+// Translation units: the kernels of ONE transposition case are compiled per file (gemm_f32_nn.hip … _tt.hip define
+// MI_GEMM_TU_NAME / _TA / _TB and include this file: four parallel compiles instead of one 2½-minute one); this
+// file compiled on its own carries only the C-ABI entry points.  Developer probes that include it directly define
+// MI_GEMM_SINGLE_TU and get everything in one unit.
 #include <atomic>
 #include <type_traits>
 
@@ -54,6 +57,18 @@
                        // 8 no LDS operand reads, 16 no LDS writes, 32 no barriers (timing only: wrong results)
 #endif
 
+#define MI_GEMM_TU_ARGS                                                                                              \
+  const float *A, const float *B, float *C, int m, int n, int k, long lda, long ldb, long ldc, long sA, long sB, long sC, \
+      int batch, bool vecA, bool vecB, bool vecC, const float *bias, hipStream_t s
+namespace mi {
+extern std::atomic<unsigned> g_gemm_launch_counter;  // one counter for every launch of every unit (see launch())
+int gemm_f32_tu_nn(MI_GEMM_TU_ARGS);
+int gemm_f32_tu_nt(MI_GEMM_TU_ARGS);
+int gemm_f32_tu_tn(MI_GEMM_TU_ARGS);
+int gemm_f32_tu_tt(MI_GEMM_TU_ARGS);
+}  // namespace mi
+
+#if defined(MI_GEMM_TU_NAME) || defined(MI_GEMM_SINGLE_TU)
 namespace {
 
 using mi::f32x4;
@@ -941,8 +956,6 @@ int launch_t16(const float* A, const float* B, float* C, int m, int n, int k, lo
   return mi::check_launch();
 }
 
-std::atomic<unsigned> g_launch_counter{0};  // one counter for every instantiation of launch()
-std::atomic<int> g_gemm_plan{MI_GEMM_PLAN_AUTO};
 
 template <int BM, int BN, bool TA, bool TB>
 int launch(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb,
@@ -959,7 +972,7 @@ int launch(const float* A, const float* B, float* C, int m, int n, int k, long l
 #ifdef MI_GEMM_NO_REVERSE
   const int rev = 0;
 #else
-  const int rev = (int)(g_launch_counter.fetch_add(1, std::memory_order_relaxed) & 1u);
+  const int rev = (int)(mi::g_gemm_launch_counter.fetch_add(1, std::memory_order_relaxed) & 1u);
 #endif
   // long k: the pipelined kernel (its prologue and double LDS buffer pay off from ≈8 k-tiles);
   // short k (BERT q·kᵀ, k = 64): the single-buffer kernel, which keeps 3–4 workgroups per CU
@@ -1047,7 +1060,7 @@ int pick_tile(const float* A, const float* B, float* C, int m, int n, int k, lon
     if (best_eff < MI_GEMM_T16_MIN_EFF && m % 32 == 0 && n % 32 == 0 && blocks_for(32, 32) >= 256 && blocks_for(64, 64) <= 512)
       best = 32, best_eff = 1.0;
     if (best_eff >= MI_GEMM_T16_MIN_EFF) {
-      const int rev = (int)(g_launch_counter.fetch_add(1, std::memory_order_relaxed) & 1u);
+      const int rev = (int)(mi::g_gemm_launch_counter.fetch_add(1, std::memory_order_relaxed) & 1u);
       if (best == 96) return launch_t16<96, MI_GEMM_T16_WAVES>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, rev, s);
       if (best == 32) return launch_t16<32, 4>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, rev, s);
       return launch_t16<64, 8>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, rev, s);
@@ -1073,6 +1086,26 @@ int pick_tile(const float* A, const float* B, float* C, int m, int n, int k, lon
 }
 
 // k == 0: C = 0 (beta = 0 semantics), or the bias row.
+}  // namespace
+
+#define MI_GEMM_TU_PASS A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, vecC, bias, s
+#ifdef MI_GEMM_TU_NAME
+int mi::MI_GEMM_TU_NAME(MI_GEMM_TU_ARGS) { return pick_tile<MI_GEMM_TU_TA, MI_GEMM_TU_TB>(MI_GEMM_TU_PASS); }
+#else
+int mi::gemm_f32_tu_nn(MI_GEMM_TU_ARGS) { return pick_tile<false, false>(MI_GEMM_TU_PASS); }
+int mi::gemm_f32_tu_nt(MI_GEMM_TU_ARGS) { return pick_tile<false, true>(MI_GEMM_TU_PASS); }
+int mi::gemm_f32_tu_tn(MI_GEMM_TU_ARGS) { return pick_tile<true, false>(MI_GEMM_TU_PASS); }
+int mi::gemm_f32_tu_tt(MI_GEMM_TU_ARGS) { return pick_tile<true, true>(MI_GEMM_TU_PASS); }
+#endif
+#endif  // MI_GEMM_TU_NAME || MI_GEMM_SINGLE_TU
+
+#ifndef MI_GEMM_TU_NAME  // the entry points: this file on its own, or a probe's single unit
+std::atomic<unsigned> mi::g_gemm_launch_counter{0};
+
+namespace {
+
+std::atomic<int> g_gemm_plan{MI_GEMM_PLAN_AUTO};
+
 __global__ void zero_rows_kernel(float* C, int m, int n, long ldc, long strideC, const float* bias) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < (long)m * n) C[blockIdx.y * strideC + (idx / n) * ldc + (idx % n)] = bias ? bias[idx % n] : 0.f;
@@ -1112,13 +1145,11 @@ extern "C" int mi_gemm_bias_f32(int transa, int transb, int32_t m, int32_t n, in
     if (st != 1) return st;
     if (plan == MI_GEMM_PLAN_DUO) return MI_EINVAL;  // pinned, but the shape is not made of whole tiles
   }
-#define MI_GEMM(TA_, TB_)                                                                       \
-  return pick_tile<TA_, TB_>(A, B, C, m, n, k, lda, ldb, ldc, strideA, strideB, strideC, batch, \
-                             vecA, vecB, vecC, bias, s)
-  if (!transa && !transb) MI_GEMM(false, false);
-  if (!transa && transb) MI_GEMM(false, true);
-  if (transa && !transb) MI_GEMM(true, false);
-  MI_GEMM(true, true);
+#define MI_GEMM(F_) return mi::F_(A, B, C, m, n, k, lda, ldb, ldc, strideA, strideB, strideC, batch, vecA, vecB, vecC, bias, s)
+  if (!transa && !transb) MI_GEMM(gemm_f32_tu_nn);
+  if (!transa && transb) MI_GEMM(gemm_f32_tu_nt);
+  if (transa && !transb) MI_GEMM(gemm_f32_tu_tn);
+  MI_GEMM(gemm_f32_tu_tt);
 #undef MI_GEMM
 }
 
@@ -1135,3 +1166,4 @@ extern "C" int mi_gemm_f32(int transa, int transb, int32_t m, int32_t n, int32_t
   return mi_gemm_bias_f32(transa, transb, m, n, k, A, lda, strideA, B, ldb, strideB, nullptr, C, ldc,
                           strideC, batch, stream);
 }
+#endif  // !MI_GEMM_TU_NAME

@@ -1,0 +1,6 @@
+// The dense fp32 kernels of gemm_f32.hip for A·Bᵀ as a translation unit of their own (four parallel compiles
+// instead of one long one; see "Translation units" in gemm_f32.hip).
+#define MI_GEMM_TU_NAME gemm_f32_tu_nt
+#define MI_GEMM_TU_TA false
+#define MI_GEMM_TU_TB true
+#include "gemm_f32.hip"

@@ -1,0 +1,6 @@
+// The dense fp32 kernels of gemm_f32.hip for Aᵀ·B as a translation unit of their own (four parallel compiles
+// instead of one long one; see "Translation units" in gemm_f32.hip).
+#define MI_GEMM_TU_NAME gemm_f32_tu_tn
+#define MI_GEMM_TU_TA true
+#define MI_GEMM_TU_TB false
+#include "gemm_f32.hip"

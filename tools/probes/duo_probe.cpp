@@ -3,6 +3,7 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -Imatrix-multiplication_amd/csrc tools/probes/duo_probe.cpp -o tools/probes/duo_probe
 //   (-DMI_DUO_ABL=1/2/4: no C stores / no MFMAs / no operand loads in the duo kernel — timing only)
 #include "../../matrix-multiplication_amd/csrc/mi_status.hip"
+#define MI_GEMM_SINGLE_TU  // everything in this unit
 #include "../../matrix-multiplication_amd/csrc/gemm_f32.hip"
 #include "../../matrix-multiplication_amd/csrc/gemm_f32_duo.hip"
 #include <algorithm>

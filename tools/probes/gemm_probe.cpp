@@ -1,6 +1,7 @@
 // Developer probe (not part of the product): per-phase cycles of gemm_f32_kernel at BERT's q.kT shape.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DMI_GEMM_TIMING -Iinclude -Imatrix-multiplication_amd/csrc tools/probes/gemm_probe.cpp -o tools/probes/gemm_probe
 #include "../../matrix-multiplication_amd/csrc/mi_status.hip"
+#define MI_GEMM_SINGLE_TU  // everything in this unit
 #include "../../matrix-multiplication_amd/csrc/gemm_f32.hip"
 #include "../../matrix-multiplication_amd/csrc/gemm_f32_duo.hip"
 #include <cstdio>

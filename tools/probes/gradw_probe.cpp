@@ -2,6 +2,7 @@
 // A^T.B) with pieces compiled out (-DMI_GEMM_ABL: 1 no C stores, 2 no MFMAs, 4 no global operand loads; timing only).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DMI_GEMM_ABL=2 -Iinclude -Imatrix-multiplication_amd/csrc tools/probes/gradw_probe.cpp -o tools/probes/gradw_probe_abl2
 #include "../../matrix-multiplication_amd/csrc/mi_status.hip"
+#define MI_GEMM_SINGLE_TU  // everything in this unit
 #include "../../matrix-multiplication_amd/csrc/gemm_f32.hip"
 #include <cstdio>
 #include <vector>
