@@ -137,7 +137,9 @@ enum {
   MI_SPMM_NARROW = 16,      /* N < 4: wave per row, lanes over non-zeros, shuffle reduction (own order) */
   MI_SPMM_SLAB = 17,        /* moderate density, N ≥ 128: 128 rows × 256 columns per workgroup, B staged
                                through LDS in 64-row slabs, one ds_read_b128 per non-zero           */
-  MI_SPMM_VARIANT_COUNT = 18
+  MI_SPMM_LDS_B = 18,       /* K·N·4 ≤ 128 KB (N ≤ 256, N % 4 == 0): an item's whole B copied into LDS, rows
+                               gather from there — batched products of small matrices (pruned attention) */
+  MI_SPMM_VARIANT_COUNT = 19
 };
 int mi_spmm_csr_f32_variant(int variant, const int32_t* rowptr, const int32_t* col,
                             const float* val, int64_t nnz, int32_t M, int32_t K,
@@ -168,6 +170,16 @@ int mi_spmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col,
                             int32_t M, int32_t K, int32_t N, const float* B,
                             int64_t ldb, int64_t strideB, float* C, int64_t ldc,
                             int64_t strideC, mi_stream_t stream);
+/* … with a kernel-variant override, for benchmarks and tests (a variant that does not take
+ * batches, or not this shape, returns MI_EINVAL), and what AUTO resolves to for a batch. */
+int mi_spmm_csr_batched_variant_f32(int variant, const int32_t* rowptr, const int32_t* col,
+                                    const float* val, int64_t nnz_total, int32_t batch,
+                                    int32_t M, int32_t K, int32_t N, const float* B,
+                                    int64_t ldb, int64_t strideB, float* C, int64_t ldc,
+                                    int64_t strideC, mi_stream_t stream);
+int mi_spmm_csr_batched_f32_plan(int64_t nnz_total, int32_t batch, int32_t M, int32_t K, int32_t N,
+                                 const float* B, int64_t ldb, int64_t strideB, const float* C,
+                                 int64_t ldc, int64_t strideC);
 
 /* ------------------------------------------------------------------------ *
  * B3 / K2 executor — column-major dense operands:

@@ -981,6 +981,9 @@ Shape classify(int32_t N, int64_t ldb, int64_t ldc, int64_t strideB, int64_t str
   return sh;
 }
 
+#ifndef MI_SPMM_LDSB_MIN_ROW
+#define MI_SPMM_LDSB_MIN_ROW 4L  // mean non-zeros per row from which MI_SPMM_LDS_B is AUTO's choice (tools/bench_attn_csr.py)
+#endif
 // The kernel AUTO resolves to.
 int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32_t K, int32_t N,
                    int64_t ldb) {
@@ -995,6 +998,14 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
       nnz * (long)N >= 8 * b_elems)
     return MI_SPMM_PANELS_2;
   if (N < 4) return MI_SPMM_NARROW;
+  // Many small products (or one tall one) whose B fits a CU's LDS: gather from LDS instead of from the L2s
+  // (spmm_ldsb.hip).  It pays once rows are long enough to amortise copying B per workgroup.
+  // (tools/bench_attn_csr.py, profiles/r03_attention_csr.log: 384 × 512² × 64 at 10 % kept 0.125 → 0.058 ms, at
+  // 1 % 0.038 → 0.032; N = 256 has the one-wave-per-row kernels, whose col / val travel through scalar registers:
+  // 65536 × 128 × 256 at 5 % 0.020 ms there vs 0.028 here, at 25 % 0.074 vs 0.046)
+  if (sh.vec4_ok && mi::spmm_ldsb_fits(K, N) && (long)batch * M >= 16384 &&
+      nnz >= (N > 128 ? 4 * MI_SPMM_LDSB_MIN_ROW : MI_SPMM_LDSB_MIN_ROW) * (long)batch * M)
+    return MI_SPMM_LDS_B;
   const int lp = (sh.wave_ok && batch == 1) ? l2_panels(M, K, N, ldb, nnz) : 0;
   // Moderate density: stage B through LDS (spmm_slab.hip) when its cost model beats the L2-blocked
   // row-split plans.  Fitted on MI355X (tools/bench_density.py, tools/bench_plans.py): a slab
@@ -1090,6 +1101,9 @@ int launch_variant(int variant, const Shape& sh, const int32_t* rowptr, const in
     case MI_SPMM_SLAB:
       if (!(vec4_ok && batch == 1 && K > 0)) return MI_EINVAL;
       return mi::launch_spmm_slab(rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la.thresh, s);
+    case MI_SPMM_LDS_B:
+      if (!(vec4_ok && mi::spmm_ldsb_fits(K, N))) return MI_EINVAL;
+      return mi::launch_spmm_ldsb(rowptr, col, val, B, C, batch, M, K, N, ldb, ldc, strideB, strideC, bias, la.thresh, s);
     case MI_SPMM_NARROW: {
       if (N >= 4) return MI_EINVAL;
       const long blocks = ((long)M + 3) / 4;
@@ -1147,7 +1161,7 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
       // the four counters start from zero; entries and the slot → entry map are written before they are read.
       // MI_LONG_ROWS_AUTO_ZEROED: the caller's workspace enters with a zero header (and leaves with one)
       if (long_mode != MI_LONG_ROWS_AUTO_ZEROED) MI_HIP_TRY(hipMemsetAsync(ws, 0, 16, s));
-      if (variant == MI_SPMM_SLAB) {  // that kernel lives in spmm_slab.hip and only skips: list here
+      if (variant == MI_SPMM_SLAB || variant == MI_SPMM_LDS_B) {  // those kernels live in files of their own and only skip: list here
         LongArg fl = la;
         fl.ws = ws;
         hipLaunchKernelGGL(find_long_rows_kernel, dim3((unsigned)(((long)M + 255) / 256)), dim3(256), 0, s, rowptr, M, fl);
@@ -1288,6 +1302,21 @@ int mi_spmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col, const flo
                        C, ldc, strideC, nullptr, nullptr, 0, static_cast<hipStream_t>(stream));
 }
 
+int mi_spmm_csr_batched_variant_f32(int variant, const int32_t* rowptr, const int32_t* col, const float* val,
+                                    int64_t nnz_total, int32_t batch, int32_t M, int32_t K, int32_t N,
+                                    const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,
+                                    int64_t strideC, mi_stream_t stream) {
+  if (strideB < 0 || strideC < 0) return MI_EINVAL;
+  return spmm_dispatch(variant, rowptr, col, val, nnz_total, batch, M, K, N, B, ldb, strideB, C, ldc, strideC, nullptr,
+                       nullptr, 0, static_cast<hipStream_t>(stream));
+}
+
+int mi_spmm_csr_batched_f32_plan(int64_t nnz_total, int32_t batch, int32_t M, int32_t K, int32_t N, const float* B,
+                                 int64_t ldb, int64_t strideB, const float* C, int64_t ldc, int64_t strideC) {
+  if (M < 0 || K < 0 || N < 0 || nnz_total < 0 || batch < 0 || strideB < 0 || strideC < 0) return MI_EINVAL;
+  return choose_variant(classify(N, ldb, ldc, strideB, strideC, B, C), nnz_total, batch, M, K, N, ldb);
+}
+
 int mi_spmm_csr_f32_plan(int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,
                          const float* C, int64_t ldc) {
   if (M < 0 || K < 0 || N < 0 || nnz < 0) return MI_EINVAL;
@@ -1310,6 +1339,7 @@ const char* mi_spmm_variant_name(int variant) {
       return "spmm_group_kernel";
     case MI_SPMM_NARROW: return "spmm_narrow_kernel";
     case MI_SPMM_SLAB: return "spmm_slab_kernel";
+    case MI_SPMM_LDS_B: return "spmm_ldsb_kernel";
     case MI_SPMM_PANELS_2: case MI_SPMM_PANELS_3: case MI_SPMM_PANELS_4: case MI_SPMM_PANELS_5:
     case MI_SPMM_PANELS_6: case MI_SPMM_PANELS_8: case MI_SPMM_COLTILE_PANELS:
       return "spmm_wave_row_panel_kernel";

@@ -1,0 +1,255 @@
+// CSR × dense with the WHOLE dense operand of an item resident in LDS (MI_SPMM_LDS_B) — batched products of many
+// small matrices: pruned attention probabilities × V (BASELINE.json configs[4]: 384 items of 512×512 · 512×64, the
+// reference reaches it through matmuls.cusparseMM / naiveSpMM and its per-slice recursion, matmuls.py:282-297).
+//
+// Why: the row-split kernels of spmm_csr.hip gather one 256-byte row of B per non-zero from the L2s.  With every B
+// (128 KB) L2-resident that gather runs at ≈30 TB/s chip-wide — the L2s' limit — and the product takes 0.87 ms at
+// 100 % kept, 0.124 ms at 10 % (tools/bench_attn_csr.py), the dense MFMA product 0.10 ms whatever the density.  The
+// CUs' LDS serve ≈150 TB/s (ds_read_b128: 256 B per clock and CU): a workgroup that first copies its item's B into
+// LDS (K·N·4 ≤ 128 KB of the 160 KB) gathers from there.
+//
+//   * persistent grid, one 16-wave workgroup per CU; a work unit = (item, block of rows); every workgroup takes a
+//     CONTIGUOUS range of units, so consecutive units of one item reuse the staged B (384 items × 2 units on 256
+//     CUs: 2 stagings per workgroup, not 3);
+//   * G = N/4 (rounded up to a power of two) lanes per row, 64/G rows per wave, one float4 of the output row per
+//     lane: the 16 lanes of a group read one whole B row per ds_read_b128 (64 distinct banks: conflict-free for any
+//     mix of rows in the wave);
+//   * a row's col / val are handed round its group as in spmm_group_kernel, but loaded 4·G entries at a time and
+//     prefetched across rows (the L2-gather kernels lean on 16+ resident waves per SIMD instead: here LDS is full);
+//   * every output element is the row's non-zeros in CSR order, one fmaf chain: the bits of every other plan.
+// Rows beyond the long-row threshold are skipped (spmm_dispatch lists them and runs its follow-up kernel), batch = 1 only.
+#include <type_traits>
+
+#include "mi_common.h"
+
+namespace {
+
+using mi::f32x4;
+
+__device__ __forceinline__ f32x4 fma4(float a, f32x4 x, f32x4 acc) {
+  acc.x = __builtin_fmaf(a, x.x, acc.x);
+  acc.y = __builtin_fmaf(a, x.y, acc.y);
+  acc.z = __builtin_fmaf(a, x.z, acc.z);
+  acc.w = __builtin_fmaf(a, x.w, acc.w);
+  return acc;
+}
+
+constexpr int kWaves = 16;
+
+// The value entry I of the caller's group's current chunk, without a trip through the LDS crossbar where the hardware
+// offers one: a DPP row broadcast (row_newbcast: a modifier of a VALU move, 16-lane rows) for groups of 8, 16 and 32
+// lanes — a 32-lane group keeps the SAME 16 entries in both of its rows, two 8-lane groups share a row and take
+// their halves through the bank mask — a scalar readlane for whole waves; ds_bpermute otherwise.  (ds_bpermute is
+// what bounds the row-split group kernels at ≈4.5 clocks per non-zero and CU — two of them per non-zero step — not
+// the L2s and not the LDS data path.)
+template <int G>
+struct Chunk {
+  static constexpr int ENTRIES = G == 32 ? 16 : G;  // entries a group holds per chunk register
+};
+template <int G, int I, typename T>
+__device__ __forceinline__ T group_lane(T x) {
+  const int bits = __builtin_bit_cast(int, x);
+  int r;
+  if constexpr (G == 16 || G == 32) {
+    r = __builtin_amdgcn_update_dpp(0, bits, 0x150 + I, 0xf, 0xf, true);
+  } else if constexpr (G == 8) {
+    r = __builtin_amdgcn_update_dpp(0, bits, 0x150 + I, 0xf, 0x3, false);      // lanes 0-7 of every row: their entry I
+    r = __builtin_amdgcn_update_dpp(r, bits, 0x150 + 8 + I, 0xf, 0xc, false);  // lanes 8-15: theirs
+  } else if constexpr (G == 64) {
+    r = __builtin_amdgcn_readlane(bits, I);
+  } else {
+    r = __shfl(bits, I, G);
+  }
+  return __builtin_bit_cast(T, r);
+}
+
+template <int N_, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N_ > 0) {
+    static_for<N_ - 1>(f);
+    f(std::integral_constant<int, N_ - 1>{});
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+    const float* __restrict__ B, float* __restrict__ C, int M, int K, int N, long ldb, long ldc, long strideB,
+    long strideC, const float* __restrict__ bias, int units_per_item, int rows_per_unit, unsigned total_units,
+    int long_thresh) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 Bs[];  // [K][N / 4]
+  constexpr int RPW = 64 / G;  // rows per wave
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gl = lane & (G - 1);
+  const int nq = N >> 2;          // float4 per row of B / C
+  const bool on = gl < nq;        // lanes beyond a row that is not a power of two wide idle
+  const unsigned per = (total_units + gridDim.x - 1) / gridDim.x;
+  const unsigned u0 = blockIdx.x * per, u1 = u0 + per < total_units ? u0 + per : total_units;
+  long staged = -1;
+  for (unsigned u = u0; u < u1; ++u) {  // workgroup-uniform
+    const long item = u / (unsigned)units_per_item;
+    const int part = (int)(u % (unsigned)units_per_item);
+    if (item != staged) {
+      if (staged >= 0) __syncthreads();  // every wave is done with the previous item's B
+      const float* Bi = B + item * strideB;
+      const int total4 = K * nq;
+      for (int i = tid; i < total4; i += kWaves * 64) {
+        const int r = i / nq, q = i - r * nq;
+        Bs[i] = *reinterpret_cast<const f32x4*>(Bi + (long)r * ldb + 4 * q);
+      }
+      if (tid < nq) Bs[total4 + tid] = f32x4{0.f, 0.f, 0.f, 0.f};  // row K: what the padding of a row's last chunk reads
+      __syncthreads();
+      staged = item;
+    }
+    const int* rp = rowptr + item * ((long)M + 1);
+    float* Ci = C + item * strideC;
+    const int r0 = part * rows_per_unit;
+    const int r1 = r0 + rows_per_unit < M ? r0 + rows_per_unit : M;
+    // Rows in a software pipeline: a group's col / val come in super-chunks of SC chunks (SC independent loads per
+    // lane), and a row's bounds are loaded two rows ahead, its first super-chunk one row ahead, the next super-chunk
+    // of a long row while the current one is processed — left to itself every chunk of G entries cost its own trip
+    // to memory (≈3 k cycles per 64 non-zeros of a wave: the first version ran at the L2-gather kernel's speed).
+    constexpr int SC = 4;
+    constexpr int EPC = Chunk<G>::ENTRIES;  // entries per chunk
+    constexpr int STRIDE = kWaves * RPW;
+    auto load_bounds = [&](int rb, int& st, int& en, bool& skip) {
+      const int row = rb + lane / G;
+      st = en = 0;
+      if (row < r1) {
+        st = rp[row];
+        en = rp[row + 1];
+      }
+      skip = en - st > long_thresh;  // left to spmm_long_rows_kernel
+      if (skip) en = st;
+    };
+    // an entry travels as {byte offset of its B row in LDS, value}; positions beyond the row's end read as value 0
+    // on the all-zero row K: fmaf(0, 0, acc) leaves every bit of acc (acc starts at +0 and can never be −0)
+    const int row_bytes = N * 4;
+    auto load_chunk = [&](int p, int en, int (&c)[SC], float (&v)[SC]) {
+#pragma unroll
+      for (int j = 0; j < SC; ++j) {
+        const int idx = p + j * EPC + (gl & (EPC - 1));
+        c[j] = (idx < en ? col[idx] : K) * row_bytes;
+        v[j] = idx < en ? val[idx] : 0.f;
+      }
+    };
+    // (lanes beyond a row that is not a power of two wide compute on column 0 and store nothing: no predicate in the loop)
+    const char* Bbytes = reinterpret_cast<const char*>(Bs) + 16 * (on ? gl : 0);
+    int rb = r0 + wave * RPW;
+    int s0, e0, s1 = 0, e1 = 0;
+    bool k0, k1 = false;
+    int c0[SC], c1[SC];
+    float v0[SC], v1[SC];
+    load_bounds(rb, s0, e0, k0);
+    load_chunk(s0, e0, c0, v0);
+    if (rb + STRIDE < r1) load_bounds(rb + STRIDE, s1, e1, k1);
+    for (; rb < r1; rb += STRIDE) {  // wave-uniform
+      load_chunk(s1, e1, c1, v1);    // nothing to load (s1 = e1) when there is no next row
+      int s2 = 0, e2 = 0;
+      bool k2 = false;
+      if (rb + 2 * STRIDE < r1) load_bounds(rb + 2 * STRIDE, s2, e2, k2);
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      int p = s0;
+      while (p < e0) {  // trip count differs between groups
+        int cn[SC];
+        float vn[SC];
+        load_chunk(p + SC * EPC, e0, cn, vn);
+#pragma unroll
+        for (int j = 0; j < SC; ++j) {
+          const int left = e0 - (p + j * EPC);  // group-uniform
+          // four entries per step, the last step of a row padded (see load_chunk); the lane index is a compile-time
+          // constant so that the broadcast can be a DPP modifier
+          static_for<(EPC + 3) / 4>([&](auto b_) {
+            constexpr int b = 4 * decltype(b_)::value;
+            if (b < left) {
+              f32x4 x[4];
+              float v[4];
+              static_for<4>([&](auto e_) {
+                constexpr int e = decltype(e_)::value;
+                constexpr int I = b + e < EPC ? b + e : EPC - 1;
+                const int off = b + e < EPC ? group_lane<G, I>(c0[j]) : K * row_bytes;  // (G < 4: the zero row)
+                v[e] = b + e < EPC ? group_lane<G, I>(v0[j]) : 0.f;
+                x[e] = *reinterpret_cast<const f32x4*>(Bbytes + off);
+              });
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc = fma4(v[e], x[e], acc);
+            }
+          });
+        }
+        p += SC * EPC;
+#pragma unroll
+        for (int j = 0; j < SC; ++j) {
+          c0[j] = cn[j];
+          v0[j] = vn[j];
+        }
+      }
+      const int row = rb + lane / G;
+      if (row < r1 && !k0 && on) {
+        if (bias) acc += *reinterpret_cast<const f32x4*>(bias + 4 * gl);
+        __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(Ci + (long)row * ldc + 4 * gl));
+      }
+      s0 = s1, e0 = e1, k0 = k1;
+      s1 = s2, e1 = e2, k1 = k2;
+#pragma unroll
+      for (int j = 0; j < SC; ++j) {
+        c0[j] = c1[j];
+        v0[j] = v1[j];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+namespace mi {
+
+// 1 when the plan can take the problem at all (shape only; the caller checked the vec4 requirements)
+bool spmm_ldsb_fits(int32_t K, int32_t N) {
+  return N >= 4 && N % 4 == 0 && N <= 256 && K >= 1 && (long)K * N * 4 <= 128L * 1024;
+}
+
+int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val, const float* B, float* C,
+                     int32_t batch, int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t ldc, int64_t strideB,
+                     int64_t strideC, const float* bias, int long_thresh, hipStream_t s) {
+  if (!spmm_ldsb_fits(K, N)) return MI_EINVAL;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+      (void)hipGetLastError();
+      n = 256;
+    }
+    cus = n;
+  }
+  // units: blocks of rows of one item, sized so that all CUs get work (two blocks per item for 384 items on 256 CUs),
+  // never below 64 rows
+  int units_per_item = 1;
+  while ((long)batch * units_per_item < 3L * cus && ((long)M + units_per_item * 2 - 1) / (units_per_item * 2) >= 64)
+    units_per_item *= 2;
+  const int rows_per_unit = (int)(((long)M + units_per_item - 1) / units_per_item);
+  const long total = (long)batch * units_per_item;
+  if (total > 0x7fffffffL) return MI_ERANGE;
+  const unsigned grid = (unsigned)(total < cus ? total : cus);
+  const size_t lds = ((size_t)K + 1) * N * 4;  // + the all-zero row
+  const int G = pow2_ceil(N / 4);
+#define MI_LDSB(G_)                                                                                                   \
+  do {                                                                                                                \
+    auto k = spmm_ldsb_kernel<G_>;                                                                                    \
+    if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kWaves * 64), lds, s, rowptr, col, val, B, C, M, K, N, (long)ldb, (long)ldc, \
+                       (long)strideB, (long)strideC, bias, units_per_item, rows_per_unit, (unsigned)total, long_thresh); \
+  } while (0)
+  switch (G) {
+    case 1: MI_LDSB(1); break;
+    case 2: MI_LDSB(2); break;
+    case 4: MI_LDSB(4); break;
+    case 8: MI_LDSB(8); break;
+    case 16: MI_LDSB(16); break;
+    case 32: MI_LDSB(32); break;
+    default: MI_LDSB(64); break;
+  }
+#undef MI_LDSB
+  return check_launch();
+}
+
+}  // namespace mi

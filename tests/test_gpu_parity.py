@@ -88,7 +88,7 @@ def test_spmm_every_variant_is_bit_identical(capi, dev, oracle_mod, M, K, N, den
     d = [t(x, dev) for x in (rowptr, col, val, B)]
     ran = 0
     chain = oracle_mod.spmm_csr_chain(rowptr, col, val, M, K, B)  # explicit group variants ignore the N < 4 rule
-    for variant in range(18):
+    for variant in range(19):
         C = torch.full((M, N), float("nan"), device=dev)
         st = capi.mi_spmm_csr_f32_variant(variant, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(val), M, K,
                                           N, d[3].data_ptr(), N, C.data_ptr(), N,
@@ -2178,3 +2178,69 @@ def test_gemm_short_k_chains_of_two_three_and_four_tiles(cmm, dev, oracle_mod, k
             C = torch.full((batch, m, n), float("nan"), device=dev)
             cmm.cublas_bmm(t(a, dev), t(b, dev), C, 3, ta, tb)
             assert np.array_equal(C.cpu().numpy(), gemm_ref(oracle_mod, a, b, ta, tb)), (n, ta, tb)
+
+
+@pytest.mark.parametrize("N", [4, 8, 16, 32, 64, 96, 128, 256])
+def test_spmm_lds_resident_b_plan_bit_exact(capi, cmm, dev, oracle_mod, N):
+    """MI_SPMM_LDS_B (spmm_ldsb.hip): an item's whole B copied into LDS, rows gather from there — every group width
+    (DPP row broadcasts for 8 / 16 / 32 lanes, readlane for 64, ds_bpermute below), batched with per-item and shared
+    B, shuffled columns, duplicates, empty rows, a row count that is not a multiple of anything: bit-identical to the
+    oracle's batched product and to the row-split group kernel.  Reference: the per-slice recursion of naive_matmul,
+    matmuls.py:282-297."""
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_spmm_csr_batched_variant_f32.argtypes = [ctypes.c_int, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp]
+    stream = torch.cuda.current_stream().cuda_stream
+    g = np.random.Generator(np.random.PCG64(N))
+    K = min(300, (128 * 1024) // (4 * N))
+    for batch, M, share_b in ((1, 777, False), (5, 333, False), (7, 130, True)):
+        lens = g.integers(0, 70, size=batch * M)
+        lens[g.integers(0, batch * M, size=5)] = 0
+        lens[3] = 2 * K + 5                                     # longer than K: duplicate columns
+        cols = [g.integers(0, K, size=int(n)).astype(np.int32) for n in lens]
+        cols = [c if i % 3 else np.sort(c) for i, c in enumerate(cols)]
+        col = np.concatenate(cols)
+        val = g.random(len(col), dtype=np.float32) - 0.5
+        off = np.zeros((batch, M + 1), np.int64)
+        off[:, 1:] = np.cumsum(lens).reshape(batch, M)
+        off[1:, 0] = off[:-1, M]
+        off = off.astype(np.int32)
+        B = g.random((K, N) if share_b else (batch, K, N), dtype=np.float32) - 0.5
+        want = oracle_mod.spmm_csr_batched(off, col, val, batch, M, K, B)
+        d_off, d_col, d_val, d_B = t(off, dev), t(col, dev), t(val, dev), t(B, dev)
+        outs = {}
+        for variant in (18, 5):
+            C = torch.full((batch, M, N), float("nan"), device=dev)
+            st = capi.mi_spmm_csr_batched_variant_f32(variant, d_off.data_ptr(), d_col.data_ptr(), d_val.data_ptr(), len(col),
+                                                      batch, M, K, N, d_B.data_ptr(), N, 0 if share_b else K * N, C.data_ptr(),
+                                                      N, M * N, stream)
+            assert st == 0, (variant, batch, M, K, N)
+            outs[variant] = C.cpu().numpy()
+        assert np.array_equal(outs[18], want), (batch, M, K, N)
+        assert np.array_equal(outs[18], outs[5])
+
+
+def test_spmm_lds_resident_b_is_autos_choice_for_pruned_attention_and_keeps_the_long_row_rule(capi, cmm, dev, oracle_mod):
+    """AUTO resolves BERT-base's pruned probs·V (384 items of 512×512 · 512×64 in batched CSR form, BASELINE.json
+    configs[4]) to MI_SPMM_LDS_B; a shape the plan does not fit (K·N·4 > 128 KB) stays on the row-split kernels.
+    With one item (a tall matrix on a small B) the long-row rule still holds under this plan: a row beyond 8192
+    non-zeros (duplicate columns) is skipped, listed and summed by the follow-up kernel in the split order, with the
+    fused bias — the oracle's statement of mi_spmm_csr_ws_f32 (reference entry src/custom_mm.cpp:166-179)."""
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_spmm_csr_batched_f32_plan.argtypes = [i64, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64]
+    capi.mi_spmm_csr_f32_plan.argtypes = [i64, i32, i32, i32, vp, i64, vp, i64]
+    assert capi.mi_spmm_csr_batched_f32_plan(10_000_000, 384, 512, 512, 64, None, 64, 512 * 64, None, 64, 512 * 64) == 18
+    assert capi.mi_spmm_csr_batched_f32_plan(10_000_000, 96, 1024, 1024, 64, None, 64, 1024 * 64, None, 64, 1024 * 64) != 18
+    g = np.random.Generator(np.random.PCG64(18))
+    M, K, N = 20000, 256, 64
+    lens = g.integers(2, 12, size=M)
+    lens[77], lens[19999] = 9000, 70000
+    col = np.concatenate([g.integers(0, K, size=int(n)).astype(np.int32) for n in lens])
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    val = g.random(len(col), dtype=np.float32) - 0.5
+    B, bias = g.random((K, N), dtype=np.float32) - 0.5, g.random(N, dtype=np.float32)
+    assert capi.mi_spmm_csr_f32_plan(len(col), M, K, N, None, N, None, N) == 18
+    want = oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B)
+    assert np.array_equal(run_spmm(cmm, dev, rowptr, col, val, M, K, B, "naive_spmm"), want)
+    C = torch.full((M, N), float("nan"), device=dev)
+    cmm.naive_spmm_bias(t(val, dev), t(col, dev), t(rowptr, dev), len(col), M, K, t(B, dev), t(bias, dev), C)
+    assert np.array_equal(C.cpu().numpy(), want + bias[None, :])
