@@ -1,0 +1,52 @@
+// Device-side lane helpers shared by the SpMM translation units (not installed).
+#ifndef MI_LANES_H_
+#define MI_LANES_H_
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+namespace mi {
+
+template <int N_, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N_ > 0) {
+    static_for<N_ - 1>(f);
+    f(std::integral_constant<int, N_ - 1>{});
+  }
+}
+
+// Entries a G-lane group keeps per chunk register: a 32-lane group keeps the SAME 16 entries in both of its 16-lane
+// DPP rows (lane l holds entry l & 15), every other width one entry per lane.
+template <int G>
+struct LaneChunk {
+  static constexpr int ENTRIES = G == 32 ? 16 : G;
+};
+
+// Entry I (a compile-time index) of the caller's group's chunk register, without a trip through the LDS crossbar
+// where the hardware offers one: a DPP row broadcast (row_newbcast, a modifier of a VALU move, 16-lane rows) for
+// groups of 8, 16 and 32 lanes — two 8-lane groups share a row and take their halves through the bank mask — a
+// scalar readlane for whole waves; ds_bpermute otherwise.  ds_bpermute is what bounded the group kernels at ≈4.5
+// clocks per non-zero and CU (two per non-zero step: column and value), not the L2s and not the LDS data path
+// (tools/bench_attn_csr.py).
+template <int G, int I, typename T>
+__device__ __forceinline__ T group_lane(T x) {
+  static_assert(sizeof(T) == 4, "one dword per lane");
+  const int bits = __builtin_bit_cast(int, x);
+  int r;
+  if constexpr (G == 16 || G == 32) {
+    r = __builtin_amdgcn_update_dpp(0, bits, 0x150 + I, 0xf, 0xf, true);
+  } else if constexpr (G == 8) {
+    r = __builtin_amdgcn_update_dpp(0, bits, 0x150 + I, 0xf, 0x3, false);      // lanes 0-7 of every row: their entry I
+    r = __builtin_amdgcn_update_dpp(r, bits, 0x150 + 8 + I, 0xf, 0xc, false);  // lanes 8-15: theirs
+  } else if constexpr (G == 64) {
+    r = __builtin_amdgcn_readlane(bits, I);
+  } else {
+    r = __shfl(bits, I, G);
+  }
+  return __builtin_bit_cast(T, r);
+}
+
+}  // namespace mi
+
+#endif  // MI_LANES_H_

@@ -24,6 +24,7 @@
 //    broadcast inside the G-lane group with ds_bpermute); arbitrary N or
 //    unaligned operands: the same kernel with one float per lane.
 #include "mi_common.h"
+#include "mi_lanes.h"
 
 namespace {
 
@@ -593,39 +594,48 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
         }
       }
     } else {
-    for (int p = start; p < end; p += G) {  // trip count differs between groups
-      const int idx = p + gl;
+    // a chunk of EPC entries per coalesced load, handed round the group with compile-time lane indices so that the
+    // broadcast is a DPP modifier / a scalar readlane instead of two ds_bpermute per non-zero (mi_lanes.h)
+    constexpr int EPC = mi::LaneChunk<G>::ENTRIES;
+    for (int p = start; p < end; p += EPC) {  // trip count differs between groups
+      const int idx = p + (gl & (EPC - 1));
       const int myc = idx < end ? col[idx] : 0;
       const float myv = idx < end ? val[idx] : 0.f;
-      const int cnt = (end - p) < G ? (end - p) : G;  // group-uniform
-      int i = 0;
-      for (; i + UI <= cnt; i += UI) {
-        vec_t x[UI][T];
-        float v[UI];
+      const int cnt = (end - p) < EPC ? (end - p) : EPC;  // group-uniform
+      mi::static_for<EPC / UI>([&](auto b_) {
+        constexpr int b = UI * decltype(b_)::value;
+        if (b + UI <= cnt) {
+          vec_t x[UI][T];
+          float v[UI];
+          mi::static_for<UI>([&](auto u_) {
+            constexpr int u = decltype(u_)::value;
+            const int c = mi::group_lane<G, b + u>(myc);
+            v[u] = mi::group_lane<G, b + u>(myv);
+            const float* src = Bi + (long)c * ldb;
 #pragma unroll
-        for (int u = 0; u < UI; ++u) {
-          const int c = __shfl(myc, i + u, G);
-          v[u] = __shfl(myv, i + u, G);
-          const float* src = Bi + (long)c * ldb;
+            for (int t = 0; t < T; ++t)
+              if (on[t]) x[u][t] = V::load(src + coff[t]);
+          });
 #pragma unroll
-          for (int t = 0; t < T; ++t)
-            if (on[t]) x[u][t] = V::load(src + coff[t]);
+          for (int u = 0; u < UI; ++u) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+              if (on[t]) acc[t] = V::fma(v[u], x[u][t], acc[t]);
+          }
+        } else if (b < cnt) {
+          mi::static_for<UI>([&](auto u_) {
+            constexpr int u = decltype(u_)::value;
+            if (b + u < cnt) {
+              const int c = mi::group_lane<G, b + u>(myc);
+              const float v = mi::group_lane<G, b + u>(myv);
+              const float* src = Bi + (long)c * ldb;
+#pragma unroll
+              for (int t = 0; t < T; ++t)
+                if (on[t]) acc[t] = V::fma(v, V::load(src + coff[t]), acc[t]);
+            }
+          });
         }
-#pragma unroll
-        for (int u = 0; u < UI; ++u) {
-#pragma unroll
-          for (int t = 0; t < T; ++t)
-            if (on[t]) acc[t] = V::fma(v[u], x[u][t], acc[t]);
-        }
-      }
-      for (; i < cnt; ++i) {
-        const int c = __shfl(myc, i, G);
-        const float v = __shfl(myv, i, G);
-        const float* src = Bi + (long)c * ldb;
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-          if (on[t]) acc[t] = V::fma(v, V::load(src + coff[t]), acc[t]);
-      }
+      });
     }
     }
     if (row < M && !skipped) {

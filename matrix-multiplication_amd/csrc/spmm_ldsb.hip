@@ -18,13 +18,14 @@
 //     prefetched across rows (the L2-gather kernels lean on 16+ resident waves per SIMD instead: here LDS is full);
 //   * every output element is the row's non-zeros in CSR order, one fmaf chain: the bits of every other plan.
 // Rows beyond the long-row threshold are skipped (spmm_dispatch lists them and runs its follow-up kernel), batch = 1 only.
-#include <type_traits>
-
 #include "mi_common.h"
+#include "mi_lanes.h"
 
 namespace {
 
 using mi::f32x4;
+using mi::group_lane;
+using mi::static_for;
 
 __device__ __forceinline__ f32x4 fma4(float a, f32x4 x, f32x4 acc) {
   acc.x = __builtin_fmaf(a, x.x, acc.x);
@@ -35,41 +36,6 @@ __device__ __forceinline__ f32x4 fma4(float a, f32x4 x, f32x4 acc) {
 }
 
 constexpr int kWaves = 16;
-
-// The value entry I of the caller's group's current chunk, without a trip through the LDS crossbar where the hardware
-// offers one: a DPP row broadcast (row_newbcast: a modifier of a VALU move, 16-lane rows) for groups of 8, 16 and 32
-// lanes — a 32-lane group keeps the SAME 16 entries in both of its rows, two 8-lane groups share a row and take
-// their halves through the bank mask — a scalar readlane for whole waves; ds_bpermute otherwise.  (ds_bpermute is
-// what bounds the row-split group kernels at ≈4.5 clocks per non-zero and CU — two of them per non-zero step — not
-// the L2s and not the LDS data path.)
-template <int G>
-struct Chunk {
-  static constexpr int ENTRIES = G == 32 ? 16 : G;  // entries a group holds per chunk register
-};
-template <int G, int I, typename T>
-__device__ __forceinline__ T group_lane(T x) {
-  const int bits = __builtin_bit_cast(int, x);
-  int r;
-  if constexpr (G == 16 || G == 32) {
-    r = __builtin_amdgcn_update_dpp(0, bits, 0x150 + I, 0xf, 0xf, true);
-  } else if constexpr (G == 8) {
-    r = __builtin_amdgcn_update_dpp(0, bits, 0x150 + I, 0xf, 0x3, false);      // lanes 0-7 of every row: their entry I
-    r = __builtin_amdgcn_update_dpp(r, bits, 0x150 + 8 + I, 0xf, 0xc, false);  // lanes 8-15: theirs
-  } else if constexpr (G == 64) {
-    r = __builtin_amdgcn_readlane(bits, I);
-  } else {
-    r = __shfl(bits, I, G);
-  }
-  return __builtin_bit_cast(T, r);
-}
-
-template <int N_, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (N_ > 0) {
-    static_for<N_ - 1>(f);
-    f(std::integral_constant<int, N_ - 1>{});
-  }
-}
 
 template <int G>
 __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
@@ -110,7 +76,7 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
     // of a long row while the current one is processed — left to itself every chunk of G entries cost its own trip
     // to memory (≈3 k cycles per 64 non-zeros of a wave: the first version ran at the L2-gather kernel's speed).
     constexpr int SC = 4;
-    constexpr int EPC = Chunk<G>::ENTRIES;  // entries per chunk
+    constexpr int EPC = mi::LaneChunk<G>::ENTRIES;  // entries per chunk
     constexpr int STRIDE = kWaves * RPW;
     auto load_bounds = [&](int rb, int& st, int& en, bool& skip) {
       const int row = rb + lane / G;
