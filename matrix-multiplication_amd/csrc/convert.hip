@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "mi_common.h"
+#include "mi_lanes.h"
 
 namespace {
 
@@ -454,6 +455,78 @@ __global__ __launch_bounds__(256) void sddmm_kernel(const int* __restrict__ rowp
   }
 }
 
+// The same sums for narrow rows (N ≤ 64, N % 4 == 0 — attention heads): G = N/4 (rounded up to a power of two) lanes
+// per row of A instead of a whole wave of which only N/4 lanes had columns, 64/G rows per wave.  Lane l of a group
+// chains columns 4l … 4l+3 — the chain of lane l of the wave above — and the joint xor tree runs over the distances
+// G/2 … 1; the levels 32 … G of the 64-lane tree only ever added the +0 of a lane without columns, which changes a
+// partial sum in one case, −0 → +0 (a chain of products that all underflow): `+ 0.0f` per skipped level restates
+// exactly that.  Same bits as sddmm_kernel and the oracle; 4× the gathers in flight at N = 64 (block-diagonal batch of
+// 384 × 512² at 10 %: 0.43 → see profiles/r03_attention_csr.log).  A row's columns travel to its group through
+// compile-time lane broadcasts (mi_lanes.h).
+template <int G>  // ≤ 16: a group's columns sit in one 16-lane DPP row
+__global__ __launch_bounds__(256) void sddmm_group_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                          int M, int N, const float* __restrict__ dC, long lddc,
+                                                          const float* __restrict__ B, long ldb,
+                                                          float* __restrict__ out) {
+  constexpr int RPW = 64 / G;
+  constexpr int U = G < 8 ? G : 8;  // gathers in flight per lane
+  const int lane = threadIdx.x & 63, gl = lane & (G - 1);
+  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / G;
+  const int nq = N >> 2;
+  const bool on = gl < nq;
+  int start = 0, end = 0;
+  if (row < M) {
+    start = rowptr[row];
+    end = rowptr[row + 1];
+  }
+  mi::f32x4 x = mi::f32x4{0.f, 0.f, 0.f, 0.f};
+  if (on && start < end) x = *reinterpret_cast<const mi::f32x4*>(dC + row * lddc + 4 * gl);
+  for (int p0 = start; p0 < end; p0 += G) {  // trip count differs between groups
+    const int cnt = end - p0 < G ? end - p0 : G;  // group-uniform
+    const int mycol = gl < cnt ? col[p0 + gl] : 0;  // past the row's end: row 0 of B (its sum is never stored)
+    float s[G];
+    mi::static_for<G / U>([&](auto b_) {
+      constexpr int i = U * decltype(b_)::value;
+      if (i < cnt) {
+        mi::f32x4 y[U];
+        mi::static_for<U>([&](auto u_) {
+          constexpr int u = decltype(u_)::value;
+          const float* brow = B + (long)mi::group_lane<G, i + u>(mycol) * ldb;
+          y[u] = on ? *reinterpret_cast<const mi::f32x4*>(brow + 4 * gl) : mi::f32x4{0.f, 0.f, 0.f, 0.f};
+        });
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float acc = 0.f;
+          if (on) {
+            acc = __builtin_fmaf(x.x, y[u].x, acc);
+            acc = __builtin_fmaf(x.y, y[u].y, acc);
+            acc = __builtin_fmaf(x.z, y[u].z, acc);
+            acc = __builtin_fmaf(x.w, y[u].w, acc);
+          }
+#pragma unroll
+          for (int w = 32; w >= G; w >>= 1) acc = acc + 0.0f;  // the tree levels whose partner never had columns
+          s[i + u] = acc;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) s[i + u] = 0.f;
+      }
+    });
+    // joint xor tree over the group (see sddmm_kernel): after the last level lane l holds the sum of entry l
+#pragma unroll
+    for (int w = G / 2; w >= 1; w >>= 1) {
+      const bool hi = (gl & w) != 0;
+#pragma unroll
+      for (int k = 0; k < w; ++k) {
+        const float keep = hi ? s[k + w] : s[k];
+        const float send = hi ? s[k] : s[k + w];
+        s[k] = keep + __shfl_xor(send, w, 64);
+      }
+    }
+    if (gl < cnt) out[p0 + gl] = s[0];
+  }
+}
+
 }  // namespace
 
 
@@ -681,6 +754,22 @@ int mi_sddmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz, int
         return mi::check_launch();
       }
     }
+  }
+  if (vec && N >= 4 && N <= 64) {  // narrow rows: N/4 lanes per row, several rows per wave (one DPP row at most)
+    const int G = mi::pow2_ceil(N / 4);
+    const long gblocks = ((long)M + 4 * (64 / G) - 1) / (4 * (64 / G));
+#define MI_SDDMM_G(G_)                                                                                               \
+  hipLaunchKernelGGL((sddmm_group_kernel<G_>), dim3((unsigned)gblocks), dim3(256), 0, s, rowptr, col, M, N, dC, (long)lddc, \
+                     B, (long)ldb, out_val)
+    switch (G) {
+      case 1: MI_SDDMM_G(1); break;
+      case 2: MI_SDDMM_G(2); break;
+      case 4: MI_SDDMM_G(4); break;
+      case 8: MI_SDDMM_G(8); break;
+      default: MI_SDDMM_G(16); break;
+    }
+#undef MI_SDDMM_G
+    return mi::check_launch();
   }
   if (vec) {
     if (T == 1) MI_SDDMM(1, true);

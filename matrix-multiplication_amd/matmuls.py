@@ -299,6 +299,45 @@ def fused_skip_pays(items: int, rows: int, cols: int, width: int = 256) -> bool:
     return cols <= 3072
 
 
+def _batched_csr_pattern(a: torch.Tensor, dev, transposed: bool = False):
+    '''The index side of a batched CSR tensor ([..., M, K], equal non-zero counts per item) as the batched kernels
+    want it, kept ON the tensor object between calls (keyed on the index tensors' storage and version counters):
+    `offsets` int32 [batch, M + 1] with every item's base added ("rowptr of rowptrs"), `columns` int32 [nnz]; with
+    `transposed`, also what the backward needs — the flat offsets [batch·M + 1] and block-diagonal columns (item i
+    shifted by i·K) of the whole batch as ONE matrix, and the pattern of every item's transpose with the permutation
+    that carries the values into it (one batched device transpose of 0, 1, 2, …: the kernels move 4-byte values
+    untouched).  A training loop with a static pattern pays the narrowing and the transpose once; values are never
+    cached (see _csr_cached).'''
+    rows, cols = a.shape[-2], a.shape[-1]
+    crow = torch.Tensor.crow_indices(a).reshape(-1, rows + 1)
+    col = torch.Tensor.col_indices(a)
+    nb, per_item = crow.shape[0], col.shape[-1]
+    total = nb * per_item
+    key = (crow.data_ptr(), col.data_ptr(), crow._version, col._version, tuple(a.shape), per_item, str(dev))
+    hit = getattr(a, '_mi_batched_pattern', None)
+    if hit is None or hit[0] != key:
+        if total >= 2 ** 31 or nb * max(rows, cols) >= 2 ** 31:
+            raise ValueError('sparse matmul: the batch holds too many non-zeros / rows for int32 indices')
+        base = torch.arange(nb, device=crow.device, dtype=crow.dtype).unsqueeze(1) * per_item
+        hit = [key, (crow + base).to(device=dev, dtype=torch.int32).contiguous(),
+               col.reshape(-1).to(device=dev, dtype=torch.int32).contiguous(), None]
+        try:
+            a._mi_batched_pattern = hit
+        except (AttributeError, RuntimeError):
+            pass  # a tensor type that takes no attributes: just no caching
+    if transposed and hit[3] is None:
+        offsets, columns = hit[1], hit[2]
+        flat_off = torch.cat([offsets[:, :-1].reshape(-1), offsets[-1:, -1]]).contiguous()
+        shift = (torch.arange(nb, device=dev, dtype=torch.int32) * cols).repeat_interleave(per_item)
+        t_perm = t_col = t_off = None
+        if nb <= 65535:
+            iota = torch.arange(total, device=dev, dtype=torch.int32).view(torch.float32)
+            t_perm, t_col, t_off = custom_mm.csr_transpose_batched(iota, columns, offsets, total, nb, rows, cols)
+            t_perm = t_perm.view(torch.int32)
+        hit[3] = (flat_off, columns + shift, t_perm, t_col, t_off)
+    return hit[1], hit[2], hit[3]
+
+
 def _batched_csr_product(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch.Tensor:
     '''A batched CSR tensor ([..., M, K], every item with the same number of non-zeros — what torch builds) as the
     sparse operand: the reference recurses over the leading dimension (matmuls.py:289-293); here the whole batch is
@@ -321,10 +360,8 @@ def _batched_csr_product(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) ->
     _b = (b.reshape(nb, cols, n) if b.dim() > 2 else b).to(dev)  # a 2-d b is shared by every item
     c = torch.empty((nb, rows, n), device=dev, dtype=torch.float32)
     if mm_op is default_op:
-        base = torch.arange(nb, device=crow.device, dtype=crow.dtype).unsqueeze(1) * per_item
-        offsets = (crow + base).to(device=dev, dtype=torch.int32).contiguous()
+        offsets, columns, _ = _batched_csr_pattern(a, dev)
         values = val.reshape(-1).to(dev).contiguous()
-        columns = col.reshape(-1).to(device=dev, dtype=torch.int32).contiguous()
         for lo in range(0, nb, 65535):
             hi = min(nb, lo + 65535)
             custom_mm.naive_spmm_batched(values, columns, offsets[lo:hi].contiguous(), total, hi - lo, rows, cols,
@@ -535,6 +572,40 @@ def _csr_cached(m1: torch.Tensor):
     return props, (values.index_select(0, hit[1]), hit[2], hit[3])
 
 
+def _batched_csr_backward(ctx, m1, m2, grad_output):
+    '''Both gradients of C[i] = m1[i] @ m2[i] for a batched CSR m1 ([..., M, K], equal non-zero counts per item — what
+    torch builds) in a handful of launches for the whole batch (the reference has no backward for this input,
+    matmuls.py:250-254):
+      grad_m2[i] = m1[i]ᵀ·dC[i] — one batched device transpose (custom_mm.csr_transpose_batched) + one batched
+        product, whose B (dC[i], M×N) sits in LDS where it fits; a shared 2-d m2 gets the sum over the items;
+      grad_m1 on m1's pattern — ONE SDDMM on the block-diagonal matrix of the batch: rows stacked, item i's columns
+        shifted by i·K, against the stacked dC [batch·M, N] and m2 [batch·K, N].'''
+    rows, cols = m1.shape[-2], m1.shape[-1]
+    n = m2.shape[-1]
+    val = torch.Tensor.values(m1)
+    nb = torch.Tensor.crow_indices(m1).reshape(-1, rows + 1).shape[0]
+    total = val.numel()
+    dev = grad_output.device
+    if nb > 65535:
+        raise NotImplementedError('sparse matmul backward: more than 65535 items in a batched CSR tensor')
+    offsets, columns, (flat_off, diag_columns, t_perm, t_col, t_off) = _batched_csr_pattern(m1, dev, transposed=True)
+    g = grad_output.reshape(nb, rows, n).contiguous()
+    shared = m2.dim() == 2
+    grad_m1 = grad_m2 = None
+    if ctx.needs_input_grad[0]:
+        b_stack = (m2.unsqueeze(0).expand(nb, cols, n) if shared else m2.reshape(nb, cols, n)).reshape(nb * cols, n)
+        gvals = custom_mm.sddmm(diag_columns, flat_off, total, nb * rows, nb * cols, g.reshape(nb * rows, n),
+                                b_stack.contiguous())
+        grad_m1 = torch.sparse_csr_tensor(torch.Tensor.crow_indices(m1), torch.Tensor.col_indices(m1),
+                                          gvals.to(val.device).reshape(val.shape), size=m1.shape)
+    if ctx.needs_input_grad[1]:
+        t_val = val.reshape(-1).to(dev).index_select(0, t_perm)
+        gb = torch.empty((nb, cols, n), device=dev, dtype=torch.float32)
+        custom_mm.naive_spmm_batched(t_val, t_col, t_off, total, nb, cols, rows, g, gb)
+        grad_m2 = gb.sum(0) if shared else gb.reshape(m2.shape)
+    return grad_m1, grad_m2
+
+
 def _sparse_backward(ctx, grad_output):
     '''Gradients of C = m1 @ m2 with m1 taken as sparse.
 
@@ -550,8 +621,7 @@ def _sparse_backward(ctx, grad_output):
 
     if m1.is_sparse_csr:
         if m1.dim() > 2:
-            raise NotImplementedError('backward through a batched CSR tensor is not supported (the reference has none '
-                                      'either, matmuls.py:250-254); differentiate item by item')
+            return _batched_csr_backward(ctx, m1, m2, grad_output)
         (values, columns, offsets, nnz, rows, cols), (t_val, t_col, t_off) = _csr_cached(m1)
         if m2.dim() == 1:
             g, b = grad_output.reshape(rows, 1), m2.unsqueeze(-1)

@@ -457,7 +457,7 @@ def test_csr_transpose_config_c3_shape(cmm, dev, oracle_mod):
     assert np.array_equal(t_off.cpu().numpy(), want_off)
 
 
-@pytest.mark.parametrize("N", [1, 8, 64, 100, 256, 300, 512, 777, 1024, 1500, 4100])
+@pytest.mark.parametrize("N", [1, 4, 8, 12, 16, 32, 48, 64, 68, 100, 128, 256, 300, 512, 777, 1024, 1500, 4100])
 def test_sddmm_bit_exact(cmm, dev, oracle_mod, N):
     """Rows of 0 … 400 pattern entries (batches of 64 with a ragged tail), every register-pass count
     of the dC row, odd widths (scalar loads) and rows wider than one register chunk; signed data."""
@@ -2244,3 +2244,31 @@ def test_spmm_lds_resident_b_is_autos_choice_for_pruned_attention_and_keeps_the_
     C = torch.full((M, N), float("nan"), device=dev)
     cmm.naive_spmm_bias(t(val, dev), t(col, dev), t(rowptr, dev), len(col), M, K, t(B, dev), t(bias, dev), C)
     assert np.array_equal(C.cpu().numpy(), want + bias[None, :])
+
+
+def test_batched_csr_tensor_backward(mm, dev):
+    """Both gradients of a product whose sparse operand is a batched CSR tensor (pruned attention probabilities × V,
+    BASELINE.json configs[4]): grad of the dense operand (per item, and summed for a shared one) against torch autograd
+    of the dense product; grad of the sparse operand comes back as a batched CSR tensor on the operand's pattern,
+    equal to the dense gradient sampled there.  The reference has no backward for this input (matmuls.py:250-254)."""
+    g = torch.Generator().manual_seed(9)
+    nb, M, K = 6, 40, 50
+    dense = torch.rand(nb, M, K, generator=g)
+    keep = torch.zeros(nb, M, K, dtype=torch.bool)
+    for i in range(nb):
+        keep[i].view(-1)[torch.randperm(M * K, generator=g)[:300]] = True
+    dense = dense * keep
+    for b in (torch.rand(nb, K, 64, generator=g), torch.rand(K, 36, generator=g), torch.rand(2, 3, K, 8, generator=g)):
+        a_shape = (2, 3, M, K) if b.dim() == 4 else (nb, M, K)
+        for cls in (mm.naiveSpMM, mm.cusparseMM):
+            a = dense.reshape(a_shape).to(dev).to_sparse_csr().requires_grad_(True)
+            b1 = b.to(dev).requires_grad_(True)
+            out = cls.apply(a, b1)
+            dc = torch.rand(out.shape, generator=torch.Generator().manual_seed(4))
+            out.backward(dc.to(dev))
+            a2, b2 = dense.reshape(a_shape).clone().requires_grad_(True), b.clone().requires_grad_(True)
+            torch.matmul(a2, b2).backward(dc)
+            assert torch.allclose(b2.grad, b1.grad.cpu(), rtol=RTOL, atol=1e-5)
+            assert a.grad.is_sparse_csr and a.grad.shape == a.shape
+            assert torch.equal(a.grad.col_indices().cpu(), a.col_indices().cpu())
+            assert torch.allclose((a2.grad * keep.reshape(a_shape)), a.grad.to_dense().cpu(), rtol=RTOL, atol=1e-5)

@@ -1,0 +1,46 @@
+"""Developer probe: pruned BERT-base attention probs·V with the probabilities as a batched CSR TENSOR through
+matmuls.cusparseMM.apply — forward and forward + backward (both gradients), beside the dense cublasMM.apply."""
+import sys
+from pathlib import Path
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "matrix-multiplication_amd"))
+import matmuls  # noqa: E402
+dev = torch.device("cuda")
+
+
+def timeit(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+g = torch.Generator(device=dev).manual_seed(0)
+items, S, D = 384, 512, 64
+v = torch.rand(items, S, D, device=dev, generator=g, requires_grad=True)
+dctx = torch.rand(items, S, D, device=dev, generator=g)
+print("# tools/bench_attn_csr_bwd.py on MI355X: 384 x (512x512 . 512x64), ms")
+for kept in (0.25, 0.1, 0.05):
+    per_item = int(S * S * kept)
+    # equal non-zero counts per item (torch's batched CSR layout)
+    idx = torch.rand(items, S * S, device=dev, generator=g).topk(per_item, dim=1).indices
+    mask = torch.zeros(items, S * S, device=dev).scatter_(1, idx, 1.0)
+    probs = ((torch.rand(items, S * S, device=dev, generator=g) * 0.9 + 0.1) * mask).reshape(items, S, S)
+    a = probs.to_sparse_csr().requires_grad_(True)
+    pd = probs.clone().requires_grad_(True)
+
+    def fb(cls, x):
+        x.grad = None
+        v.grad = None
+        cls.apply(x, v).backward(dctx)
+    t_f = timeit(lambda: matmuls.cusparseMM.apply(a, v))
+    t_fb = timeit(lambda: fb(matmuls.cusparseMM, a))
+    d_f = timeit(lambda: matmuls.cublasMM.apply(pd, v))
+    d_fb = timeit(lambda: fb(matmuls.cublasMM, pd))
+    print(f"kept {kept:4.2f}: CSR tensor fwd {t_f:.3f} fwd+bwd {t_fb:.3f}   dense cublasMM fwd {d_f:.3f} fwd+bwd {d_fb:.3f}", flush=True)
