@@ -70,6 +70,7 @@ def build_library(force=False, verbose=False) -> Path:
     headers = sorted(CSRC.glob("*.h")) + sorted(INCLUDE.glob("*.h"))
     flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}",
              "-Wall", "-Wno-unused-function"]
+    flags += shlex.split(os.environ.get("MI_HIPCC_FLAGS", ""))  # developer A/B builds (-DMI_…); part of the stamp
     hdr_digest = _digest(headers, " ".join(flags))
 
     def compile_one(src: Path):

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void sddmm_group_kernel(const int* __restrict_
         mi::f32x4 y[U];
         mi::static_for<U>([&](auto u_) {
           constexpr int u = decltype(u_)::value;
-          const float* brow = B + (long)mi::group_lane<G, i + u>(mycol) * ldb;
+          const float* brow = B + (long)mi::group_lane<G, i + u, true>(mycol) * ldb;
           y[u] = on ? *reinterpret_cast<const mi::f32x4*>(brow + 4 * gl) : mi::f32x4{0.f, 0.f, 0.f, 0.f};
         });
 #pragma unroll

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
     } else {
     // a chunk of EPC entries per coalesced load, handed round the group with compile-time lane indices so that the
     // broadcast is a DPP modifier / a scalar readlane instead of two ds_bpermute per non-zero (mi_lanes.h)
-    constexpr int EPC = mi::LaneChunk<G>::ENTRIES;
+    constexpr int EPC = mi::LaneChunk<G, false>::ENTRIES;
     for (int p = start; p < end; p += EPC) {  // trip count differs between groups
       const int idx = p + (gl & (EPC - 1));
       const int myc = idx < end ? col[idx] : 0;
@@ -609,8 +609,8 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
           float v[UI];
           mi::static_for<UI>([&](auto u_) {
             constexpr int u = decltype(u_)::value;
-            const int c = mi::group_lane<G, b + u>(myc);
-            v[u] = mi::group_lane<G, b + u>(myv);
+            const int c = mi::group_lane<G, b + u, false>(myc);
+            v[u] = mi::group_lane<G, b + u, false>(myv);
             const float* src = Bi + (long)c * ldb;
 #pragma unroll
             for (int t = 0; t < T; ++t)
@@ -626,8 +626,8 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
           mi::static_for<UI>([&](auto u_) {
             constexpr int u = decltype(u_)::value;
             if (b + u < cnt) {
-              const int c = mi::group_lane<G, b + u>(myc);
-              const float v = mi::group_lane<G, b + u>(myv);
+              const int c = mi::group_lane<G, b + u, false>(myc);
+              const float v = mi::group_lane<G, b + u, false>(myv);
               const float* src = Bi + (long)c * ldb;
 #pragma unroll
               for (int t = 0; t < T; ++t)

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
     // of a long row while the current one is processed — left to itself every chunk of G entries cost its own trip
     // to memory (≈3 k cycles per 64 non-zeros of a wave: the first version ran at the L2-gather kernel's speed).
     constexpr int SC = 4;
-    constexpr int EPC = mi::LaneChunk<G>::ENTRIES;  // entries per chunk
+    constexpr int EPC = mi::LaneChunk<G, true>::ENTRIES;  // entries per chunk
     constexpr int STRIDE = kWaves * RPW;
     auto load_bounds = [&](int rb, int& st, int& en, bool& skip) {
       const int row = rb + lane / G;
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
               static_for<4>([&](auto e_) {
                 constexpr int e = decltype(e_)::value;
                 constexpr int I = b + e < EPC ? b + e : EPC - 1;
-                const int off = b + e < EPC ? group_lane<G, I>(c0[j]) : K * row_bytes;  // (G < 4: the zero row)
-                v[e] = b + e < EPC ? group_lane<G, I>(v0[j]) : 0.f;
+                const int off = b + e < EPC ? group_lane<G, I, true>(c0[j]) : K * row_bytes;  // (G < 4: the zero row)
+                v[e] = b + e < EPC ? group_lane<G, I, true>(v0[j]) : 0.f;
                 x[e] = *reinterpret_cast<const f32x4*>(Bbytes + off);
               });
 #pragma unroll

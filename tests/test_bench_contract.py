@@ -32,7 +32,11 @@ def test_recorded_bench_lines_follow_the_contract(name):
         assert roof["kernel_ms_per_step_min"] <= roof["kernel_ms_per_step_median"] and roof["kernel_ms_per_step"] > 0
     if name[:3] in ("r02", "r03"):
         # a cache-resident B (C2) is priced against the cache-gather figure, never as an HBM fraction > 1
-        assert roof["frac"] <= 1.0 and (roof["bound"] == "cache") == ("64k" in rec["config"]["workload"])
+        # (that figure is the guide's MEASURED gather rate from a cache-resident table, 8.6 TB/s — a reference, not a
+        # hardware limit: C2 passed it by 2 % once its kernel stopped paying for ds_bpermute in round 3; the HBM and
+        # MFMA peaks are limits)
+        assert roof["frac"] <= (1.05 if roof["bound"] == "cache" else 1.0)
+        assert (roof["bound"] == "cache") == ("64k" in rec["config"]["workload"])
     if roof["bound"] in ("hbm", "cache"):
         assert roof["peak"] == (8000.0 if roof["bound"] == "hbm" else 8600.0)
         cpu = rec["cpu_baseline"]
