@@ -2272,3 +2272,64 @@ def test_batched_csr_tensor_backward(mm, dev):
             assert a.grad.is_sparse_csr and a.grad.shape == a.shape
             assert torch.equal(a.grad.col_indices().cpu(), a.col_indices().cpu())
             assert torch.allclose((a2.grad * keep.reshape(a_shape)), a.grad.to_dense().cpu(), rtol=RTOL, atol=1e-5)
+
+
+def test_batched_spmm_variants_fuzz_against_oracle(capi, dev, oracle_mod):
+    """Random batched products through `mi_spmm_csr_batched_variant_f32` — the LDS-resident-B plan (18), the group
+    kernels with float4 / scalar lanes (4, 5: DPP row broadcasts for 8- and 16-lane groups, 32-entry ds_bpermute chunks
+    for 32 lanes, readlane for 64) and AUTO (0): random widths (every group width, widths that are not powers of two),
+    padded ldb / ldc and item strides, shared B, shuffled rows with duplicates, empty rows and items — each bit-identical
+    to the oracle's batched product, padding of C untouched.  MI_FUZZ_CASES / MI_FUZZ_SEED as above."""
+    import os
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_spmm_csr_batched_variant_f32.argtypes = [ctypes.c_int, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp]
+    stream = torch.cuda.current_stream().cuda_stream
+    g = np.random.Generator(np.random.PCG64(int(os.environ.get("MI_FUZZ_SEED", "505"))))
+    cases = int(os.environ.get("MI_FUZZ_CASES", "40"))
+    took = {}
+    for case in range(cases):
+        batch = int(g.choice([1, 1, 2, 3, 6]))
+        M, K = int(g.integers(1, 500)), int(g.integers(1, 400))
+        N = int(g.choice([4, 8, 12, 16, 20, 32, 36, 48, 64, 68, 96, 128, 132, 200, 256, 7, 30, 100]))
+        mean = float(g.choice([0.5, 3, 12, 40, 90]))
+        lens = g.poisson(mean, size=batch * M)
+        lens[g.integers(0, batch * M, size=3)] = 0
+        cols = []
+        for i, n in enumerate(lens):
+            c = g.integers(0, K, size=int(n)).astype(np.int32)
+            cols.append(np.sort(c) if i % 4 else c)
+        col = np.concatenate(cols) if len(cols) else np.zeros(0, np.int32)
+        val = g.random(len(col), dtype=np.float32) - 0.5
+        off = np.zeros((batch, M + 1), np.int64)
+        off[:, 1:] = np.cumsum(lens).reshape(batch, M)
+        off[1:, 0] = off[:-1, M]
+        off = off.astype(np.int32)
+        share_b = batch > 1 and bool(g.integers(0, 3) == 0)
+        pad = int(g.choice([0, 0, 4, 8])) if N % 4 == 0 else int(g.choice([0, 1, 3]))
+        ldb, ldc = N + pad, N + (pad if g.integers(0, 2) else 0)
+        sb = 0 if share_b else K * ldb + (8 if pad else 0)
+        sc = M * ldc + (12 if pad else 0)
+        Bbuf = g.random((1 if share_b else batch) * max(sb, K * ldb) + 16, dtype=np.float32) - 0.5
+        view = lambda buf, i, stride, rows, cols_, ld: np.lib.stride_tricks.as_strided(buf[i * stride:], shape=(rows, cols_), strides=(ld * 4, 4))
+        Bs = np.stack([np.ascontiguousarray(view(Bbuf, 0 if share_b else i, sb, K, N, ldb)) for i in range(batch)])
+        want = oracle_mod.spmm_csr_batched(off, col, val, batch, M, K, Bs)
+        d_off, d_col, d_val, d_B = t(off, dev), t(col, dev), t(val, dev), t(Bbuf, dev)
+        ran = 0
+        for variant in (0, 4, 5, 18):
+            C = torch.full((batch * sc + 16,), float("nan"), device=dev)
+            st = capi.mi_spmm_csr_batched_variant_f32(variant, d_off.data_ptr(), d_col.data_ptr(), d_val.data_ptr(), len(col),
+                                                      batch, M, K, N, d_B.data_ptr(), ldb, sb, C.data_ptr(), ldc, sc, stream)
+            what = (case, variant, batch, M, K, N, ldb, ldc, sb, sc, len(col))
+            if st == -1 and variant in (4, 18):   # not float4-able (N % 4, padding) or B does not fit LDS
+                continue
+            assert st == 0, what
+            ran += 1
+            took[variant] = took.get(variant, 0) + 1
+            got = C.cpu().numpy()
+            written = np.zeros(got.shape, dtype=bool)
+            for i in range(batch):
+                assert np.array_equal(view(got, i, sc, M, N, ldc), want[i]), what
+                written[(i * sc + np.arange(M)[:, None] * ldc + np.arange(N)[None, :]).ravel()] = True
+            assert np.isnan(got[~written]).all(), what
+        assert ran >= 2
+    assert took.get(18, 0) >= cases // 4 and took.get(4, 0) >= cases // 4 and took[0] == took[5] == cases, took
