@@ -1013,8 +1013,9 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
   // (tools/bench_attn_csr.py, profiles/r03_attention_csr.log: 384 × 512² × 64 at 10 % kept 0.125 → 0.058 ms, at
   // 1 % 0.038 → 0.032; N = 256 has the one-wave-per-row kernels, whose col / val travel through scalar registers:
   // 65536 × 128 × 256 at 5 % 0.020 ms there vs 0.028 here, at 25 % 0.074 vs 0.046)
+  // (a B that needs column tiles re-reads col / val per tile: rows must be that much longer)
   if (sh.vec4_ok && mi::spmm_ldsb_fits(K, N) && (long)batch * M >= 16384 &&
-      nnz >= (N > 128 ? 4 * MI_SPMM_LDSB_MIN_ROW : MI_SPMM_LDSB_MIN_ROW) * (long)batch * M)
+      nnz >= (N > 128 ? 4 * MI_SPMM_LDSB_MIN_ROW : MI_SPMM_LDSB_MIN_ROW) * mi::spmm_ldsb_tiles(K, N) * (long)batch * M)
     return MI_SPMM_LDS_B;
   const int lp = (sh.wave_ok && batch == 1) ? l2_panels(M, K, N, ldb, nnz) : 0;
   // Moderate density: stage B through LDS (spmm_slab.hip) when its cost model beats the L2-blocked

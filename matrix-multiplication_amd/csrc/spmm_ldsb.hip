@@ -41,8 +41,8 @@ template <int G>
 __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ B, float* __restrict__ C, int M, int K, int N, long ldb, long ldc, long strideB,
-    long strideC, const float* __restrict__ bias, int units_per_item, int rows_per_unit, unsigned total_units,
-    int long_thresh) {
+    long strideC, const float* __restrict__ bias, int ctiles, int units_per_item, int rows_per_unit,
+    unsigned total_units, int long_thresh) {  // N: width of one column tile (the whole row when ctiles = 1)
   extern __shared__ __attribute__((aligned(16))) f32x4 Bs[];  // [K][N / 4]
   constexpr int RPW = 64 / G;  // rows per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -53,11 +53,14 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
   const unsigned u0 = blockIdx.x * per, u1 = u0 + per < total_units ? u0 + per : total_units;
   long staged = -1;
   for (unsigned u = u0; u < u1; ++u) {  // workgroup-uniform
-    const long item = u / (unsigned)units_per_item;
+    // unit → (item, column tile, block of rows), blocks of one (item, tile) adjacent: they share the staged slice
+    const long slice = u / (unsigned)units_per_item;  // item · ctiles + tile
     const int part = (int)(u % (unsigned)units_per_item);
-    if (item != staged) {
-      if (staged >= 0) __syncthreads();  // every wave is done with the previous item's B
-      const float* Bi = B + item * strideB;
+    const long item = slice / ctiles;
+    const int col0 = (int)(slice % ctiles) * N;
+    if (slice != staged) {
+      if (staged >= 0) __syncthreads();  // every wave is done with the previous slice of B
+      const float* Bi = B + item * strideB + col0;
       const int total4 = K * nq;
       for (int i = tid; i < total4; i += kWaves * 64) {
         const int r = i / nq, q = i - r * nq;
@@ -65,10 +68,11 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
       }
       if (tid < nq) Bs[total4 + tid] = f32x4{0.f, 0.f, 0.f, 0.f};  // row K: what the padding of a row's last chunk reads
       __syncthreads();
-      staged = item;
+      staged = slice;
     }
     const int* rp = rowptr + item * ((long)M + 1);
-    float* Ci = C + item * strideC;
+    float* Ci = C + item * strideC + col0;
+    const float* bias_t = bias ? bias + col0 : nullptr;
     const int r0 = part * rows_per_unit;
     const int r1 = r0 + rows_per_unit < M ? r0 + rows_per_unit : M;
     // Rows in a software pipeline: a group's col / val come in super-chunks of SC chunks (SC independent loads per
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
       }
       const int row = rb + lane / G;
       if (row < r1 && !k0 && on) {
-        if (bias) acc += *reinterpret_cast<const f32x4*>(bias + 4 * gl);
+        if (bias_t) acc += *reinterpret_cast<const f32x4*>(bias_t + 4 * gl);
         __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(Ci + (long)row * ldc + 4 * gl));
       }
       s0 = s1, e0 = e1, k0 = k1;
@@ -169,15 +173,31 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
 
 namespace mi {
 
-// 1 when the plan can take the problem at all (shape only; the caller checked the vec4 requirements)
-bool spmm_ldsb_fits(int32_t K, int32_t N) {
-  return N >= 4 && N % 4 == 0 && N <= 256 && K >= 1 && (long)K * N * 4 <= 128L * 1024;
+// Column tiles: when K·N·4 exceeds the 128 KB an LDS image may take, the columns are cut into 2 or 4 tiles of W = N / tiles
+// (W ≥ 32: 8-lane groups, the narrowest with DPP broadcasts — 2048 × 64 as four tiles of 16 ran 25 % behind the group
+// kernel) and a unit covers one tile — every output element still sees its row's non-zeros in CSR
+// order (no assumption on the order of columns inside a row, which cutting K would need); the row's col / val are read
+// once per tile.  1024 tokens × 64: two tiles of 32 columns (0.114 → 0.090 ms at 10 % kept); 1024 × 128: four of 32 (0.207 → 0.162).
+static int ldsb_column_tiles(int32_t K, int32_t N) {
+  if (N < 4 || N % 4 != 0 || N > 256 || K < 1) return 0;
+  for (int tiles = 1; tiles <= 4; tiles *= 2) {
+    const int w = N / tiles;
+    if (N % tiles != 0 || w % 4 != 0 || (tiles > 1 && w < 32)) return 0;
+    if ((long)K * w * 4 <= 128L * 1024) return tiles;
+  }
+  return 0;
 }
+
+// whether the plan can take the problem at all (shape only; the caller checked the vec4 requirements)
+bool spmm_ldsb_fits(int32_t K, int32_t N) { return ldsb_column_tiles(K, N) > 0; }
+int spmm_ldsb_tiles(int32_t K, int32_t N) { return ldsb_column_tiles(K, N); }
 
 int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val, const float* B, float* C,
                      int32_t batch, int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t ldc, int64_t strideB,
                      int64_t strideC, const float* bias, int long_thresh, hipStream_t s) {
-  if (!spmm_ldsb_fits(K, N)) return MI_EINVAL;
+  const int ctiles = ldsb_column_tiles(K, N);
+  if (ctiles == 0) return MI_EINVAL;
+  const int W = N / ctiles;
   static int cus = 0;
   if (cus == 0) {
     int dev = 0, n = 0;
@@ -190,20 +210,21 @@ int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val
   // units: blocks of rows of one item, sized so that all CUs get work (two blocks per item for 384 items on 256 CUs),
   // never below 64 rows
   int units_per_item = 1;
-  while ((long)batch * units_per_item < 3L * cus && ((long)M + units_per_item * 2 - 1) / (units_per_item * 2) >= 64)
+  while ((long)batch * ctiles * units_per_item < 3L * cus && ((long)M + units_per_item * 2 - 1) / (units_per_item * 2) >= 64)
     units_per_item *= 2;
   const int rows_per_unit = (int)(((long)M + units_per_item - 1) / units_per_item);
-  const long total = (long)batch * units_per_item;
+  const long total = (long)batch * ctiles * units_per_item;
   if (total > 0x7fffffffL) return MI_ERANGE;
   const unsigned grid = (unsigned)(total < cus ? total : cus);
-  const size_t lds = ((size_t)K + 1) * N * 4;  // + the all-zero row
-  const int G = pow2_ceil(N / 4);
+  const size_t lds = ((size_t)K + 1) * W * 4;  // + the all-zero row
+  const int G = pow2_ceil(W / 4);
 #define MI_LDSB(G_)                                                                                                   \
   do {                                                                                                                \
     auto k = spmm_ldsb_kernel<G_>;                                                                                    \
     if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kWaves * 64), lds, s, rowptr, col, val, B, C, M, K, N, (long)ldb, (long)ldc, \
-                       (long)strideB, (long)strideC, bias, units_per_item, rows_per_unit, (unsigned)total, long_thresh); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kWaves * 64), lds, s, rowptr, col, val, B, C, M, K, W, (long)ldb, (long)ldc, \
+                       (long)strideB, (long)strideC, bias, ctiles, units_per_item, rows_per_unit, (unsigned)total,        \
+                       long_thresh);                                                                                   \
   } while (0)
   switch (G) {
     case 1: MI_LDSB(1); break;

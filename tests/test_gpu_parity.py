@@ -2192,6 +2192,8 @@ def test_spmm_lds_resident_b_plan_bit_exact(capi, cmm, dev, oracle_mod, N):
     stream = torch.cuda.current_stream().cuda_stream
     g = np.random.Generator(np.random.PCG64(N))
     K = min(300, (128 * 1024) // (4 * N))
+    if N in (64, 128, 256):
+        K = 2 * (128 * 1024) // (4 * N) - 3   # B no longer fits as a whole: two column tiles
     for batch, M, share_b in ((1, 777, False), (5, 333, False), (7, 130, True)):
         lens = g.integers(0, 70, size=batch * M)
         lens[g.integers(0, batch * M, size=5)] = 0
@@ -2229,7 +2231,9 @@ def test_spmm_lds_resident_b_is_autos_choice_for_pruned_attention_and_keeps_the_
     capi.mi_spmm_csr_batched_f32_plan.argtypes = [i64, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64]
     capi.mi_spmm_csr_f32_plan.argtypes = [i64, i32, i32, i32, vp, i64, vp, i64]
     assert capi.mi_spmm_csr_batched_f32_plan(10_000_000, 384, 512, 512, 64, None, 64, 512 * 64, None, 64, 512 * 64) == 18
-    assert capi.mi_spmm_csr_batched_f32_plan(10_000_000, 96, 1024, 1024, 64, None, 64, 1024 * 64, None, 64, 1024 * 64) != 18
+    # 1024 tokens: B (256 KB) goes in as two column tiles of 32; 2048 tokens would need tiles of 16 columns: row-split
+    assert capi.mi_spmm_csr_batched_f32_plan(10_000_000, 96, 1024, 1024, 64, None, 64, 1024 * 64, None, 64, 1024 * 64) == 18
+    assert capi.mi_spmm_csr_batched_f32_plan(10_000_000, 48, 2048, 2048, 64, None, 64, 2048 * 64, None, 64, 2048 * 64) != 18
     g = np.random.Generator(np.random.PCG64(18))
     M, K, N = 20000, 256, 64
     lens = g.integers(2, 12, size=M)

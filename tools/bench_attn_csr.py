@@ -45,6 +45,7 @@ g = torch.Generator(device=dev).manual_seed(0)
 print("# tools/bench_attn_csr.py on MI355X (ms; best of 3 blocks of 20)")
 print("# items x M x K x N   kept     nnz        group(L2)  LDS-B    AUTO(plan)      dense MFMA")
 shapes = [(384, 512, 512, 64, (1.0, 0.5, 0.25, 0.1, 0.05, 0.02, 0.01)),
+          (96, 1024, 1024, 64, (0.25, 0.1, 0.05, 0.02)), (48, 2048, 2048, 64, (0.1, 0.05, 0.02)), (96, 1024, 1024, 128, (0.1,)),
           (384, 128, 128, 64, (0.5, 0.1)), (384, 256, 256, 64, (0.5, 0.1)), (96, 1024, 512, 64, (0.1, 0.02)),
           (192, 512, 256, 128, (0.25, 0.05)), (768, 512, 1024, 32, (0.1, 0.02)), (1, 131072, 512, 64, (0.1, 0.02)),
           (1, 65536, 128, 256, (0.25, 0.05)), (4096, 64, 64, 64, (0.5,))]
