@@ -38,7 +38,10 @@ def run(variant, off, col, val, nnz, items, M, K, N, b, c):
     st = lib.mi_spmm_csr_batched_variant_f32(variant, off.data_ptr(), col.data_ptr(), val.data_ptr(), nnz, items, M, K, N,
                                              b.data_ptr(), N, K * N, c.data_ptr(), N, M * N,
                                              torch.cuda.current_stream().cuda_stream)
+    if st == -1 and variant == LDSB:
+        return False  # the plan does not take this shape
     assert st == 0, (variant, st)
+    return True
 
 
 g = torch.Generator(device=dev).manual_seed(0)
@@ -59,8 +62,9 @@ for items, M, K, N, kepts in shapes:
         val, col, off = custom_mm.dense_to_csr(probs)
         nnz = val.numel()
         t_grp = timeit(lambda: run(GROUP, off, col, val, nnz, items, M, K, N, v, c1))
-        t_lds = timeit(lambda: run(LDSB, off, col, val, nnz, items, M, K, N, v, c2))
-        assert torch.equal(c1, c2), "the two CSR kernels must agree bit for bit"
+        fits = run(LDSB, off, col, val, nnz, items, M, K, N, v, c2)
+        t_lds = timeit(lambda: run(LDSB, off, col, val, nnz, items, M, K, N, v, c2)) if fits else float("nan")
+        assert not fits or torch.equal(c1, c2), "the two CSR kernels must agree bit for bit"
         t_auto = timeit(lambda: custom_mm.naive_spmm_batched(val, col, off, nnz, items, M, K, v, c3))
         assert torch.equal(c1, c3)
         plan = lib.mi_spmm_csr_batched_f32_plan(nnz, items, M, K, N, v.data_ptr(), N, K * N, c3.data_ptr(), N, M * N)
