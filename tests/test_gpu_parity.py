@@ -2337,3 +2337,39 @@ def test_batched_spmm_variants_fuzz_against_oracle(capi, dev, oracle_mod):
             assert np.isnan(got[~written]).all(), what
         assert ran >= 2
     assert took.get(18, 0) >= cases // 4 and took.get(4, 0) >= cases // 4 and took[0] == took[5] == cases, took
+
+
+def test_lds_resident_b_product_is_graph_capturable(capi, cmm, dev, oracle_mod):
+    """`custom_mm.naive_spmm_batched` on a batch AUTO resolves to MI_SPMM_LDS_B (function attribute for > 64 KB of LDS,
+    device query for the grid) captured into a hipGraph and replayed on new values and a new B."""
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_spmm_csr_batched_f32_plan.argtypes = [i64, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64]
+    batch, M, K, N = 80, 256, 300, 64
+    g = np.random.Generator(np.random.PCG64(31))
+    lens = g.integers(4, 30, size=batch * M)
+    col = np.concatenate([np.sort(g.choice(K, size=int(n), replace=False)).astype(np.int32) for n in lens])
+    off = np.zeros((batch, M + 1), np.int64)
+    off[:, 1:] = np.cumsum(lens).reshape(batch, M)
+    off[1:, 0] = off[:-1, M]
+    off = off.astype(np.int32)
+    assert capi.mi_spmm_csr_batched_f32_plan(len(col), batch, M, K, N, None, N, K * N, None, N, M * N) == 18
+    d_off, d_col = t(off, dev), t(col, dev)
+    d_val = torch.zeros(len(col), device=dev)
+    B = torch.zeros(batch, K, N, device=dev)
+    C = torch.empty(batch, M, N, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        cmm.naive_spmm_batched(d_val, d_col, d_off, len(col), batch, M, K, B, C)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        cmm.naive_spmm_batched(d_val, d_col, d_off, len(col), batch, M, K, B, C)
+    for _ in range(2):
+        val = g.random(len(col), dtype=np.float32) - 0.5
+        Bh = g.random((batch, K, N), dtype=np.float32) - 0.5
+        d_val.copy_(torch.from_numpy(val))
+        B.copy_(torch.from_numpy(Bh))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr_batched(off, col, val, batch, M, K, Bh))
