@@ -90,6 +90,19 @@ def csr_transpose(vals, cols, offs, nnz, rows, kcols):
     return torch.from_numpy(v.copy()), torch.from_numpy(c.copy()), torch.from_numpy(rp.copy())
 
 
+def csr_transpose_batched(vals, cols, offs, nnz, batch, rows, kcols):
+    """offs: [batch, rows + 1] with every item's base included; returns offsets [batch, kcols + 1] in the same form."""
+    calls.append(("csr_transpose_batched", (batch, rows, kcols)))
+    o, c, v = _np(offs).reshape(batch, rows + 1), _np(cols)[:nnz], _np(vals)[:nnz]
+    t_val, t_col = np.empty(nnz, v.dtype), np.empty(nnz, np.int32)
+    t_off = np.empty((batch, kcols + 1), np.int32)
+    for b in range(batch):
+        s0, s1 = int(o[b, 0]), int(o[b, rows])
+        rp, cc, vv = oracle.csr_transpose((o[b] - s0).astype(np.int32), c[s0:s1], v[s0:s1], rows, kcols)
+        t_val[s0:s1], t_col[s0:s1], t_off[b] = vv, cc, rp + s0
+    return torch.from_numpy(t_val), torch.from_numpy(t_col), torch.from_numpy(t_off)
+
+
 def sddmm(cols, offs, nnz, rows, kcols, dC, B):
     calls.append(("sddmm", (rows, kcols)))
     return torch.from_numpy(oracle.sddmm(_np(offs), _np(cols)[:nnz], rows, _np(dC), _np(B)).copy())

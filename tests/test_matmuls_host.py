@@ -216,6 +216,38 @@ def test_csr_times_batched_operand_backward_and_transpose_cache(mm):
     assert torch.allclose(b3.grad, (2 * a).t() @ torch.ones(9, 6), rtol=RTOL, atol=1e-6)
 
 
+def test_batched_csr_operand_backward_and_pattern_cache(mm):
+    """A batched CSR tensor as the sparse operand (reference matmuls.py:289-293 recurses; no backward there): both
+    gradients equal torch autograd of the dense product — per-item and shared dense operand — the gradient of the
+    sparse operand comes back as a batched CSR tensor on its pattern, and the int32 pattern + the batched transpose are
+    built once per tensor: a second backward transposes nothing."""
+    matmuls, fake = mm
+    g = torch.Generator().manual_seed(33)
+    nb, M, K = 4, 7, 9
+    keep = torch.zeros(nb, M * K, dtype=torch.bool)
+    for i in range(nb):  # torch's batched CSR wants the same number of non-zeros in every item
+        keep[i, torch.randperm(M * K, generator=g)[:20]] = True
+    dense = (rand(g, nb, M, K) + 0.1) * keep.reshape(nb, M, K)
+    for b in (rand(g, nb, K, 5), rand(g, K, 6), rand(g, 2, 2, K, 3)):
+        shape = (2, 2, M, K) if b.dim() == 4 else (nb, M, K)
+        a = dense.reshape(shape).to_sparse_csr().requires_grad_(True)
+        n0 = sum(c[0] == "csr_transpose_batched" for c in fake.calls)
+        for rep in range(2):
+            a.grad = None
+            b1 = b.clone().requires_grad_(True)
+            out = matmuls.cusparseMM.apply(a, b1)
+            a2, b2 = dense.reshape(shape).clone().requires_grad_(True), b.clone().requires_grad_(True)
+            ref = torch.matmul(a2, b2)
+            assert out.shape == ref.shape and torch.allclose(ref, out, rtol=RTOL, atol=1e-6)
+            dc = rand(g, *ref.shape)
+            out.backward(dc)
+            ref.backward(dc)
+            assert torch.allclose(b2.grad, b1.grad, rtol=RTOL, atol=1e-6)
+            assert a.grad.is_sparse_csr and a.grad.shape == a.shape
+            assert torch.allclose(a2.grad * keep.reshape(shape), a.grad.to_dense(), rtol=RTOL, atol=1e-6)
+        assert sum(c[0] == "csr_transpose_batched" for c in fake.calls) == n0 + 1
+
+
 def test_get_sparse_tensor_properties_contract(mm):
     """Argument order = naive_spmm / cusparse_mmul signature (reference matmuls.py:178-187)."""
     matmuls, _ = mm
