@@ -198,15 +198,14 @@ int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val
   const int ctiles = ldsb_column_tiles(K, N);
   if (ctiles == 0) return MI_EINVAL;
   const int W = N / ctiles;
-  static int cus = 0;
-  if (cus == 0) {
+  static const int cus = [] {  // thread-safe one-time query (every device of a node has the same CU count)
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
       (void)hipGetLastError();
       n = 256;
     }
-    cus = n;
-  }
+    return n;
+  }();
   // units: blocks of rows of one item, sized so that all CUs get work (two blocks per item for 384 items on 256 CUs),
   // never below 64 rows
   int units_per_item = 1;
