@@ -164,10 +164,10 @@ def cpu_baseline(rowptr, col, val, M, K, B, N, gpu_C=None):
     a_csr = torch.sparse_csr_tensor(torch.from_numpy(rowptr.astype(np.int64)), torch.from_numpy(col.astype(np.int64)),
                                     torch.from_numpy(val), (M, K))
     b_t = torch.from_numpy(B)
-    t_best = float("inf")
+    t_best, ref = float("inf"), None
     for i in range(4):
         t0 = time.perf_counter()
-        a_csr @ b_t
+        ref = a_csr @ b_t
         dt = time.perf_counter() - t0
         if i > 0:
             t_best = min(t_best, dt)
@@ -176,7 +176,48 @@ def cpu_baseline(rowptr, col, val, M, K, B, N, gpu_C=None):
     if gpu_C is not None:
         rec["gpu_matches_oracle_on_sample"] = "bit-exact" if np.array_equal(gpu_C, out) else "MISMATCH"
         assert rec["gpu_matches_oracle_on_sample"] == "bit-exact", "GPU result differs from the oracle"
+        # the reference's own CPU expression (`a @ b`, matmuls.py:41,...) at its tests' criterion
+        # (tests/naive_kernel_test.py:30,36-37: torch.allclose defaults) on the FULL output
+        got = torch.from_numpy(gpu_C)
+        denom = ref.abs().clamp_min(1e-30)
+        rec["max_rel_err_vs_torch_cpu"] = float(((got - ref).abs() / denom).max())
+        rec["allclose_vs_torch_cpu_rtol1e-5_atol1e-8"] = bool(torch.allclose(got, ref, rtol=1e-5, atol=1e-8))
+        assert rec["allclose_vs_torch_cpu_rtol1e-5_atol1e-8"], \
+            f"GPU result differs from torch-CPU A_csr @ B beyond 1e-5 (max rel {rec['max_rel_err_vs_torch_cpu']})"
     return rec
+
+
+def load_inputs(M, K, density, N, rank, world, dist):
+    """The pinned synthetic inputs.  One rank: generated in place.  N ranks of one node: rank 0
+    generates ONCE and publishes the arrays under /dev/shm; the others wait at a barrier and memory-map them (each
+    then copies only its own row blocks to its GPU) — instead of N ranks each spending 2 s and 2 GB of host memory on
+    the same matrix on shared cores.  The files are removed by rank 0 when it exits."""
+    import synthetic
+    if world == 1:
+        rowptr, col, val = synthetic.make_csr(M, K, density, seed=0)
+        return rowptr, col, val, synthetic.make_dense(K, N, seed=1)
+    import atexit
+    import warnings
+    shm = Path("/dev/shm") if Path("/dev/shm").is_dir() else Path(os.environ.get("TMPDIR", "/tmp"))
+    tag = f"mi_bench_{os.environ.get('MASTER_PORT', '0')}_{M}_{K}_{N}"
+    names = {k: shm / f"{tag}_{k}.npy" for k in ("rowptr", "col", "val", "B")}
+    if rank == 0:
+        def cleanup():
+            for f in names.values():
+                try:
+                    f.unlink()
+                except OSError:
+                    pass
+        atexit.register(cleanup)
+        rowptr, col, val = synthetic.make_csr(M, K, density, seed=0)
+        B = synthetic.make_dense(K, N, seed=1)
+        for k, arr in (("rowptr", rowptr), ("col", col), ("val", val), ("B", B)):
+            np.save(names[k], arr)
+    dist.barrier()
+    if rank == 0:
+        return rowptr, col, val, B
+    warnings.filterwarnings("ignore", message="The given NumPy array is not writable")
+    return tuple(np.load(names[k], mmap_mode="r") for k in ("rowptr", "col", "val", "B"))
 
 
 def self_launch(args):
@@ -281,12 +322,13 @@ def main():
     ap.add_argument("--split", choices=["rows", "nnz"], default="rows",
                     help="N > 1: equal-row blocks (one all_gather_into_tensor per step) or nnz-balanced split "
                          "points (one in-place broadcast per owner and step)")
-    ap.add_argument("--exchange", choices=["auto", "allgather", "allgather_copy", "p2p", "try-p2p"], default="auto",
-                    help="N > 1: how a step's blocks reach the other ranks.  auto / allgather: one in-place RCCL "
-                         "collective per step (falling back by itself to gather + copy if the build refuses the in-place "
-                         "form); allgather_copy pins that fallback; p2p: direct sends to every peer (one xGMI link each); "
-                         "try-p2p: the collective and the direct sends are both timed before the timed region (a p2p "
-                         "exchange that fails ends the run: a process group is not reused after a failed exchange)")
+    ap.add_argument("--exchange", choices=["auto", "allgather", "allgather_copy", "alltoall", "p2p", "try-p2p"], default="auto",
+                    help="N > 1: how a step's blocks reach the other ranks.  allgather: one in-place RCCL all-gather per "
+                         "step (gather + copy if the build refuses the in-place form: allgather_copy pins that); alltoall: one "
+                         "list-form all_to_all per step (every block straight to every peer: one xGMI link each, still a "
+                         "collective); auto (default): both are timed before the timed region and the faster one runs; p2p: "
+                         "independent direct sends to every peer; try-p2p: as auto, plus p2p if a probe of direct sends in "
+                         "its own process group (short timeout) succeeds on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -345,11 +387,10 @@ def main():
     auto_chunks = args.chunks <= 0
     if auto_chunks:
         args.chunks = 4 if world <= 4 else 8
-    chunk_trials = None
+    chunk_trials, trial_fallbacks, p2p_probe = None, [], None
     M, K, density, N, desc = WORKLOADS[args.workload]
     t0 = time.perf_counter()
-    rowptr, col, val = synthetic.make_csr(M, K, density, seed=0)
-    B_host = synthetic.make_dense(K, N, seed=1)
+    rowptr, col, val, B_host = load_inputs(M, K, density, N, rank, world, dist)
     nnz = int(rowptr[-1])
     gen_s = time.perf_counter() - t0
     flops = 2.0 * nnz * N
@@ -366,51 +407,49 @@ def main():
         kernel_name, launches_per_step = spmm_plan(nnz, M, K, B, C)
         local_bytes_alg = bytes_alg
     else:
-        rp_t, col_t, val_t = torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val)
-        try_p2p = args.exchange == "try-p2p"
-        if args.exchange in ("auto", "try-p2p"):
-            args.exchange = "allgather"
-        if auto_chunks or try_p2p:
-            # Before anything is timed: how finely to cut a rank's rows is a trade between starting the
-            # first exchange early (many chunks) and RCCL's efficiency on larger messages (few chunks) — and, on
-            # request (--exchange try-p2p), whether direct sends to every peer beat the collective on this node's
-            # fabric — so try the candidates for a few steps each and keep the fastest (max over ranks, so every
-            # rank decides alike).  Setup, like the warm-up: not in the timed region.
-            # The collective cannot half-fail: the only refusal seen in the wild (the aliased in-place form) is an
-            # argument check that every rank hits alike before anything is sent, and ShardedSpMM then gathers out
-            # of place by itself.  A p2p exchange CAN fail on some ranks only, which would leave the others inside
-            # their sends: it is therefore never part of the default trial, and an exception in it ends this rank
-            # (and with it the job) instead of reusing the group.
+        rp_t, col_t, val_t = torch.from_numpy(np.asarray(rowptr)), torch.from_numpy(col), torch.from_numpy(val)
+        # Which exchange?  The in-place all-gather (RCCL picks rings / trees) and the list-form all_to_all (every block
+        # straight to every peer: one xGMI link each) are both COLLECTIVES: every rank calls them alike, a build that
+        # refuses one does so at an argument check on every rank, which ShardedSpMM probes at construction and settles
+        # by agreement — so both are part of the default trial.  Independent direct sends (p2p) can fail on some ranks
+        # only; they join the trial only on request AND after sharded.probe_p2p (own process group, short timeout,
+        # outcome agreed over the main group) succeeded everywhere.  A failed probe costs nothing but the option.
+        exch_cands = {"auto": ("allgather", "alltoall"), "try-p2p": ("allgather", "alltoall")}.get(args.exchange, (args.exchange,))
+        if args.exchange == "try-p2p":
+            p2p_probe = sharded.probe_p2p(dev, timeout_s=20.0)
+            if p2p_probe:
+                exch_cands += ("p2p",)
+        if auto_chunks or len(exch_cands) > 1:
+            # Before anything is timed: how finely to cut a rank's rows is a trade between starting the first
+            # exchange early (many chunks) and RCCL's efficiency on larger messages (few chunks); try the candidates
+            # for a few steps each and keep the fastest (max over ranks, so every rank decides alike).  Setup, like the
+            # warm-up: not in the timed region.
             chunk_trials = {}
             chunk_cands = ((2, 4) if world <= 2 else (2, 4, 8)) if auto_chunks else (args.chunks,)
-            exch_cands = (args.exchange, "p2p") if try_p2p else (args.exchange,)
-
-            def try_candidate(exch, cand):
-                trial = sharded.ShardedSpMM(rp_t, col_t, val_t, M, K, dev, chunks=cand, split=args.split, exchange=exch)
-                Ct = trial.alloc_output(N)
-                for _ in range(2):
-                    trial.forward(B, out=Ct)
-                dist.barrier()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(3):
-                    trial.forward(B, out=Ct)
-                torch.cuda.synchronize()
-                return time.perf_counter() - t1, trial.exchange
 
             for exch in exch_cands:
                 for cand in chunk_cands:
-                    try:
-                        seconds, used = try_candidate(exch, cand)
-                    except Exception as e:
-                        print(f"bench: rank {rank}: exchange '{exch}' with {cand} chunks failed ({type(e).__name__}: {e}); "
-                              "the process group is not reused after a failed exchange", file=sys.stderr, flush=True)
-                        os._exit(3)
-                    tt = torch.tensor([seconds], device=dev, dtype=torch.float64)
+                    trial = sharded.ShardedSpMM(rp_t, col_t, val_t, M, K, dev, chunks=cand, split=args.split, exchange=exch)
+                    trial_fallbacks.extend(x for x in trial.fallbacks if x not in trial_fallbacks)
+                    if (trial.exchange, cand) in chunk_trials:
+                        continue  # a refused form fell back to one that is tried under its own name
+                    Ct = trial.alloc_output(N)
+                    for _ in range(2):
+                        trial.forward(B, out=Ct)
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(3):
+                        trial.forward(B, out=Ct)
+                    torch.cuda.synchronize()
+                    tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    chunk_trials[(used, cand)] = float(tt[0]) / 3 * 1e3
+                    chunk_trials[(trial.exchange, cand)] = float(tt[0]) / 3 * 1e3
+                    del trial, Ct
             args.exchange, args.chunks = min(chunk_trials, key=chunk_trials.get)
             torch.cuda.empty_cache()
+        else:
+            args.exchange = exch_cands[0]
         op = sharded.ShardedSpMM(rp_t, col_t, val_t, M, K, dev, chunks=args.chunks, split=args.split, exchange=args.exchange)
         C = op.alloc_output(N)
 
@@ -440,7 +479,7 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
-    compute_only_ms = None
+    compute_only_ms = gather_only_ms = None
     if world > 1:
         # the same steps without the all-gather: what the row shards alone cost (reported beside the
         # end-to-end figure; `value` stays end-to-end)
@@ -454,16 +493,26 @@ def main():
         compute_only_ms = float(tc) / args.steps * 1e3
         op.forward(B, out=C)  # leave the gathered result in C
         barrier()
+        # the exchanges alone (what is in C travels again): with compute-only and end-to-end this says whether the
+        # gather or the kernels bound the step, and the implied per-rank receive rate says which algorithm RCCL ran
+        # (one ring: per-link bound; multi-link / direct: several links' worth)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            op.forward(B, out=C, compute=False)
+        barrier()
+        tg = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        gather_only_ms = float(tg) / args.steps * 1e3
         # placement self-check of the all-gather (no oracle involved): recompute a block that ANOTHER rank
         # owns with the same kernel and compare it bit-for-bit with what arrived in its slot of C
         peer = (rank + 1) % world
         r0 = min(int(op.bounds[peer]), M)
         r1 = min(int(op.bounds[peer + 1]), M)
         if r1 > r0:
-            rp_t = torch.from_numpy(rowptr)
+            rp_t = torch.from_numpy(np.asarray(rowptr))
             p0, p1 = int(rowptr[r0]), int(rowptr[r1])
             chk = torch.empty(r1 - r0, N, device=dev)
-            custom_mm.naive_spmm(torch.from_numpy(val[p0:p1]).to(dev), torch.from_numpy(col[p0:p1]).to(dev),
+            custom_mm.naive_spmm(torch.from_numpy(np.array(val[p0:p1])).to(dev), torch.from_numpy(np.array(col[p0:p1])).to(dev),
                                  (rp_t[r0:r1 + 1] - rp_t[r0]).to(torch.int32).to(dev), p1 - p0, r1 - r0, K, B, chk)
             assert torch.equal(chk, C[r0:r1]), f"rank {rank}: gathered block of rank {peer} differs from a local recompute"
     step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
@@ -497,11 +546,13 @@ def main():
                                f"A row-sharded over {world} GPUs ({args.split}-balanced blocks), block-cyclic "
                                f"x{args.chunks}, " + {"allgather": "RCCL all-gather of C, in place",
                                                       "allgather_copy": "RCCL all-gather of C into a scratch span + copy",
+                                                      "alltoall": "C exchanged by one list-form RCCL all_to_all per step (every block "
+                                                                  "straight to every peer, in place)",
                                                       "p2p": "C exchanged by direct RCCL sends to every peer"}[op.exchange if world > 1 else "allgather"],
                 "rccl_ranks": world if world > 1 else None,
                 "chunks": None if world == 1 else args.chunks,
                 "exchange": None if world == 1 else op.exchange,
-                "exchange_fallbacks": None if world == 1 else op.fallbacks,
+                "exchange_fallbacks": None if world == 1 else (op.fallbacks + [x for x in trial_fallbacks if x not in op.fallbacks]),
                 "rank_devices": rank_devices,
                 "nccl_debug_env": os.environ.get("NCCL_DEBUG"),
                 "chunk_trials_ms_per_step": None if not chunk_trials else {f"{e}/{c}": round(v, 4) for (e, c), v in chunk_trials.items()},
@@ -511,6 +562,14 @@ def main():
                 "effective_GBps_whole_job": round(bytes_alg * args.steps / elapsed / 1e9, 1),
                 "input_generation_s": round(gen_s, 1),
                 "compute_only_ms_per_step": None if compute_only_ms is None else round(compute_only_ms, 4),
+                "gather_only_ms_per_step": None if gather_only_ms is None else round(gather_only_ms, 4),
+                # bytes every rank RECEIVES per step (the other ranks' rows of C) / the gather-only time
+                "gather_receive_GBps_per_rank": None if gather_only_ms is None else
+                                                round(4.0 * N * (op.padded_rows - op.local_rows) / (gather_only_ms * 1e-3) / 1e9, 1),
+                "gather_note": None if gather_only_ms is None else
+                               "xGMI: 7 links x ~153 GB/s per GPU; a single ring is bound by ONE link, direct / multi-link "
+                               "exchanges by several: compare gather_receive_GBps_per_rank with those",
+                "p2p_probe_ok": p2p_probe,
             },
             "roofline": {
                 # C2's B (32 MiB) sits in the Infinity Cache: its rate is a cache-gather rate and is priced

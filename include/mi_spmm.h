@@ -266,6 +266,25 @@ int mi_spmm_dense_skip_f32(const float* A, int64_t lda, int64_t strideA, int32_t
                            int64_t strideB, const float* bias, float* C, int64_t ldc,
                            int64_t strideC, mi_stream_t stream);
 
+/* Gated form of the product above, for callers that must keep the zero-skipping
+ * semantics of `a.to_sparse_csr()` (reference matmuls.py:295-296: a zero of A
+ * never meets B) while normally taking the dense MFMA product (mi_gemm_f32), in
+ * which 0·inf = nan: the launch does nothing unless *gate != 0 (device memory,
+ * read when the kernel starts), so
+ *     mi_gemm_f32(...);  mi_nonfinite_flag_f32(B, ..., gate);  this(..., gate)
+ * leaves the dense product in C when B is finite (where both agree bit for bit)
+ * and overwrites it with the zero-skipping product when B holds an inf / nan —
+ * decided on the device, nothing read back, graph-capturable.  Any N % 4 == 0
+ * (column tiles of 256 inside one launch); gate == NULL always runs.
+ * mi_nonfinite_flag_f32 writes *flag = 1 if x (rows×cols, leading dimension ld)
+ * holds an inf or nan, else 0. */
+int mi_spmm_dense_skip_gated_f32(const float* A, int64_t lda, int64_t strideA, int32_t batch,
+                                 int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,
+                                 int64_t strideB, const float* bias, float* C, int64_t ldc,
+                                 int64_t strideC, const int32_t* gate, mi_stream_t stream);
+int mi_nonfinite_flag_f32(const float* x, int64_t rows, int64_t cols, int64_t ld, int32_t* flag,
+                          mi_stream_t stream);
+
 /* ------------------------------------------------------------------------ *
  * Fused FC-layer epilogues:  C = (product) + bias, bias[N] (resp. bias[n]) added
  * to every row AFTER the accumulation chain (one extra rounding, exactly what

@@ -586,6 +586,62 @@ bool naive_spmm_dense_bias(torch::Tensor A, torch::Tensor B, torch::Tensor bias,
   return spmm_dense_impl(A, B, &bias, C, "naive_spmm_dense_bias");
 }
 
+// int32[1] on B's device: 1 when B holds an inf or a nan, else 0 (stream-ordered, nothing read back).
+torch::Tensor nonfinite_flag(torch::Tensor B) {
+  check_device_f32(B, "B");
+  torch::Tensor Bc = B.contiguous();
+  c10::hip::HIPGuard guard(B.device().index());
+  torch::Tensor flag = torch::empty({1}, torch::dtype(torch::kInt32).device(B.device()));
+  check_status(mi_nonfinite_flag_f32(Bc.data_ptr<float>(), 1, Bc.numel(), std::max<int64_t>(Bc.numel(), 1),
+                                     flag.data_ptr<int32_t>(), stream_of(B)),
+               "nonfinite_flag");
+  return flag;
+}
+
+// The zero-skipping product of naive_spmm_dense as a GATED launch: it runs only when flag[0] != 0 on the device
+// (see mi_spmm_dense_skip_gated_f32).  A [batch…, M, K] dense, B [K, N] or [batch…, K, N], C [batch…, M, N].
+// `dry_run` only answers whether the shape is covered (no launch).  Returns false when it is not.
+bool naive_spmm_dense_gated(torch::Tensor A, torch::Tensor B, torch::Tensor C, torch::Tensor flag, bool dry_run) {
+  const char* what = "naive_spmm_dense_gated";
+  check_device_f32(A, "A");
+  check_device_f32(B, "B");
+  check_device_f32(C, "C");
+  check_same_device(A, C, what);
+  check_same_device(B, C, what);
+  TORCH_CHECK(A.dim() >= 2 && C.dim() == A.dim(), what, ": A and C must have the same rank (>= 2)");
+  TORCH_CHECK(C.is_contiguous(), what, ": C must be contiguous");
+  const int64_t M = A.size(-2), K = A.size(-1), N = C.size(-1);
+  const int64_t batch = M * K > 0 ? A.numel() / (M * K) : (C.numel() / std::max<int64_t>(C.size(-2) * N, 1));
+  TORCH_CHECK(C.size(-2) == M, what, ": C must have ", M, " rows");
+  int64_t strideB = 0;
+  if (B.dim() == 2) {
+    TORCH_CHECK(B.size(0) == K && B.size(1) == N, what, ": B must be [", K, ", ", N, "]");
+  } else {
+    TORCH_CHECK(B.dim() == A.dim() && B.size(-2) == K && B.size(-1) == N && B.numel() == batch * K * N, what,
+                ": B must be [batch…, ", K, ", ", N, "] with A's batch dims");
+    strideB = K * N;
+  }
+  TORCH_CHECK(C.numel() == batch * M * N, what, ": C must be [batch…, ", M, ", ", N, "]");
+  TORCH_CHECK(M <= INT32_MAX && K <= INT32_MAX && N <= INT32_MAX && batch <= INT32_MAX, what, ": dimension too large");
+  if (N % 4 != 0 || (K * N) % 4 != 0 || (M * N) % 4 != 0 || N > 256 * 65535) return false;
+  if (dry_run) return true;
+  TORCH_CHECK(flag.defined() && flag.is_cuda() && flag.scalar_type() == torch::kInt32 && flag.numel() >= 1 &&
+                  flag.device() == C.device(),
+              what, ": flag must be an int32 device tensor on C's device");
+  if (batch == 0 || M == 0 || N == 0) return true;
+  torch::Tensor Ac = A.contiguous(), Bc = B.contiguous();
+  if ((reinterpret_cast<uintptr_t>(Bc.data_ptr<float>()) & 15u) || (reinterpret_cast<uintptr_t>(C.data_ptr<float>()) & 15u)) {
+    Bc = Bc.clone();  // a contiguous view at an odd offset: give the kernel an aligned copy
+    TORCH_CHECK((reinterpret_cast<uintptr_t>(C.data_ptr<float>()) & 15u) == 0, what, ": C must be 16-byte aligned");
+  }
+  c10::hip::HIPGuard guard(C.device().index());
+  check_status(mi_spmm_dense_skip_gated_f32(Ac.data_ptr<float>(), std::max<int64_t>(K, 1), M * K, (int32_t)batch,
+                                            (int32_t)M, (int32_t)K, (int32_t)N, Bc.data_ptr<float>(), N, strideB, nullptr,
+                                            C.data_ptr<float>(), N, M * N, flag.data_ptr<int32_t>(), stream_of(C)),
+               what);
+  return true;
+}
+
 // CSR of A (A_rows×A_cols) → CSR of Aᵀ: (values, columns, offsets[A_cols+1]).
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> csr_transpose(torch::Tensor A_values,
                                                                       torch::Tensor A_columns,
@@ -1032,6 +1088,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("naive_spmm_dense", &naive_spmm_dense,
         "A·B with A dense, zeros skipped in the kernel; False if the shape is not covered");
   m.def("naive_spmm_dense_bias", &naive_spmm_dense_bias, "as naive_spmm_dense, + bias in the epilogue");
+  m.def("nonfinite_flag", &nonfinite_flag, "int32[1] device tensor: 1 if the tensor holds an inf / nan (nothing read back)");
+  m.def("naive_spmm_dense_gated", &naive_spmm_dense_gated,
+        "naive_spmm_dense as a launch that runs only when flag[0] != 0 on the device; (A, B, C, flag, dry_run) -> covered?");
   m.def("cublas_mmul_bias", &cublas_mmul_bias, "op(A) op(B) + bias, fused epilogue");
   m.def("column_sums", &column_sums, "sum over rows of a 2-d tensor (bias gradient)");
   m.def("naive_spmm_bias", &naive_spmm_bias, "CSR x dense + bias, fused epilogue");

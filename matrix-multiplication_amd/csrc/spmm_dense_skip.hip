@@ -23,6 +23,8 @@
 // measured: it forces one 768-thread workgroup per CU and ran SLOWER than this form at both
 // densities tried (B 32·12 × 512×512 × 512×64: 0.229 vs 0.181 ms at 10 % non-zeros, 0.869 vs
 // 0.812 ms at 100 %) — occupancy, not the L2 round trip, is what this kernel needs.
+#include <algorithm>
+
 #include "mi_common.h"
 
 #ifndef MI_SKIP_ABL
@@ -57,7 +59,19 @@ template <int G, bool VECA, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void spmm_dense_skip_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int K,
     int N, long lda, long ldb, long ldc, long strideA, long strideB, long strideC,
-    int rows_per_block, const float* __restrict__ bias, int batch, unsigned row_blocks) {
+    int rows_per_block, const float* __restrict__ bias, int batch, unsigned row_blocks,
+    const int* __restrict__ gate) {
+  // gated form (mi_spmm_dense_skip_gated_f32): the launch is a no-op unless *gate != 0 (one scalar load)
+  if (gate != nullptr && *gate == 0) return;
+  // column tile of 256 output columns (gridDim.y > 1 only in the gated form)
+  if (blockIdx.y != 0) {
+    B += 256L * blockIdx.y;
+    C += 256L * blockIdx.y;
+    if (bias) bias += 256L * blockIdx.y;
+    N = min(256, N - 256 * (int)blockIdx.y);
+  } else if (gridDim.y > 1) {
+    N = min(256, N);
+  }
   constexpr int R = 64 / G;
   constexpr int CH = 4 * G;
   constexpr int CAP = 3 * CH;            // list entries per row group: several sparse chunks share one walk
@@ -164,7 +178,8 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_dense_skip_kernel(
 
 template <int G>
 int launch_for_width(bool veca, const float* A, const float* B, float* C, int batch, int M, int K, int N, long lda,
-                     long ldb, long ldc, long sA, long sB, long sC, const float* bias, hipStream_t s) {
+                     long ldb, long ldc, long sA, long sB, long sC, const float* bias, hipStream_t s,
+                     const int* gate = nullptr, unsigned col_tiles = 1) {
   constexpr int WAVES = 4;
   constexpr int R = 64 / G;
   constexpr size_t lds_bytes = (size_t)WAVES * R * (3 * 4 * G + 1) * sizeof(Pair);
@@ -173,14 +188,37 @@ int launch_for_width(bool veca, const float* A, const float* B, float* C, int ba
   const long blocks = 8L * ((batch + 7) / 8) * row_blocks;  // every XCD gets the same count; extras exit
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   if (veca)
-    hipLaunchKernelGGL((spmm_dense_skip_kernel<G, true, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), lds_bytes,
-                       s, A, B, C, M, K, N, lda, ldb, ldc, sA, sB, sC, rows_per_block, bias, batch,
-                       (unsigned)row_blocks);
+    hipLaunchKernelGGL((spmm_dense_skip_kernel<G, true, WAVES>), dim3((unsigned)blocks, col_tiles), dim3(WAVES * 64),
+                       lds_bytes, s, A, B, C, M, K, N, lda, ldb, ldc, sA, sB, sC, rows_per_block, bias, batch,
+                       (unsigned)row_blocks, gate);
   else
-    hipLaunchKernelGGL((spmm_dense_skip_kernel<G, false, WAVES>), dim3((unsigned)blocks), dim3(WAVES * 64), lds_bytes,
-                       s, A, B, C, M, K, N, lda, ldb, ldc, sA, sB, sC, rows_per_block, bias, batch,
-                       (unsigned)row_blocks);
+    hipLaunchKernelGGL((spmm_dense_skip_kernel<G, false, WAVES>), dim3((unsigned)blocks, col_tiles), dim3(WAVES * 64),
+                       lds_bytes, s, A, B, C, M, K, N, lda, ldb, ldc, sA, sB, sC, rows_per_block, bias, batch,
+                       (unsigned)row_blocks, gate);
   return mi::check_launch();
+}
+
+// flag |= 1 when x (rows × cols, leading dimension ld) holds an inf or a nan.  Grid-stride over 16-byte pieces when the
+// rows are dense in memory (ld == cols), element-wise otherwise; one atomic per wave that saw one.
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ x, long rows, long cols, long ld,
+                                                             int* __restrict__ flag) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nthreads = (long)gridDim.x * blockDim.x;
+  bool bad = false;
+  auto nonfinite = [](float v) { return (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u; };
+  if (ld == cols && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+    const long n = rows * cols, n4 = n / 4;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    for (long i = tid; i < n4; i += nthreads) {
+      const f32x4 v = x4[i];
+      bad |= nonfinite(v.x) | nonfinite(v.y) | nonfinite(v.z) | nonfinite(v.w);
+    }
+    for (long i = n4 * 4 + tid; i < n; i += nthreads) bad |= nonfinite(x[i]);
+  } else {
+    const long n = rows * cols;
+    for (long i = tid; i < n; i += nthreads) bad |= nonfinite(x[(i / cols) * ld + i % cols]);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
 }  // namespace
@@ -213,6 +251,42 @@ int mi_spmm_dense_skip_f32(const float* A, int64_t lda, int64_t strideA, int32_t
   if (N <= 128) MI_SKIP(32);
   MI_SKIP(64);
 #undef MI_SKIP
+}
+
+int mi_spmm_dense_skip_gated_f32(const float* A, int64_t lda, int64_t strideA, int32_t batch, int32_t M,
+                                 int32_t K, int32_t N, const float* B, int64_t ldb, int64_t strideB,
+                                 const float* bias, float* C, int64_t ldc, int64_t strideC,
+                                 const int32_t* gate, mi_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (batch < 0 || M < 0 || K < 0 || N < 0 || strideA < 0 || strideB < 0 || strideC < 0) return MI_EINVAL;
+  if (batch == 0 || M == 0 || N == 0) return MI_OK;
+  if (!C || ldc < N) return MI_EINVAL;
+  if (K > 0 && (!A || !B || lda < K || ldb < N)) return MI_EINVAL;
+  if (N % 4 != 0 || ldb % 4 != 0 || ldc % 4 != 0 || !mi::aligned16(B) || !mi::aligned16(C) || strideB % 4 != 0 ||
+      strideC % 4 != 0 || (bias && !mi::aligned16(bias)))
+    return MI_EINVAL;
+  const unsigned tiles = (unsigned)((N + 255) / 256);
+  if (tiles > 65535u) return MI_ERANGE;
+  const bool veca = lda % 4 == 0 && strideA % 4 == 0 && mi::aligned16(A);
+#define MI_SKIP(G_)                                                                                                 \
+  return launch_for_width<G_>(veca, A, B, C, batch, M, K, N, lda, ldb, ldc, strideA, strideB, strideC, bias, s, gate, \
+                              tiles)
+  if (N <= 64) MI_SKIP(16);
+  if (N <= 128) MI_SKIP(32);
+  MI_SKIP(64);
+#undef MI_SKIP
+}
+
+int mi_nonfinite_flag_f32(const float* x, int64_t rows, int64_t cols, int64_t ld, int32_t* flag, mi_stream_t stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!flag || rows < 0 || cols < 0 || (rows > 0 && cols > 0 && (!x || ld < cols))) return MI_EINVAL;
+  if (hipMemsetAsync(flag, 0, sizeof(int32_t), s) != hipSuccess) return mi::check_launch();
+  const long n = rows * cols;
+  if (n == 0) return MI_OK;
+  const long want = (n / 4 + 255) / 256;
+  const unsigned blocks = (unsigned)std::min<long>(std::max<long>(want, 1), 2048);
+  hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(blocks), dim3(256), 0, s, x, (long)rows, (long)cols, (long)ld, flag);
+  return mi::check_launch();
 }
 
 }  // extern "C"

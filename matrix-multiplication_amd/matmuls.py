@@ -23,6 +23,9 @@ math = `torch.matmul` and its autograd (SURVEY.md §8a "known defects"):
     Python recursion with one to_sparse_csr() per slice (reference :289-297).
 '''
 
+import os
+import weakref
+
 import torch
 from torch.autograd.function import InplaceFunction
 import custom_mm
@@ -376,7 +379,33 @@ def _batched_csr_product(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) ->
 
 
 _DENSE_SAMPLE_ROWS = 128
-_density_of_shape = {}  # (shape of a, shape of b, device) -> {'est', 'n', 'host', 'event'}: see _dense_route
+_density_of_shape = {}   # (shape of a, shape of b, device) -> {'est', 'n', 'host', 'event', 'src'}: see _dense_route
+_density_of_tensor = {}  # id(a) -> (weakref to a, a._version, density) of an `a` whose own sample has landed
+
+# How a DENSE tensor handed to naiveSpMM / cusparseMM (zeros to be skipped) may be multiplied:
+#   'auto'   (default) the exact-fp32 MFMA product where it is faster (dense_route_pays), with the zero-skipping
+#            semantics of the reference's `a.to_sparse_csr()` (matmuls.py:295-296) GUARANTEED on the device: a gated
+#            launch of the zero-skipping kernel recomputes the product iff `b` holds an inf / nan (the only operands
+#            on which the two routes differ: 0·inf = nan) — so the route affects time only, never the result;
+#   'never'  always a zero-skipping route (in-kernel skip or dense→CSR + CSR kernels);
+#   'always' always the MFMA product, torch.matmul semantics (a zero of `a` facing an inf / nan of `b` gives nan —
+#            what the reference's tests compare with, tests/naive_kernel_test.py:30).
+# Set with MI_DENSE_ROUTE in the environment, matmuls.set_dense_route(mode), or per call:
+# naive_matmul(a, b, dense_route='never').
+_DENSE_ROUTE_MODES = ('auto', 'never', 'always')
+_dense_route_mode = os.environ.get('MI_DENSE_ROUTE', 'auto').strip().lower() or 'auto'
+if _dense_route_mode not in _DENSE_ROUTE_MODES:
+    raise ValueError(f"MI_DENSE_ROUTE must be one of {_DENSE_ROUTE_MODES}, not {_dense_route_mode!r}")
+
+
+def set_dense_route(mode: str) -> str:
+    '''Pin how dense-with-zeros inputs of the sparse classes are multiplied ('auto', 'never', 'always' — see
+    above); returns the previous mode.'''
+    global _dense_route_mode
+    if mode not in _DENSE_ROUTE_MODES:
+        raise ValueError(f"dense route must be one of {_DENSE_ROUTE_MODES}, not {mode!r}")
+    prev, _dense_route_mode = _dense_route_mode, mode
+    return prev
 
 
 def dense_route_pays(density: float, items: int, rows: int, cols: int, width: int) -> bool:
@@ -392,48 +421,99 @@ def dense_route_pays(density: float, items: int, rows: int, cols: int, width: in
     return t_dense < t_skip
 
 
-def _dense_route(a: torch.Tensor, b: torch.Tensor, items: int, rows: int, cols: int, width: int) -> bool:
-    '''Whether a dense-with-zeros `a` should take the dense MFMA product, decided from the density of an evenly
+def _own_density(a: torch.Tensor):
+    '''The sampled density of this very tensor OBJECT at its current version, if one has landed (keyed on the Python
+    object through a weak reference — not on data_ptr: the caching allocator hands a freed block to the next
+    iteration's tensor, which is a different matrix at the same address).'''
+    hit = _density_of_tensor.get(id(a))
+    if hit is not None and hit[0]() is a and hit[1] == a._version:
+        return hit[2]
+    return None
+
+
+def _dense_route(a: torch.Tensor, b: torch.Tensor, items: int, rows: int, cols: int, width: int, owner=None) -> bool:
+    '''Whether a dense-with-zeros `a` is worth the dense MFMA product, decided from the density of an evenly
     spaced sample of ≤ 128 rows of `a` (one small count kernel).  The count comes back WITHOUT stalling the stream:
-    it is copied to pinned memory behind an event, and a call decides from the most recent count that has landed for
-    operands of the same shapes — the previous call's, in a loop — so only the first call of a shape waits (the
-    reference converts with `to_sparse_csr()` on every call, which synchronises every time, matmuls.py:295-296).  A
-    stale estimate can only cost time: with finite operands every route returns the same bits (the skipped terms
-    are exact zeros).  The one semantic difference is pinned in
-    tests/test_gpu_parity.py::test_dense_inputs_of_the_sparse_classes_take_the_matrix_cores_above_the_crossover:
-    on the dense route a zero of `a` multiplies the entry of `b` it faces, so a NON-FINITE entry there gives nan,
-    exactly as `torch.matmul(a, b)` — the oracle of the reference's own tests, tests/naive_kernel_test.py:30-37 —
-    while the zero-skipping routes leave it out as `to_sparse_csr()` does.
+    it is copied to pinned memory behind an event.  A call decides from the count of THIS tensor (storage, version
+    counter, shape) when that has landed before; otherwise from the most recent count that has landed for operands
+    of the same shapes — the previous call's, in a loop — so only the first call of a shape waits (the reference
+    converts with `to_sparse_csr()` on every call, which synchronises every time, matmuls.py:295-296).  A stale
+    estimate can only cost time: in 'auto' mode the result does not depend on the route (see _DENSE_ROUTE_MODES).
     Under stream capture nothing is read back: the question is not asked.  Products whose dense form takes under
     ≈20 µs are not worth the question either.'''
     if not a.is_cuda or torch.cuda.is_current_stream_capturing() or a.numel() == 0 or b.numel() == 0:
         return False
     if 2.0 * items * rows * cols * width / 110e12 < 20e-6:
         return False
+    owner = a if owner is None else owner  # the caller's tensor object (`a` may be a flattened view of it)
+    own = _own_density(owner)
+    if own is not None:
+        return dense_route_pays(own, items, rows, cols, width)
     key = (tuple(a.shape), tuple(b.shape), a.device.index)
     ent = _density_of_shape.get(key)
     if ent is None:
         if len(_density_of_shape) >= 64:
             _density_of_shape.clear()
-        ent = _density_of_shape[key] = {'est': None, 'n': 1, 'event': None,
+        ent = _density_of_shape[key] = {'est': None, 'n': 1, 'event': None, 'src': None,
                                         'host': torch.empty((), dtype=torch.int64, pin_memory=True)}
-    if ent['event'] is not None and ent['event'].query():
+
+    def landed():
         ent['est'], ent['event'] = float(ent['host']) / ent['n'], None
+        ref, version = ent['src']
+        src = ref()
+        if src is not None and src._version == version:
+            if len(_density_of_tensor) >= 64:
+                _density_of_tensor.clear()
+            _density_of_tensor[id(src)] = (ref, version, ent['est'])
+        ent['src'] = None
+
+    if ent['event'] is not None and ent['event'].query():
+        landed()
+        own = _own_density(owner)
+        if own is not None:  # it was this tensor's own sample
+            return dense_route_pays(own, items, rows, cols, width)
     if ent['event'] is None:  # no read-back in flight: start one on this call's operand
         flat = a.reshape(-1, cols)
         step = max(1, flat.shape[0] // _DENSE_SAMPLE_ROWS)
         sample = flat[::step][:_DENSE_SAMPLE_ROWS]
         ent['host'].copy_(torch.count_nonzero(sample), non_blocking=True)
         ent['n'] = sample.numel()
+        ent['src'] = (weakref.ref(owner), owner._version)
         ent['event'] = torch.cuda.Event()
         ent['event'].record()
     if ent['est'] is None:  # first call of this shape: wait for its own count
         ent['event'].synchronize()
-        ent['est'], ent['event'] = float(ent['host']) / ent['n'], None
+        landed()
     return dense_route_pays(ent['est'], items, rows, cols, width)
 
 
-def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch.Tensor:
+def _on_matrix_cores(_a: torch.Tensor, _b: torch.Tensor, c: torch.Tensor, mode: str, owner=None) -> bool:
+    '''c = _a·_b for a dense-with-zeros _a ([M, K] or [nb, M, K]; _b [K, N] or [nb, K, N]; c preallocated) on the
+    MFMA kernel, if `mode` allows it and (auto) the product is worth it.  In 'auto' mode the zero-skipping semantics
+    are kept without reading anything back: custom_mm.nonfinite_flag(_b) leaves one int on the device and a gated
+    launch of the zero-skipping kernel overwrites c iff that int is set (an inf / nan in _b); with a finite _b both
+    products are the same bits (the skipped terms are exact zeros, added in the same ascending-k order).'''
+    if mode == 'never':
+        return False
+    batched = _a.dim() == 3
+    nb = _a.shape[0] if batched else 1
+    rows, cols, width = _a.shape[-2], _a.shape[-1], c.shape[-1]
+    if mode == 'auto':
+        if not _dense_route(_a, _b, nb, rows, cols, width, owner):
+            return False
+        if not custom_mm.naive_spmm_dense_gated(_a, _b, c, c, True):  # dry run: is the gated form available?
+            return False
+    if batched:
+        _bb = _b if _b.dim() == 3 else _b.unsqueeze(0).expand(nb, cols, width)
+        custom_mm.cublas_bmm(_a.contiguous(), _bb, c, 3, False, False)
+    else:
+        custom_mm.cublas_mmul(_a.contiguous(), _b.contiguous(), c, False, False)
+    if mode == 'auto':
+        custom_mm.naive_spmm_dense_gated(_a, _b, c, custom_mm.nonfinite_flag(_b), False)
+    return True
+
+
+def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op, dense_route=None) -> torch.Tensor:
     '''Shared body of sparse_matmul / naive_matmul: op = ``a @ b`` with ``a``
     taken as sparse (a CSR tensor, or a dense tensor whose exact zeros are
     dropped), semantics of torch.matmul for every rank combination.'''
@@ -442,7 +522,7 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch
             raise ValueError('sparse matmul: both arguments need to be at least 1-d')
         a2 = a.unsqueeze(0) if a.dim() == 1 else a
         b2 = b.unsqueeze(-1) if b.dim() == 1 else b
-        c = _spmm_dispatch(a2, b2, mm_op, default_op)
+        c = _spmm_dispatch(a2, b2, mm_op, default_op, dense_route)
         if b.dim() == 1:
             c = c.squeeze(-1)
         if a.dim() == 1:
@@ -457,21 +537,16 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch
 
     fused = mm_op is default_op and not a.is_sparse_csr  # dense A + stock kernel: skip zeros in the kernel
     capturing = b.is_cuda and torch.cuda.is_current_stream_capturing()
-    if fused:
-        # A dense matrix that is not sparse enough belongs on the matrix cores: same result (see _dense_route),
-        # 6× faster on the reference's own naive test shapes (tests/naive_kernel_test.py:48-49 feeds torch.rand).
-        items = 1
-        for d in torch.broadcast_shapes(tuple(a_shape[:-2]), tuple(b_shape[:-2])):
-            items *= d
-        if a.dim() > 2 and b.dim() == 2:
-            items, rows_eff = 1, a.numel() // a_shape[-1]
-        else:
-            rows_eff = c_rows
-        if _dense_route(a, b, items, rows_eff, a_shape[-1], c_cols):
-            return custom_matmul(a.contiguous(), b.contiguous())
+    # A dense matrix that is not sparse enough belongs on the matrix cores (same result, see _on_matrix_cores):
+    # 6× faster on the reference's own naive test shapes (tests/naive_kernel_test.py:48-49 feeds torch.rand).
+    mode = (dense_route or _dense_route_mode) if fused and a.is_cuda and b.is_cuda else 'never'
+    if mode not in _DENSE_ROUTE_MODES:
+        raise ValueError(f"dense_route must be one of {_DENSE_ROUTE_MODES}, not {mode!r}")
 
     if a.dim() == 2 and b.dim() == 2:
         c = torch.empty((c_rows, c_cols), device=dev, dtype=torch.float32)
+        if _on_matrix_cores(a, b, c, mode, a):
+            return c
         # (under capture the conversion's read-back of nnz is not possible: the in-kernel route whenever it applies)
         if fused and (capturing or fused_skip_pays(1, c_rows, a_shape[-1], c_cols)) and custom_mm.naive_spmm_dense(a, b, c):
             return c
@@ -482,7 +557,8 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch
         batch = tuple(b_shape[:-2])
         _b = b.reshape((-1,) + tuple(b_shape[-2:])).permute(1, 0, 2).reshape(b_shape[-2], -1)
         c = torch.empty((c_rows, _b.shape[1]), device=dev, dtype=torch.float32)
-        c = _csr_product(a, _b, c, mm_op, default_op)
+        if not _on_matrix_cores(a, _b, c, mode, a):
+            c = _csr_product(a, _b, c, mm_op, default_op)
         return c.view(c_rows, -1, c_cols).permute(1, 0, 2).reshape(batch + (c_rows, c_cols))
 
     if a.is_sparse_csr:
@@ -492,6 +568,8 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch
         # batch of A × one B (the FC-layer call shape): flatten A's rows
         _a = a.reshape(-1, a_shape[-1])
         c = torch.empty((_a.shape[0], c_cols), device=dev, dtype=torch.float32)
+        if _on_matrix_cores(_a, b, c, mode, a):
+            return c.view(tuple(a_shape[:-1]) + (c_cols,))
         if not (fused and (capturing or fused_skip_pays(1, _a.shape[0], _a.shape[1], c_cols))
                 and custom_mm.naive_spmm_dense(_a, b, c)):
             c = _csr_product(_a, b, c, mm_op, default_op)
@@ -503,7 +581,9 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch
     _b = b.expand(batch + tuple(b_shape[-2:])).reshape((-1,) + tuple(b_shape[-2:]))
     nb = _a.shape[0]
     c = torch.empty((nb, c_rows, c_cols), device=dev, dtype=torch.float32)
-    if fused and (capturing or fused_skip_pays(nb, c_rows, a_shape[-1], c_cols)) and custom_mm.naive_spmm_dense(_a, _b, c):
+    if _on_matrix_cores(_a, _b, c, mode, a):
+        pass
+    elif fused and (capturing or fused_skip_pays(nb, c_rows, a_shape[-1], c_cols)) and custom_mm.naive_spmm_dense(_a, _b, c):
         pass  # one launch, A read once, no CSR materialised
     elif mm_op is default_op:
         # one dense→CSR conversion and one launch for the whole batch
@@ -521,7 +601,8 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op) -> torch
 
 def sparse_matmul(a: torch.Tensor,
                   b: torch.Tensor,
-                  mm_op=custom_mm.cusparse_mmul) -> torch.Tensor:
+                  mm_op=custom_mm.cusparse_mmul,
+                  dense_route=None) -> torch.Tensor:
     '''
     Uses a sparse kernel to perform matrix multiplication (reference matmuls.py:189-235).
 
@@ -529,23 +610,26 @@ def sparse_matmul(a: torch.Tensor,
     :param b:
     :param mm_op: kernel to perform basic matrix multiplication,
                   ``mm_op(values, columns, offsets, nnz, rows, cols, B, C) -> C``
+    :param dense_route: 'auto' / 'never' / 'always' for a dense `a` (default: matmuls.set_dense_route / MI_DENSE_ROUTE)
     :returns: Matrix multiplication output
     '''
-    return _spmm_dispatch(a, b, mm_op, custom_mm.cusparse_mmul)
+    return _spmm_dispatch(a, b, mm_op, custom_mm.cusparse_mmul, dense_route)
 
 
 def naive_matmul(a: torch.Tensor,
                  b: torch.Tensor,
-                 mm_op=custom_mm.naive_spmm) -> torch.Tensor:
+                 mm_op=custom_mm.naive_spmm,
+                 dense_route=None) -> torch.Tensor:
     '''
     Uses a sparse kernel to perform matrix multiplication (reference matmuls.py:258-303).
 
     :param a: Torch CSR matrix (a dense tensor is converted)
     :param b:
     :param mm_op: kernel to perform basic matrix multiplication
+    :param dense_route: 'auto' / 'never' / 'always' for a dense `a` (default: matmuls.set_dense_route / MI_DENSE_ROUTE)
     :returns: Matrix multiplication output
     '''
-    return _spmm_dispatch(a, b, mm_op, custom_mm.naive_spmm)
+    return _spmm_dispatch(a, b, mm_op, custom_mm.naive_spmm, dense_route)
 
 
 def _csr_cached(m1: torch.Tensor):
@@ -581,6 +665,9 @@ def _batched_csr_backward(ctx, m1, m2, grad_output):
       grad_m1 on m1's pattern — ONE SDDMM on the block-diagonal matrix of the batch: rows stacked, item i's columns
         shifted by i·K, against the stacked dC [batch·M, N] and m2 [batch·K, N].'''
     rows, cols = m1.shape[-2], m1.shape[-1]
+    vec = m2.dim() == 1  # batched CSR × vector (the forward's unsqueeze): a one-column shared matrix
+    if vec:
+        m2, grad_output = m2.unsqueeze(-1), grad_output.unsqueeze(-1)
     n = m2.shape[-1]
     val = torch.Tensor.values(m1)
     nb = torch.Tensor.crow_indices(m1).reshape(-1, rows + 1).shape[0]
@@ -603,6 +690,8 @@ def _batched_csr_backward(ctx, m1, m2, grad_output):
         gb = torch.empty((nb, cols, n), device=dev, dtype=torch.float32)
         custom_mm.naive_spmm_batched(t_val, t_col, t_off, total, nb, cols, rows, g, gb)
         grad_m2 = gb.sum(0) if shared else gb.reshape(m2.shape)
+        if vec:
+            grad_m2 = grad_m2.squeeze(-1)
     return grad_m1, grad_m2
 
 

@@ -35,8 +35,16 @@ Two ways to cut the rows:
 Ways to exchange a step's blocks:
   * exchange="allgather": the collective above (RCCL picks its rings / trees), IN PLACE.  Should a torch / RCCL
     build refuse the aliased in-place form — an argument check, raised on every rank alike before anything is
-    sent — the operator falls back for good to exchange="allgather_copy": the same collective into a scratch span
-    followed by one device copy into C (an extra M·N·4/chunks bytes of traffic per step; same bits);
+    sent — the operator uses exchange="allgather_copy": the same collective into a scratch span followed by one
+    device copy into C (an extra M·N·4/chunks bytes of traffic per step; same bits).  The form is PROBED ONCE at
+    construction on a tiny tensor and the outcome agreed over the group with an all-reduce (never caught inside
+    forward(): a communicator / transport failure — torch.distributed.DistBackendError — is re-raised, not mistaken
+    for a refusal);
+  * exchange="alltoall": ONE collective per step as well, but the list form of all_to_all — every rank hands its block
+    to every peer and receives each peer's block straight into its final position; RCCL runs it as one group of
+    send / recv pairs, i.e. the one-shard-per-link pattern below without leaving collective semantics (every rank
+    calls it alike; nothing can half-fail the way independent sends can).  Probed and agreed like the in-place form;
+    a build that refuses it (gloo has no list all_to_all) falls back to "allgather";
   * exchange="p2p": every rank sends its block straight to every peer and receives each peer's block
     straight into its final position (one grouped batch of isend / irecv per step).  On a fully connected
     xGMI node that uses each of the 7 peer links for exactly one shard at a time — the pattern SURVEY.md
@@ -83,6 +91,41 @@ def shard_rowptr(rowptr: torch.Tensor, r0: int, r1: int, M: int) -> torch.Tensor
     return (rp - rp[0]).to(torch.int32)
 
 
+def probe_p2p(device, timeout_s: float = 20.0, _fail_here: bool = False) -> bool:
+    '''Can every rank exchange a tiny message with every peer by direct sends (the pattern of exchange="p2p")?
+    Tried in its OWN process group with a short timeout, so a send that never completes cannot leave anything queued
+    on the group the measured exchange runs on; the outcome is agreed on the default group (all-reduce MIN): True only
+    if every rank saw every peer's message.  Never raises for a failed probe — direct sends are optional.
+    (`_fail_here`: tests — this rank fails before posting anything.)'''
+    import datetime
+    world, rank = dist.get_world_size(), dist.get_rank()
+    device = torch.device(device)
+    ok = True
+    try:
+        pg = dist.new_group(timeout=datetime.timedelta(seconds=timeout_s))  # collective: every rank creates it
+        if _fail_here:
+            raise RuntimeError("probe_p2p: forced failure")
+        send = torch.full((4,), float(rank + 1), device=device)
+        recv = torch.zeros((world, 4), device=device)
+        ops = []
+        for r in range(world):
+            if r != rank:
+                ops.append(dist.P2POp(dist.irecv, recv[r], r, group=pg))
+                ops.append(dist.P2POp(dist.isend, send, r, group=pg))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        recv[rank] = float(rank + 1)
+        expect = torch.arange(1, world + 1, device=device, dtype=torch.float32).unsqueeze(1).expand(world, 4)
+        ok = bool(torch.equal(recv, expect))
+    except Exception:  # noqa: BLE001 — whatever went wrong, direct sends are off the table
+        ok = False
+    flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag[0]))
+
+
 class ShardedSpMM:
     '''C = A·B with A row-sharded over the process group.
 
@@ -98,8 +141,8 @@ class ShardedSpMM:
                  layout=None, exchange="allgather"):
         if split not in ("rows", "nnz"):
             raise ValueError("split must be 'rows' or 'nnz'")
-        if exchange not in ("allgather", "allgather_copy", "p2p"):
-            raise ValueError("exchange must be 'allgather', 'allgather_copy' or 'p2p'")
+        if exchange not in ("allgather", "allgather_copy", "alltoall", "p2p"):
+            raise ValueError("exchange must be 'allgather', 'allgather_copy', 'alltoall' or 'p2p'")
         self.exchange = exchange
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -146,6 +189,51 @@ class ShardedSpMM:
         self._side = None
         self._scratch = {}     # (step, shape) -> out-of-place gather target (exchange="allgather_copy")
         self.fallbacks = []    # what was refused and replaced: reported by bench.py
+        if self.world > 1 and not self.modelled and dist.is_initialized():
+            self._probe_exchange()
+
+    def _agreed(self, ok: bool) -> bool:
+        '''True iff EVERY rank of the group reports ok (all-reduce MIN on the group the exchange runs on).'''
+        flag = torch.tensor([1 if ok else 0], device=self.device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(flag[0]))
+
+    def _probe_exchange(self):
+        '''Try the chosen collective form once, on a tiny tensor, and agree on the outcome over the group.  A refusal
+        (argument validation: RuntimeError / ValueError / TypeError / NotImplementedError raised before anything is
+        enqueued, on every rank alike) moves every rank to the next form: alltoall → allgather → allgather_copy.  A
+        DistBackendError (communicator, transport) is not a refusal: it is re-raised.'''
+        refusals = (RuntimeError, ValueError, TypeError, NotImplementedError)
+        while self.exchange == "alltoall" or (self.exchange == "allgather" and self.split == "rows"):
+            ok, why = True, ""
+            try:
+                if self.exchange == "alltoall":
+                    buf = torch.zeros((self.world, 4), device=self.device, dtype=torch.float32)
+                    buf[self.rank] = float(self.rank + 1)
+                    empty = buf[self.rank][:0]
+                    ins = [buf[self.rank] if r != self.rank else empty for r in range(self.world)]
+                    outs = [buf[r] if r != self.rank else empty for r in range(self.world)]
+                    dist.all_to_all(outs, ins, group=self.group)
+                    expect = torch.arange(1, self.world + 1, device=self.device, dtype=torch.float32)
+                    if not torch.equal(buf, expect.unsqueeze(1).expand(self.world, 4)):
+                        ok, why = False, "all_to_all delivered the wrong blocks"
+                else:
+                    # the shapes forward() uses: a [world·rows, N] span and this rank's [rows, N] slice of it
+                    span = torch.zeros((self.world * 2, 4), device=self.device, dtype=torch.float32)
+                    span[2 * self.rank:2 * self.rank + 2] = float(self.rank + 1)
+                    dist.all_gather_into_tensor(span, span[2 * self.rank:2 * self.rank + 2], group=self.group)
+                    expect = torch.arange(1, self.world + 1, device=self.device, dtype=torch.float32)
+                    if not torch.equal(span, expect.repeat_interleave(2).unsqueeze(1).expand(2 * self.world, 4)):
+                        ok, why = False, "in-place all_gather_into_tensor delivered the wrong blocks"
+            except refusals as err:
+                if isinstance(err, getattr(dist, "DistBackendError", ())):
+                    raise
+                ok, why = False, f"{type(err).__name__}: {str(err)[:120]}"
+            if self._agreed(ok):
+                return
+            nxt = "allgather" if self.exchange == "alltoall" else "allgather_copy"
+            self.fallbacks.append(f"{self.exchange} refused on some rank ({why or 'on a peer'}): {nxt} from now on")
+            self.exchange = nxt
 
     def alloc_output(self, N: int) -> torch.Tensor:
         return torch.empty((self.padded_rows, N), device=self.device, dtype=torch.float32)
@@ -192,10 +280,12 @@ class ShardedSpMM:
         return dist.get_global_rank(self.group, r) if self.group is not None else r
 
     def forward(self, B: torch.Tensor, out: torch.Tensor = None, gather: bool = True,
-                force_collective: bool = False) -> torch.Tensor:
+                force_collective: bool = False, compute: bool = True) -> torch.Tensor:
         '''Returns C [M, N] (a view of the padded buffer), complete on every rank
         when `gather` is true; with gather=False only this rank's blocks are valid.
-        `force_collective` issues the collective even in a one-rank group (tests).'''
+        `force_collective` issues the collective even in a one-rank group (tests).
+        compute=False issues only the exchanges of a step (what is in `out` travels): the gather-only
+        leg bench.py times beside compute-only and end-to-end.'''
         N = B.shape[1]
         if out is None:
             out = self.alloc_output(N)
@@ -205,7 +295,7 @@ class ShardedSpMM:
         if collective and self.modelled:
             raise RuntimeError("a modelled layout has no process group: call forward(..., gather=False)")
         streams = None
-        if self._alternate(B, out):
+        if compute and self._alternate(B, out):
             main = torch.cuda.current_stream(self.device)
             if self._side is None:
                 self._side = torch.cuda.Stream(self.device)
@@ -215,7 +305,8 @@ class ShardedSpMM:
         def step(j, blk):
             r0, r1 = int(self.bounds[blk[0]]), int(self.bounds[blk[0] + 1])
             mine = out[r0:r1]
-            self._multiply(blk, B, mine, out)
+            if compute:
+                self._multiply(blk, B, mine, out)
             if not collective:
                 return
             first = j * self.world
@@ -231,19 +322,22 @@ class ShardedSpMM:
                         ops.append(dist.P2POp(dist.isend, mine, self._src(r), group=self.group))
                 if ops:  # one group: the sends and receives of a step run side by side, one peer link each
                     works.extend(dist.batch_isend_irecv(ops))
+            elif self.exchange == "alltoall":
+                # list form: entry r of the input goes to rank r, entry r of the output comes from rank r; the
+                # own entry is empty on both sides (the block is already in place).  Blocks may differ in height.
+                empty = mine[:0]
+                ins = [mine if (r != self.rank and r1 > r0) else empty for r in range(self.world)]
+                outs = [out[int(self.bounds[first + r]):int(self.bounds[first + r + 1])] if r != self.rank else empty
+                        for r in range(self.world)]
+                works.append(dist.all_to_all(outs, ins, group=self.group, async_op=True))
             elif self.split == "rows":
                 span = out[int(self.bounds[first]):int(self.bounds[first + self.world])]
                 if self.exchange == "allgather":
                     # in place: `mine` is span[rank*br : (rank+1)*br]; the collective is ordered after
-                    # the kernel above (same stream) and runs beside the next step's kernel
-                    try:
-                        works.append(dist.all_gather_into_tensor(span, mine, group=self.group, async_op=True))
-                    except (RuntimeError, ValueError, TypeError) as err:
-                        # refused at call time (argument validation: identical on every rank, nothing was sent)
-                        self.fallbacks.append(f"in-place all_gather_into_tensor refused ({type(err).__name__}: "
-                                              f"{str(err)[:120]}): out-of-place gather + copy from now on")
-                        self.exchange = "allgather_copy"
-                if self.exchange == "allgather_copy":
+                    # the kernel above (same stream) and runs beside the next step's kernel.  (The aliased form
+                    # was probed at construction; an error here is a real failure and propagates.)
+                    works.append(dist.all_gather_into_tensor(span, mine, group=self.group, async_op=True))
+                else:
                     # one scratch span per step (together: a second C), copied into place after the waits
                     key = (j, tuple(span.shape))
                     if key not in self._scratch:

@@ -55,6 +55,21 @@ def t(x, dev):
     return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
 
 
+def torch_cpu_csr_matmul(rowptr, col, val, M, K, B):
+    """The reference's own CPU expression `a @ b` (reference matmuls.py:41,71,210,234,279,302) with A as a torch
+    CSR tensor, evaluated by torch-CPU: the expectation of the reference's tests (tests/naive_kernel_test.py:30)."""
+    a_csr = torch.sparse_csr_tensor(torch.from_numpy(rowptr.astype(np.int64)), torch.from_numpy(col.astype(np.int64)),
+                                    torch.from_numpy(val), (M, K))
+    return (a_csr @ torch.from_numpy(B)).numpy()
+
+
+def assert_matches_reference_expression(got, ref):
+    """tests/naive_kernel_test.py:36-37: shape equality + torch.allclose at its defaults, on the FULL output."""
+    assert got.shape == ref.shape
+    assert torch.allclose(torch.from_numpy(got), torch.from_numpy(ref), rtol=RTOL, atol=ATOL), \
+        f"max rel err vs torch-CPU A_csr @ B: {np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-30))}"
+
+
 def run_spmm(cmm, dev, rowptr, col, val, M, K, B, op="naive_spmm"):
     C = torch.full((M, B.shape[1]), float("nan"), device=dev)
     out = getattr(cmm, op)(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, t(B, dev), C)
@@ -177,6 +192,8 @@ def test_spmm_config_c2_full_output_bit_exact(cmm, dev, oracle_mod):
     B = np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32)
     got = run_spmm(cmm, dev, rowptr, col, val, M, K, B)
     assert np.array_equal(got, oracle_mod.spmm_csr_omp(rowptr, col, val, M, K, B))
+    # last link of the chain GPU -> oracle -> reference expression, at full size
+    assert_matches_reference_expression(got, torch_cpu_csr_matmul(rowptr, col, val, M, K, B))
 
 
 def test_spmm_config_c3_full_size(cmm, dev, oracle_mod):
@@ -194,6 +211,9 @@ def test_spmm_config_c3_full_size(cmm, dev, oracle_mod):
     expect = oracle_mod.spmm_csr_omp(rowptr, col, val, M, K, B)
     assert np.array_equal(got, expect)
     del expect
+    # the reference's own CPU expression on the whole 1M x 256 output (rows average 105 non-zeros), at its tests'
+    # tolerance: closes GPU -> oracle -> torch at the size the metric is quoted on
+    assert_matches_reference_expression(got, torch_cpu_csr_matmul(rowptr, col, val, M, K, B))
     # a row shard computed alone gives the same bits as the same rows of the full product
     r0, r1 = 300_000, 431_072
     rp_s = (d_rp[r0:r1 + 1] - d_rp[r0]).contiguous()
@@ -1054,6 +1074,24 @@ def test_sharded_collective_on_a_one_rank_rccl_group(cmm, dev, oracle_mod):
         C2 = op2.forward(B, force_collective=True)
         torch.cuda.synchronize()
         assert np.array_equal(C2.cpu().numpy(), want)
+        # round 4: the list-form all_to_all exchange on RCCL (own entry empty on both sides), its construction-time
+        # probe and the agreement all-reduce, the gather-only leg, and the direct-send probe in its own group
+        for split in ("rows", "nnz"):
+            op3 = sharded.ShardedSpMM(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), M, K, dev,
+                                      chunks=4, split=split, exchange="alltoall")
+            op3._probe_exchange()   # (a one-rank group skips it at construction)
+            assert op3.exchange == "alltoall" and op3.fallbacks == [], op3.fallbacks
+            out3 = op3.alloc_output(N)
+            C3 = op3.forward(B, out=out3, force_collective=True)
+            op3.forward(B, out=out3, force_collective=True, compute=False)   # exchanges only: C unchanged
+            torch.cuda.synchronize()
+            assert np.array_equal(C3.cpu().numpy(), want), split
+        op._probe_exchange()
+        assert op.exchange == "allgather" and op.fallbacks == []
+        src, dst = torch.arange(8, device=dev, dtype=torch.float32), torch.zeros(8, device=dev)
+        dist.all_to_all([dst], [src])   # RCCL's list form with a non-empty entry
+        assert torch.equal(src, dst)
+        assert sharded.probe_p2p(dev, timeout_s=20.0) is True
     finally:
         dist.destroy_process_group()
 
@@ -1641,15 +1679,21 @@ def test_bench_multi_gpu_path_rehearsal(dev):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and "REHEARSAL" in rec["data"]
     cfg = rec["config"]
-    # the default trial times the collective only (direct sends can half-fail: they are tried on request)
+    # the default trial times the two COLLECTIVE forms (in-place all-gather, list all_to_all); gloo has no list
+    # all_to_all: the construction-time probe sees the refusal, the ranks agree and that candidate folds into the
+    # all-gather (recorded in exchange_fallbacks).  Direct sends can half-fail: they are tried on request only.
     assert cfg["rccl_ranks"] == 2 and cfg["chunks"] in (2, 4) and cfg["exchange"] == "allgather"
-    assert set(cfg["chunk_trials_ms_per_step"]) == {"allgather/2", "allgather/4"} and cfg["exchange_fallbacks"] == []
+    assert set(cfg["chunk_trials_ms_per_step"]) == {"allgather/2", "allgather/4"}
+    assert len(cfg["exchange_fallbacks"]) == 1 and "alltoall refused" in cfg["exchange_fallbacks"][0]
     assert [d["rank"] for d in cfg["rank_devices"]] == [0, 1] and all("name" in d and "pid" in d for d in cfg["rank_devices"])
     assert cfg["compute_only_ms_per_step"] > 0 and rec["value"] > 0 and "cpu_baseline" not in rec
+    # the gather-only leg: its time and the implied per-rank receive rate are in the line
+    assert cfg["gather_only_ms_per_step"] > 0 and cfg["gather_receive_GBps_per_rank"] > 0 and cfg["p2p_probe_ok"] is None
     proc = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
                            "--workload", "c2", "--exchange", "try-p2p"], capture_output=True, text=True, timeout=600, env=env)
     assert proc.returncode == 0, proc.stderr[-3000:]
     cfg = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')][0])["config"]
+    assert cfg["p2p_probe_ok"] is True  # probed in its own group before the trial
     assert set(cfg["chunk_trials_ms_per_step"]) == {"allgather/2", "allgather/4", "p2p/2", "p2p/4"}
     assert cfg["exchange"] in ("allgather", "p2p")
     # and the nnz-balanced split (in-place broadcasts) through the same driver
@@ -1734,14 +1778,23 @@ def test_dense_inputs_of_the_sparse_classes_take_the_matrix_cores_above_the_cros
     (the reference's own naive test feeds torch.rand, tests/naive_kernel_test.py:48-49,62-68).  With finite operands
     every route returns the same bits: the skipped terms are exact zeros.  The route is decided from a sampled
     density that comes back without stalling the stream (the most recent count that has landed for operands of the
-    same shapes).  THE RULE for non-finite operands: on the dense route a zero of `a` multiplies the entry of `b`
-    it faces — nan, exactly as torch.matmul (the reference tests' oracle) — while the zero-skipping routes leave
-    it out, as `to_sparse_csr()` does."""
+    same shapes, or this very tensor's own).  THE RULE for non-finite operands (round 4, advisor): in the default
+    'auto' mode the route has NO semantic effect — a gated launch of the zero-skipping kernel recomputes the product
+    on the device iff `b` holds an inf / nan, so a zero of `a` never meets `b`, as with `to_sparse_csr()` (reference
+    matmuls.py:295-296), whatever ran before; dense_route='always' pins torch.matmul's semantics (0·inf = nan),
+    'never' pins the zero-skipping kernels."""
     g = torch.Generator(device=dev).manual_seed(5)
     calls = []
-    real = mm.custom_matmul  # (its kernels are default arguments bound at import: spy on the wrapper itself)
-    monkeypatch.setattr(mm, "custom_matmul", lambda *a, **k: (calls.append("dense"), real(*a, **k))[1])
+    real = mm._on_matrix_cores
+
+    def spy(*a, **k):
+        took = real(*a, **k)
+        if took:
+            calls.append("dense")
+        return took
+    monkeypatch.setattr(mm, "_on_matrix_cores", spy)
     mm._density_of_shape.clear()
+    mm._density_of_tensor.clear()
     for kept, expect_dense in ((1.0, True), (0.1, True), (0.005, False)):
         probs = torch.rand(8, 12, 512, 512, device=dev, generator=g)
         probs = probs * (torch.rand(probs.shape, device=dev, generator=g) < kept)
@@ -1763,27 +1816,71 @@ def test_dense_inputs_of_the_sparse_classes_take_the_matrix_cores_above_the_cros
     del calls[:]
     out = mm.cusparseMM.apply(x, w)
     assert calls and torch.allclose(out, x @ w, rtol=RTOL, atol=1e-4)
-    # the rule for a non-finite entry of b facing zeros of a
+    # the rule for a non-finite entry of b facing zeros of a: same shapes, different densities, back to back —
+    # in 'auto' the result never depends on the route nor on what ran before
     b = torch.rand(512, 256, device=dev, generator=g)
     b[7, 3] = float("inf")
     b[7, 5] = float("nan")
+    b[9, 11] = float("-inf")   # faces non-zeros of a: a genuine -inf in column 11 on every route
     b0 = b.clone()
     b0[7] = 0.0
-    a_dense = torch.rand(16384, 512, device=dev, generator=g)
+    a_dense = torch.rand(16384, 512, device=dev, generator=g) + 0.1
     a_dense[:, 7] = 0.0
     a_sparse = a_dense * (torch.rand(16384, 512, device=dev, generator=g) < 0.004)
-    for a, dense in ((a_dense, True), (a_sparse, False)):
-        mm.naiveSpMM.apply(a, b)
-        torch.cuda.synchronize()
+    a_sparse[:, 9] = a_dense[:, 9]
+    for order in ((a_dense, a_sparse, a_dense), (a_sparse, a_dense, a_sparse)):
+        mm._density_of_shape.clear()
+        mm._density_of_tensor.clear()
+        for a in order:
+            del calls[:]
+            out = mm.naiveSpMM.apply(a, b)
+            skip = mm.naive_matmul(a, b, dense_route="never")
+            assert torch.equal(out.view(torch.int32), skip.view(torch.int32)), "auto must keep the zero-skipping result"
+            # the zero in column 7 of a is not a term of the sum: columns 3 and 5 stay finite, column 11 is -inf
+            assert bool(torch.isfinite(out[:, [3, 5]]).all()) and bool((out[:, 11] == float("-inf")).all())
+            ref0 = mm.naive_matmul(a, b0, dense_route="never")
+            keep = [c for c in range(256) if c != 11]
+            assert torch.equal(out[:, keep], ref0[:, keep])
+    # the dense operand did take the matrix cores (its own density is known by now), the sparse one did not
+    del calls[:]
+    mm.naiveSpMM.apply(a_dense, b)
+    assert calls
+    del calls[:]
+    mm.naiveSpMM.apply(a_sparse, b)
+    assert not calls
+    # pinned modes: 'always' = torch.matmul (0·inf = nan in columns 3 and 5), 'never' = no MFMA product
+    del calls[:]
+    out = mm.naive_matmul(a_sparse, b, dense_route="always")
+    assert calls
+    ref = torch.matmul(a_sparse, b)
+    assert torch.equal(torch.isnan(out), torch.isnan(ref)) and bool(torch.isnan(out[:, 3]).all())
+    prev = mm.set_dense_route("never")
+    try:
         del calls[:]
-        out = mm.naiveSpMM.apply(a, b)
-        assert bool(calls) == dense
-        if dense:   # as torch.matmul: 0·inf = nan in columns 3 and 5, every other column untouched
-            ref = torch.matmul(a, b)
-            assert torch.equal(torch.isnan(out), torch.isnan(ref)) and bool(torch.isnan(out[:, 3]).all())
-            assert torch.equal(out[:, :3], mm.naiveSpMM.apply(a, b0)[:, :3])
-        else:       # as to_sparse_csr(): the zero is not a term of the sum
-            assert bool(torch.isfinite(out).all()) and torch.equal(out, mm.naiveSpMM.apply(a, b0))
+        mm.naiveSpMM.apply(a_dense, b)
+        assert not calls
+    finally:
+        mm.set_dense_route(prev)
+    with pytest.raises(ValueError):
+        mm.naive_matmul(a_dense, b, dense_route="sometimes")
+    # the gated launch by itself: runs iff the flag is set; covers N beyond 256 in one launch
+    x = torch.rand(300, 96, device=dev, generator=g) * (torch.rand(300, 96, device=dev, generator=g) < 0.3)
+    w = torch.rand(96, 1300 * 4, device=dev, generator=g) - 0.5
+    want = torch.empty(300, 5200, device=dev)
+    for n0 in range(0, 5200, 1024):
+        n1 = min(5200, n0 + 1024)
+        blk = torch.empty(300, n1 - n0, device=dev)
+        assert cmm.naive_spmm_dense(x, w[:, n0:n1].contiguous(), blk)
+        want[:, n0:n1] = blk
+    c = torch.full((300, 5200), -7.0, device=dev)
+    flag = cmm.nonfinite_flag(w)
+    assert int(flag) == 0
+    assert cmm.naive_spmm_dense_gated(x, w, c, flag, False) and bool((c == -7.0).all())
+    w2 = w.clone()
+    w2[95, 5199] = float("nan")
+    flag = cmm.nonfinite_flag(w2)
+    assert int(flag) == 1
+    assert cmm.naive_spmm_dense_gated(x, w, c, flag, False) and torch.equal(c, want)
 
 
 def test_naive_matmul_of_a_dense_matrix_is_graph_capturable(mm, dev):
@@ -1844,7 +1941,7 @@ def test_transpose_cache_keeps_the_pattern_not_the_values(mm, dev):
     assert torch.allclose(3.0 * (a.t() @ dc), b1.grad.cpu(), rtol=RTOL, atol=1e-4)
 
 
-def test_reference_test_shapes_at_full_size(mm, cmm, dev):
+def test_reference_test_shapes_at_full_size(mm, cmm, dev, oracle_mod):
     """reference tests/naive_kernel_test.py:67-68 and tests/cublas_kernel_test.py:68-69 at their own size:
     (256,16,512,512) × (256,16,512,64) through cublasMM, cublasTransbMM and naiveSpMM against torch.matmul at the
     reference's tolerance, and the CSR route on the fully dense "sparse" input — 1.07 × 10⁹ non-zeros in one batched
@@ -1856,9 +1953,20 @@ def test_reference_test_shapes_at_full_size(mm, cmm, dev):
     a = torch.rand(256, 16, 512, 512, device=dev, generator=g)
     b = torch.rand(256, 16, 512, 64, device=dev, generator=g)
     exp = torch.matmul(a, b)
-    assert torch.allclose(exp, mm.cublasMM.apply(a, b), rtol=RTOL, atol=ATOL)
+    dense_out = mm.cublasMM.apply(a, b)
+    assert torch.allclose(exp, dense_out, rtol=RTOL, atol=ATOL)
     out = mm.naiveSpMM.apply(a, b)  # dense input: the matrix cores
     assert torch.allclose(exp, out, rtol=RTOL, atol=ATOL)
+    # sampled heads against the CPU oracle (bit-exact: same ascending-k fmaf chain) and against torch-CPU matmul —
+    # the reference tests' own expectation — so this test does not rest on hipBLASLt's GPU matmul alone
+    heads = [(0, 0), (131, 7), (255, 15)]
+    for (i, j) in heads:
+        ah, bh = a[i, j].cpu().numpy(), b[i, j].cpu().numpy()
+        want = oracle_mod.gemm(ah, bh)
+        assert np.array_equal(dense_out[i, j].cpu().numpy(), want), (i, j)
+        assert np.array_equal(out[i, j].cpu().numpy(), want), (i, j)
+        assert torch.allclose(torch.from_numpy(want), torch.matmul(a[i, j].cpu(), b[i, j].cpu()), rtol=RTOL, atol=ATOL)
+    del dense_out
     # the CSR route at 2³⁰ non-zeros, in chunks of ≤ 65535 items as matmuls does
     values, columns, offsets = cmm.dense_to_csr(a.reshape(-1, 512, 512))
     # (torch.rand draws an exact 0 about once in 2²⁴ samples: a few dozen of the 2³⁰ entries)
@@ -1871,6 +1979,10 @@ def test_reference_test_shapes_at_full_size(mm, cmm, dev):
     scores = mm.cublasTransbMM.apply(q, b)
     ref = torch.matmul(q, b.transpose(-1, -2))
     assert torch.allclose(ref, scores, rtol=RTOL, atol=ATOL)
+    for (i, j) in heads:
+        want = oracle_mod.gemm(q[i, j].cpu().numpy(), b[i, j].cpu().numpy(), False, True)
+        assert np.array_equal(scores[i, j].cpu().numpy(), want), (i, j)
+        assert torch.allclose(torch.from_numpy(want), torch.matmul(q[i, j].cpu(), b[i, j].cpu().t()), rtol=RTOL, atol=ATOL)
 
 
 @pytest.mark.parametrize("K", [301, 302, 303])
@@ -2276,6 +2388,69 @@ def test_batched_csr_tensor_backward(mm, dev):
             assert a.grad.is_sparse_csr and a.grad.shape == a.shape
             assert torch.equal(a.grad.col_indices().cpu(), a.col_indices().cpu())
             assert torch.allclose((a2.grad * keep.reshape(a_shape)), a.grad.to_dense().cpu(), rtol=RTOL, atol=1e-5)
+
+
+@pytest.mark.parametrize("kept", [0.10, 0.25])
+def test_config_c5_pruned_attention_as_batched_csr_full_size_forward_and_backward(mm, cmm, dev, oracle_mod, kept):
+    """BASELINE.json configs[4], the SpMM leg at FULL size: attention probabilities (32, 12, 512, 512) pruned to the
+    top `kept` share of every row, handed over as ONE 4-d batched CSR tensor, times V (32, 12, 512, 64) through
+    cusparseMM.apply and naiveSpMM.apply, forward + both gradients (the reference reaches this through the per-slice
+    recursion matmuls.py:289-297 and has no working backward for it, :245-256).  Checked on sampled (b, h) items
+    against torch-CPU autograd of the dense product (the reference tests' criterion, tests/naive_kernel_test.py:30-37)
+    and bit-exact against the oracle: forward = oracle.spmm_csr_batched, grad of the values = oracle.sddmm,
+    grad of V = the oracle's CSR product with the oracle's transpose."""
+    Bz, H, S, D = 32, 12, 512, 64
+    g = torch.Generator(device=dev).manual_seed(21)
+    probs = torch.softmax(torch.rand(Bz, H, S, S, device=dev, generator=g) * 4, dim=-1)
+    keep_n = int(round(S * kept))
+    idx = probs.topk(keep_n, dim=-1).indices.sort(dim=-1).values           # [Bz, H, S, keep_n], ascending columns
+    vals = probs.gather(-1, idx)
+    crow = (torch.arange(S + 1, device=dev, dtype=torch.int64) * keep_n).expand(Bz, H, S + 1).contiguous()
+    v = torch.rand(Bz, H, S, D, device=dev, generator=g) - 0.5
+    d_ctx = torch.rand(Bz, H, S, D, device=dev, generator=g) - 0.5
+    items = [(0, 0), (17, 5), (31, 11)]
+    outs = {}
+    for cls in (mm.cusparseMM, mm.naiveSpMM):
+        a = torch.sparse_csr_tensor(crow, idx.reshape(Bz, H, -1), vals.reshape(Bz, H, -1), size=(Bz, H, S, S),
+                                    device=dev).requires_grad_(True)
+        v1 = v.clone().requires_grad_(True)
+        out = cls.apply(a, v1)
+        assert out.shape == (Bz, H, S, D)
+        out.backward(d_ctx)
+        assert a.grad.is_sparse_csr and a.grad.shape == a.shape and v1.grad.shape == v.shape
+        gvals = a.grad.values().reshape(Bz, H, S * keep_n)
+        outs[cls.__name__] = (out.detach(), v1.grad, gvals)
+        for (i, j) in items:
+            rp = (np.arange(S + 1) * keep_n).astype(np.int32)
+            col = idx[i, j].reshape(-1).cpu().numpy().astype(np.int32)
+            val = vals[i, j].reshape(-1).cpu().numpy()
+            vh, dh = v[i, j].cpu().numpy(), d_ctx[i, j].cpu().numpy()
+            # forward: the CSR-order chain
+            want = oracle_mod.spmm_csr_batched(rp.reshape(1, -1), col, val, 1, S, S, vh.reshape(1, S, D))[0]
+            assert np.array_equal(out[i, j].detach().cpu().numpy(), want), (cls.__name__, i, j)
+            # grad of the values on the pattern: <dC[row], V[col]>
+            assert np.array_equal(gvals[i, j].cpu().numpy(), oracle_mod.sddmm(rp, col, S, dh, vh)), (cls.__name__, i, j)
+            # grad of V = Aᵀ·dC, Aᵀ by the oracle's transpose (rows of Aᵀ keep A's row order: ascending columns)
+            t_rp, t_col, t_val = oracle_mod.csr_transpose(rp, col, val, S, S)
+            assert np.array_equal(v1.grad[i, j].cpu().numpy(), oracle_mod.spmm_csr(t_rp, t_col, t_val, S, S, dh)), \
+                (cls.__name__, i, j)
+            # torch-CPU autograd of the dense product on the same item
+            ad = torch.zeros(S, S)
+            ad[torch.arange(S).repeat_interleave(keep_n), torch.from_numpy(col.astype(np.int64))] = torch.from_numpy(val)
+            ad.requires_grad_(True)
+            vd = torch.from_numpy(vh).clone().requires_grad_(True)
+            ref = torch.matmul(ad, vd)
+            ref.backward(torch.from_numpy(dh))
+            assert torch.allclose(ref.detach(), out[i, j].detach().cpu(), rtol=RTOL, atol=1e-6)
+            assert torch.allclose(vd.grad, v1.grad[i, j].cpu(), rtol=RTOL, atol=1e-6)
+            picked = ad.grad[torch.arange(S).repeat_interleave(keep_n), torch.from_numpy(col.astype(np.int64))]
+            assert torch.allclose(picked, gvals[i, j].cpu(), rtol=RTOL, atol=1e-6)
+    # both classes run the same kernels: identical bits over the WHOLE batch
+    for x, y in zip(outs["cusparseMM"], outs["naiveSpMM"]):
+        assert torch.equal(x, y)
+    # whole-batch property: the product is linear in V — A·(2V) == 2·(A·V) exactly
+    a = torch.sparse_csr_tensor(crow, idx.reshape(Bz, H, -1), vals.reshape(Bz, H, -1), size=(Bz, H, S, S), device=dev)
+    assert torch.equal(mm.cusparseMM.apply(a, v * 2), outs["cusparseMM"][0] * 2)
 
 
 def test_batched_spmm_variants_fuzz_against_oracle(capi, dev, oracle_mod):

@@ -228,7 +228,8 @@ def test_batched_csr_operand_backward_and_pattern_cache(mm):
     for i in range(nb):  # torch's batched CSR wants the same number of non-zeros in every item
         keep[i, torch.randperm(M * K, generator=g)[:20]] = True
     dense = (rand(g, nb, M, K) + 0.1) * keep.reshape(nb, M, K)
-    for b in (rand(g, nb, K, 5), rand(g, K, 6), rand(g, 2, 2, K, 3)):
+    # (the 1-d operand: batched CSR × vector — the forward promotes it to a one-column matrix, the backward must too)
+    for b in (rand(g, nb, K, 5), rand(g, K, 6), rand(g, 2, 2, K, 3), rand(g, K)):
         shape = (2, 2, M, K) if b.dim() == 4 else (nb, M, K)
         a = dense.reshape(shape).to_sparse_csr().requires_grad_(True)
         n0 = sum(c[0] == "csr_transpose_batched" for c in fake.calls)

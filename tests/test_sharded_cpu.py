@@ -40,8 +40,33 @@ def _skewed_csr(M, K):
     return rowptr, col, val
 
 
+def _emulated_all_to_all(outs, ins, group=None, async_op=False):
+    """gloo has no list all_to_all: the same semantics (entry r of `ins` goes to rank r, entry r of `outs` comes from
+    rank r, empty entries are skipped) out of isend / irecv, so the operator's index arithmetic can be tested on CPU."""
+    rank = dist.get_rank(group)
+    ops = []
+    for r, (o, i) in enumerate(zip(outs, ins)):
+        if r == rank:
+            if i.numel():
+                o.copy_(i)
+            continue
+        if o.numel():
+            ops.append(dist.P2POp(dist.irecv, o, r, group=group))
+        if i.numel():
+            ops.append(dist.P2POp(dist.isend, i, r, group=group))
+    works = dist.batch_isend_irecv(ops) if ops else []
+
+    class _All:
+        def wait(self):
+            for w in works:
+                w.wait()
+    if async_op:
+        return _All()
+    _All().wait()
+
+
 def _worker(rank, world, port, M, K, N, chunks, out_dir, split="rows", skew=False, exchange="allgather",
-            refuse_in_place=False):
+            refuse_in_place=False, emulate_all_to_all=False, refuse_on_rank=None, expect_exchange=None):
     for p in (str(REPO), str(REPO / "matrix-multiplication_amd")):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -60,10 +85,24 @@ def _worker(rank, world, port, M, K, N, chunks, out_dir, split="rows", skew=Fals
                     raise RuntimeError("all_gather_into_tensor: input aliases output (refused by this build)")
                 return real(output, input, *a, **k)
             dist.all_gather_into_tensor = picky
+        if refuse_on_rank is not None and rank == refuse_on_rank:
+            # ONE rank's build refuses the in-place form at its argument check (nothing enqueued there)
+            real_ag = dist.all_gather_into_tensor
+
+            def picky_here(output, input, *a, **k):
+                lo, hi = output.data_ptr(), output.data_ptr() + output.numel() * output.element_size()
+                if lo <= input.data_ptr() < hi:
+                    raise RuntimeError("all_gather_into_tensor: input aliases output (refused on this rank)")
+                return real_ag(output, input, *a, **k)
+            dist.all_gather_into_tensor = picky_here
+        if emulate_all_to_all:
+            dist.all_to_all = _emulated_all_to_all
         rowptr, col, val = _skewed_csr(M, K) if skew else oracle.make_csr(M, K, 0.05, seed=0)
         B = torch.from_numpy(np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32))
         op = sharded.ShardedSpMM(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), M, K, "cpu",
                                  chunks=chunks, mm_op=_oracle_mm_op, split=split, exchange=exchange)
+        if expect_exchange is not None:
+            assert op.exchange == expect_exchange, (op.exchange, op.fallbacks)
         # integer artefacts: block ownership and rebased rowptrs
         assert [b[0] for b in op.blocks] == [j * world + rank for j in range(chunks)]
         for blk, rp, ci, v, nnz, rows, has_long in op.blocks:
@@ -143,6 +182,108 @@ def test_refused_in_place_gather_falls_back_to_gather_plus_copy(tmp_path, oracle
     for r in range(world):
         got = np.load(tmp_path / f"c_{r}.npy")
         assert got.shape == (M, N) and np.array_equal(got, single), f"rank {r}"
+
+
+@pytest.mark.parametrize("M,chunks,split,skew,world", [(96, 2, "rows", False, 2), (101, 3, "nnz", True, 2), (7, 4, "rows", False, 2),
+                                                       (90, 2, "nnz", True, 3)])
+def test_all_to_all_exchange_equals_single_rank(tmp_path, oracle_mod, M, chunks, split, skew, world):
+    """exchange="alltoall" (round 4): one list-form all_to_all per step — every rank's block to every peer, straight
+    into its final position, own entry empty — on equal-row and nnz-balanced blocks, ragged tails, empty blocks, two
+    and three ranks.  gloo has no list all_to_all, so the collective is emulated here out of isend / irecv (same
+    semantics); what is tested is the operator's index arithmetic and the construction-time probe."""
+    K, N = 64, 24
+    mp.spawn(_worker, args=(world, _free_port(), M, K, N, chunks, str(tmp_path), split, skew, "alltoall", False, True, None,
+                            "alltoall"), nprocs=world, join=True)
+    rowptr, col, val = _skewed_csr(M, K) if skew else oracle_mod.make_csr(M, K, 0.05, seed=0)
+    B = np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32)
+    single = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    for r in range(world):
+        got = np.load(tmp_path / f"c_{r}.npy")
+        assert got.shape == (M, N) and np.array_equal(got, single), f"rank {r}"
+
+
+def test_all_to_all_refused_by_the_backend_falls_back_to_the_all_gather_by_agreement(tmp_path, oracle_mod):
+    """A backend without the list form (gloo: "does not support alltoall", raised on every rank at call time): the
+    construction-time probe catches it, the ranks agree (all-reduce MIN) and every rank runs the in-place all-gather."""
+    M, K, N, world, chunks = 101, 64, 24, 2, 3
+    mp.spawn(_worker, args=(world, _free_port(), M, K, N, chunks, str(tmp_path), "rows", False, "alltoall", False, False, None,
+                            "allgather"), nprocs=world, join=True)
+    rowptr, col, val = oracle_mod.make_csr(M, K, 0.05, seed=0)
+    B = np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32)
+    single = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"c_{r}.npy"), single), f"rank {r}"
+
+
+def test_probe_refused_on_one_rank_only_moves_every_rank_to_the_fallback(tmp_path, oracle_mod):
+    """The probe's outcome is AGREED, not assumed identical on every rank: here rank 1 alone judges its probe of the
+    in-place all_gather_into_tensor a failure (the collective went through, so nothing is left pending on rank 0); the
+    all-reduce carries that verdict to rank 0, both ranks end on allgather_copy and return the single-rank bits."""
+    M, K, N, world, chunks = 96, 64, 24, 2, 2
+    mp.spawn(_worker_disagree, args=(world, _free_port(), M, K, N, chunks, str(tmp_path)), nprocs=world, join=True)
+    rowptr, col, val = oracle_mod.make_csr(M, K, 0.05, seed=0)
+    B = np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32)
+    single = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"c_{r}.npy"), single), f"rank {r}"
+
+
+def _worker_disagree(rank, world, port, M, K, N, chunks, out_dir):
+    for p in (str(REPO), str(REPO / "matrix-multiplication_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        import sharded
+        real = sharded.ShardedSpMM._agreed
+        seen = []
+
+        def agreed(self, ok):
+            # rank 1 reports that its probe of the in-place form failed although the collective itself went through
+            # (e.g. it delivered the wrong blocks there): the all-reduce must carry that verdict to rank 0
+            mine = ok and not (rank == 1 and self.exchange == "allgather")
+            out = real(self, mine)
+            seen.append((self.exchange, mine, out))
+            return out
+        sharded.ShardedSpMM._agreed = agreed
+        rowptr, col, val = oracle.make_csr(M, K, 0.05, seed=0)
+        B = torch.from_numpy(np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32))
+        op = sharded.ShardedSpMM(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), M, K, "cpu",
+                                 chunks=chunks, mm_op=_oracle_mm_op, exchange="allgather")
+        assert seen == [("allgather", rank == 0, False)], seen
+        assert op.exchange == "allgather_copy" and len(op.fallbacks) == 1
+        np.save(os.path.join(out_dir, f"c_{rank}.npy"), op.forward(B).numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def _worker_p2p_probe(rank, world, port, fail_rank, out_dir):
+    for p in (str(REPO), str(REPO / "matrix-multiplication_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sharded
+        ok = sharded.probe_p2p("cpu", timeout_s=3.0, _fail_here=(rank == fail_rank))
+        # the default group is still usable afterwards, whatever the probe's group went through
+        t = torch.tensor([rank + 1.0])
+        dist.all_reduce(t)
+        assert float(t) == world * (world + 1) / 2
+        with open(os.path.join(out_dir, f"p2p_{rank}.txt"), "w") as f:
+            f.write(str(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fail_rank", [(2, None), (2, 1), (3, 0)])
+def test_p2p_probe_is_agreed_and_a_failure_on_one_rank_keeps_everyone_on_the_collective(tmp_path, world, fail_rank):
+    """bench.py --exchange try-p2p probes direct sends BEFORE its trial, in the probe's own group with a short
+    timeout: all ranks fine → True everywhere; one rank fails before posting its sends (its peers' receives time out in
+    the probe group) → False everywhere, no exception, and the default group still works."""
+    mp.spawn(_worker_p2p_probe, args=(world, _free_port(), fail_rank, str(tmp_path)), nprocs=world, join=True)
+    got = [(tmp_path / f"p2p_{r}.txt").read_text() for r in range(world)]
+    assert got == [str(fail_rank is None)] * world, got
 
 
 def test_balanced_boundaries_are_exact_lower_bounds():
