@@ -340,6 +340,25 @@ int mi_csr_transpose_f32(const int32_t* rowptr, const int32_t* col, const float*
                          int64_t nnz, int32_t M, int32_t K, int32_t* t_rowptr,
                          int32_t* t_col, float* t_val, void* workspace,
                          size_t workspace_bytes, mi_stream_t stream);
+/* Which plan transposes (process-wide; every plan gives the same bits — tests pin one to compare it with the other):
+ *   TABLES    per-(tile, digit) count tables, one count launch + three scan launches ahead of every scatter pass;
+ *   ONE_SWEEP the columns are read once for counting: the first pass's count launch also counts the last pass's
+ *             digits per group of bins, and the last scatter launch finds its tiles' offsets by decoupled look-back
+ *             inside those groups (status words published / polled with agent-scope accesses, tiles handed out by
+ *             tickets so every wait is on a running workgroup) — no second count pass over the intermediate array,
+ *             no scan of its table; one matrix, 2¹⁰ < K ≤ 2²⁰ (two passes), ≥ 4 M non-zeros, nnz < 2³⁰ —
+ *             mi_csr_transpose_one_sweep_applies says whether a problem qualifies;
+ *   AUTO      ONE_SWEEP where it applies and pays (≥ 33 M non-zeros), else TABLES.  Pinning ONE_SWEEP on a problem it
+ *             does not cover: MI_EINVAL.
+ * mi_csr_transpose_check (synchronises `stream`; a debugging aid) reads back the one-sweep plan's give-up flag from
+ * the workspace of the last transpose: MI_EHIP if a look-back poll ran into its limit (never on a correct run). */
+#define MI_TRANSPOSE_PLAN_AUTO 0
+#define MI_TRANSPOSE_PLAN_TABLES 1
+#define MI_TRANSPOSE_PLAN_ONE_SWEEP 2
+int mi_csr_transpose_set_plan(int plan);
+int mi_csr_transpose_one_sweep_applies(int32_t batch, int32_t M, int32_t K, int64_t nnz);
+int mi_csr_transpose_check(const void* workspace, size_t workspace_bytes, int32_t batch, int32_t M,
+                           int32_t K, int64_t nnz, mi_stream_t stream);
 size_t mi_csr_transpose_batched_workspace_bytes(int32_t batch, int32_t M, int32_t K, int64_t nnz);
 int mi_csr_transpose_batched_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                                  int64_t nnz, int32_t batch, int32_t M, int32_t K,

@@ -27,6 +27,8 @@
 // Larger key spaces (K·batch > 2²⁰) take three passes and keep the full key to find the row
 // boundaries with one extra pass; entries that do not fit the 8-byte form ((remaining key bits) +
 // (row bits) > 32) or an 11-bit digit take a simpler path that scatters straight from registers.
+#include <atomic>
+
 #include "mi_common.h"
 
 namespace {
@@ -41,6 +43,14 @@ constexpr int TR_GROUPS = 256;                // tile groups of the column-wise 
 #endif
 constexpr int TR_COUNT_THREADS = MI_TR_COUNT_THREADS;  // count kernel (512: same, 1024: first pass 133 -> 187 µs)
 constexpr int TR_GRID = 256;                  // persistent scatter workgroups: one per CU of an MI355X
+// One-sweep plan: the tiles of a pass are cut into TR_LB_GROUPS contiguous groups; a group's per-digit base comes from
+// the histogram launch, offsets inside a group by decoupled look-back over at most its own tiles.  XCD x (workgroups
+// with blockIdx % 8 == x) works on groups 4x … 4x+3 — a contiguous eighth of the tiles, as in the table plan — with
+// 8 workgroups per group, so a look-back usually finds a finished prefix within 8 tiles.
+constexpr int TR_LB_GROUPS = 32;
+constexpr unsigned TR_LB_AGG = 1u << 30, TR_LB_PREFIX = 2u << 30, TR_LB_VALUE = (1u << 30) - 1u;
+constexpr int TR_LB_WALK = 8;                 // predecessors read in one go
+constexpr int TR_LB_SPIN_LIMIT = 1 << 22;     // polls before a look-back gives up (seconds; a correct run needs a handful)
 
 __host__ __device__ inline int bits_for(unsigned long long n) {  // bits needed for values 0 … n-1
   int b = 0;
@@ -78,6 +88,16 @@ struct TrArgs {
   float* t_val;
   unsigned* keys_out;  // three passes: full key per output position (row boundaries), else nullptr
   uint2* dump;         // [2·TR_GRID]: where a workgroup's not-yet-existing previous tile "streams out" to
+  // one-sweep plan (decoupled look-back, see tr_hist_kernel): no per-(tile, digit) table is scanned ahead of the scatter
+  unsigned* status;       // [ntiles][1 << bits] look-back words of this pass: flag (bits 31-30) | value
+  const int* grp_first;   // [TR_LB_GROUPS + 1] first tile of every tile group of this pass
+  const int* grp_base;    // [TR_LB_GROUPS][1 << bits] global offset of (group, digit) at the group's first tile
+  int* tickets;           // [TR_LB_GROUPS] next tile of each group (relative to its first)
+  const int* tile_bin;    // last pass: the low digit (bin) every tile belongs to
+  const int* first_tile;  // last pass: first tile of every bin
+  int* rowoff;            // last pass: [bins][1 << bits] offset of (bin, digit) = row offset of Aᵀ for that column
+  unsigned* lb_dump;      // [TR_THREADS] where lanes without a digit publish to
+  int* errflag;           // set when a look-back spin gives up (never on a correct run)
 };
 
 // flat rowptr index i (in [lo, hi]) of the row that holds entry e: the last i with rowptr[i] ≤ e.
@@ -353,6 +373,185 @@ __global__ __launch_bounds__(1024) void tr_bin_tiles_kernel(const int* __restric
   const int total = carry_s;
   if (threadIdx.x == 0) first_tile[nb0] = total;
   for (int t = total + threadIdx.x; t < max_tiles; t += 1024) desc[t] = make_int2(0, 0);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// One-sweep plan (two packed, staged passes; one matrix; nnz < 2³⁰): the columns are read ONCE for counting.
+// tr_hist_kernel is the first pass's count kernel made persistent — per-tile low-digit histograms into the tile-major
+// table (scanned as before; the first scatter launch is the table plan's) — that ALSO counts, in the same sweep,
+//   h2g[g][hi]  entries with high digit hi whose LOW digit lies in bin group g (bins g·2^gshift …): the last pass walks
+//               the bins in order, so a group of bins is a contiguous range of its tiles → (after tr_lb_setup_kernel)
+//               the global offset of (group g, digit hi) at the group's first tile.
+// Inside a group the last pass finds a tile's offsets by decoupled look-back (tr_scatter_staged_kernel<false, true, 1>):
+// the second count pass over the intermediate array (a second read of all 8-byte entries), its three scan launches
+// and the bin-tiles launch are gone.  (Tried and dropped: giving every workgroup of the FIRST pass a contiguous run of
+// tiles with a running offset in registers — no table, no look-back — ran 0.73 ms against 0.58: with 256 runs × 1024
+// digits open at once the partially written lines no longer meet their neighbours in the L2s; the XCD-interleaved
+// tile order of the table plan stays.)
+// Persistent: workgroup w counts tiles [w·tpw, (w+1)·tpw), the next tile's columns in flight while one is counted.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TR_THREADS) void tr_hist_kernel(TrArgs a, int bits0, int bits1, int gshift,
+                                                             int* __restrict__ h2g) {
+  extern __shared__ int hist_lds[];
+  const int nb0 = 1 << bits0, nb1 = 1 << bits1;
+  const int G = ((nb0 - 1) >> gshift) + 1;
+  int* h1 = hist_lds;        // [nb0] this tile
+  int* h2 = hist_lds + nb0;  // [G][nb1] this workgroup's whole run
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int ntiles = a.ntiles;
+  const int tpw = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t0 = blockIdx.x * tpw, t1 = t0 + tpw < ntiles ? t0 + tpw : ntiles;
+  for (int i = tid; i < nb0 + G * nb1; i += TR_THREADS) hist_lds[i] = 0;
+  __syncthreads();
+  if (t0 >= t1) return;
+  const int last = a.batch * (a.M + 1) - 1;
+  if (tid < 64) {  // the row holding every tile's first entry (a binary search per lane; wave 0 joins the counting late)
+    for (int i = lane; i < t1 - t0; i += 64) {
+      const long st = (long)(t0 + i) * TR_TILE;
+      a.tile_row[t0 + i] = st < a.nnz ? row_of(a.rowptr, 0, last, (int)st) : last;
+    }
+    if (t1 == ntiles && lane == 0) a.tile_row[ntiles] = last;
+  }
+  const unsigned m0 = (unsigned)nb0 - 1u, m1 = (unsigned)nb1 - 1u;
+  unsigned c[TR_PER], cn[TR_PER];
+  auto fetch = [&](int t, unsigned* dst) {
+#pragma unroll
+    for (int k = 0; k < TR_PER; ++k) {
+      const long q = (long)t * TR_TILE + k * TR_THREADS + tid;
+      dst[k] = q < a.nnz ? (unsigned)a.col[q] : ~0u;
+    }
+  };
+  fetch(t0, c);
+  for (int t = t0; t < t1; ++t) {
+    if (t + 1 < t1) fetch(t + 1, cn);
+#pragma unroll
+    for (int k = 0; k < TR_PER; ++k) {
+      if (c[k] != ~0u) {
+        const unsigned lo = c[k] & m0, hi = (c[k] >> bits0) & m1;
+        atomicAdd(&h1[lo], 1);
+        atomicAdd(&h2[(lo >> gshift) * nb1 + hi], 1);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < nb0; i += TR_THREADS) {
+      a.table[(long)t * nb0 + i] = h1[i];
+      h1[i] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TR_PER; ++k) c[k] = cn[k];
+  }
+  for (int i = tid; i < G * nb1; i += TR_THREADS) {
+    const int v = h2[i];
+    if (v != 0) atomicAdd(&h2g[i], v);
+  }
+}
+
+// exclusive scan of one value per thread over a 1024-thread workgroup (wsum: 16 ints of LDS); total → all threads
+__device__ __forceinline__ int tr_block_scan_1024(int v, int* wsum, int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const int u = __shfl_up(incl, s, 64);
+    if (lane >= s) incl += u;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int wbase = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const int u = wsum[w];
+    if (w < wave) wbase += u;
+    all += u;
+  }
+  __syncthreads();
+  total = all;
+  return wbase + incl - v;
+}
+
+// One workgroup, after the first pass's table is scanned (its row 0 = every low digit's global offset): the bins of the
+// intermediate array cut into the last pass's tiles (as tr_bin_tiles_kernel does) with every tile's bin, the last
+// pass's per-(bin group, high digit) offsets (h2g, in place) and the first tile of each of its tile groups.
+__global__ __launch_bounds__(1024) void tr_lb_setup_kernel(int bits0, int bits1, int gshift, long nnz, int max_tiles1,
+                                                           const int* __restrict__ table0, int* __restrict__ h2g,
+                                                           int* __restrict__ hibase, int* __restrict__ first_tile,
+                                                           int2* __restrict__ desc, int* __restrict__ tile_bin,
+                                                           int* __restrict__ grp_first2) {
+  __shared__ int wsum[16];
+  __shared__ int s_first[1025];
+  const int nb0 = 1 << bits0, nb1 = 1 << bits1;
+  const int G = ((nb0 - 1) >> gshift) + 1;
+  const int tid = threadIdx.x;
+  int total = 0;
+  // high digit first: its loads are in flight while the bins are cut
+  int h2v[TR_LB_GROUPS];
+#pragma unroll
+  for (int g = 0; g < TR_LB_GROUPS; ++g) h2v[g] = (tid < nb1 && g < G) ? h2g[g * nb1 + tid] : 0;
+  int lobase = 0, cnt = 0;
+  if (tid < nb0) {
+    lobase = table0[tid];
+    cnt = (tid + 1 < nb0 ? table0[tid + 1] : (int)nnz) - lobase;
+  }
+  // the bins of the intermediate array as tiles of the last pass (no tile holds two low digits)
+  const int nt = tid < nb0 ? (cnt + TR_TILE - 1) / TR_TILE : 0;
+  int total_tiles = 0;
+  const int first = tr_block_scan_1024(nt, wsum, total_tiles);
+  if (tid < nb0) {
+    s_first[tid] = first;
+    first_tile[tid] = first;
+    for (int j = 0; j < nt && first + j < max_tiles1; ++j) {
+      const int st = lobase + j * TR_TILE;
+      desc[first + j] = make_int2(st, cnt - j * TR_TILE < TR_TILE ? cnt - j * TR_TILE : TR_TILE);
+      tile_bin[first + j] = tid;
+    }
+  }
+  if (tid == 0) first_tile[nb0] = total_tiles;
+  for (int t = total_tiles + tid; t < max_tiles1; t += 1024) desc[t] = make_int2(0, 0);
+  int cnt2 = 0;
+#pragma unroll
+  for (int g = 0; g < TR_LB_GROUPS; ++g) {
+    const int v = h2v[g];
+    h2v[g] = cnt2;
+    cnt2 += v;
+  }
+  const int hb = tr_block_scan_1024(cnt2, wsum, total);
+  if (tid < nb1) {
+    hibase[tid] = hb;
+#pragma unroll
+    for (int g = 0; g < TR_LB_GROUPS; ++g)
+      if (g < G) h2g[g * nb1 + tid] = h2v[g] + hb;
+  }
+  if (tid == 0) hibase[nb1] = (int)nnz;
+  __syncthreads();  // s_first complete
+  if (tid <= TR_LB_GROUPS) {
+    const int bin = tid << gshift;
+    grp_first2[tid] = (tid < G && bin < nb0) ? s_first[bin] : total_tiles;
+  }
+}
+
+// Row offsets of Aᵀ for the one-sweep plan: rowoff[lo][hi], written by the last pass at every bin's first tile, is the
+// offset of column hi·2^bits0 + lo; an empty bin has no tile, its columns start where the next non-empty bin's do.
+__global__ __launch_bounds__(256) void tr_rowptr_lb_kernel(const int* __restrict__ rowoff, const int* __restrict__ first_tile,
+                                                           const int* __restrict__ hibase, int bits0, int bits1, int batch,
+                                                           int K, long nnz, int* __restrict__ t_rowptr) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)batch * ((long)K + 1);
+  if (idx >= total) return;
+  const long b = idx / ((long)K + 1);
+  const long key = b * K + (idx - b * ((long)K + 1));
+  int v;
+  if (key >= (long)batch * K) {
+    v = (int)nnz;
+  } else {
+    const int nb0 = 1 << bits0;
+    int lo = (int)(key & (nb0 - 1));
+    const int hi = (int)(key >> bits0);
+    while (lo < nb0 && first_tile[lo] == first_tile[lo + 1]) ++lo;
+    v = lo < nb0 ? rowoff[((long)lo << bits1) + hi] : hibase[hi + 1];
+  }
+  t_rowptr[idx] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -649,10 +848,32 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_kernel(TrArgs a) {
 #ifndef MI_TR_SLICE_PLAN
 #define MI_TR_SLICE_PLAN {0, 0, 3, 7, 9, 9, 10, 10}
 #endif
+#ifndef MI_TR_LB_SKEW
+#define MI_TR_LB_SKEW 0
+#endif
+#ifndef MI_TR_LB_EARLY  // 1: a tile's look-back loads are issued when it has been staged, 0: at the top of the next tile
+#define MI_TR_LB_EARLY 1
+#endif
 #ifndef MI_TR_ABL  // timing-only builds (tools/probes/tr_time.cpp): 1 = no global stores, 3 = no tile loads either
 #define MI_TR_ABL 0
 #endif
-template <bool FIRST, bool LAST>
+// LB = true: the one-sweep plan.  There is no scanned table; a tile's per-digit global offsets are found by decoupled
+// look-back inside its tile group (TR_LB_GROUPS contiguous groups per pass, each with a per-digit base from
+// tr_lb_setup_kernel).  Every digit of every tile has one 32-bit status word {flag, value} written with ONE agent-scope
+// (sc1) store and read with agent-scope loads — a self-contained granule, no ordering with any other data is needed:
+//   * in its prefix phase a tile publishes AGG | (its count of the digit);
+//   * at the top of the workgroup's NEXT tile — the staged tile only streams out from then on — thread d reads the words
+//     of the TR_LB_WALK tiles before it in one go (issued before the row fill, consumed after it), adds counts until it
+//     meets a PREFIX word or the group's first tile, re-polls a word it found empty, and publishes
+//     PREFIX | (count of the digit in the group up to and including this tile) for the tiles behind it;
+//   * tiles are handed out by per-group tickets (one returning atomic per tile, by thread 0, a tile ahead like the
+//     loads): whoever holds a ticket is running, tickets ascend, and a workgroup publishes a tile's AGG word before it
+//     waits for anything that tile's successors could hold — so every wait is on a lower-numbered tile of a RESIDENT
+//     workgroup and the lowest unfinished tile can always finish: no dependence on the grid being co-resident or on
+//     dispatch order.  A workgroup whose group is used up helps the next group.  A poll that does not succeed within
+//     TR_LB_SPIN_LIMIT tries sets *errflag and goes on with a wrong offset rather than hang the GPU.
+//   * last pass: the first tile of a bin also records its offsets as the row offsets of Aᵀ (rowoff[bin][digit]).
+template <bool FIRST, bool LAST, bool LB>
 __global__ __launch_bounds__(TR_THREADS) void tr_scatter_staged_kernel(TrArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int nb = 1 << a.bits;
@@ -662,7 +883,10 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_staged_kernel(TrArgs a)
   uint2* sorted = reinterpret_cast<uint2*>(gadj2 + 2 * nb);                   // [TR_TILE]
   unsigned short* sorted_d = reinterpret_cast<unsigned short*>(sorted + TR_TILE);  // [TR_TILE]
   unsigned* rowid = reinterpret_cast<unsigned*>(sorted_d + TR_TILE);               // [TR_TILE] (FIRST)
+  int* lb_tot = reinterpret_cast<int*>(sorted_d + TR_TILE);  // [nb] (LB, a last pass: no rowid) the staged tile's counts
   __shared__ int wsum[16];
+  __shared__ int s_next[4];
+  __shared__ int s_grp;  // (LB) the tile group thread 0 draws tickets from
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in a scalar register: loops over "my rows" stay scalar
@@ -694,7 +918,9 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_staged_kernel(TrArgs a)
       n_rp0 = a.rowptr[r];
       n_rp1 = a.rowptr[r < last_slot ? r + 1 : last_slot];
     }
-    n_goff = a.table[(long)t * nb + (tid & (nb - 1))];
+    if (!LB) {
+      n_goff = a.table[(long)t * nb + (tid & (nb - 1))];
+    }
   };
   // slice c of the NEXT tile's keys (first pass: columns; later: the whole packed entry) …
   auto fetch_slice = [&](int c) {
@@ -745,10 +971,148 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_staged_kernel(TrArgs a)
     }           // (non-temporal stores measured 3.9 ms vs 2.6 ms for the whole transpose)
   };
 
+  // ---- one-sweep plan: tickets and look-back ----
+  static_assert(!(LB && FIRST), "the look-back form keeps its counts where the first pass keeps its row ids");
+  if (LB && tid == 0) s_grp = (int)((blockIdx.x & 7u) * (TR_LB_GROUPS / 8) + ((blockIdx.x >> 3) & (TR_LB_GROUPS / 8 - 1)));
+  // thread 0: a ticket of this workgroup's group is ISSUED at the top of a tile (one returning atomic) and turned into a
+  // tile at the tile's end, a whole tile later — two tiles ahead of its use, so the atomic's round trip (≈1–3 µs from a
+  // streaming CU) is never waited for.  A group that is used up sends the workgroup on to the next group that still
+  // has tiles (then with a wait, rarely); −1 when none is left.
+  int aq_tk = 0;
+  auto acquire_issue = [&]() {
+    const int my_grp = __builtin_amdgcn_readfirstlane(s_grp);
+    const int gf = sload(a.grp_first + my_grp), gl = sload(a.grp_first + my_grp + 1);
+    aq_tk = gl > gf ? atomicAdd(&a.tickets[my_grp], 1) : 0x7fffffff;
+  };
+  auto acquire_finish = [&](int slot) {
+    int tile = -1, grp = 0;
+    int my_grp = __builtin_amdgcn_readfirstlane(s_grp);
+    const int aq_gf = sload(a.grp_first + my_grp), aq_gl = sload(a.grp_first + my_grp + 1);
+    if (aq_tk < aq_gl - aq_gf) {
+      tile = aq_gf + aq_tk;
+      grp = my_grp;
+    } else {
+      for (int tries = 1; tries < TR_LB_GROUPS; ++tries) {
+        my_grp = my_grp + 1 < TR_LB_GROUPS ? my_grp + 1 : 0;
+        const int gf = a.grp_first[my_grp], gl = a.grp_first[my_grp + 1];
+        if (gl > gf) {
+          const int k = atomicAdd(&a.tickets[my_grp], 1);
+          if (k < gl - gf) {
+            tile = gf + k;
+            grp = my_grp;
+            break;
+          }
+        }
+      }
+    }
+    s_grp = my_grp;
+    s_next[slot] = tile;
+    s_next[slot + 1] = grp;
+  };
+  // (threads beyond nb shadow digit 0 and publish to a dump word)
+  unsigned lbv[TR_LB_WALK];
+  int lb_base = 0;
+  int p_tile = 0, p_grp = 0;  // the tile staged in LDS: id, its group (its per-digit counts: lb_tot)
+  // read the status words of the TR_LB_WALK tiles before tile p (clamped into its group) and the group's base
+  auto lookback_issue = [&]() {
+    const int dd = tid < nb ? tid : 0;
+    const int p_gf = sload(a.grp_first + p_grp);
+#pragma unroll
+    for (int j = 0; j < TR_LB_WALK; ++j) {
+      int k = p_tile - 1 - j;
+      k = k < p_gf ? p_gf : k;
+      // (32-bit element offsets from ONE base pointer: the status area is far below 2³² words)
+      lbv[j] = __hip_atomic_load(a.status + ((unsigned)k * (unsigned)nb + (unsigned)dd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    lb_base = a.grp_base[(unsigned)p_grp * (unsigned)nb + (unsigned)dd];
+  };
+  // finish tile p's look-back, publish its inclusive prefix, set its offsets (gadj) and, last pass, the row offsets
+  auto lookback_resolve = [&](int* gadj) {
+    const int dd = tid < nb ? tid : 0;
+    const int p_gf = sload(a.grp_first + p_grp);
+    unsigned sum = 0;
+    int k = p_tile - 1;
+    bool done = k < p_gf, stalled = false;
+#pragma unroll
+    for (int j = 0; j < TR_LB_WALK; ++j) {
+      if (!done && !stalled) {
+        const unsigned w = lbv[j], f = w >> 30;
+        if (f == 0) {
+          stalled = true;  // not published yet: poll it below
+        } else {
+          sum += w & TR_LB_VALUE;
+          --k;
+          done = f == 2 || k < p_gf;
+        }
+      }
+    }
+    int spins = 0;
+    while (__any(!done)) {  // wave-uniform; in step with its neighbours a tile does not come here
+      if (!done) {
+        const unsigned w = __hip_atomic_load(a.status + ((unsigned)k * (unsigned)nb + (unsigned)dd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned f = w >> 30;
+        if (f != 0) {
+          sum += w & TR_LB_VALUE;
+          --k;
+          done = f == 2 || k < p_gf;
+        }
+      }
+      if (++spins > TR_LB_SPIN_LIMIT) {
+        if (!done) *a.errflag = 1;
+        break;
+      }
+      if (spins > 4) __builtin_amdgcn_s_sleep(8);
+    }
+    int excl = lb_base + (int)sum;
+    const int p_tot = lb_tot[dd];
+    // a run must lie inside the output whatever went wrong upstream (a store outside it would fault the GPU)
+    if ((unsigned)excl > (unsigned)((int)a.nnz - p_tot)) {
+      excl = 0;
+      *a.errflag = 2;
+    }
+    unsigned* pub = tid < nb ? a.status + ((unsigned)p_tile * (unsigned)nb + (unsigned)tid) : a.lb_dump + tid;
+    // (relative to the group's first tile, like the counts: a reader adds its group's base itself)
+    __hip_atomic_store(pub, TR_LB_PREFIX | (sum + (unsigned)p_tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < nb) {
+      gadj[tid] = excl - binstart[tid];
+      if (LAST) {
+        const int p_bin = sload(a.tile_bin + p_tile);
+        if (sload(a.first_tile + p_bin) == p_tile) a.rowoff[((long)p_bin << a.bits) + tid] = excl;
+      }
+    }
+  };
+
   // XCD-aware tile order (see tr_scatter_kernel): every XCD walks a contiguous range of the tiles in use
   const int ntiles = a.used_tiles ? sload(a.used_tiles) : a.ntiles;
   int t = blockIdx.x, t_end = ntiles, t_step = gridDim.x;
-  if (gridDim.x == TR_GRID) {
+  int cur_grp = 0, n1_tile = -1, n1_grp = 0;  // one-sweep last pass: the group of the tile in hand; the tile after it
+  if (LB) {
+    // (MI_TR_LB_SKEW: the workgroups of a group start a fraction of a tile apart, ≈1.4 µs each, so that a tile's
+    // predecessors published their counts well before it looks back; measured: no gain — off.)
+#if MI_TR_LB_SKEW
+    for (int i = 0; i < (int)(blockIdx.x >> 5); ++i) __builtin_amdgcn_s_sleep(52);
+#endif
+    if (tid == 0) {
+      acquire_issue();
+      acquire_finish(0);
+      if (s_next[0] >= 0) {
+        acquire_issue();
+        acquire_finish(2);
+      } else {
+        s_next[2] = -1;
+        s_next[3] = 0;
+      }
+    }
+    __syncthreads();
+    t = __builtin_amdgcn_readfirstlane(s_next[0]);
+    cur_grp = __builtin_amdgcn_readfirstlane(s_next[1]);
+    n1_tile = __builtin_amdgcn_readfirstlane(s_next[2]);
+    n1_grp = __builtin_amdgcn_readfirstlane(s_next[3]);
+    t_end = 0x7fffffff;
+    t_step = 0;
+    if (t < 0) return;
+    __syncthreads();  // s_next is rewritten by the next acquire
+  } else if (gridDim.x == TR_GRID) {
     const int per = (ntiles + 7) / 8, xcd = blockIdx.x & 7;
     t = xcd * per + (blockIdx.x >> 3);
     t_end = (xcd + 1) * per < ntiles ? (xcd + 1) * per : ntiles;
@@ -771,17 +1135,25 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_staged_kernel(TrArgs a)
   static_assert(TR_PER == 8, "MI_TR_SLICE_PLAN places eight slices");
   static_assert(TR_GROUPS % 16 == 0, "tr_group_bases_kernel: sixteen waves share the groups");
   int tile_no = 0;
-  for (; t < t_end; t += t_step) {
+  for (; t < t_end && t >= 0;) {
     const int cur_len = n_len;  // block-uniform, ≥ 1: every tile below `ntiles` is in use
     const long start = n_start;
     const int row_lo = n_row_lo, row_hi = n_row_hi;
     TR_STAMP(0);
     int* gadj = gadj2 + ((tile_no & 1) ? nb : 0);
+    if (LB) {
+      // (the staged tile's predecessors' words were requested when it was staged); the ticket after next
+#if !MI_TR_LB_EARLY
+      if (plen > 0) lookback_issue();
+#endif
+      if (tid == 0 && n1_tile >= 0) acquire_issue();
+    } else {
 #if MI_TR_INTERLEAVE
 #pragma unroll
-    for (int k = 0; k < TR_PER; ++k)
-      if (slice_at[k] == 0) store_slice(k);
+      for (int k = 0; k < TR_PER; ++k)
+        if (slice_at[k] == 0) store_slice(k);
 #endif
+    }
     // every wave zeroes ITS counters (nobody else touches them between the prefix phase and here)
     for (int i = lane; i < nb / 2; i += 64) reinterpret_cast<unsigned*>(mycnt)[i] = 0u;
     if (FIRST) {
@@ -799,8 +1171,10 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_staged_kernel(TrArgs a)
         fill(row_lo + k * TR_WAVES + wave, __builtin_amdgcn_readlane(rp0, k), __builtin_amdgcn_readlane(rp1, k));
       for (int r = row_lo + 64 * TR_WAVES + wave; r <= row_hi; r += TR_WAVES)  // tiles spanning > 1024 rows
         fill(r, sload(a.rowptr + r), sload(a.rowptr + (r < last_slot ? r + 1 : last_slot)));
-      __syncthreads();  // rows known
     }
+    if (FIRST) __syncthreads();  // rows known
+    const int next_tile = n1_tile, next_grp = n1_grp;
+    if (LB && plen > 0) lookback_resolve(const_cast<int*>(gadj_out));  // the staged tile's offsets
     TR_STAMP(7);
     Slot e[TR_PER];
 #pragma unroll
@@ -830,9 +1204,17 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_staged_kernel(TrArgs a)
       }
     }
     const int goff = n_goff;
-    const bool more = t + t_step < t_end;  // block-uniform
-    if (more) fetch_meta(t + t_step);
+    const bool more = LB ? next_tile >= 0 : t + t_step < t_end;  // block-uniform
+    if (more) fetch_meta(LB ? next_tile : t + t_step);
     TR_STAMP(1);
+    if (LB) {
+      __syncthreads();  // the staged tile's offsets (gadj_out) are complete
+#if MI_TR_INTERLEAVE
+#pragma unroll
+      for (int k = 0; k < TR_PER; ++k)
+        if (slice_at[k] == 0) store_slice(k);
+#endif
+    }
 
     // Rank inside the wave.  A lane's rank among equal digits = the wave's running count of the digit
     // (wave-private 16-bit LDS word: count in bits 0-9, ≤ 512) + the number of "peers" (lanes of this
@@ -909,6 +1291,12 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_staged_kernel(TrArgs a)
           tot += v[w];
         }
       }
+      if (LB) {
+        // this tile's count of the digit, for the tiles behind it (one self-contained word, agent scope)
+        unsigned* pub = d < nb ? a.status + ((unsigned)t * (unsigned)nb + (unsigned)d) : a.lb_dump + tid;
+        __hip_atomic_store(pub, TR_LB_AGG | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d < nb) lb_tot[d] = tot;  // read again when this tile's look-back is resolved (top of the next tile)
+      }
       int incl = tot;
 #pragma unroll
       for (int s2 = 1; s2 < 64; s2 <<= 1) {
@@ -931,7 +1319,7 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_staged_kernel(TrArgs a)
       if (d < nb) {
         const int bs = wbase + incl - tot;
         binstart[d] = bs;
-        gadj[d] = goff - bs;
+        if (!LB) gadj[d] = goff - bs;
       }
 #if MI_TR_INTERLEAVE
 #pragma unroll
@@ -955,13 +1343,43 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_staged_kernel(TrArgs a)
     }
     plen = cur_len;
     gadj_out = gadj;
+    if (LB) {
+      p_tile = t;
+      p_grp = cur_grp;
+#if MI_TR_LB_EARLY
+      lookback_issue();  // in flight across the barrier below and the top of the next tile
+#endif
+      cur_grp = next_grp;
+      t = next_tile;
+      if (tid == 0) {
+        if (next_tile >= 0) {
+          acquire_finish(0);  // the ticket issued at the top of this tile
+        } else {
+          s_next[0] = -1;
+          s_next[1] = 0;
+        }
+      }
+    } else {
+      t += t_step;
+    }
     ++tile_no;
     TR_STAMP(5);
     __syncthreads();  // the tile is staged (and, first pass: rowid may be refilled)
+    if (LB) {
+      n1_tile = __builtin_amdgcn_readfirstlane(s_next[0]);
+      n1_grp = __builtin_amdgcn_readfirstlane(s_next[1]);
+    }
     TR_STAMP(6);
   }
   // the last tile of this workgroup
   if (plen > 0) {
+    if (LB) {
+#if !MI_TR_LB_EARLY
+      lookback_issue();
+#endif
+      lookback_resolve(const_cast<int*>(gadj_out));
+      __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < TR_PER; ++k) store_slice(k);
   }
@@ -1063,8 +1481,19 @@ TrPlan make_plan(int batch, int M, int K, long nnz) {
 }
 
 struct TrWs {
-  size_t inter[2], tables[3], gsum, tile_row, desc, first_tile, keys, dump, total;
+  size_t inter[2], tables[3], lbz, lbz_bytes, gsum, tile_row, desc, first_tile, keys, dump, total;
+  size_t h2g, tickets, errflag;                          // inside the zeroed region lbz
+  size_t hibase, grp_first, tile_bin, rowoff, lb_dump;   // one-sweep plan, not zeroed
 };
+
+// Which plan transposes a matrix (process-wide; same bits): AUTO takes the one-sweep plan where it applies.
+std::atomic<int> g_tr_plan{MI_TRANSPOSE_PLAN_AUTO};
+
+// The one-sweep plan covers: one matrix, two packed + staged passes, 30-bit offsets, enough tiles to fill the chip.
+bool one_sweep_applies(const TrPlan& p, int batch, long nnz) {
+  return batch == 1 && p.passes == 2 && p.packed && p.staged[0] && p.staged[1] && p.bits[0] >= 5 && nnz < (1L << 30) &&
+         p.ntiles0 >= 2 * TR_GRID;
+}
 
 TrWs ws_layout(const TrPlan& p, long nnz) {
   TrWs w{};
@@ -1079,6 +1508,18 @@ TrWs ws_layout(const TrPlan& p, long nnz) {
   w.inter[1] = take(p.passes >= 3 ? (size_t)nnz * entry : 0);
   for (int i = 0; i < 3; ++i)
     w.tables[i] = take(i < p.passes ? (size_t)(p.ntiles_max[i] + 1) * ((size_t)1 << p.bits[i]) * 4 : 0);
+  // one-sweep plan: histograms, tickets and the error flag follow the tables (= its status words): ONE memset zeroes all
+  const bool lb = p.passes == 2;
+  w.lbz = off;
+  w.h2g = take(lb ? (size_t)TR_LB_GROUPS * ((size_t)1 << p.bits[1]) * 4 : 0);
+  w.tickets = take(lb ? (size_t)TR_LB_GROUPS * 4 : 0);
+  w.errflag = take(lb ? 4 : 0);
+  w.lbz_bytes = off - w.lbz;
+  w.hibase = take(lb ? (((size_t)1 << p.bits[1]) + 1) * 4 : 0);
+  w.grp_first = take(lb ? (size_t)(TR_LB_GROUPS + 1) * 4 : 0);
+  w.tile_bin = take(lb ? (size_t)p.ntiles_max[1] * 4 : 0);
+  w.rowoff = take(lb ? ((size_t)1 << (p.bits[0] + p.bits[1])) * 4 : 0);
+  w.lb_dump = take(lb ? (size_t)TR_THREADS * 4 : 0);
   w.gsum = take((size_t)(TR_GROUPS + 1) * 2048 * 4);  // group sums + per-digit totals
   w.tile_row = take((size_t)(p.ntiles0 + 2) * 4);
   w.desc = take(p.passes == 2 ? (size_t)p.ntiles_max[1] * 8 : 0);
@@ -1087,6 +1528,18 @@ TrWs ws_layout(const TrPlan& p, long nnz) {
   w.dump = take((size_t)TR_GRID * 16);
   w.total = off;
   return w;
+}
+
+template <bool FIRST, bool LAST>
+int launch_scatter_one_sweep(const TrArgs& a, hipStream_t s) {
+  const int nb = 1 << a.bits;
+  size_t lds = (size_t)TR_WAVES * nb * 2 + (size_t)nb * 8 + (size_t)nb * 4 + (size_t)TR_TILE * 8 + (size_t)TR_TILE * 2;
+  if (FIRST) lds += (size_t)TR_TILE * 4;  // rowid
+  if (!FIRST) lds += (size_t)nb * 4;      // lb_tot
+  auto k = tr_scatter_staged_kernel<FIRST, LAST, true>;
+  if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, dim3(TR_GRID), dim3(TR_THREADS), lds, s, a);
+  return mi::check_launch();
 }
 
 template <bool FIRST, bool LAST>
@@ -1102,7 +1555,7 @@ int launch_scatter(const TrArgs& a, bool packed, bool staged, hipStream_t s) {
     if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL(k, grid, dim3(TR_THREADS), lds, s, a);                                                       \
   } while (0)
-  if (packed && staged) MI_TR((tr_scatter_staged_kernel<FIRST, LAST>));
+  if (packed && staged) MI_TR((tr_scatter_staged_kernel<FIRST, LAST, false>));
   else if (packed) MI_TR((tr_scatter_kernel<FIRST, LAST, true>));
   else MI_TR((tr_scatter_kernel<FIRST, LAST, false>));
 #undef MI_TR
@@ -1169,6 +1622,75 @@ int transpose_impl(const int32_t* rowptr, const int32_t* col, const float* val, 
       }
     }
   };
+
+  const int plan = g_tr_plan.load(std::memory_order_relaxed);
+  if (plan == MI_TRANSPOSE_PLAN_ONE_SWEEP && !one_sweep_applies(p, batch, nnz)) return MI_EINVAL;
+  // AUTO: where it pays — measured on MI355X (tools/bench_transpose_plans.py): 110 M non-zeros (13 422 tiles) 1.73 → 1.56 ms,
+  // 6 M / 10.5 M non-zeros (733 / 1 283 tiles) 0.147 → 0.196 / 0.258 → 0.330 ms: the look-back costs ≈1 µs per tile and
+  // workgroup, the launches it replaces ≈19 ns per tile of the whole problem
+  if (plan != MI_TRANSPOSE_PLAN_TABLES && one_sweep_applies(p, batch, nnz) &&
+      (plan == MI_TRANSPOSE_PLAN_ONE_SWEEP || p.ntiles0 >= 16 * TR_GRID)) {
+    const int nb0 = 1 << p.bits[0], nb1 = 1 << p.bits[1];
+    const int gshift = p.bits[0] - 5;                      // 32 groups of bins for the last pass
+    const int ntiles0 = (int)p.ntiles0;
+    int* h2g = reinterpret_cast<int*>(base + w.h2g);
+    int* tickets = reinterpret_cast<int*>(base + w.tickets);
+    int* hibase = reinterpret_cast<int*>(base + w.hibase);
+    int* grp_first = reinterpret_cast<int*>(base + w.grp_first);
+    int* tile_bin = reinterpret_cast<int*>(base + w.tile_bin);
+    // status words of the last pass (its table area), h2, tickets, error flag: zero; so is the first table's extra row
+    MI_HIP_TRY(hipMemsetAsync(base + w.tables[1], 0, (w.lbz + w.lbz_bytes) - w.tables[1], s));
+    MI_HIP_TRY(hipMemsetAsync(tables[0] + (size_t)ntiles0 * nb0, 0, (size_t)nb0 * 4, s));
+    a.ntiles = ntiles0;
+    a.lb_dump = reinterpret_cast<unsigned*>(base + w.lb_dump);
+    a.errflag = reinterpret_cast<int*>(base + w.errflag);
+    // first pass: by the low digit, CSR arrays → packed intermediate — the table plan's, its count launch also counting
+    // the last pass's per-(bin group, high digit) totals
+    a.shift = p.shift[0];
+    a.bits = p.bits[0];
+    a.drop_after_first = 1;
+    a.desc = nullptr;
+    a.used_tiles = nullptr;
+    a.table = tables[0];
+    set_inter(0, false);
+    const size_t hist_lds = ((size_t)nb0 + (size_t)TR_LB_GROUPS * nb1) * 4;
+    MI_HIP_TRY(hipFuncSetAttribute((const void*)tr_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds));
+    hipLaunchKernelGGL(tr_hist_kernel, dim3(TR_GRID), dim3(TR_THREADS), hist_lds, s, a, p.bits[0], p.bits[1], gshift, h2g);
+    {
+      const int rows = ntiles0 + 1;
+      const dim3 sg(TR_GROUPS, (unsigned)((nb0 + 255) / 256));
+      hipLaunchKernelGGL(tr_group_sums_kernel, sg, dim3(256), 0, s, tables[0], rows, nb0, gsum);
+      int* dtot = gsum + (size_t)TR_GROUPS * 2048;
+      hipLaunchKernelGGL(tr_group_bases_kernel, dim3((unsigned)((nb0 + 63) / 64)), dim3(1024), 0, s, gsum, nb0, dtot);
+      hipLaunchKernelGGL(tr_apply_kernel, sg, dim3(256), 0, s, tables[0], rows, nb0, gsum, dtot);
+    }
+    int st = mi::check_launch();
+    if (st != MI_OK) return st;
+    st = launch_scatter<true, false>(a, true, true, s);
+    if (st != MI_OK) return st;
+    hipLaunchKernelGGL(tr_lb_setup_kernel, dim3(1), dim3(1024), 0, s, p.bits[0], p.bits[1], gshift, (long)nnz,
+                       (int)p.ntiles_max[1], tables[0], h2g, hibase, first_tile, desc, tile_bin, grp_first);
+    // last pass: by the high digit, one tile never holds two bins; offsets by look-back inside 32 groups of bins
+    a.shift = p.shift[1];
+    a.bits = p.bits[1];
+    a.drop_after_first = 0;
+    a.desc = desc;
+    a.ntiles = (int)p.ntiles_max[1];
+    set_inter(0, true);
+    a.status = reinterpret_cast<unsigned*>(tables[1]);
+    a.grp_first = grp_first;
+    a.grp_base = h2g;
+    a.tickets = tickets;
+    a.tile_bin = tile_bin;
+    a.first_tile = first_tile;
+    a.rowoff = reinterpret_cast<int*>(base + w.rowoff);
+    st = launch_scatter_one_sweep<false, true>(a, s);
+    if (st != MI_OK) return st;
+    const long total = (long)batch * ((long)K + 1);
+    hipLaunchKernelGGL(tr_rowptr_lb_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.rowoff, first_tile, hibase,
+                       p.bits[0], p.bits[1], batch, K, (long)nnz, t_rowptr);
+    return mi::check_launch();
+  }
 
   for (int pass = 0; pass < p.passes; ++pass) {
     const bool first = pass == 0, last = pass == p.passes - 1;
@@ -1244,6 +1766,31 @@ int mi_csr_transpose_f32(const int32_t* rowptr, const int32_t* col, const float*
                          size_t workspace_bytes, mi_stream_t stream) {
   return transpose_impl(rowptr, col, val, nnz, 1, M, K, t_rowptr, t_col, t_val, workspace, workspace_bytes,
                         static_cast<hipStream_t>(stream));
+}
+
+int mi_csr_transpose_set_plan(int plan) {
+  if (plan != MI_TRANSPOSE_PLAN_AUTO && plan != MI_TRANSPOSE_PLAN_TABLES && plan != MI_TRANSPOSE_PLAN_ONE_SWEEP) return MI_EINVAL;
+  g_tr_plan.store(plan, std::memory_order_relaxed);
+  return MI_OK;
+}
+
+int mi_csr_transpose_one_sweep_applies(int32_t batch, int32_t M, int32_t K, int64_t nnz) {
+  if (batch <= 0 || M <= 0 || K <= 0 || nnz <= 0 || nnz > 0x7fffffffLL) return 0;
+  return one_sweep_applies(make_plan(batch, M, K, nnz), batch, nnz) ? 1 : 0;
+}
+
+int mi_csr_transpose_check(const void* workspace, size_t workspace_bytes, int32_t batch, int32_t M, int32_t K,
+                           int64_t nnz, mi_stream_t stream) {
+  if (batch <= 0 || M < 0 || K < 0 || nnz < 0 || nnz > 0x7fffffffLL) return MI_EINVAL;
+  const TrPlan p = make_plan(batch, M, K, nnz);
+  if (!one_sweep_applies(p, batch, nnz)) return MI_OK;  // only the one-sweep plan has anything to report
+  const TrWs w = ws_layout(p, nnz);
+  if (!workspace || workspace_bytes < w.total) return MI_EINVAL;
+  int flag = 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  MI_HIP_TRY(hipMemcpyAsync(&flag, static_cast<const char*>(workspace) + w.errflag, sizeof(int), hipMemcpyDeviceToHost, s));
+  MI_HIP_TRY(hipStreamSynchronize(s));
+  return flag == 0 ? MI_OK : MI_EHIP;
 }
 
 int mi_csr_transpose_batched_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,

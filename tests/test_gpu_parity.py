@@ -461,9 +461,76 @@ def test_csr_transpose_many_tiles_per_workgroup_skewed(cmm, dev, batch, M, K, nn
     assert np.array_equal(t_off.cpu().numpy().astype(np.int64), want_off)
 
 
+def _transpose_through_the_c_abi(capi, dev, rowptr, col, val, M, K, plan):
+    """mi_csr_transpose_f32 with the plan pinned (1 tables, 2 one-sweep); returns (t_rowptr, t_col, t_val) on the host and
+    checks the one-sweep plan's give-up flag."""
+    vp, i64, i32, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_size_t
+    capi.mi_csr_transpose_workspace_bytes.restype = sz
+    capi.mi_csr_transpose_workspace_bytes.argtypes = [i32, i32, i64]
+    capi.mi_csr_transpose_f32.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, sz, vp]
+    capi.mi_csr_transpose_check.argtypes = [vp, sz, i32, i32, i32, i64, vp]
+    nnz = len(val)
+    d_rp, d_col, d_val = t(rowptr, dev), t(col, dev), t(val, dev)
+    ws_bytes = capi.mi_csr_transpose_workspace_bytes(M, K, nnz)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    t_rp = torch.full((K + 1,), -1, dtype=torch.int32, device=dev)
+    t_col = torch.full((nnz,), -1, dtype=torch.int32, device=dev)
+    t_val = torch.full((nnz,), -1.0, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert capi.mi_csr_transpose_set_plan(plan) == 0
+    try:
+        st = capi.mi_csr_transpose_f32(d_rp.data_ptr(), d_col.data_ptr(), d_val.data_ptr(), nnz, M, K, t_rp.data_ptr(),
+                                       t_col.data_ptr(), t_val.data_ptr(), ws.data_ptr(), ws_bytes, stream)
+    finally:
+        capi.mi_csr_transpose_set_plan(0)
+    assert st == 0, st
+    assert capi.mi_csr_transpose_check(ws.data_ptr(), ws_bytes, 1, M, K, nnz, stream) == 0, "a look-back poll gave up"
+    return t_rp.cpu().numpy(), t_col.cpu().numpy(), t_val.cpu().numpy()
+
+
+@pytest.mark.parametrize("M,K,nnz,skew,holes", [(200_000, 300_000, 6_000_000, 0.3, False),   # digits of 10 + 9 bits
+                                                (150_000, 1 << 20, 7_000_000, 1.0, False),   # 10 + 10 bits
+                                                (90_000, 1 << 20, 5_000_000, 0.05, True)])   # most low-digit bins empty
+def test_csr_transpose_one_sweep_plan_bit_exact(capi, dev, M, K, nnz, skew, holes):
+    """Round 4: the one-sweep plan (the first pass's count launch also counts the last pass's digits per group of bins;
+    the last scatter launch finds its tiles' offsets by decoupled look-back inside those groups, tiles handed out by
+    tickets) against numpy's stable sort of the columns AND bit for bit against the table plan — on skewed data:
+    Dirichlet row lengths with runs of empty rows, a hub column (every lane of a ranking step with the same digit: one
+    tile's whole count in one status word), duplicates, rows out of column order, bins without a single entry (their row
+    offsets come from the next bin that has one).  The plan's give-up flag (a poll that ran into its limit) must stay 0."""
+    rng = np.random.Generator(np.random.PCG64(M + K))
+    lens = rng.multinomial(nnz, rng.dirichlet(np.full(M, skew)))
+    col = rng.integers(0, K, size=nnz).astype(np.int32)
+    if holes:
+        col &= ~np.int32(0x3F8)                                # low digits 0..7 only (+ the hub's)
+    col[rng.random(nnz) < 0.05] = K // 3                       # the hub column
+    rowptr = np.zeros(M + 1, np.int64)
+    rowptr[1:] = np.cumsum(lens)
+    rows = np.repeat(np.arange(M, dtype=np.int64), lens)
+    order = np.lexsort((col, rows))
+    unsorted = (rows % 7) == 3                                 # ascending columns … except in every 7th row
+    col = np.where(unsorted, col, col[order]).astype(np.int32)
+    val = rng.random(nnz, dtype=np.float32) - 0.5
+    rowptr = rowptr.astype(np.int32)
+    assert capi.mi_csr_transpose_one_sweep_applies(1, M, K, nnz) == 1
+    got = _transpose_through_the_c_abi(capi, dev, rowptr, col, val, M, K, plan=2)
+    ref = _transpose_through_the_c_abi(capi, dev, rowptr, col, val, M, K, plan=1)
+    for x, y, what in zip(got, ref, ("t_rowptr", "t_col", "t_val")):
+        assert np.array_equal(x, y), what
+    order = np.argsort(col, kind="stable")
+    assert np.array_equal(got[1], rows.astype(np.int32)[order])
+    assert np.array_equal(got[2], val[order])
+    want_off = np.concatenate([[0], np.cumsum(np.bincount(col, minlength=K))]).astype(np.int32)
+    assert np.array_equal(got[0], want_off)
+    # a problem the plan does not cover cannot be pinned onto it
+    assert capi.mi_csr_transpose_one_sweep_applies(1, 1000, 1000, 50_000) == 0
+    assert capi.mi_csr_transpose_one_sweep_applies(4, M, K // 4, nnz) == 0
+
+
 def test_csr_transpose_config_c3_shape(cmm, dev, oracle_mod):
     """The transpose at BASELINE config C3's matrix (1M x 1M, 110 M non-zeros): integer artefacts
-    (offsets, row indices) and values bit-exact against numpy's stable argsort of the columns."""
+    (offsets, row indices) and values bit-exact against numpy's stable argsort of the columns.  (At this size AUTO
+    takes the one-sweep plan, round 4.)"""
     import synthetic
     M = K = 1 << 20
     rowptr, col, val = synthetic.make_csr(M, K, 1e-4, seed=0)
