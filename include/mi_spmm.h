@@ -172,6 +172,16 @@ int mi_spmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col,
                             int64_t strideC, mi_stream_t stream);
 /* … with a kernel-variant override, for benchmarks and tests (a variant that does not take
  * batches, or not this shape, returns MI_EINVAL), and what AUTO resolves to for a batch. */
+/* The batched product with the values read THROUGH A PERMUTATION: entry p of the batched CSR (rowptr, col) has the
+ * value val[perm[p]] — the transposed pattern of a batched CSR tensor with the permutation that carries the values
+ * into it (matmuls caches both per tensor; the reference has no backward for this input, matmuls.py:245-256), so a
+ * backward needs no gathered copy of the values.  Same bits as mi_spmm_csr_batched_f32 on the gathered values.
+ * Returns MI_OK after launching, 1 (nothing launched) when AUTO's plan for the problem is not the LDS-resident-B
+ * kernel, the only one that takes a permutation — the caller then gathers and calls mi_spmm_csr_batched_f32. */
+int mi_spmm_csr_batched_perm_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                                 const int32_t* perm, int64_t nnz_total, int32_t batch, int32_t M,
+                                 int32_t K, int32_t N, const float* B, int64_t ldb, int64_t strideB,
+                                 float* C, int64_t ldc, int64_t strideC, mi_stream_t stream);
 int mi_spmm_csr_batched_variant_f32(int variant, const int32_t* rowptr, const int32_t* col,
                                     const float* val, int64_t nnz_total, int32_t batch,
                                     int32_t M, int32_t K, int32_t N, const float* B,

@@ -520,6 +520,53 @@ torch::Tensor naive_spmm_batched(torch::Tensor A_values, torch::Tensor A_columns
   return C;
 }
 
+// naive_spmm_batched with the values read through a permutation (entry p has the value A_values[perm[p]]): the
+// transposed pattern of a batched CSR tensor in a backward, without a gathered copy of the values.  Returns false
+// (nothing launched) when the plan for the problem does not take a permutation: gather and call naive_spmm_batched.
+bool naive_spmm_batched_perm(torch::Tensor A_values, torch::Tensor perm, torch::Tensor A_columns, torch::Tensor A_offsets,
+                             int64_t nnzA, int64_t batch, int64_t A_rows, int64_t A_cols, torch::Tensor B,
+                             torch::Tensor C) {
+  const char* what = "naive_spmm_batched_perm";
+  check_device_f32(A_values, "A_values");
+  check_device_i32(perm, "perm");
+  check_device_i32(A_columns, "A_columns");
+  check_device_i32(A_offsets, "A_offsets");
+  check_device_f32(B, "B");
+  check_device_f32(C, "C");
+  check_same_device(A_values, C, what);
+  check_same_device(perm, C, what);
+  check_same_device(A_columns, C, what);
+  check_same_device(A_offsets, C, what);
+  check_same_device(B, C, what);
+  TORCH_CHECK(batch >= 0 && A_rows >= 0 && A_cols >= 0 && nnzA >= 0, what, ": negative size");
+  TORCH_CHECK(batch <= 65535, what, ": at most 65535 items per launch");
+  TORCH_CHECK(A_values.is_contiguous() && perm.is_contiguous() && A_columns.is_contiguous() && A_offsets.is_contiguous(),
+              what, ": CSR arrays must be contiguous");
+  TORCH_CHECK(A_offsets.numel() == batch * (A_rows + 1), what, ": A_offsets must be [batch, A_rows + 1]");
+  TORCH_CHECK(perm.numel() >= nnzA && A_columns.numel() >= nnzA && A_values.numel() >= nnzA, what,
+              ": nnzA exceeds the CSR arrays");
+  TORCH_CHECK(C.dim() == 3 && C.is_contiguous() && C.size(0) == batch && C.size(1) == A_rows, what,
+              ": C must be contiguous [batch, A_rows, N]");
+  const int64_t N = C.size(2);
+  torch::Tensor Bc = B.contiguous();
+  int64_t strideB = 0;
+  if (Bc.dim() == 3) {
+    TORCH_CHECK(Bc.size(0) == batch && Bc.size(1) == A_cols && Bc.size(2) == N, what, ": B must be [batch, A_cols, N]");
+    strideB = A_cols * N;
+  } else {
+    TORCH_CHECK(Bc.dim() == 2 && Bc.size(0) == A_cols && Bc.size(1) == N, what, ": B must be [A_cols, N]");
+  }
+  c10::hip::HIPGuard guard(C.device().index());
+  const int st = mi_spmm_csr_batched_perm_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
+                                              A_values.data_ptr<float>(), perm.data_ptr<int32_t>(), nnzA, (int32_t)batch,
+                                              (int32_t)A_rows, (int32_t)A_cols, (int32_t)N, Bc.data_ptr<float>(),
+                                              std::max<int64_t>(N, 1), strideB, C.data_ptr<float>(),
+                                              std::max<int64_t>(N, 1), A_rows * N, stream_of(C));
+  if (st == 1) return false;
+  check_status(st, what);
+  return true;
+}
+
 // C[b] = A[b]·B[b] (+ bias) with A DENSE [batch…, M, K]: exact zeros are skipped inside the
 // kernel (no CSR is built).  B is [batch…, K, N] or [K, N] (shared), C [batch…, M, N].
 // Returns false (and does nothing) when the fused kernel does not cover the shape, so the
@@ -1085,6 +1132,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("csr_transpose", &csr_transpose, "Device CSR transpose (values, columns, offsets)");
   m.def("csr_transpose_batched", &csr_transpose_batched, "Batched device CSR transpose (values, columns, offsets [batch, cols+1])");
   m.def("sddmm", &sddmm, "Sampled dense-dense product on a CSR pattern");
+  m.def("naive_spmm_batched_perm", &naive_spmm_batched_perm,
+        "naive_spmm_batched with entry p's value = A_values[perm[p]]; False (nothing launched) if the plan takes no permutation");
   m.def("naive_spmm_dense", &naive_spmm_dense,
         "A·B with A dense, zeros skipped in the kernel; False if the shape is not covered");
   m.def("naive_spmm_dense_bias", &naive_spmm_dense_bias, "as naive_spmm_dense, + bias in the epilogue");

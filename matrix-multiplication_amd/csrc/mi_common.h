@@ -38,9 +38,11 @@ int launch_spmm_slab(const int32_t* rowptr, const int32_t* col, const float* val
 // vec4 requirements and spmm_ldsb_fits(); rows beyond long_thresh non-zeros are skipped (the caller lists them)
 bool spmm_ldsb_fits(int32_t K, int32_t N);
 int spmm_ldsb_tiles(int32_t K, int32_t N);  // column tiles the plan cuts N into (0: does not fit)
+// perm (may be null): the value of entry p is val[perm[p]] (the transposed pattern of a batched CSR with its
+// permutation: no gathered copy of the values)
 int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val, const float* B, float* C,
                      int32_t batch, int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t ldc, int64_t strideB,
-                     int64_t strideC, const float* bias, int long_thresh, hipStream_t s);
+                     int64_t strideC, const float* bias, int long_thresh, hipStream_t s, const int32_t* perm = nullptr);
 
 // the same kernel on column-major operands (X = Bᵀ [N, ldx], Y = Cᵀ [N, ldy]); caller checks the requirements
 int launch_spmm_slab_colmajor(const int32_t* rowptr, const int32_t* col, const float* val, const float* X, float* Y,

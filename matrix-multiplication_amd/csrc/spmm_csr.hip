@@ -1313,6 +1313,25 @@ int mi_spmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col, const flo
                        C, ldc, strideC, nullptr, nullptr, 0, static_cast<hipStream_t>(stream));
 }
 
+int mi_spmm_csr_batched_perm_f32(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* perm,
+                                 int64_t nnz_total, int32_t batch, int32_t M, int32_t K, int32_t N, const float* B,
+                                 int64_t ldb, int64_t strideB, float* C, int64_t ldc, int64_t strideC,
+                                 mi_stream_t stream) {
+  if (M < 0 || K < 0 || N < 0 || nnz_total < 0 || batch < 0 || strideB < 0 || strideC < 0) return MI_EINVAL;
+  if (nnz_total > 0x7fffffffLL || batch > 65535) return MI_ERANGE;
+  if (M == 0 || N == 0 || batch == 0) return MI_OK;
+  if (!rowptr || !C || !perm) return MI_EINVAL;
+  if (nnz_total > 0 && (!col || !val || !B)) return MI_EINVAL;
+  if (ldb < N || ldc < N) return MI_EINVAL;
+  const Shape sh = classify(N, ldb, ldc, strideB, strideC, B, C);
+  // only the LDS-resident-B kernel reads its values through a permutation; every row keeps the plain CSR-order chain
+  // (what mi_spmm_csr_batched_f32 gives a batch: no long-row rule without a workspace)
+  if (choose_variant(sh, nnz_total, batch, M, K, N, ldb) != MI_SPMM_LDS_B || !sh.vec4_ok || !mi::spmm_ldsb_fits(K, N))
+    return 1;
+  return mi::launch_spmm_ldsb(rowptr, col, val, B, C, batch, M, K, N, ldb, ldc, strideB, strideC, nullptr, 0x7fffffff,
+                              static_cast<hipStream_t>(stream), perm);
+}
+
 int mi_spmm_csr_batched_variant_f32(int variant, const int32_t* rowptr, const int32_t* col, const float* val,
                                     int64_t nnz_total, int32_t batch, int32_t M, int32_t K, int32_t N,
                                     const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,

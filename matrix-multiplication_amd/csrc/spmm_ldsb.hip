@@ -18,6 +18,10 @@
 //     prefetched across rows (the L2-gather kernels lean on 16+ resident waves per SIMD instead: here LDS is full);
 //   * every output element is the row's non-zeros in CSR order, one fmaf chain: the bits of every other plan.
 // Rows beyond the long-row threshold are skipped (spmm_dispatch lists them and runs its follow-up kernel), batch = 1 only.
+// Round 4, measured and NOT kept (384 × 512² × 64): v_pk_fma_f32 for the chain (0.385 → 0.466 ms at 100 % kept: a packed
+// f32 FMA does not issue faster than its two halves), eight staging loads per lane in flight before their LDS writes
+// (0.0590 → 0.0592 ms at 10 %: the plain loop was not the cost), one more row step of col / val look-ahead (0.0592 →
+// 0.0619 at 10 %, 0.1116 → 0.1152 at 25 %).
 #include "mi_common.h"
 #include "mi_lanes.h"
 
@@ -37,12 +41,14 @@ __device__ __forceinline__ f32x4 fma4(float a, f32x4 x, f32x4 acc) {
 
 constexpr int kWaves = 16;
 
-template <int G>
+template <int G, bool PERM>
 __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ B, float* __restrict__ C, int M, int K, int N, long ldb, long ldc, long strideB,
     long strideC, const float* __restrict__ bias, int ctiles, int units_per_item, int rows_per_unit,
-    unsigned total_units, int long_thresh) {  // N: width of one column tile (the whole row when ctiles = 1)
+    unsigned total_units, int long_thresh, const int* __restrict__ perm) {
+  // N: width of one column tile (the whole row when ctiles = 1); PERM: entry p's value is val[perm[p]] (a template
+  // parameter: as a run-time test inside load_chunk it cost 20 % — 0.385 → 0.462 ms at 100 % kept)
   extern __shared__ __attribute__((aligned(16))) f32x4 Bs[];  // [K][N / 4]
   constexpr int RPW = 64 / G;  // rows per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -92,15 +98,18 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
       skip = en - st > long_thresh;  // left to spmm_long_rows_kernel
       if (skip) en = st;
     };
-    // an entry travels as {byte offset of its B row in LDS, value}; positions beyond the row's end read as value 0
-    // on the all-zero row K: fmaf(0, 0, acc) leaves every bit of acc (acc starts at +0 and can never be −0)
+    // an entry travels as {byte offset of its B row in LDS, value}; positions beyond the row's end read as value −0 on
+    // the all-zero (+0) row K: fmaf(−0, +0, acc) = acc + (−0) leaves EVERY accumulator's bits — +0 stays +0, and a −0
+    // accumulator (a row whose products all underflow negatively) stays −0, which padding with +0 would turn into +0
+    // where every other plan and the oracle keep −0 — so the four-entry steps carry no predicate
     const int row_bytes = N * 4;
     auto load_chunk = [&](int p, int en, int (&c)[SC], float (&v)[SC]) {
 #pragma unroll
       for (int j = 0; j < SC; ++j) {
         const int idx = p + j * EPC + (gl & (EPC - 1));
         c[j] = (idx < en ? col[idx] : K) * row_bytes;
-        v[j] = idx < en ? val[idx] : 0.f;
+        if (PERM) v[j] = idx < en ? val[perm[idx]] : -0.f;
+        else v[j] = idx < en ? val[idx] : -0.f;
       }
     };
     // (lanes beyond a row that is not a power of two wide compute on column 0 and store nothing: no predicate in the loop)
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
                 constexpr int e = decltype(e_)::value;
                 constexpr int I = b + e < EPC ? b + e : EPC - 1;
                 const int off = b + e < EPC ? group_lane<G, I, true>(c0[j]) : K * row_bytes;  // (G < 4: the zero row)
-                v[e] = b + e < EPC ? group_lane<G, I, true>(v0[j]) : 0.f;
+                v[e] = b + e < EPC ? group_lane<G, I, true>(v0[j]) : -0.f;
                 x[e] = *reinterpret_cast<const f32x4*>(Bbytes + off);
               });
 #pragma unroll
@@ -194,7 +203,7 @@ int spmm_ldsb_tiles(int32_t K, int32_t N) { return ldsb_column_tiles(K, N); }
 
 int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val, const float* B, float* C,
                      int32_t batch, int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t ldc, int64_t strideB,
-                     int64_t strideC, const float* bias, int long_thresh, hipStream_t s) {
+                     int64_t strideC, const float* bias, int long_thresh, hipStream_t s, const int32_t* perm) {
   const int ctiles = ldsb_column_tiles(K, N);
   if (ctiles == 0) return MI_EINVAL;
   const int W = N / ctiles;
@@ -219,11 +228,11 @@ int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val
   const int G = pow2_ceil(W / 4);
 #define MI_LDSB(G_)                                                                                                   \
   do {                                                                                                                \
-    auto k = spmm_ldsb_kernel<G_>;                                                                                    \
+    auto k = perm ? spmm_ldsb_kernel<G_, true> : spmm_ldsb_kernel<G_, false>;                                         \
     if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL(k, dim3(grid), dim3(kWaves * 64), lds, s, rowptr, col, val, B, C, M, K, W, (long)ldb, (long)ldc, \
                        (long)strideB, (long)strideC, bias, ctiles, units_per_item, rows_per_unit, (unsigned)total,        \
-                       long_thresh);                                                                                   \
+                       long_thresh, perm);                                                                             \
   } while (0)
   switch (G) {
     case 1: MI_LDSB(1); break;

@@ -332,11 +332,22 @@ def _batched_csr_pattern(a: torch.Tensor, dev, transposed: bool = False):
         offsets, columns = hit[1], hit[2]
         flat_off = torch.cat([offsets[:, :-1].reshape(-1), offsets[-1:, -1]]).contiguous()
         shift = (torch.arange(nb, device=dev, dtype=torch.int32) * cols).repeat_interleave(per_item)
-        t_perm = t_col = t_off = None
+        iota = torch.arange(total, device=dev, dtype=torch.int32).view(torch.float32)
         if nb <= 65535:
-            iota = torch.arange(total, device=dev, dtype=torch.int32).view(torch.float32)
             t_perm, t_col, t_off = custom_mm.csr_transpose_batched(iota, columns, offsets, total, nb, rows, cols)
-            t_perm = t_perm.view(torch.int32)
+        else:
+            # more items than one launch takes: transpose chunks of ≤ 65535 items on their own slices of the arrays
+            # (offsets rebased to the slice, then put back) — the values are 0, 1, 2, … of the WHOLE batch, so the
+            # permutation stays global
+            parts = []
+            for lo in range(0, nb, 65535):
+                hi = min(nb, lo + 65535)
+                p0, p1 = lo * per_item, hi * per_item
+                tp, tc, to = custom_mm.csr_transpose_batched(iota[p0:p1], columns[p0:p1], (offsets[lo:hi] - p0).contiguous(),
+                                                             p1 - p0, hi - lo, rows, cols)
+                parts.append((tp, tc, to + p0))
+            t_perm, t_col, t_off = (torch.cat([x[i] for x in parts]) for i in range(3))
+        t_perm = t_perm.view(torch.int32)
         hit[3] = (flat_off, columns + shift, t_perm, t_col, t_off)
     return hit[1], hit[2], hit[3]
 
@@ -673,8 +684,6 @@ def _batched_csr_backward(ctx, m1, m2, grad_output):
     nb = torch.Tensor.crow_indices(m1).reshape(-1, rows + 1).shape[0]
     total = val.numel()
     dev = grad_output.device
-    if nb > 65535:
-        raise NotImplementedError('sparse matmul backward: more than 65535 items in a batched CSR tensor')
     offsets, columns, (flat_off, diag_columns, t_perm, t_col, t_off) = _batched_csr_pattern(m1, dev, transposed=True)
     g = grad_output.reshape(nb, rows, n).contiguous()
     shared = m2.dim() == 2
@@ -686,9 +695,20 @@ def _batched_csr_backward(ctx, m1, m2, grad_output):
         grad_m1 = torch.sparse_csr_tensor(torch.Tensor.crow_indices(m1), torch.Tensor.col_indices(m1),
                                           gvals.to(val.device).reshape(val.shape), size=m1.shape)
     if ctx.needs_input_grad[1]:
-        t_val = val.reshape(-1).to(dev).index_select(0, t_perm)
+        # m1[i]ᵀ·dC[i] on the cached transposed pattern; the values travel through the cached permutation INSIDE the
+        # kernel where its plan allows (the LDS-resident-B kernel: pruned attention), else as one gathered copy
+        flat_val = val.reshape(-1).to(dev).contiguous()
+        t_val = None
         gb = torch.empty((nb, cols, n), device=dev, dtype=torch.float32)
-        custom_mm.naive_spmm_batched(t_val, t_col, t_off, total, nb, cols, rows, g, gb)
+        for lo in range(0, nb, 65535):  # (items per launch, as in the forward)
+            hi = min(nb, lo + 65535)
+            off_c, g_c = t_off[lo:hi].contiguous(), g[lo:hi]
+            if hasattr(custom_mm, 'naive_spmm_batched_perm') and \
+                    custom_mm.naive_spmm_batched_perm(flat_val, t_perm, t_col, off_c, total, hi - lo, cols, rows, g_c, gb[lo:hi]):
+                continue
+            if t_val is None:
+                t_val = flat_val.index_select(0, t_perm)
+            custom_mm.naive_spmm_batched(t_val, t_col, off_c, total, hi - lo, cols, rows, g_c, gb[lo:hi])
         grad_m2 = gb.sum(0) if shared else gb.reshape(m2.shape)
         if vec:
             grad_m2 = grad_m2.squeeze(-1)

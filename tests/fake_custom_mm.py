@@ -84,6 +84,19 @@ def naive_spmm_batched(vals, cols, offs, nnz, batch, rows, kcols, B, C):
                                              np.ascontiguousarray(_np(B))))
 
 
+perm_plan = True  # tests flip this: the plan for a problem may or may not take a permutation
+
+
+def naive_spmm_batched_perm(vals, perm, cols, offs, nnz, batch, rows, kcols, B, C):
+    calls.append(("naive_spmm_batched_perm", (batch, rows, kcols)))
+    if not perm_plan:
+        return False
+    gathered = _np(vals)[_np(perm)[:nnz].astype(np.int64)]
+    _write(C, oracle.spmm_csr_batched(_np(offs), _np(cols)[:nnz], gathered, batch, rows, kcols,
+                                      np.ascontiguousarray(_np(B))))
+    return True
+
+
 def csr_transpose(vals, cols, offs, nnz, rows, kcols):
     calls.append(("csr_transpose", (rows, kcols)))
     rp, c, v = oracle.csr_transpose(_np(offs), _np(cols)[:nnz], _np(vals)[:nnz], rows, kcols)

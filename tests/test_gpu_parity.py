@@ -2400,6 +2400,80 @@ def test_spmm_lds_resident_b_plan_bit_exact(capi, cmm, dev, oracle_mod, N):
         assert np.array_equal(outs[18], outs[5])
 
 
+def test_lds_resident_b_keeps_negative_zero_and_reads_values_through_a_permutation(capi, cmm, dev, oracle_mod):
+    """Round 4.  (1) Advisor: a row whose products all underflow negatively ends as −0 in the oracle and in every plan;
+    the LDS-resident-B kernel pads a row's last four-entry step — with value −0 on an all-zero row, which leaves every
+    accumulator's bits (padding with +0 turned −0 into +0).  Compared as raw bits.  (2) The batched product with the
+    values read through a permutation (custom_mm.naive_spmm_batched_perm: what the backward of a batched CSR tensor
+    uses instead of a gathered copy of the values) is the plain product bit for bit, and reports False — launching
+    nothing — on a problem whose plan takes no permutation."""
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_spmm_csr_batched_variant_f32.argtypes = [ctypes.c_int, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp]
+    stream = torch.cuda.current_stream().cuda_stream
+    g = np.random.Generator(np.random.PCG64(44))
+    batch, M, K, N = 64, 256, 256, 64
+    lens = g.integers(1, 60, size=batch * M)
+    col = np.concatenate([np.sort(g.choice(K, int(n), replace=False)) for n in lens]).astype(np.int32)
+    val = g.random(len(col), dtype=np.float32) - 0.5
+    off = np.zeros((batch, M + 1), np.int64)
+    off[:, 1:] = np.cumsum(lens).reshape(batch, M)
+    off[1:, 0] = off[:-1, M]
+    off = off.astype(np.int32)
+    B = g.random((batch, K, N), dtype=np.float32) + 0.5
+    # rows 0, 5 and 9 of every item: tiny negative values against tiny positive entries of B → every product underflows
+    # to −0 (row lengths 1 … 59: every tail length of the four-entry steps occurs)
+    rows = np.repeat(np.arange(batch * M), lens)
+    tiny = np.isin(rows % M, (0, 5, 9))
+    val[tiny] = -1e-30
+    B[:, :, 7] = 1e-30                      # column 7: −1e-30 · 1e-30 underflows for the tiny rows …
+    want = oracle_mod.spmm_csr_batched(off, col, val, batch, M, K, B)
+    assert np.signbit(want[0, 0, 7]) and want[0, 0, 7] == 0.0   # … to −0 in the oracle's chain
+    d_off, d_col, d_val, d_B = t(off, dev), t(col, dev), t(val, dev), t(B, dev)
+    for variant in (18, 5, 0):
+        C = torch.full((batch, M, N), float("nan"), device=dev)
+        st = capi.mi_spmm_csr_batched_variant_f32(variant, d_off.data_ptr(), d_col.data_ptr(), d_val.data_ptr(), len(col),
+                                                  batch, M, K, N, d_B.data_ptr(), N, K * N, C.data_ptr(), N, M * N, stream)
+        assert st == 0
+        assert np.array_equal(C.cpu().numpy().view(np.int32), want.view(np.int32)), f"variant {variant}: bits differ (−0?)"
+    # (2) the same product with the values stored in another order and a permutation leading to them
+    shuffle = g.permutation(len(val))
+    stored = np.empty_like(val)
+    stored[shuffle] = val                    # stored[shuffle[p]] = val[p]
+    C = torch.full((batch, M, N), float("nan"), device=dev)
+    took = cmm.naive_spmm_batched_perm(t(stored, dev), t(shuffle.astype(np.int32), dev), d_col, d_off, len(col), batch, M, K,
+                                       d_B, C)
+    assert took is True and np.array_equal(C.cpu().numpy().view(np.int32), want.view(np.int32))
+    small = torch.full((2, 3, 8), -7.0, device=dev)
+    took = cmm.naive_spmm_batched_perm(torch.ones(4, device=dev), torch.arange(4, dtype=torch.int32, device=dev),
+                                       torch.zeros(4, dtype=torch.int32, device=dev),
+                                       torch.tensor([[0, 1, 2, 2], [2, 3, 4, 4]], dtype=torch.int32, device=dev), 4, 2, 3, 5,
+                                       torch.rand(5, 8, device=dev), small)
+    assert took is False and bool((small == -7.0).all())
+
+
+def test_batched_csr_tensor_backward_beyond_65535_items(mm, dev):
+    """The reference's recursion takes any number of slices (matmuls.py:289-293); round 3's backward stopped at 65535 items
+    (the launch's grid.y).  Now chunked like the forward, the batched transpose included: 70 000 items of 3×5, both
+    gradients against torch autograd of the dense product."""
+    g = torch.Generator().manual_seed(12)
+    nb, M, K, N, per = 70_000, 3, 5, 4, 6
+    keep = torch.zeros(nb, M * K, dtype=torch.bool)
+    keep.scatter_(1, torch.rand(nb, M * K, generator=g).topk(per, dim=1).indices, True)
+    dense = (torch.rand(nb, M, K, generator=g) + 0.1) * keep.reshape(nb, M, K)
+    b = torch.rand(nb, K, N, generator=g)
+    a = dense.to(dev).to_sparse_csr().requires_grad_(True)
+    b1 = b.to(dev).requires_grad_(True)
+    out = mm.cusparseMM.apply(a, b1)
+    dc = torch.rand(nb, M, N, generator=g)
+    out.backward(dc.to(dev))
+    a2, b2 = dense.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.matmul(a2, b2)
+    ref.backward(dc)
+    assert torch.allclose(ref, out.detach().cpu(), rtol=RTOL, atol=1e-6)
+    assert torch.allclose(b2.grad, b1.grad.cpu(), rtol=RTOL, atol=1e-6)
+    assert torch.allclose(a2.grad * keep.reshape(nb, M, K), a.grad.to_dense().cpu(), rtol=RTOL, atol=1e-6)
+
+
 def test_spmm_lds_resident_b_is_autos_choice_for_pruned_attention_and_keeps_the_long_row_rule(capi, cmm, dev, oracle_mod):
     """AUTO resolves BERT-base's pruned probs·V (384 items of 512×512 · 512×64 in batched CSR form, BASELINE.json
     configs[4]) to MI_SPMM_LDS_B; a shape the plan does not fit (K·N·4 > 128 KB) stays on the row-split kernels.

@@ -247,6 +247,24 @@ def test_batched_csr_operand_backward_and_pattern_cache(mm):
             assert a.grad.is_sparse_csr and a.grad.shape == a.shape
             assert torch.allclose(a2.grad * keep.reshape(shape), a.grad.to_dense(), rtol=RTOL, atol=1e-6)
         assert sum(c[0] == "csr_transpose_batched" for c in fake.calls) == n0 + 1
+    # the values reach the transposed product through the cached permutation inside the kernel where the plan takes one
+    # (no gathered copy); where it does not, one index_select + the plain batched product — same gradients either way
+    a = dense.to_sparse_csr().requires_grad_(True)
+    grads = []
+    for take in (True, False):
+        fake.perm_plan = take
+        try:
+            del fake.calls[:]
+            a.grad = None
+            b1 = rand(torch.Generator().manual_seed(5), nb, K, 5).requires_grad_(True)
+            matmuls.cusparseMM.apply(a, b1).backward(torch.ones(nb, M, 5))
+            names = [c[0] for c in fake.calls]
+            assert "naive_spmm_batched_perm" in names
+            assert (names.count("naive_spmm_batched") == 1) == take  # forward only / forward + the gathered fallback
+            grads.append(b1.grad.clone())
+        finally:
+            fake.perm_plan = True
+    assert torch.equal(grads[0], grads[1])
 
 
 def test_get_sparse_tensor_properties_contract(mm):
