@@ -385,6 +385,18 @@ int mi_sddmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz,
                      const float* B, int64_t ldb, float* out_val,
                      mi_stream_t stream);
 
+/* SDDMM on a BATCHED CSR pattern (rowptr [batch, M+1] with global offsets, as mi_spmm_csr_batched_f32):
+ *   out[p] = Σ_j dC[item][row(p), j] · B[item][col[p], j]      (strideB = 0: one B shared by every item)
+ * = the gradient of the stored values of a batched CSR tensor (the reference has no backward for this input,
+ * matmuls.py:245-256).  Same bits as mi_sddmm_csr_f32 on the block-diagonal matrix of the batch.  Returns MI_OK after
+ * launching the LDS-resident form (an item's B staged in LDS once per workgroup, N ≤ 64, K·N·4 ≤ 128 KB, ≥ 16384 rows
+ * of ≥ 4 non-zeros on average), 1 — nothing launched — for every other problem: the caller then runs mi_sddmm_csr_f32
+ * on the block-diagonal form. */
+int mi_sddmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz_total, int32_t batch,
+                             int32_t M, int32_t K, int32_t N, const float* dC, int64_t lddc,
+                             int64_t strideDC, const float* B, int64_t ldb, int64_t strideB,
+                             float* out_val, mi_stream_t stream);
+
 /* Column sums dst[j] = Σ_r src[r, j] (src rows×n, leading dimension ld): the bias gradient of
  * the FC layers (autograd of `output += self.bias`, reference benchmarks/cublas_fc_layer.py:44-45).
  * Fixed summation order (per row chunk: 4 waves × 4 interleaved row chains, added in a fixed

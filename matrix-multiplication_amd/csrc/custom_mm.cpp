@@ -755,6 +755,48 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> csr_transpose_batched(to
   return std::make_tuple(t_val, t_col, t_off);
 }
 
+// The same on a batched CSR pattern (offsets [batch, A_rows + 1], global), dC [batch, A_rows, N], B [batch, A_cols, N] or
+// [A_cols, N] (shared), into the caller's out [nnzA]; False (nothing launched) when the LDS-resident form does not take
+// the problem: run sddmm on the block-diagonal matrix of the batch instead (same bits).
+bool sddmm_batched(torch::Tensor A_columns, torch::Tensor A_offsets, int64_t nnzA, int64_t batch, int64_t A_rows,
+                   int64_t A_cols, torch::Tensor dC, torch::Tensor B, torch::Tensor out) {
+  const char* what = "sddmm_batched";
+  check_device_i32(A_columns, "A_columns");
+  check_device_i32(A_offsets, "A_offsets");
+  check_device_f32(dC, "dC");
+  check_device_f32(B, "B");
+  check_device_f32(out, "out");
+  check_same_device(A_columns, out, what);
+  check_same_device(A_offsets, out, what);
+  check_same_device(dC, out, what);
+  check_same_device(B, out, what);
+  TORCH_CHECK(batch >= 0 && A_rows >= 0 && A_cols >= 0 && nnzA >= 0 && batch <= INT32_MAX && A_rows <= INT32_MAX &&
+                  A_cols <= INT32_MAX,
+              what, ": bad size");
+  TORCH_CHECK(A_columns.is_contiguous() && A_offsets.is_contiguous() && out.is_contiguous(), what,
+              ": CSR arrays and out must be contiguous");
+  TORCH_CHECK(A_offsets.numel() == batch * (A_rows + 1) && A_columns.numel() >= nnzA && out.numel() >= nnzA, what,
+              ": CSR array sizes do not match");
+  TORCH_CHECK(dC.dim() == 3 && dC.size(0) == batch && dC.size(1) == A_rows, what, ": dC must be [batch, A_rows, N]");
+  const int64_t N = dC.size(2);
+  torch::Tensor dCc = dC.contiguous(), Bc = B.contiguous();
+  int64_t strideB = 0;
+  if (Bc.dim() == 3) {
+    TORCH_CHECK(Bc.size(0) == batch && Bc.size(1) == A_cols && Bc.size(2) == N, what, ": B must be [batch, A_cols, N]");
+    strideB = A_cols * N;
+  } else {
+    TORCH_CHECK(Bc.dim() == 2 && Bc.size(0) == A_cols && Bc.size(1) == N, what, ": B must be [A_cols, N]");
+  }
+  c10::hip::HIPGuard guard(out.device().index());
+  const int st = mi_sddmm_csr_batched_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(), nnzA, (int32_t)batch,
+                                          (int32_t)A_rows, (int32_t)A_cols, (int32_t)N, dCc.data_ptr<float>(),
+                                          std::max<int64_t>(N, 1), A_rows * N, Bc.data_ptr<float>(),
+                                          std::max<int64_t>(N, 1), strideB, out.data_ptr<float>(), stream_of(out));
+  if (st == 1) return false;
+  check_status(st, what);
+  return true;
+}
+
 // out[p] = <dC[row(p), :], B[col[p], :]> on A's pattern: d(A·B)/d(A values).
 torch::Tensor sddmm(torch::Tensor A_columns, torch::Tensor A_offsets, int64_t nnzA, int64_t A_rows,
                     int64_t A_cols, torch::Tensor dC, torch::Tensor B) {
@@ -1132,6 +1174,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("csr_transpose", &csr_transpose, "Device CSR transpose (values, columns, offsets)");
   m.def("csr_transpose_batched", &csr_transpose_batched, "Batched device CSR transpose (values, columns, offsets [batch, cols+1])");
   m.def("sddmm", &sddmm, "Sampled dense-dense product on a CSR pattern");
+  m.def("sddmm_batched", &sddmm_batched,
+        "SDDMM on a batched CSR pattern into out[nnz]; False (nothing launched) if the LDS-resident form does not take it");
   m.def("naive_spmm_batched_perm", &naive_spmm_batched_perm,
         "naive_spmm_batched with entry p's value = A_values[perm[p]]; False (nothing launched) if the plan takes no permutation");
   m.def("naive_spmm_dense", &naive_spmm_dense,

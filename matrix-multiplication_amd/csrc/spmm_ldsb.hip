@@ -178,6 +178,127 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// SDDMM on a batched CSR pattern with the item's B resident in LDS (round 4): out[p] = <dC[item][row(p)], B[item][col[p]]>
+// — the gradient of the stored values of a batched CSR tensor (pruned attention probabilities: d probs = dctx · Vᵀ on
+// the pattern).  matmuls ran it as ONE SDDMM on the block-diagonal matrix of the batch (sddmm_group_kernel, convert.hip):
+// every non-zero gathers a 256-byte row of V from the L2s — 0.2 ms at 384 × 512² × 64 and 10–25 % kept, the largest
+// item of that backward.  Here a workgroup stages its item's B once (as spmm_ldsb_kernel does, same units, same
+// persistent grid) and the gathers come from LDS.  Arithmetic = sddmm_group_kernel's, bit for bit: G = N/4 lanes per
+// row, lane l chains columns 4l … 4l+3 of the product, the tree levels whose partner never had columns add +0, and the G
+// sums of a chunk of G entries go through one joint xor tree (distances G/2 … 1) that leaves entry l's sum in lane l.
+// A chunk's columns are loaded one chunk ahead, a row's bounds and its dC row one row step ahead.
+// ---------------------------------------------------------------------------------------------
+template <int G>  // ≤ 16: a group's columns sit in one 16-lane DPP row
+__global__ __launch_bounds__(kWaves * 64) void sddmm_ldsb_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dC,
+    const float* __restrict__ B, float* __restrict__ out, int M, int K, int N, long lddc, long strideDC, long ldb,
+    long strideB, int units_per_item, int rows_per_unit, unsigned total_units) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 Bs[];  // [K][N / 4]
+  constexpr int RPW = 64 / G;
+  constexpr int U = G < 8 ? G : 8;  // gathers in flight per lane
+  constexpr int STRIDE = kWaves * RPW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gl = lane & (G - 1);
+  const int nq = N >> 2;
+  const bool on = gl < nq;
+  const unsigned per = (total_units + gridDim.x - 1) / gridDim.x;
+  const unsigned u0 = blockIdx.x * per, u1 = u0 + per < total_units ? u0 + per : total_units;
+  long staged = -1;
+  const int row_bytes = N * 4;
+  const char* Bbytes = reinterpret_cast<const char*>(Bs) + 16 * (on ? gl : 0);
+  for (unsigned u = u0; u < u1; ++u) {  // workgroup-uniform
+    const long item = u / (unsigned)units_per_item;
+    const int part = (int)(u % (unsigned)units_per_item);
+    if (item != staged) {
+      if (staged >= 0) __syncthreads();  // every wave is done with the previous item's B
+      const float* Bi = B + item * strideB;
+      const int total4 = K * nq;
+      for (int i = tid; i < total4; i += kWaves * 64) {
+        const int r = i / nq, q = i - r * nq;
+        Bs[i] = *reinterpret_cast<const f32x4*>(Bi + (long)r * ldb + 4 * q);
+      }
+      __syncthreads();
+      staged = item;
+    }
+    const int* rp = rowptr + item * ((long)M + 1);
+    const float* dCi = dC + item * strideDC;
+    const int r0 = part * rows_per_unit;
+    const int r1 = r0 + rows_per_unit < M ? r0 + rows_per_unit : M;
+    auto load_row = [&](int rb, int& st, int& en, f32x4& x) {
+      const int row = rb + lane / G;
+      st = en = 0;
+      x = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row < r1) {
+        st = rp[row];
+        en = rp[row + 1];
+        if (on && st < en) x = *reinterpret_cast<const f32x4*>(dCi + (long)row * lddc + 4 * gl);
+      }
+    };
+    int rb = r0 + wave * RPW;
+    int s0, e0, s1 = 0, e1 = 0;
+    f32x4 x0, x1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_row(rb, s0, e0, x0);
+    int c0 = s0 + gl < e0 ? col[s0 + gl] : 0;  // past the row's end: row 0 of B (its sum is never stored)
+    for (; rb < r1; rb += STRIDE) {  // wave-uniform
+      if (rb + STRIDE < r1) load_row(rb + STRIDE, s1, e1, x1);
+      else s1 = e1 = 0;
+      const bool empty_row = s0 >= e0;
+      for (int p0 = s0; p0 < e0; p0 += G) {  // trip count differs between groups
+        const int cnt = e0 - p0 < G ? e0 - p0 : G;  // group-uniform
+        const int mycol = c0;
+        // the next chunk's columns — of this row, or behind its last chunk the first of the next row — are in flight meanwhile
+        const int pn = p0 + G;
+        if (pn < e0) c0 = pn + gl < e0 ? col[pn + gl] : 0;
+        else c0 = s1 + gl < e1 ? col[s1 + gl] : 0;
+        float s[G];
+        static_for<G / U>([&](auto b_) {
+          constexpr int i = U * decltype(b_)::value;
+          if (i < cnt) {
+            f32x4 y[U];
+            static_for<U>([&](auto u_) {
+              constexpr int uu = decltype(u_)::value;
+              const int off = group_lane<G, i + uu, true>(mycol) * row_bytes;
+              y[uu] = *reinterpret_cast<const f32x4*>(Bbytes + off);
+            });
+#pragma unroll
+            for (int uu = 0; uu < U; ++uu) {
+              float acc = 0.f;
+              if (on) {
+                acc = __builtin_fmaf(x0.x, y[uu].x, acc);
+                acc = __builtin_fmaf(x0.y, y[uu].y, acc);
+                acc = __builtin_fmaf(x0.z, y[uu].z, acc);
+                acc = __builtin_fmaf(x0.w, y[uu].w, acc);
+              }
+#pragma unroll
+              for (int w = 32; w >= G; w >>= 1) acc = acc + 0.0f;  // the tree levels whose partner never had columns
+              s[i + uu] = acc;
+            }
+          } else {
+#pragma unroll
+            for (int uu = 0; uu < U; ++uu) s[i + uu] = 0.f;
+          }
+        });
+        // joint xor tree over the group: after the last level lane l holds the sum of entry l
+#pragma unroll
+        for (int w = G / 2; w >= 1; w >>= 1) {
+          const bool hi = (gl & w) != 0;
+#pragma unroll
+          for (int k = 0; k < w; ++k) {
+            const float keep = hi ? s[k + w] : s[k];
+            const float send = hi ? s[k] : s[k + w];
+            s[k] = keep + __shfl_xor(send, w, 64);
+          }
+        }
+        if (gl < cnt) out[p0 + gl] = s[0];
+      }
+      if (empty_row) c0 = s1 + gl < e1 ? col[s1 + gl] : 0;  // (a row without entries prefetched nothing)
+      s0 = s1, e0 = e1, x0 = x1;
+    }
+  }
+}
+
 }  // namespace
 
 namespace mi {
@@ -247,4 +368,67 @@ int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val
   return check_launch();
 }
 
+
+// whether the LDS-resident SDDMM takes a batched problem (shape only; the caller checked alignment): what
+// sddmm_group_kernel covers (N ≤ 64, N % 4 == 0) with an item's B fitting the LDS image
+bool sddmm_ldsb_fits(int32_t K, int32_t N) { return N >= 4 && N <= 64 && N % 4 == 0 && K >= 1 && (long)K * N * 4 <= 128L * 1024; }
+
+int launch_sddmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* dC, const float* B, float* out,
+                      int32_t batch, int32_t M, int32_t K, int32_t N, int64_t lddc, int64_t strideDC, int64_t ldb,
+                      int64_t strideB, hipStream_t s) {
+  if (!sddmm_ldsb_fits(K, N)) return MI_EINVAL;
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+      (void)hipGetLastError();
+      n = 256;
+    }
+    return n;
+  }();
+  int units_per_item = 1;
+  while ((long)batch * units_per_item < 3L * cus && ((long)M + units_per_item * 2 - 1) / (units_per_item * 2) >= 64)
+    units_per_item *= 2;
+  const int rows_per_unit = (int)(((long)M + units_per_item - 1) / units_per_item);
+  const long total = (long)batch * units_per_item;
+  if (total > 0x7fffffffL) return MI_ERANGE;
+  const unsigned grid = (unsigned)(total < cus ? total : cus);
+  const size_t lds = (size_t)K * N * 4;
+  const int G = pow2_ceil(N / 4);
+#define MI_SDDMM_LDSB(G_)                                                                                            \
+  do {                                                                                                                \
+    auto k = sddmm_ldsb_kernel<G_>;                                                                                   \
+    if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kWaves * 64), lds, s, rowptr, col, dC, B, out, M, K, N, (long)lddc,         \
+                       (long)strideDC, (long)ldb, (long)strideB, units_per_item, rows_per_unit, (unsigned)total);      \
+  } while (0)
+  switch (G) {
+    case 1: MI_SDDMM_LDSB(1); break;
+    case 2: MI_SDDMM_LDSB(2); break;
+    case 4: MI_SDDMM_LDSB(4); break;
+    case 8: MI_SDDMM_LDSB(8); break;
+    default: MI_SDDMM_LDSB(16); break;
+  }
+#undef MI_SDDMM_LDSB
+  return check_launch();
+}
+
 }  // namespace mi
+
+extern "C" {
+
+int mi_sddmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz_total, int32_t batch, int32_t M,
+                             int32_t K, int32_t N, const float* dC, int64_t lddc, int64_t strideDC, const float* B,
+                             int64_t ldb, int64_t strideB, float* out_val, mi_stream_t stream) {
+  if (batch < 0 || M < 0 || K < 0 || N < 0 || nnz_total < 0 || strideDC < 0 || strideB < 0) return MI_EINVAL;
+  if (nnz_total > 0x7fffffffLL) return MI_ERANGE;
+  if (batch == 0 || M == 0 || nnz_total == 0) return MI_OK;
+  if (!rowptr || !col || !out_val || !dC || !B || lddc < N || ldb < N) return MI_EINVAL;
+  const bool vec = N % 4 == 0 && lddc % 4 == 0 && ldb % 4 == 0 && strideDC % 4 == 0 && strideB % 4 == 0 &&
+                   mi::aligned16(dC) && mi::aligned16(B);
+  // taken where the forward's LDS-resident-B plan is (enough rows to fill the chip, rows of a few non-zeros at least)
+  if (!vec || !mi::sddmm_ldsb_fits(K, N) || (long)batch * M < 16384 || nnz_total < 4L * batch * M) return 1;
+  return mi::launch_sddmm_ldsb(rowptr, col, dC, B, out_val, batch, M, K, N, lddc, strideDC, ldb, strideB,
+                               static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -689,9 +689,15 @@ def _batched_csr_backward(ctx, m1, m2, grad_output):
     shared = m2.dim() == 2
     grad_m1 = grad_m2 = None
     if ctx.needs_input_grad[0]:
-        b_stack = (m2.unsqueeze(0).expand(nb, cols, n) if shared else m2.reshape(nb, cols, n)).reshape(nb * cols, n)
-        gvals = custom_mm.sddmm(diag_columns, flat_off, total, nb * rows, nb * cols, g.reshape(nb * rows, n),
-                                b_stack.contiguous())
+        # the batched form keeps an item's m2 in LDS where that fits (pruned attention); else (False: nothing ran) ONE
+        # SDDMM on the block-diagonal matrix of the batch — the same sums, bit for bit
+        gvals = torch.empty(total, device=dev, dtype=torch.float32)
+        if not (hasattr(custom_mm, 'sddmm_batched') and
+                custom_mm.sddmm_batched(columns, offsets, total, nb, rows, cols, g,
+                                        m2.to(dev) if shared else m2.reshape(nb, cols, n).to(dev), gvals)):
+            b_stack = (m2.unsqueeze(0).expand(nb, cols, n) if shared else m2.reshape(nb, cols, n)).reshape(nb * cols, n)
+            gvals = custom_mm.sddmm(diag_columns, flat_off, total, nb * rows, nb * cols, g.reshape(nb * rows, n),
+                                    b_stack.contiguous())
         grad_m1 = torch.sparse_csr_tensor(torch.Tensor.crow_indices(m1), torch.Tensor.col_indices(m1),
                                           gvals.to(val.device).reshape(val.shape), size=m1.shape)
     if ctx.needs_input_grad[1]:

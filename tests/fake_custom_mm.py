@@ -121,6 +121,23 @@ def sddmm(cols, offs, nnz, rows, kcols, dC, B):
     return torch.from_numpy(oracle.sddmm(_np(offs), _np(cols)[:nnz], rows, _np(dC), _np(B)).copy())
 
 
+batched_sddmm = True  # tests flip this: the LDS-resident batched form may or may not take a problem
+
+
+def sddmm_batched(cols, offs, nnz, batch, rows, kcols, dC, B, out):
+    calls.append(("sddmm_batched", (batch, rows, kcols)))
+    if not batched_sddmm:
+        return False
+    o, c = _np(offs).reshape(batch, rows + 1), _np(cols)[:nnz]
+    res = np.empty(nnz, np.float32)
+    for b in range(batch):
+        s0, s1 = int(o[b, 0]), int(o[b, rows])
+        Bb = _np(B) if B.dim() == 2 else _np(B)[b]
+        res[s0:s1] = oracle.sddmm((o[b] - s0).astype(np.int32), c[s0:s1], rows, _np(dC)[b], Bb)
+    out[:nnz] = torch.from_numpy(res)
+    return True
+
+
 fused_dense = True  # tests flip this to exercise the CSR route as well
 
 

@@ -2451,6 +2451,49 @@ def test_lds_resident_b_keeps_negative_zero_and_reads_values_through_a_permutati
     assert took is False and bool((small == -7.0).all())
 
 
+@pytest.mark.parametrize("N,shared", [(64, False), (64, True), (32, False), (48, False), (16, False), (8, True), (4, False)])
+def test_sddmm_batched_lds_resident_form_bit_exact(cmm, dev, oracle_mod, N, shared):
+    """Round 4: custom_mm.sddmm_batched — the gradient of a batched CSR tensor's stored values with the item's dense
+    operand resident in LDS — against the oracle's SDDMM per item and, bit for bit, against custom_mm.sddmm on the
+    block-diagonal matrix of the batch (what matmuls ran before and still runs where the form does not apply): rows of
+    0 … 150 entries (every tail length of the G-entry chunks), shuffled columns, duplicates, empty rows, an item count
+    that leaves the last workgroups short; a problem the form does not take reports False and writes nothing."""
+    g = np.random.Generator(np.random.PCG64(100 + N))
+    batch, M, K = 70, 260, 300
+    lens = g.integers(0, 150, size=batch * M)
+    lens[g.integers(0, batch * M, size=50)] = 0
+    cols = [g.integers(0, K, size=int(n)).astype(np.int32) for n in lens]
+    cols = [c if i % 3 else np.sort(c) for i, c in enumerate(cols)]
+    col = np.concatenate(cols)
+    off = np.zeros((batch, M + 1), np.int64)
+    off[:, 1:] = np.cumsum(lens).reshape(batch, M)
+    off[1:, 0] = off[:-1, M]
+    off = off.astype(np.int32)
+    dC = g.random((batch, M, N), dtype=np.float32) - 0.5
+    B = g.random((K, N) if shared else (batch, K, N), dtype=np.float32) - 0.5
+    out = torch.full((len(col),), float("nan"), device=dev)
+    took = cmm.sddmm_batched(t(col, dev), t(off, dev), len(col), batch, M, K, t(dC, dev), t(B, dev), out)
+    assert took is True
+    got = out.cpu().numpy()
+    for b in (0, 1, batch // 2, batch - 1):
+        s0, s1 = int(off[b, 0]), int(off[b, M])
+        want = oracle_mod.sddmm((off[b] - s0).astype(np.int32), col[s0:s1], M, dC[b], B if shared else B[b])
+        assert np.array_equal(got[s0:s1].view(np.int32), want.view(np.int32)), (N, b)
+    # the block-diagonal form on the whole batch
+    flat_off = np.concatenate([off[:, :-1].reshape(-1), off[-1:, -1]]).astype(np.int32)
+    diag_col = (col.astype(np.int64) + np.repeat(np.arange(batch), np.diff(off, axis=1).sum(1)) * K).astype(np.int32)
+    b_stack = np.ascontiguousarray(np.broadcast_to(B, (batch, K, N)).reshape(batch * K, N))
+    ref = cmm.sddmm(t(diag_col, dev), t(flat_off, dev), len(col), batch * M, batch * K, t(dC.reshape(batch * M, N), dev),
+                    t(b_stack, dev))
+    assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+    # not taken: too few rows / an operand beyond the LDS image
+    small = torch.full((6,), -7.0, device=dev)
+    assert cmm.sddmm_batched(torch.zeros(6, dtype=torch.int32, device=dev),
+                             torch.tensor([[0, 3], [3, 6]], dtype=torch.int32, device=dev), 6, 2, 1, 5,
+                             torch.rand(2, 1, 8, device=dev), torch.rand(5, 8, device=dev), small) is False
+    assert bool((small == -7.0).all())
+
+
 def test_batched_csr_tensor_backward_beyond_65535_items(mm, dev):
     """The reference's recursion takes any number of slices (matmuls.py:289-293); round 3's backward stopped at 65535 items
     (the launch's grid.y).  Now chunked like the forward, the batched transpose included: 70 000 items of 3×5, both

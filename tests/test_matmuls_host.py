@@ -265,6 +265,21 @@ def test_batched_csr_operand_backward_and_pattern_cache(mm):
         finally:
             fake.perm_plan = True
     assert torch.equal(grads[0], grads[1])
+    # the gradient of the stored values: the batched SDDMM where it takes the problem, else the block-diagonal one
+    grads = []
+    for take in (True, False):
+        fake.batched_sddmm = take
+        try:
+            del fake.calls[:]
+            a.grad = None
+            b1 = rand(torch.Generator().manual_seed(5), nb, K, 5).requires_grad_(True)
+            matmuls.cusparseMM.apply(a, b1).backward(torch.ones(nb, M, 5))
+            names = [c[0] for c in fake.calls]
+            assert "sddmm_batched" in names and ("sddmm" in names) == (not take)
+            grads.append(a.grad.values().clone())
+        finally:
+            fake.batched_sddmm = True
+    assert torch.equal(grads[0], grads[1])
 
 
 def test_get_sparse_tensor_properties_contract(mm):

@@ -26,7 +26,8 @@ items, S, D = 384, 512, 64
 v = torch.rand(items, S, D, device=dev, generator=g, requires_grad=True)
 dctx = torch.rand(items, S, D, device=dev, generator=g)
 print("# tools/bench_attn_csr_bwd.py on MI355X: 384 x (512x512 . 512x64), ms")
-for kept in (0.25, 0.1, 0.05):
+import os
+for kept in tuple(float(x) for x in os.environ.get('MI_KEPT','0.25,0.1,0.05').split(',')):
     per_item = int(S * S * kept)
     # equal non-zero counts per item (torch's batched CSR layout)
     idx = torch.rand(items, S * S, device=dev, generator=g).topk(per_item, dim=1).indices
