@@ -248,6 +248,17 @@ int mi_gemm_f32(int transa, int transb, int32_t m, int32_t n, int32_t k,
                 int64_t ldb, int64_t strideB, float* C, int64_t ldc,
                 int64_t strideC, int32_t batch, mi_stream_t stream);
 
+/* Two products that share one large operand, in ONE launch that reads it once:
+ *     C1[b] = A[b] · B1[b]   ([m, k]·[k, n])        C2[b] = A[b]ᵀ · B2[b]   ([k, m]·[m, n])
+ * all operands contiguous row-major, `batch` items.  The backward of `scores = cublasTransbMM.apply(q, k)` (reference
+ * README.md:69-77, matmuls.py:131-152): dQ = dS·K (A = dS, B1 = K) and dK = dSᵀ·Q (B2 = Q) — two launches of
+ * mi_gemm_f32 read the 403 MB of dS twice.  Every output element is the same k-ordered fused-multiply-add chain as
+ * mi_gemm_f32's: same bits.  Returns MI_OK after launching, 1 (nothing launched) for shapes the fused form does not
+ * cover — it takes n = 64, k = 64, 128, 256 or 512, m a multiple of 64 (BERT-base / -large attention heads) — the
+ * caller then runs the two plain products. */
+int mi_gemm_pair_a_at_f32(const float* A, const float* B1, const float* B2, float* C1, float* C2,
+                          int32_t batch, int32_t m, int32_t k, int32_t n, mi_stream_t stream);
+
 /* Which kernel family mi_gemm_f32 / mi_gemm_bias_f32 take (process-wide; every
  * plan produces the same bits — tests pin one to compare it with another):
  * AUTO picks; TILES = one output tile (or a short chain) per 4-wave workgroup;

@@ -633,6 +633,34 @@ bool naive_spmm_dense_bias(torch::Tensor A, torch::Tensor B, torch::Tensor bias,
   return spmm_dense_impl(A, B, &bias, C, "naive_spmm_dense_bias");
 }
 
+// dA = dC·B and dB = dCᵀ·A of C = A·Bᵀ (the backward of cublasTransbMM) in ONE launch that reads dC once:
+// dC [batch…, m, k], B [batch…, k, n], A [batch…, m, n] contiguous with equal batch dims → dA [batch…, m, n],
+// dB [batch…, k, n] (caller-allocated).  False (nothing launched) when the fused form does not cover the shapes.
+bool cublas_bmm_pair(torch::Tensor dC, torch::Tensor B, torch::Tensor A, torch::Tensor dA, torch::Tensor dB) {
+  const char* what = "cublas_bmm_pair";
+  for (const torch::Tensor* t : {&dC, &B, &A, &dA, &dB}) check_device_f32(*t, "operand");
+  check_same_device(dC, dA, what);
+  check_same_device(B, dA, what);
+  check_same_device(A, dA, what);
+  check_same_device(dB, dA, what);
+  if (dC.dim() < 2 || B.dim() != dC.dim() || A.dim() != dC.dim() || dA.dim() != dC.dim() || dB.dim() != dC.dim()) return false;
+  const int64_t m = dC.size(-2), k = dC.size(-1), n = B.size(-1);
+  const int64_t batch = m * k > 0 ? dC.numel() / (m * k) : 0;
+  if (!(dC.is_contiguous() && B.is_contiguous() && A.is_contiguous() && dA.is_contiguous() && dB.is_contiguous())) return false;
+  if (B.size(-2) != k || A.size(-2) != m || A.size(-1) != n || B.numel() != batch * k * n || A.numel() != batch * m * n ||
+      dA.numel() != batch * m * n || dB.numel() != batch * k * n || dA.size(-2) != m || dA.size(-1) != n ||
+      dB.size(-2) != k || dB.size(-1) != n)
+    return false;
+  if (batch <= 0 || batch > INT32_MAX || m > INT32_MAX || k > INT32_MAX || n > INT32_MAX) return false;
+  c10::hip::HIPGuard guard(dA.device().index());
+  const int st = mi_gemm_pair_a_at_f32(dC.data_ptr<float>(), B.data_ptr<float>(), A.data_ptr<float>(), dA.data_ptr<float>(),
+                                       dB.data_ptr<float>(), (int32_t)batch, (int32_t)m, (int32_t)k, (int32_t)n,
+                                       stream_of(dA));
+  if (st == 1) return false;
+  check_status(st, what);
+  return true;
+}
+
 // int32[1] on B's device: 1 when B holds an inf or a nan, else 0 (stream-ordered, nothing read back).
 torch::Tensor nonfinite_flag(torch::Tensor B) {
   check_device_f32(B, "B");
@@ -1174,6 +1202,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("csr_transpose", &csr_transpose, "Device CSR transpose (values, columns, offsets)");
   m.def("csr_transpose_batched", &csr_transpose_batched, "Batched device CSR transpose (values, columns, offsets [batch, cols+1])");
   m.def("sddmm", &sddmm, "Sampled dense-dense product on a CSR pattern");
+  m.def("cublas_bmm_pair", &cublas_bmm_pair,
+        "dA = dC.B and dB = dC^T.A in one launch that reads dC once; (dC, B, A, dA, dB) -> launched?");
   m.def("sddmm_batched", &sddmm_batched,
         "SDDMM on a batched CSR pattern into out[nnz]; False (nothing launched) if the LDS-resident form does not take it");
   m.def("naive_spmm_batched_perm", &naive_spmm_batched_perm,

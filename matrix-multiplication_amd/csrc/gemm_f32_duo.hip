@@ -310,11 +310,9 @@ __global__ __launch_bounds__(512) void gemm_f32_duo_kernel(const float* __restri
 
 }
 
-int g_cu_count = 0;
-
 template <int BN, bool AK, bool BKC, bool HAS_BIAS>
 int launch_duo_b(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb, long ldc, long sA,
-               long sB, long sC, int batch, const float* bias, hipStream_t s) {
+               long sB, long sC, int batch, const float* bias, hipStream_t s, int cu_count) {
   typedef DuoOperand<DBM, AK> LA;
   typedef DuoOperand<BN, BKC> LB;
 #ifdef MI_DUO_TIMING
@@ -328,7 +326,7 @@ int launch_duo_b(const float* A, const float* B, float* C, int m, int n, int k, 
   MI_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
   const int tiles_n = n / BN, tiles_per_item = (m / DBM) * tiles_n;
   const long total = (long)tiles_per_item * batch;
-  const long grid = total / 2 < g_cu_count ? total / 2 : g_cu_count;
+  const long grid = total / 2 < cu_count ? total / 2 : cu_count;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds_bytes, s, A, B, C, k / DBK, lda, ldb, ldc, sA, sB, sC,
                      tiles_n, tiles_per_item, (int)total, bias);
   return mi::check_launch();
@@ -336,9 +334,9 @@ int launch_duo_b(const float* A, const float* B, float* C, int m, int n, int k, 
 
 template <int BN, bool AK, bool BKC>
 int launch_duo(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb, long ldc, long sA,
-               long sB, long sC, int batch, const float* bias, hipStream_t s) {
-  return bias ? launch_duo_b<BN, AK, BKC, true>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, bias, s)
-              : launch_duo_b<BN, AK, BKC, false>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, bias, s);
+               long sB, long sC, int batch, const float* bias, hipStream_t s, int cu_count) {
+  return bias ? launch_duo_b<BN, AK, BKC, true>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, bias, s, cu_count)
+              : launch_duo_b<BN, AK, BKC, false>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, bias, s, cu_count);
 }
 
 }  // namespace
@@ -352,19 +350,22 @@ int launch_gemm_duo(int transa, int transb, int32_t m, int32_t n, int32_t k, con
   if (m % DBM != 0 || n % 64 != 0 || k % DBK != 0 || k == 0) return 1;
   if (lda % 4 != 0 || ldb % 4 != 0 || strideA % 4 != 0 || strideB % 4 != 0 || !aligned16(A) || !aligned16(B)) return 1;
   if (lda >= (1 << 21) || ldb >= (1 << 21) || ldc >= (1 << 21)) return 1;  // a tile's byte offsets stay below 2^31
+  // the current device's CU count, asked per call and handed down as an argument (a namespace-scope variable written
+  // here and read in launch_duo_b raced between host threads and could size one device's grid with another's count)
+  int cu_count = 256;
   {
-    int dev = 0, cus = 0;  // the current device's CU count (devices of one node are alike, but ask anyway)
+    int dev = 0, cus = 0;
     MI_HIP_TRY(hipGetDevice(&dev));
     MI_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    g_cu_count = cus > 0 ? cus : 256;
+    if (cus > 0) cu_count = cus;
   }
   const int bn = (n % 128 == 0) ? 128 : 64;
   const long total = (long)(m / DBM) * (n / bn) * batch;
   if (total > 0x7fffffffL) return 1;
-  if (!force && total < 2L * g_cu_count) return 1;  // a persistent workgroup wants at least one tile per half
+  if (!force && total < 2L * cu_count) return 1;  // a persistent workgroup wants at least one tile per half
   if (total < 2) return 1;
 #define MI_DUO(BN_, AK_, BKC_) \
-  return launch_duo<BN_, AK_, BKC_>(A, B, C, m, n, k, lda, ldb, ldc, strideA, strideB, strideC, batch, bias, s)
+  return launch_duo<BN_, AK_, BKC_>(A, B, C, m, n, k, lda, ldb, ldc, strideA, strideB, strideC, batch, bias, s, cu_count)
   if (bn == 128) {
     if (!transa && !transb) MI_DUO(128, true, false);
     if (!transa && transb) MI_DUO(128, true, true);

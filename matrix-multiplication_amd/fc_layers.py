@@ -23,7 +23,7 @@ import torch.nn as nn
 from torch.autograd.function import InplaceFunction
 
 import custom_mm
-from matmuls import custom_matmul
+from matmuls import custom_matmul, sampled_density
 
 
 def _column_sums(g2d):
@@ -85,13 +85,17 @@ class _SparseLinearBias(InplaceFunction):
     '''y = sparse(x)·Wᵀ (+ bias): the activations' exact zeros are skipped when that pays.
 
     The layer first estimates the density from an evenly spaced sample of ≤ 512 token rows (one small
-    count kernel and one host read-back — the reference's cusparseDenseToSparse analysis step syncs as
-    well, src/baseline_mm.cu:232-247).  Only when the model says the sparse route wins does it pay for
-    the exact count and the fill (CSR route: conversion + row-split kernel, bias fused); otherwise the
-    dense MFMA product runs, at the cost of that sample (measured: the full count alone cost 10–25 % of
-    a cheap layer's forward).  Both routes sum the same terms in the same (column) order, the skipped
-    ones being exact zeros, so the result does not depend on the route.  Under stream capture nothing
-    may be read back: the dense product is used.  (The fused zero-skipping kernel of naiveSpMM is not
+    count kernel).  Since round 4 the count comes back WITHOUT stalling the stream (matmuls.sampled_density:
+    pinned memory behind an event; a forward decides from the most recent count that has landed for this
+    layer's shapes — the previous step's, in a loop — so only the first forward of a shape waits; the
+    reference's cusparseDenseToSparse analysis step synchronises on every call, src/baseline_mm.cu:232-247).
+    When the model says the sparse route wins, the conversion needs no read-back either where the layer is no
+    wider than the long-row threshold: the CSR arrays get room for every element of x (the fill cannot
+    overflow) and the kernels walk the rows through the offsets; the estimate only steers their choice of
+    plan.  Otherwise the dense MFMA product runs.  Both routes sum the same terms in the same (column)
+    order, the skipped ones being exact zeros, so the result does not depend on the route (finite weights;
+    a zero of x facing an inf / nan weight gives nan on the dense route, as in torch.matmul).  Under stream
+    capture nothing may be read back: the dense product is used.  (The fused zero-skipping kernel of naiveSpMM is not
     used here: it scans every element of x per 64 output columns and lost to both routes at FC sizes —
     0.46 ms vs 0.20 ms dense at 16384 × 3072 → 256, 99 % zeros.)'''
 
@@ -104,27 +108,36 @@ class _SparseLinearBias(InplaceFunction):
         csr = None
         capturing = inp.is_cuda and torch.cuda.is_current_stream_capturing()
         ctx.x_density = 1.0
+        nnz_arg = 0
+        ctx.exact_csr = True
         if not capturing and x2.numel() > 0 and worth_sampling(tokens, fin, fout):
-            step = max(1, tokens // _SAMPLE_ROWS)
-            sample = x2[::step][:_SAMPLE_ROWS]
-            est = int(custom_mm.dense_row_offsets(sample).view(-1)[-1]) / sample.numel()
+            est = sampled_density(x2, ('fc', tuple(x2.shape), fout, inp.device.index), fin, owner=inp,
+                                  sample_rows=_SAMPLE_ROWS)
             ctx.x_density = est
             if sparse_forward_pays(est * x2.numel(), tokens, fin, fout):
                 offsets = custom_mm.dense_row_offsets(x2)
-                nnz = int(offsets.view(-1)[-1])
-                ctx.x_density = nnz / x2.numel()
-                if sparse_forward_pays(nnz, tokens, fin, fout):
-                    values, columns = custom_mm.dense_to_csr_fill(x2, offsets, nnz)
+                if fin <= custom_mm.long_row_threshold():
+                    # no read-back: room for every element; the count the kernels are told is the estimate (plan choice only)
+                    values, columns = custom_mm.dense_to_csr_fill(x2, offsets, x2.numel())
                     csr = (values, columns, offsets.view(-1))
+                    nnz_arg = min(x2.numel(), max(1, int(est * x2.numel())))
+                    ctx.exact_csr = False
+                else:
+                    nnz = int(offsets.view(-1)[-1])  # wide layers: the long-row rule sizes its lists from the exact count
+                    ctx.x_density = nnz / x2.numel()
+                    if sparse_forward_pays(nnz, tokens, fin, fout):
+                        values, columns = custom_mm.dense_to_csr_fill(x2, offsets, nnz)
+                        csr = (values, columns, offsets.view(-1))
+                        nnz_arg = nnz
         if csr is not None:
             wt = weight.t().contiguous()                                 # [in, out] row-major B operand
             # rows of x have at most `fin` non-zeros (no duplicate columns): a layer no wider than the long-row
             # threshold runs as ONE launch, without the workspace and the helper kernels of the long-row rule
             rule = 0 if fin <= custom_mm.long_row_threshold() else -1
             if bias is not None:
-                custom_mm.naive_spmm_bias_ex(csr[0], csr[1], csr[2], csr[0].numel(), tokens, fin, wt, bias, out, rule)
+                custom_mm.naive_spmm_bias_ex(csr[0], csr[1], csr[2], nnz_arg, tokens, fin, wt, bias, out, rule)
             else:
-                custom_mm.naive_spmm_ex(csr[0], csr[1], csr[2], csr[0].numel(), tokens, fin, wt, out, rule)
+                custom_mm.naive_spmm_ex(csr[0], csr[1], csr[2], nnz_arg, tokens, fin, wt, out, rule)
         elif bias is not None:
             custom_mm.cublas_mmul_bias(x2, weight, bias, out, False, True)
         else:
@@ -150,10 +163,12 @@ class _SparseLinearBias(InplaceFunction):
         elif ctx.needs_input_grad[1]:
             # dYᵀ·x = (xᵀ·dY)ᵀ with x sparse: the CSR kept from forward, transposed, then the row-split kernel
             values, columns, offsets = ctx.saved_tensors[2:]
-            t_val, t_col, t_off = custom_mm.csr_transpose(values, columns, offsets, values.numel(),
+            # (arrays sized for every element of x: the transpose needs the exact count — the one read-back of this route)
+            nnz = values.numel() if ctx.exact_csr else int(offsets[-1])
+            t_val, t_col, t_off = custom_mm.csr_transpose(values[:nnz], columns[:nnz], offsets, nnz,
                                                           x2.shape[0], x2.shape[1])
             gwt = torch.empty((x2.shape[1], g2.shape[1]), device=g2.device, dtype=torch.float32)
-            custom_mm.naive_spmm(t_val, t_col, t_off, values.numel(), x2.shape[1], x2.shape[0], g2, gwt)
+            custom_mm.naive_spmm(t_val, t_col, t_off, nnz, x2.shape[1], x2.shape[0], g2, gwt)
             grad_w = gwt.t()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_b = _column_sums(g2)

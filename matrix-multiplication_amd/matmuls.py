@@ -127,6 +127,9 @@ To add another, just change the mm/bmm operation
 '''
 
 
+_fused_pair = os.environ.get('MI_GEMM_PAIR', '1') != '0'  # 0: the two plain products (developer A/B)
+
+
 def _dense_backward(ctx, grad_output, transa, transb):
     '''Gradients of C = op(m1)·op(m2) (= torch autograd of torch.matmul).'''
     m1, m2 = ctx.saved_tensors
@@ -141,6 +144,16 @@ def _dense_backward(ctx, grad_output, transa, transb):
         g = g.unsqueeze(-1)
     if v1:
         g = g.unsqueeze(-2)
+
+    if (_fused_pair and not ta and tb and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and a.dim() >= 3 and
+            tuple(a.shape[:-2]) == tuple(b.shape[:-2]) == tuple(g.shape[:-2]) and hasattr(custom_mm, 'cublas_bmm_pair')):
+        # C = A·Bᵀ (the BERT drop-in scores = cublasTransbMM.apply(q, k), README.md:69-77): dA = dC·B and dB = dCᵀ·A both
+        # stream dC — one fused launch reads it once (custom_mm.cublas_bmm_pair; same bits as the two plain products,
+        # False when the shapes are not its)
+        gc, ac, bc = g.contiguous(), a.contiguous(), b.contiguous()
+        ga, gb = torch.empty_like(ac), torch.empty_like(bc)
+        if custom_mm.cublas_bmm_pair(gc, bc, ac, ga, gb):
+            return (ga.squeeze(0) if v1 else ga), (gb.squeeze(-1) if v2 else gb)
 
     if ctx.needs_input_grad[0]:
         if not ta and not tb:      # dA = dC·Bᵀ
@@ -266,12 +279,26 @@ def _csr_props_cached(a: torch.Tensor):
     return props
 
 
+def _dense_to_csr(a: torch.Tensor):
+    '''(values, columns, offsets, nnz) of a dense tensor's last two dims (batched: the "rowptr of rowptrs" layout).
+    Outside stream capture: the exact arrays (one read-back of the count sizes them; the kernels' plan choice sees the
+    true number of non-zeros).  Under capture nothing may be read back: the arrays get room for EVERY element
+    (capacity = a.numel(): the fill cannot overflow) and `nnz` is that bound — the product kernels walk the rows through
+    `offsets`, the count only steers their choice of plan, so the result is the same bits.'''
+    if a.is_cuda and torch.cuda.is_current_stream_capturing():
+        offsets = custom_mm.dense_row_offsets(a)
+        values, columns = custom_mm.dense_to_csr_fill(a, offsets, a.numel())
+        return values, columns, offsets, a.numel()
+    values, columns, offsets = custom_mm.dense_to_csr(a)
+    return values, columns, offsets, values.numel()
+
+
 def _csr_of(a: torch.Tensor):
     '''(values, columns, offsets, nnz, rows, cols) of a 2-d dense or CSR tensor.'''
     if a.is_sparse_csr:
         return _csr_props_cached(a)
-    values, columns, offsets = custom_mm.dense_to_csr(a)
-    return values, columns, offsets.view(-1), values.numel(), a.shape[-2], a.shape[-1]
+    values, columns, offsets, nnz = _dense_to_csr(a)
+    return values, columns, offsets.view(-1), nnz, a.shape[-2], a.shape[-1]
 
 
 def _csr_product(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, mm_op, default_op):
@@ -442,25 +469,21 @@ def _own_density(a: torch.Tensor):
     return None
 
 
-def _dense_route(a: torch.Tensor, b: torch.Tensor, items: int, rows: int, cols: int, width: int, owner=None) -> bool:
-    '''Whether a dense-with-zeros `a` is worth the dense MFMA product, decided from the density of an evenly
-    spaced sample of ≤ 128 rows of `a` (one small count kernel).  The count comes back WITHOUT stalling the stream:
-    it is copied to pinned memory behind an event.  A call decides from the count of THIS tensor (storage, version
-    counter, shape) when that has landed before; otherwise from the most recent count that has landed for operands
-    of the same shapes — the previous call's, in a loop — so only the first call of a shape waits (the reference
-    converts with `to_sparse_csr()` on every call, which synchronises every time, matmuls.py:295-296).  A stale
-    estimate can only cost time: in 'auto' mode the result does not depend on the route (see _DENSE_ROUTE_MODES).
-    Under stream capture nothing is read back: the question is not asked.  Products whose dense form takes under
-    ≈20 µs are not worth the question either.'''
-    if not a.is_cuda or torch.cuda.is_current_stream_capturing() or a.numel() == 0 or b.numel() == 0:
-        return False
-    if 2.0 * items * rows * cols * width / 110e12 < 20e-6:
-        return False
+def sampled_density(a: torch.Tensor, key, cols: int, owner=None, sample_rows: int = _DENSE_SAMPLE_ROWS):
+    '''Density (share of non-zeros) of a dense-with-zeros `a` from an evenly spaced sample of ≤ `sample_rows` rows (one
+    small count kernel).  The count comes back WITHOUT stalling the stream: it is copied to pinned memory behind an
+    event.  A call gets the count of THIS tensor object (`owner`, at its current version) when that has landed before;
+    otherwise the most recent count that has landed under `key` (operands of the same shapes: the previous call's, in a
+    loop) — so only the first call of a key waits (the reference converts with `to_sparse_csr()` on every call, which
+    synchronises every time, matmuls.py:295-296).  Callers use it to pick a ROUTE, never a result.'''
+    if not a.is_cuda:  # (host tensors only meet this in the host-logic tests: no stream to keep running)
+        flat = a.reshape(-1, cols)
+        sample = flat[::max(1, flat.shape[0] // sample_rows)][:sample_rows]
+        return float(torch.count_nonzero(sample)) / max(1, sample.numel())
     owner = a if owner is None else owner  # the caller's tensor object (`a` may be a flattened view of it)
     own = _own_density(owner)
     if own is not None:
-        return dense_route_pays(own, items, rows, cols, width)
-    key = (tuple(a.shape), tuple(b.shape), a.device.index)
+        return own
     ent = _density_of_shape.get(key)
     if ent is None:
         if len(_density_of_shape) >= 64:
@@ -482,20 +505,34 @@ def _dense_route(a: torch.Tensor, b: torch.Tensor, items: int, rows: int, cols: 
         landed()
         own = _own_density(owner)
         if own is not None:  # it was this tensor's own sample
-            return dense_route_pays(own, items, rows, cols, width)
+            return own
     if ent['event'] is None:  # no read-back in flight: start one on this call's operand
         flat = a.reshape(-1, cols)
-        step = max(1, flat.shape[0] // _DENSE_SAMPLE_ROWS)
-        sample = flat[::step][:_DENSE_SAMPLE_ROWS]
+        step = max(1, flat.shape[0] // sample_rows)
+        sample = flat[::step][:sample_rows]
         ent['host'].copy_(torch.count_nonzero(sample), non_blocking=True)
         ent['n'] = sample.numel()
         ent['src'] = (weakref.ref(owner), owner._version)
         ent['event'] = torch.cuda.Event()
         ent['event'].record()
-    if ent['est'] is None:  # first call of this shape: wait for its own count
+    if ent['est'] is None:  # first call of this key: wait for its own count
         ent['event'].synchronize()
         landed()
-    return dense_route_pays(ent['est'], items, rows, cols, width)
+    return ent['est']
+
+
+def _dense_route(a: torch.Tensor, b: torch.Tensor, items: int, rows: int, cols: int, width: int, owner=None) -> bool:
+    '''Whether a dense-with-zeros `a` is worth the dense MFMA product, decided from its sampled density (see
+    sampled_density: nothing stalls the stream after the first call of a shape).  A stale estimate can only cost
+    time: in 'auto' mode the result does not depend on the route (see _DENSE_ROUTE_MODES).  Under stream capture
+    nothing is read back: the question is not asked.  Products whose dense form takes under ≈20 µs are not worth the
+    question either.'''
+    if not a.is_cuda or torch.cuda.is_current_stream_capturing() or a.numel() == 0 or b.numel() == 0:
+        return False
+    if 2.0 * items * rows * cols * width / 110e12 < 20e-6:
+        return False
+    est = sampled_density(a, (tuple(a.shape), tuple(b.shape), a.device.index), cols, owner)
+    return dense_route_pays(est, items, rows, cols, width)
 
 
 def _on_matrix_cores(_a: torch.Tensor, _b: torch.Tensor, c: torch.Tensor, mode: str, owner=None) -> bool:
@@ -600,8 +637,8 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op, dense_ro
         # one dense→CSR conversion and one launch for the whole batch
         for lo in range(0, nb, 65535):
             hi = min(nb, lo + 65535)
-            values, columns, offsets = custom_mm.dense_to_csr(_a[lo:hi])
-            custom_mm.naive_spmm_batched(values, columns, offsets, values.numel(), hi - lo,
+            values, columns, offsets, nnz = _dense_to_csr(_a[lo:hi])
+            custom_mm.naive_spmm_batched(values, columns, offsets, nnz, hi - lo,
                                          c_rows, a_shape[-1], _b[lo:hi], c[lo:hi])
     else:
         # a caller-supplied 2-d kernel: apply it slice by slice (reference matmuls.py:289-293)

@@ -40,7 +40,10 @@ def _spmm(name, vals, cols, offs, nnz, rows, kcols, B, C):
     calls.append((name, (rows, kcols)))
     assert offs.dtype == torch.int32 and cols.dtype == torch.int32 and vals.dtype == torch.float32
     assert offs.numel() == rows + 1 and B.shape[0] == kcols
-    return _write(C, oracle.spmm_csr(_np(offs), _np(cols)[:nnz], _np(vals)[:nnz], rows, kcols, _np(B)))
+    # `nnz` may be a bound or an estimate (arrays sized for every element, no read-back): the rows are walked through offs
+    true_nnz = int(offs[-1]) if offs.numel() else 0
+    assert vals.numel() >= max(nnz, true_nnz) and cols.numel() >= max(nnz, true_nnz)
+    return _write(C, oracle.spmm_csr(_np(offs), _np(cols)[:true_nnz], _np(vals)[:true_nnz], rows, kcols, _np(B)))
 
 
 def naive_spmm(vals, cols, offs, nnz, rows, kcols, B, C):
@@ -68,8 +71,10 @@ def dense_row_offsets(dense):
 def dense_to_csr_fill(dense, offsets, nnz):
     calls.append(("dense_to_csr_fill", tuple(dense.shape)))
     rp, c, v = oracle.dense_to_csr(_np(dense))
-    assert np.array_equal(rp, offsets.numpy()) and len(v) == nnz
-    return torch.from_numpy(v.copy()), torch.from_numpy(c.copy())
+    assert np.array_equal(rp, offsets.numpy()) and len(v) <= nnz  # nnz: the arrays' capacity (≥ the true count)
+    vals, cols = np.full(nnz, np.nan, np.float32), np.full(nnz, -1, np.int32)
+    vals[:len(v)], cols[:len(v)] = v, c
+    return torch.from_numpy(vals), torch.from_numpy(cols)
 
 
 def dense_to_csr(dense):
@@ -160,7 +165,8 @@ def cublas_mmul_bias(A, B, bias, C, transa, transb):
 
 def naive_spmm_bias(vals, cols, offs, nnz, rows, kcols, B, bias, C):
     calls.append(("naive_spmm_bias", (rows, kcols)))
-    return _write(C, oracle.spmm_csr(_np(offs), _np(cols)[:nnz], _np(vals)[:nnz], rows, kcols, _np(B)) + _np(bias)[None, :])
+    n = int(offs[-1]) if offs.numel() else 0  # (`nnz` may be a bound or an estimate: see _spmm)
+    return _write(C, oracle.spmm_csr(_np(offs), _np(cols)[:n], _np(vals)[:n], rows, kcols, _np(B)) + _np(bias)[None, :])
 
 
 def naive_spmm_bias_ex(vals, cols, offs, nnz, rows, kcols, B, bias, C, long_rows):

@@ -692,6 +692,44 @@ def test_gemm_bert_base_attention_shapes(cmm, dev, oracle_mod):
 
 # ------------------------------------------------ inspector–executor APIs ----
 
+@pytest.mark.parametrize("batch,m,k", [((3, 2), 512, 512), ((5,), 256, 256), ((2, 3), 128, 512), ((9,), 512, 64), ((1,), 64, 128)])
+def test_fused_pair_of_products_sharing_an_operand_bit_exact(cmm, mm, dev, oracle_mod, batch, m, k):
+    """Round 4: custom_mm.cublas_bmm_pair — dA = dC·B and dB = dCᵀ·A (the backward of cublasTransbMM, reference
+    matmuls.py:131-152 / README.md:69-77) in ONE launch that reads dC once — against the oracle's k-ordered chain and, bit
+    for bit, against the two plain products it replaces; item counts that are no multiple of 8 (the XCD mapping leaves
+    blocks without work), rectangular dC, the smallest and an odd multiple of the key tile; shapes it does not cover
+    report False and write nothing; matmuls takes it in cublasTransbMM's backward when both gradients are wanted."""
+    n = 64
+    g = torch.Generator(device=dev).manual_seed(m + k)
+    dC = torch.rand(*batch, m, k, device=dev, generator=g) - 0.5
+    B = torch.rand(*batch, k, n, device=dev, generator=g) - 0.5
+    A = torch.rand(*batch, m, n, device=dev, generator=g) - 0.5
+    dA = torch.full((*batch, m, n), float("nan"), device=dev)
+    dB = torch.full((*batch, k, n), float("nan"), device=dev)
+    assert cmm.cublas_bmm_pair(dC, B, A, dA, dB) is True
+    ref_a = mm.custom_matmul(dC, B)
+    ref_b = mm.custom_matmul(dC, A, transa=True)
+    assert torch.equal(dA.view(torch.int32), ref_a.view(torch.int32))
+    assert torch.equal(dB.view(torch.int32), ref_b.view(torch.int32))
+    first = (0,) * len(batch)
+    last = tuple(x - 1 for x in batch)
+    for it in {first, last}:
+        assert np.array_equal(dA[it].cpu().numpy(), oracle_mod.gemm(dC[it].cpu().numpy(), B[it].cpu().numpy()))
+        assert np.array_equal(dB[it].cpu().numpy(), oracle_mod.gemm(dC[it].cpu().numpy(), A[it].cpu().numpy(), True, False))
+    # through autograd: the drop-in's backward
+    q = A.clone().requires_grad_(True)
+    kk = B.clone().requires_grad_(True)
+    mm.cublasTransbMM.apply(q, kk).backward(dC)
+    assert torch.equal(q.grad, dA) and torch.equal(kk.grad, dB)
+    # not covered: head dim 32, k beyond 512, strided operands
+    d32 = torch.full((2, 64, 32), -7.0, device=dev)
+    assert cmm.cublas_bmm_pair(torch.rand(2, 64, 64, device=dev), torch.rand(2, 64, 32, device=dev),
+                               torch.rand(2, 64, 32, device=dev), d32, d32.clone()) is False and bool((d32 == -7.0).all())
+    assert cmm.cublas_bmm_pair(torch.rand(1, 32, 1024, device=dev), torch.rand(1, 1024, 64, device=dev),
+                               torch.rand(1, 32, 64, device=dev), torch.empty(1, 32, 64, device=dev),
+                               torch.empty(1, 1024, 64, device=dev)) is False
+
+
 def test_config_c5_bert_base_attention_full_size_forward_and_backward(mm, dev, oracle_mod):
     """BASELINE config C5 at full size (B 32, H 12, S 512, D 64) through the drop-in wrappers, forward
     AND backward: scores = cublasTransbMM.apply(q, k), ctx = cublasMM.apply(probs, v) (reference
@@ -1965,6 +2003,60 @@ def test_naive_matmul_of_a_dense_matrix_is_graph_capturable(mm, dev):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.allclose(out, a @ b, rtol=RTOL, atol=1e-4)
+
+
+def test_dense_inputs_beyond_the_fused_shapes_are_graph_capturable_and_fc_layers_read_nothing_back(mm, cmm, dev, monkeypatch):
+    """Round 4 (review item 7).  (1) A dense-with-zeros operand whose shape the in-kernel zero-skipping product does not
+    cover (1030 output columns: not a multiple of 4) takes dense→CSR + the CSR kernels; under stream capture the
+    conversion may not read the count back, so the arrays get room for every element and the kernels walk the rows
+    through the offsets: the capture goes through, the replay follows new data — a different number of non-zeros
+    included — and the bits equal the uncaptured call's.  (2) cusparseLinear's forward: its density comes from the
+    stream-ordered sample (matmuls.sampled_density) and its conversion is sized the same way — after the first forward
+    of a shape no `.item()` / int() read-back happens (checked by forbidding synchronisation)."""
+    g = torch.Generator(device=dev).manual_seed(16)
+
+    def sparse(shape, p):
+        return torch.rand(shape, device=dev, generator=g) * (torch.rand(shape, device=dev, generator=g) < p)
+    a = sparse((1500, 700), 0.05)
+    b = torch.rand(700, 1030, device=dev, generator=g) - 0.5
+    mm.naive_matmul(a, b, dense_route="never")  # warm-up outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = mm.naive_matmul(a, b, dense_route="never")
+    for p in (0.05, 0.3, 0.0):
+        a.copy_(sparse((1500, 700), p))
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = mm.naive_matmul(a, b, dense_route="never")
+        assert torch.equal(out, ref), p
+        assert torch.allclose(out, a @ b, rtol=RTOL, atol=1e-4)
+    # (2) a ReLU-sparse FC layer: first forward of the shape may wait for its own sample, later ones may not wait at all
+    import fc_layers
+    layer = fc_layers.cusparseLinear(3072, 768).to(dev)
+    x = sparse((4, 4096, 3072), 0.01)
+    y0 = layer(x)
+    torch.cuda.synchronize()
+    calls = []
+    real_fill = cmm.dense_to_csr_fill
+    monkeypatch.setattr(fc_layers.custom_mm, "dense_to_csr_fill",
+                        lambda d, o, n: (calls.append(n), real_fill(d, o, n))[1])
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        y1 = layer(x)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert calls == [x.numel()], "the sparse route ran with arrays sized for every element"
+    ref = torch.nn.functional.linear(x, layer.weight, layer.bias)
+    assert torch.equal(y0, y1) and torch.allclose(y1, ref, rtol=RTOL, atol=1e-5)
+    x.requires_grad_(True)
+    y2 = layer(x)
+    y2.backward(torch.ones_like(y2))
+    xr = x.detach().clone().requires_grad_(True)
+    wr = layer.weight.detach().clone().requires_grad_(True)
+    torch.nn.functional.linear(xr, wr, layer.bias.detach()).backward(torch.ones_like(y2))
+    assert torch.allclose(layer.weight.grad, wr.grad, rtol=1e-4, atol=1e-4) and torch.allclose(x.grad, xr.grad, rtol=RTOL, atol=1e-5)
+
 
 
 def test_batched_csr_tensor_as_the_sparse_operand(mm, dev):
