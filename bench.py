@@ -312,8 +312,9 @@ def bench_c5(args):
         "config": {"workload": "BERT-base attention B=32 H=12 S=512 D=64 via cublasTransbMM / cublasMM .apply, fwd+bwd "
                                "(BASELINE.json configs[4])", "flops_per_step": flops},
         "roofline": {"bound": "mfma",
-                     "kernel": "per step: gemm_f32_pipe_kernel<128,64,false,false> ×2 (probs·V, dS·K) + gemm_f32_pipe_kernel<128,64,true,false> ×2 "
-                               "(dSᵀ·Q, Pᵀ·dC), k = 512; gemm_f32_pair_kernel<128,128,false,true,2,4> ×2 (q·kᵀ, dC·Vᵀ), k = 64",
+                     "kernel": "per step: gemm_pair_a_at_kernel<8> ×1 (dS·K and dSᵀ·Q in one launch), gemm_f32_pipe_kernel<128,64,false,false> "
+                               "×1 (probs·V), gemm_f32_pipe_kernel<128,64,true,false> ×1 (Pᵀ·dC), k = 512; "
+                               "gemm_f32_pair_kernel<128,128,false,true,2,4> ×2 (q·kᵀ, dC·Vᵀ), k = 64",
                      "achieved": round(flops / kern_ms / 1e9, 2),
                      "peak": 157.3, "unit": "TFLOP/s", "frac": round(flops / kern_ms / 1e9 / 157.3, 4), "traffic": None,
                      "kernel_ms_per_step": round(kern_ms, 4), "kernel_ms_per_step_median": round(float(np.median(step_ms)), 4),
