@@ -55,7 +55,7 @@ def test_recorded_bench_lines_follow_the_contract(name):
         assert abs(roof["achieved"] - alg / (roof["kernel_ms_per_step"] * 1e-3) / 1e9) / roof["achieved"] < 0.01
 
 
-@pytest.mark.parametrize("rnd", ["r01", "r02", "r03"])
+@pytest.mark.parametrize("rnd", ["r01", "r02", "r03", "r04"])
 def test_c3_kernel_stats_agree_with_the_bench_line(rnd):
     """rocprofv3's average launch durations (same command) add up to bench.py's HIP-event time per product."""
     import csv
@@ -65,15 +65,18 @@ def test_c3_kernel_stats_agree_with_the_bench_line(rnd):
     assert len(main) == rec["roofline"]["launches_per_step"] == 2
     total_ms = sum(float(r["AverageNs"]) for r in main) / 1e6
     assert abs(total_ms - rec["roofline"]["kernel_ms_per_step"]) / total_ms < 0.03
-    if rnd == "r03":
+    traffic = json.loads((PROFILES / "pmc_traffic.json").read_text())["c3"]
+    assert traffic["round"] in ("r03", "r04")
+    if rnd == traffic["round"]:
         # the bench line quotes the committed PMC record only while it was taken with the very sources that print it
-        traffic = json.loads((PROFILES / "pmc_traffic.json").read_text())["c3"]
-        assert traffic["round"] == "r03" and len(traffic["source_fingerprint"]) == 16
+        assert len(traffic["source_fingerprint"]) == 16
+        if rec["roofline"]["traffic"] is None:
+            pytest.skip("the committed bench line was printed by sources newer than the PMC record: re-collect both")
         assert abs(traffic["hbm_bytes_per_product"] - rec["roofline"]["traffic"]) < 1e-3 * rec["roofline"]["traffic"]
         assert 1.0 <= traffic["hbm_bytes_per_product"] / rec["config"]["algorithmic_bytes_per_step"] < 1.05
         assert rec["roofline"]["traffic_dram"] is None and "TARGET" in traffic["dram_note"]
         # two dispatches per product at C2: the main kernel and the (empty) follow-up — no memset, no scan of rowptr
-        c2 = [r["Name"] for r in csv.DictReader(open(PROFILES / "r03_bench_c2_kernel_stats.csv"))]
+        c2 = [r["Name"] for r in csv.DictReader(open(PROFILES / f"{rnd}_bench_c2_kernel_stats.csv"))]
         spmm = [n for n in c2 if "spmm_" in n or "find_long" in n or "combine_long" in n]
         assert len(spmm) == 2 and any("spmm_group_kernel" in n for n in spmm) and any("spmm_long_rows_kernel" in n for n in spmm)
 
