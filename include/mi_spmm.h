@@ -141,6 +141,10 @@ enum {
                                gather from there — batched products of small matrices (pruned attention) */
   MI_SPMM_VARIANT_COUNT = 19
 };
+/* The two forms of MI_SPMM_LDS_B (same bits): 16 lanes per row (any tile width), or — tiles of 64 / 128 columns — a
+ * quad per row with 16-byte loads of col / val (what BERT's head size runs).  form: -1 by rule (default), 0 the 16-lane
+ * form only, 1 the quad form wherever it covers the shape.  Process-wide; a developer / test knob. */
+int mi_spmm_ldsb_set_form(int form);
 int mi_spmm_csr_f32_variant(int variant, const int32_t* rowptr, const int32_t* col,
                             const float* val, int64_t nnz, int32_t M, int32_t K,
                             int32_t N, const float* B, int64_t ldb, float* C,

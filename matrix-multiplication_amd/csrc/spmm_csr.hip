@@ -1114,7 +1114,8 @@ int launch_variant(int variant, const Shape& sh, const int32_t* rowptr, const in
       return mi::launch_spmm_slab(rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la.thresh, s);
     case MI_SPMM_LDS_B:
       if (!(vec4_ok && mi::spmm_ldsb_fits(K, N))) return MI_EINVAL;
-      return mi::launch_spmm_ldsb(rowptr, col, val, B, C, batch, M, K, N, ldb, ldc, strideB, strideC, bias, la.thresh, s);
+      return mi::launch_spmm_ldsb(rowptr, col, val, B, C, batch, M, K, N, ldb, ldc, strideB, strideC, bias, la.thresh, s,
+                                  nullptr, nnz);
     case MI_SPMM_NARROW: {
       if (N >= 4) return MI_EINVAL;
       const long blocks = ((long)M + 3) / 4;
@@ -1329,7 +1330,7 @@ int mi_spmm_csr_batched_perm_f32(const int32_t* rowptr, const int32_t* col, cons
   if (choose_variant(sh, nnz_total, batch, M, K, N, ldb) != MI_SPMM_LDS_B || !sh.vec4_ok || !mi::spmm_ldsb_fits(K, N))
     return 1;
   return mi::launch_spmm_ldsb(rowptr, col, val, B, C, batch, M, K, N, ldb, ldc, strideB, strideC, nullptr, 0x7fffffff,
-                              static_cast<hipStream_t>(stream), perm);
+                              static_cast<hipStream_t>(stream), perm, nnz_total);
 }
 
 int mi_spmm_csr_batched_variant_f32(int variant, const int32_t* rowptr, const int32_t* col, const float* val,

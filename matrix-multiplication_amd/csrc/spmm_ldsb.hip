@@ -22,6 +22,8 @@
 // f32 FMA does not issue faster than its two halves), eight staging loads per lane in flight before their LDS writes
 // (0.0590 → 0.0592 ms at 10 %: the plain loop was not the cost), one more row step of col / val look-ahead (0.0592 →
 // 0.0619 at 10 %, 0.1116 → 0.1152 at 25 %).
+#include <atomic>
+
 #include "mi_common.h"
 #include "mi_lanes.h"
 
@@ -40,6 +42,18 @@ __device__ __forceinline__ f32x4 fma4(float a, f32x4 x, f32x4 acc) {
 }
 
 constexpr int kWaves = 16;
+
+#ifdef MI_LDSB_TIMING
+// developer build (tools/probes/ldsb_timing.py): wave 0 of every workgroup stamps the 100 MHz wall clock at its phase
+// boundaries — entry, after each staging, after each unit, exit — into g_ldsq_stamps[workgroup][slot]
+__device__ unsigned long long g_ldsq_stamps[512][16];
+__device__ unsigned long long g_ldsq_wave_end[512][16][4];  // [workgroup][wave][unit]: when the wave left the unit's rows
+#define LDSQ_WAVE_END(unit) do { if (lane == 0 && (unit) < 4) g_ldsq_wave_end[blockIdx.x & 511][wave][unit] = wall_clock64(); } while (0)
+#define LDSQ_STAMP(slot) do { const int s_ = (slot); if (tid == 0 && s_ < 16) g_ldsq_stamps[blockIdx.x & 511][s_] = wall_clock64(); } while (0)
+#else
+#define LDSQ_STAMP(slot) do {} while (0)
+#define LDSQ_WAVE_END(unit) do {} while (0)
+#endif
 
 template <int G, bool PERM>
 __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
@@ -175,6 +189,241 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
         v0[j] = v1[j];
       }
     }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The same product with FOUR lanes per row (a DPP quad) and Q float4 of the output row per lane (tile width W = 16·Q:
+// 64 or 128 columns) — "quad form", what AUTO runs at BERT's head size.  Why a second form: in spmm_ldsb_kernel a
+// 16-lane group pays two DPP moves (column, value) per non-zero and ONE ds_read_b128; a quad pays them once per
+// non-zero for Q reads, a wave carries 16 rows instead of 4, and a row's col / val arrive as 16-byte vector loads
+// (16 entries per quad and instruction instead of 16 dwords), so the bookkeeping per non-zero — loads, bounds, row
+// steps, stores — shrinks fourfold: a workgroup of 16 waves covers a 256-row unit in ONE row step (the 16-lane form:
+// four, each waiting for its own bounds → col / val chain).  Same arithmetic: one fmaf chain per output element over
+// the row's non-zeros in CSR order.
+//   * LDS banking: ds_read_b128 is served 16 lanes at a time in the fixed groups {0–3,12–15,20–27}, {4–11,16–19,
+//     28–31} (+32), i.e. four quads whose indices differ mod 4, and they read four DIFFERENT rows.  A quad's lanes read
+//     64 contiguous bytes (16 banks); quad q takes the row's 64-byte pieces in the order (j + q) mod Q, so the four
+//     quads of a service group are always on four different bank quarters: conflict-free for any mix of rows;
+//   * an entry travels as {byte offset of its B row in LDS, value} in component e & 3 of lane e >> 2 of the quad's
+//     chunk registers (16 entries) and is handed round by a quad permute; positions past the row's end are (row K, −0)
+//     as in spmm_ldsb_kernel, so a chunk's steps carry no lane predicate — only wave-uniform early exits;
+//   * the vector loads of col / val start at any entry (dword-aligned 16-byte loads) and are clamped to the arrays'
+//     last 16 bytes; the one lane in the whole launch that this shifts rotates its components back;
+//   * bounds two row steps ahead, the first chunk of the next row step one ahead, chunk k + 1 of a row while chunk k is
+//     processed (16 entry steps of four waves per SIMD: ≈1.5 µs) — all of it ACROSS units and stagings (registers
+//     only), so the staging of B hides the first trip to memory for col / val.  (Two chunks ahead spilled: 128 VGPRs.)
+// ---------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+struct QuadChunk {  // 16 entries of a row as its quad holds them: lane e >> 2, component e & 3
+  i32x4 c;          // as loaded: column indices; finished: byte offsets of the B rows in LDS
+  f32x4 v;
+};
+
+template <int Q, bool PERM>
+__global__ __launch_bounds__(kWaves * 64) void spmm_ldsq_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+    const float* __restrict__ B, float* __restrict__ C, int M, int K, long ldb, long ldc, long strideB,
+    long strideC, const float* __restrict__ bias, int ctile_shift, int units_per_item, int rows_per_unit,
+    unsigned total_units, int long_thresh, const int* __restrict__ perm, int last4) {
+  // last4 = nnz_total − 4 (≥ 0): the last index a 16-byte load of col / val may start at; 1 << ctile_shift column tiles
+  extern __shared__ __attribute__((aligned(16))) f32x4 Bs[];  // [K + 1][W / 4]
+  constexpr int W = 16 * Q, ROWB = 4 * W, RPW = 16, STRIDE = kWaves * RPW;
+  static_assert((Q & (Q - 1)) == 0 && Q >= 4, "the rotation needs Q = 4, 8, …");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qd = lane >> 2, gl = lane & 3;
+  const unsigned per = (total_units + gridDim.x - 1) / gridDim.x;
+  const unsigned u0 = blockIdx.x * per, u1 = u0 + per < total_units ? u0 + per : total_units;
+  typedef const f32x4 __attribute__((address_space(3))) * LdsRow;
+  const unsigned lds0 = (unsigned)(unsigned long)((LdsRow)Bs);
+  unsigned lb[Q];  // lane's address inside a B row for its j-th piece (LDS base included: + entry offset = one DPP add)
+#pragma unroll
+  for (int j = 0; j < Q; ++j) lb[j] = lds0 + 64 * ((j + qd) & (Q - 1)) + 16 * gl;
+  const int zero_off = K * ROWB;
+
+  // The wave's row steps in unit order — (unit, its slice and part, first row of the step) — wave-uniform and advanced
+  // without divisions (there is no scalar divide: a uniform quotient costs ≈40 vector instructions).
+  struct Cursor {
+    unsigned u;
+    int slice, part, rb;
+  };
+  auto unit_r1 = [&](int part) {
+    const long e = ((long)part + 1) * rows_per_unit;
+    return e < M ? (int)e : M;
+  };
+  auto settle = [&](Cursor& c) {  // onto the first existing step at or behind (u, rb); u = u1 when there is none
+    while (c.u < u1 && c.rb >= unit_r1(c.part)) {
+      ++c.u;
+      if (++c.part == units_per_item) c.part = 0, ++c.slice;
+      c.rb = c.part * rows_per_unit + wave * RPW;
+    }
+  };
+  // Every global load below is UNCONDITIONAL on a clamped address and sits in straight-line code: vmcnt retires in order
+  // and the compiler counts a wait from the memory operations on every path — one predicated load (a branch round it)
+  // turns the waits into vmcnt(0) and puts the latency of the loads just issued in front of work that needs older ones.
+  auto issue_bounds = [&](const Cursor& c, int& st, int& en) {  // (no row here: the same word twice, an empty row)
+    // (uniform 64-bit base + 32-bit lane offset: the scalar-base form of the load, no 64-bit vector arithmetic)
+    const bool unit = c.u < u1;
+    const bool there = unit && c.rb + qd < unit_r1(c.part);
+    const char* rp = reinterpret_cast<const char*>(rowptr + (unit ? (long)(c.slice >> ctile_shift) * ((long)M + 1) : 0L));
+    const unsigned o = there ? 4u * (unsigned)(c.rb + qd) : 0u;
+    st = *reinterpret_cast<const int*>(rp + o);
+    en = *reinterpret_cast<const int*>(rp + (there ? o + 4u : 0u));
+  };
+  auto finish_bounds = [&](int& st, int& en, bool& skip) {  // (skip: left to spmm_long_rows_kernel)
+    skip = en - st > long_thresh;
+    if (skip) en = st;
+  };
+  auto issue_chunk = [&](int p, QuadChunk& q) {
+    const int idx = p + 4 * gl;
+    const unsigned a = 4u * (unsigned)(idx < last4 ? idx : last4);  // bytes (nnz < 2^29 … checked by the launcher)
+    q.c = *reinterpret_cast<const i32x4_u*>(reinterpret_cast<const char*>(col) + a);
+    if (PERM) {
+      const i32x4 pm = *reinterpret_cast<const i32x4_u*>(reinterpret_cast<const char*>(perm) + a);
+      const char* vb = reinterpret_cast<const char*>(val);
+      q.v = f32x4{*reinterpret_cast<const float*>(vb + 4u * (unsigned)pm.x), *reinterpret_cast<const float*>(vb + 4u * (unsigned)pm.y),
+                  *reinterpret_cast<const float*>(vb + 4u * (unsigned)pm.z), *reinterpret_cast<const float*>(vb + 4u * (unsigned)pm.w)};
+    } else {
+      q.v = *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const char*>(val) + a);
+    }
+  };
+  auto finish_chunk = [&](int p, int en, QuadChunk& q) {
+    const int idx = p + 4 * gl;
+    const int left = en - idx;   // entries of this lane inside the row
+    const int sh = idx - last4;  // 1 … 3: the load was clamped to the arrays' last 16 bytes and starts sh entries early
+    if (__builtin_amdgcn_ballot_w64(left > 0 && sh > 0) != 0) {  // wave-uniform; at most one lane of the whole launch
+      if (sh > 0) {
+        q.c = sh == 1 ? i32x4{q.c.y, q.c.z, q.c.w, 0} : sh == 2 ? i32x4{q.c.z, q.c.w, 0, 0} : i32x4{q.c.w, 0, 0, 0};
+        q.v = sh == 1 ? f32x4{q.v.y, q.v.z, q.v.w, 0.f} : sh == 2 ? f32x4{q.v.z, q.v.w, 0.f, 0.f} : f32x4{q.v.w, 0.f, 0.f, 0.f};
+      }
+    }
+    // positions past the row's end: value −0 on the all-zero row K (see spmm_ldsb_kernel)
+    q.c.x = left > 0 ? q.c.x * ROWB : zero_off;
+    q.c.y = left > 1 ? q.c.y * ROWB : zero_off;
+    q.c.z = left > 2 ? q.c.z * ROWB : zero_off;
+    q.c.w = left > 3 ? q.c.w * ROWB : zero_off;
+    q.v.x = left > 0 ? q.v.x : -0.f;
+    q.v.y = left > 1 ? q.v.y : -0.f;
+    q.v.z = left > 2 ? q.v.z : -0.f;
+    q.v.w = left > 3 ? q.v.w : -0.f;
+  };
+
+  Cursor c0, c1, c2;
+  c0.u = u0;
+  c0.slice = (int)(u0 / (unsigned)units_per_item);
+  c0.part = (int)(u0 % (unsigned)units_per_item);
+  c0.rb = c0.part * rows_per_unit + wave * RPW;
+  settle(c0);
+  c1 = c0;
+  c1.rb += STRIDE;
+  settle(c1);
+  int s0, e0, s1, e1, s2, e2;
+  bool k0, k1;
+  issue_bounds(c0, s0, e0);
+  issue_bounds(c1, s1, e1);
+  finish_bounds(s0, e0, k0);
+  QuadChunk r0, rn;  // the chunk being processed; the next one of the wave's chunk stream (this row's, or the next row's first)
+  issue_chunk(s0, r0);
+  finish_bounds(s1, e1, k1);
+
+  long staged = -1;
+  [[maybe_unused]] int stamp = 0;
+  LDSQ_STAMP(stamp++);
+  for (unsigned u = u0; u < u1; ++u) {  // workgroup-uniform
+    const long slice = u / (unsigned)units_per_item;
+    const int part = (int)(u % (unsigned)units_per_item);
+    const long item = slice >> ctile_shift;
+    const int col0 = (int)(slice & ((1 << ctile_shift) - 1)) * W;
+    if (slice != staged) {
+      if (staged >= 0) __syncthreads();  // every wave is done with the previous slice of B
+      // LDS-DMA: a wave-instruction copies 1 KiB (four rows of the slice) straight into the image — no registers, so all
+      // of a wave's eight pieces are in flight at once (through registers the compiler waited for every 16-byte load
+      // before its ds_write: eight trips to memory one behind the other, 6–15 µs per staging under load)
+      const float* Bi = B + item * strideB + col0;
+      constexpr int nq = W / 4;
+      const int total4 = K * nq;
+      for (int f0 = wave * 64; f0 < total4; f0 += kWaves * 64) {  // wave-uniform
+        const int f = f0 + lane;
+        if (f < total4)
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void*>(
+                                               reinterpret_cast<unsigned long>(Bi + (long)(f / nq) * ldb + 4 * (f % nq))),
+                                           (__attribute__((address_space(3))) void*)(Bs + f0), 16, 0, 0);
+      }
+      if (tid < nq) Bs[total4 + tid] = f32x4{0.f, 0.f, 0.f, 0.f};  // row K: what the padding reads
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the pieces have landed (expcnt / lgkmcnt left alone)
+      __syncthreads();
+      staged = slice;
+      LDSQ_STAMP(stamp++);
+    }
+    const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(C + item * strideC + col0, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias ? bias + col0 : B), 0, 0x7fffffff, 0x00020000);
+    const int r1 = unit_r1(part);
+    while (c0.u == u) {  // wave-uniform: this wave's row steps inside the unit
+      // the bounds of the step two ahead go out first; the next step's first chunk follows this row's last one
+      c2 = c1;
+      c2.rb += STRIDE;
+      settle(c2);
+      issue_bounds(c2, s2, e2);
+
+      f32x4 acc[Q];
+#pragma unroll
+      for (int j = 0; j < Q; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      int p = s0;
+      for (;;) {  // wave-uniform trip count: the longest row of the wave's sixteen, in chunks of 16 entries
+        const bool more = __builtin_amdgcn_ballot_w64(p + 16 < e0) != 0;
+        issue_chunk(more ? p + 16 : s1, rn);  // (uniform choice: one load sequence on every path)
+        finish_chunk(p, e0, r0);
+        const int left = e0 - p;
+        static_for<4>([&](auto b_) {
+          constexpr int b = 4 * decltype(b_)::value;
+          if (b == 0 || __builtin_amdgcn_ballot_w64(b < left) != 0) {  // wave-uniform; a row that has ended reads padding
+            static_for<4>([&](auto e_) {
+              constexpr int e = b + decltype(e_)::value;
+              constexpr int src = e >> 2, comp = e & 3;
+              const unsigned off = (unsigned)group_lane<4, src, true>(r0.c[comp]);
+              const float v = group_lane<4, src, true>(r0.v[comp]);
+              f32x4 x[Q];
+#pragma unroll
+              for (int j = 0; j < Q; ++j) x[j] = *(LdsRow)(unsigned long)(off + lb[j]);
+#pragma unroll
+              for (int j = 0; j < Q; ++j) acc[j] = fma4(v, x[j], acc[j]);
+              // two entries' reads in flight, not sixteen: the workgroup's 128 VGPRs per lane also hold two chunks
+              if constexpr ((e & 1) == 1 || Q > 4) __builtin_amdgcn_sched_barrier(0);
+            });
+          }
+        });
+        r0 = rn;
+        p += 16;
+        if (!more) break;
+      }
+      const int row = c0.rb + qd;
+      if (row < r1 && !k0) {
+        // buffer stores — the item's C as a scalar descriptor + a 32-bit lane offset (a piece's byte offset inside the
+        // row is lb[j] without the LDS base): as global stores the compiler kept four 64-bit lane addresses per unit
+        // alive through the row loop and spilled them
+        const unsigned crow = (unsigned)row * (unsigned)ldc * 4u - lds0;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+          f32x4 o = acc[j];
+          if (bias)
+            o += __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(brsrc, (int)(lb[j] - lds0), 0, 0));
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), crsrc, (int)(crow + lb[j]), 0, 2 /* nt */);
+        }
+      }
+      c0 = c1, c1 = c2;
+      s0 = s1, e0 = e1, k0 = k1;
+      s1 = s2, e1 = e2;
+      finish_bounds(s1, e1, k1);
+    }
+    LDSQ_WAVE_END((int)(u - u0));
+    LDSQ_STAMP(stamp++);
   }
 }
 
@@ -322,9 +571,13 @@ static int ldsb_column_tiles(int32_t K, int32_t N) {
 bool spmm_ldsb_fits(int32_t K, int32_t N) { return ldsb_column_tiles(K, N) > 0; }
 int spmm_ldsb_tiles(int32_t K, int32_t N) { return ldsb_column_tiles(K, N); }
 
+// 0: the 16-lane form only, 1: the quad form wherever it covers the shape, -1 (default): by rule (developer A/B and tests)
+static std::atomic<int> g_ldsb_form{-1};
+
 int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val, const float* B, float* C,
                      int32_t batch, int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t ldc, int64_t strideB,
-                     int64_t strideC, const float* bias, int long_thresh, hipStream_t s, const int32_t* perm) {
+                     int64_t strideC, const float* bias, int long_thresh, hipStream_t s, const int32_t* perm,
+                     int64_t nnz_total) {
   const int ctiles = ldsb_column_tiles(K, N);
   if (ctiles == 0) return MI_EINVAL;
   const int W = N / ctiles;
@@ -336,6 +589,28 @@ int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val
     }
     return n;
   }();
+  // Quad form (spmm_ldsq_kernel): tiles of 64 or 128 columns, 256-row steps.  Units of whole steps, as many as keep
+  // every CU at work; taken by rule when that split leaves at most a tenth of the persistent grid's time idle.
+  const int form = g_ldsb_form.load(std::memory_order_relaxed);
+  // quad form: column tiles of 64 whatever the 16-lane form's tiling (a 128-column tile — Q = 8 — spills registers)
+  const int qtiles = (N % 64 == 0 && (N == 64 || N == 128 || N == 256) && K <= 512) ? N / 64 : 0;
+  if (form != 0 && qtiles != 0 && qtiles <= 4 && nnz_total >= 4 && nnz_total < (1LL << 29) && (int64_t)M * ldc < (1LL << 29)) {
+    int upi = 1;
+    while ((long)batch * qtiles * upi < 3L * cus && ((long)M + upi * 2 - 1) / (upi * 2) >= 256) upi *= 2;
+    const int rpu = (int)((((long)M + upi - 1) / upi + 255) / 256 * 256);  // whole 256-row steps
+    upi = (int)(((long)M + rpu - 1) / rpu);
+    const long total = (long)batch * qtiles * upi;
+    if (total > 0x7fffffffL) return MI_ERANGE;
+    const long per = (total + cus - 1) / cus;
+    const unsigned grid = (unsigned)((total + per - 1) / per);
+    const size_t lds = ((size_t)K + 1) * 64 * 4;
+    auto k = perm ? spmm_ldsq_kernel<4, true> : spmm_ldsq_kernel<4, false>;
+    if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kWaves * 64), lds, s, rowptr, col, val, B, C, M, K, (long)ldb, (long)ldc,
+                       (long)strideB, (long)strideC, bias, qtiles == 4 ? 2 : qtiles == 2 ? 1 : 0, upi, rpu, (unsigned)total,
+                       long_thresh, perm, (int)(nnz_total - 4));
+    return check_launch();
+  }
   // units: blocks of rows of one item, sized so that all CUs get work (two blocks per item for 384 items on 256 CUs),
   // never below 64 rows
   int units_per_item = 1;
@@ -415,6 +690,27 @@ int launch_sddmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* dC
 }  // namespace mi
 
 extern "C" {
+
+#ifdef MI_LDSB_TIMING
+int mi_ldsb_probe(const int32_t* rowptr, const int32_t* col, const float* val, const float* B, float* C, int32_t batch,
+                  int32_t M, int32_t K, int32_t N, int64_t nnz, void* stamps_out) {
+  const int st = mi::launch_spmm_ldsb(rowptr, col, val, B, C, batch, M, K, N, N, N, (int64_t)K * N, (int64_t)M * N, nullptr,
+                                      0x7fffffff, nullptr, nullptr, nnz);
+  if (st != MI_OK) return st;
+  MI_HIP_TRY(hipDeviceSynchronize());
+  if (stamps_out) MI_HIP_TRY(hipMemcpyFromSymbol(stamps_out, HIP_SYMBOL(g_ldsq_stamps), sizeof(g_ldsq_stamps)));
+  if (stamps_out)
+    MI_HIP_TRY(hipMemcpyFromSymbol(static_cast<char*>(stamps_out) + sizeof(g_ldsq_stamps), HIP_SYMBOL(g_ldsq_wave_end),
+                                   sizeof(g_ldsq_wave_end)));
+  return MI_OK;
+}
+#endif
+
+int mi_spmm_ldsb_set_form(int form) {
+  if (form < -1 || form > 1) return MI_EINVAL;
+  mi::g_ldsb_form.store(form, std::memory_order_relaxed);
+  return MI_OK;
+}
 
 int mi_sddmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz_total, int32_t batch, int32_t M,
                              int32_t K, int32_t N, const float* dC, int64_t lddc, int64_t strideDC, const float* B,

@@ -2492,6 +2492,71 @@ def test_spmm_lds_resident_b_plan_bit_exact(capi, cmm, dev, oracle_mod, N):
         assert np.array_equal(outs[18], outs[5])
 
 
+@pytest.mark.parametrize("N", [64, 128, 256])
+def test_spmm_lds_resident_b_quad_form_bit_exact(capi, cmm, dev, oracle_mod, N):
+    """The quad form of MI_SPMM_LDS_B (spmm_ldsq_kernel: four lanes per row, 16-byte loads of col / val clamped to the
+    arrays' last 16 bytes, LDS-DMA staging, 256-row steps) pinned through mi_spmm_ldsb_set_form, beside the 16-lane
+    form and the oracle: column tiles of 64 (N = 128, 256), K from a few rows to the 512 the image holds, row counts
+    below / across / beyond a 256-row step, empty rows, duplicate and unsorted columns, a last row of 1 … 3 entries
+    (the lane whose clamped load starts early), per-item and shared B; the values through a permutation; bias and the
+    long-row rule on one item.  Reference: the per-slice recursion of naive_matmul, matmuls.py:282-297."""
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_spmm_csr_batched_variant_f32.argtypes = [ctypes.c_int, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp]
+    capi.mi_spmm_ldsb_set_form.argtypes = [ctypes.c_int]
+    stream = torch.cuda.current_stream().cuda_stream
+    g = np.random.Generator(np.random.PCG64(1000 + N))
+    try:
+        for case, (batch, M, K, share_b, tail) in enumerate(((1, 777, 512, False, 1), (5, 333, 300, False, 2), (7, 130, 17, True, 3),
+                                                             (3, 9, 512, False, 1), (2, 256, 64, False, 0), (40, 512, 128, False, 2))):
+            lens = g.integers(0, 70, size=batch * M)
+            lens[g.integers(0, batch * M, size=5)] = 0
+            lens[3] = 2 * K + 5                                     # longer than K: duplicate columns
+            lens[-1] = tail                                          # the arrays end 0 … 3 entries into a 16-byte load
+            cols = [g.integers(0, K, size=int(n)).astype(np.int32) for n in lens]
+            cols = [c if i % 3 else np.sort(c) for i, c in enumerate(cols)]
+            col = np.concatenate(cols)
+            val = g.random(len(col), dtype=np.float32) - 0.5
+            off = np.zeros((batch, M + 1), np.int64)
+            off[:, 1:] = np.cumsum(lens).reshape(batch, M)
+            off[1:, 0] = off[:-1, M]
+            off = off.astype(np.int32)
+            B = g.random((K, N) if share_b else (batch, K, N), dtype=np.float32) - 0.5
+            want = oracle_mod.spmm_csr_batched(off, col, val, batch, M, K, B)
+            d_off, d_col, d_val, d_B = t(off, dev), t(col, dev), t(val, dev), t(B, dev)
+            for form in (1, 0, -1):
+                assert capi.mi_spmm_ldsb_set_form(form) == 0
+                C = torch.full((batch, M, N), float("nan"), device=dev)
+                st = capi.mi_spmm_csr_batched_variant_f32(18, d_off.data_ptr(), d_col.data_ptr(), d_val.data_ptr(), len(col),
+                                                          batch, M, K, N, d_B.data_ptr(), N, 0 if share_b else K * N,
+                                                          C.data_ptr(), N, M * N, stream)
+                assert st == 0, (form, batch, M, K, N)
+                assert np.array_equal(C.cpu().numpy().view(np.int32), want.view(np.int32)), (form, case, batch, M, K, N)
+            if not share_b and batch * M >= 16384:   # (what AUTO hands the permuted entry point)
+                capi.mi_spmm_ldsb_set_form(1)
+                shuffle = g.permutation(len(val))
+                stored = np.empty_like(val)
+                stored[shuffle] = val
+                C = torch.full((batch, M, N), float("nan"), device=dev)
+                took = cmm.naive_spmm_batched_perm(t(stored, dev), t(shuffle.astype(np.int32), dev), d_col, d_off, len(col),
+                                                   batch, M, K, d_B, C)
+                assert took is True and np.array_equal(C.cpu().numpy().view(np.int32), want.view(np.int32))
+        # one item, a row beyond the long-row threshold (skipped by the kernel, summed by the follow-up), fused bias
+        capi.mi_spmm_ldsb_set_form(1)
+        M, K = 20000, 256
+        lens = g.integers(2, 12, size=M)
+        lens[77], lens[19999] = 9000, 3
+        col = np.concatenate([g.integers(0, K, size=int(n)).astype(np.int32) for n in lens])
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        val = g.random(len(col), dtype=np.float32) - 0.5
+        B, bias = g.random((K, N), dtype=np.float32) - 0.5, g.random(N, dtype=np.float32)
+        want = oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B)
+        C = torch.full((M, N), float("nan"), device=dev)
+        cmm.naive_spmm_bias(t(val, dev), t(col, dev), t(rowptr, dev), len(col), M, K, t(B, dev), t(bias, dev), C)
+        assert np.array_equal(C.cpu().numpy(), want + bias[None, :])
+    finally:
+        capi.mi_spmm_ldsb_set_form(-1)
+
+
 def test_lds_resident_b_keeps_negative_zero_and_reads_values_through_a_permutation(capi, cmm, dev, oracle_mod):
     """Round 4.  (1) Advisor: a row whose products all underflow negatively ends as −0 in the oracle and in every plan;
     the LDS-resident-B kernel pads a row's last four-entry step — with value −0 on an all-zero row, which leaves every
