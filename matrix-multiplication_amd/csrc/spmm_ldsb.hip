@@ -548,6 +548,188 @@ __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsb_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The batched SDDMM in quad form (N = 64): as spmm_ldsq_kernel — four lanes per row, a wave carries 16 rows, 16-byte
+// loads of the columns, LDS-DMA staging, one 256-row step per unit — with sddmm_ldsb_kernel's arithmetic bit for bit.
+// That kernel's order: 16 lanes l chain columns 4l … 4l+3 (p[l]), every chain takes "+0" twice (the tree levels 32 and
+// 16, whose partners never had columns), then a xor tree over the distances 8, 4, 2, 1.  Here lane g of the quad holds
+// the four pieces 16c + 4g … of the dC row, i.e. the chains l = g + 4c: the levels 8 and 4 pair chains of ONE lane
+// ((p[c=0] + p[c=2]) + (p[c=1] + p[c=3]), whatever the bank rotation: addition commutes), the levels 2 and 1 are two
+// quad-permute adds.  The "+0"s: replacing −0 leaves by +0 changes a tree's result only when EVERY leaf is −0 (the only
+// sum that gives −0) — so one "+0" on the result is the same bits as one on every leaf.
+// Results of a chunk are held until the next chunk's loads are out: a store between a load and its wait would make the
+// wait cover the store.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWaves * 64) void sddmm_ldsq_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dC,
+    const float* __restrict__ B, float* __restrict__ out, int M, int K, long lddc, long strideDC, long ldb,
+    long strideB, int units_per_item, int rows_per_unit, unsigned total_units, int last4) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 Bs[];  // [K][16]
+  constexpr int Q = 4, W = 64, ROWB = 4 * W, RPW = 16, STRIDE = kWaves * RPW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qd = lane >> 2, gl = lane & 3;
+  const unsigned per = (total_units + gridDim.x - 1) / gridDim.x;
+  const unsigned u0 = blockIdx.x * per, u1 = u0 + per < total_units ? u0 + per : total_units;
+  typedef const f32x4 __attribute__((address_space(3))) * LdsRow;
+  const unsigned lds0 = (unsigned)(unsigned long)((LdsRow)Bs);
+  unsigned lb[Q];
+#pragma unroll
+  for (int j = 0; j < Q; ++j) lb[j] = lds0 + 64 * ((j + qd) & (Q - 1)) + 16 * gl;
+
+  struct Cursor {
+    unsigned u;
+    int slice, part, rb;
+  };
+  auto unit_r1 = [&](int part) {
+    const long e = ((long)part + 1) * rows_per_unit;
+    return e < M ? (int)e : M;
+  };
+  auto settle = [&](Cursor& c) {
+    while (c.u < u1 && c.rb >= unit_r1(c.part)) {
+      ++c.u;
+      if (++c.part == units_per_item) c.part = 0, ++c.slice;
+      c.rb = c.part * rows_per_unit + wave * RPW;
+    }
+  };
+  // a step's bounds, and its dC row (the lane's four pieces); no row here: the same word twice / row 0 of item 0
+  auto issue_bounds = [&](const Cursor& c, int& st, int& en) {
+    const bool unit = c.u < u1;
+    const bool there = unit && c.rb + qd < unit_r1(c.part);
+    const char* rp = reinterpret_cast<const char*>(rowptr + (unit ? (long)c.slice * ((long)M + 1) : 0L));
+    const unsigned o = there ? 4u * (unsigned)(c.rb + qd) : 0u;
+    st = *reinterpret_cast<const int*>(rp + o);
+    en = *reinterpret_cast<const int*>(rp + (there ? o + 4u : 0u));
+  };
+  auto issue_x = [&](const Cursor& c, f32x4 (&x)[Q]) {
+    const bool unit = c.u < u1;
+    const bool there = unit && c.rb + qd < unit_r1(c.part);
+    const __amdgpu_buffer_rsrc_t xr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dC + (unit ? (long)c.slice * strideDC : 0L)), 0, 0x7fffffff, 0x00020000);
+    const unsigned xo = (there ? (unsigned)(c.rb + qd) * (unsigned)lddc * 4u : 0u) - lds0;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) x[j] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(xr, (int)(xo + lb[j]), 0, 0));
+  };
+  auto issue_chunk = [&](int p, i32x4& c) {
+    const int idx = p + 4 * gl;
+    c = *reinterpret_cast<const i32x4_u*>(reinterpret_cast<const char*>(col) + 4u * (unsigned)(idx < last4 ? idx : last4));
+  };
+  auto finish_chunk = [&](int p, int en, i32x4& c) {  // → byte offsets of the B rows in LDS
+    const int idx = p + 4 * gl;
+    const int sh = idx - last4;  // see spmm_ldsq_kernel
+    if (__builtin_amdgcn_ballot_w64(en - idx > 0 && sh > 0) != 0) {
+      if (sh > 0) c = sh == 1 ? i32x4{c.y, c.z, c.w, 0} : sh == 2 ? i32x4{c.z, c.w, 0, 0} : i32x4{c.w, 0, 0, 0};
+    }
+    c *= ROWB;  // (positions past the row's end hold some column of the arrays: a row of the image, its sum is not stored)
+  };
+  auto store_chunk = [&](int p, int en, const f32x4& o) {
+    const int idx = p + 4 * gl;
+    const int left = en - idx;
+    char* dst = reinterpret_cast<char*>(out) + 4u * (unsigned)idx;
+    if (left >= 4) {
+      *reinterpret_cast<f32x4_u*>(dst) = o;
+    } else if (left > 0) {
+      *reinterpret_cast<float*>(dst) = o.x;
+      if (left > 1) *reinterpret_cast<float*>(dst + 4) = o.y;
+      if (left > 2) *reinterpret_cast<float*>(dst + 8) = o.z;
+    }
+  };
+
+  Cursor c0, c1, c2;
+  c0.u = u0;
+  c0.slice = (int)(u0 / (unsigned)units_per_item);
+  c0.part = (int)(u0 % (unsigned)units_per_item);
+  c0.rb = c0.part * rows_per_unit + wave * RPW;
+  settle(c0);
+  c1 = c0;
+  c1.rb += STRIDE;
+  settle(c1);
+  int s0, e0, s1, e1, s2, e2;
+  f32x4 x0[Q], x1[Q];
+  issue_bounds(c0, s0, e0);
+  issue_bounds(c1, s1, e1);
+  issue_x(c0, x0);
+  i32x4 r0, rn;
+  issue_chunk(s0, r0);
+
+  long staged = -1;
+  for (unsigned u = u0; u < u1; ++u) {  // workgroup-uniform
+    const long item = u / (unsigned)units_per_item;
+    if (item != staged) {
+      if (staged >= 0) __syncthreads();
+      const float* Bi = B + item * strideB;
+      constexpr int nq = W / 4;
+      const int total4 = K * nq;
+      for (int f0 = wave * 64; f0 < total4; f0 += kWaves * 64) {  // wave-uniform; LDS-DMA, see spmm_ldsq_kernel
+        const int f = f0 + lane;
+        if (f < total4)
+          __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void*>(
+                                               reinterpret_cast<unsigned long>(Bi + (long)(f / nq) * ldb + 4 * (f % nq))),
+                                           (__attribute__((address_space(3))) void*)(Bs + f0), 16, 0, 0);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+      __syncthreads();
+      staged = item;
+    }
+    while (c0.u == u) {  // wave-uniform: this wave's row steps inside the unit
+      // the bounds of the step two ahead and the dC row of the next step go out first
+      c2 = c1;
+      c2.rb += STRIDE;
+      settle(c2);
+      issue_bounds(c2, s2, e2);
+      issue_x(c1, x1);
+      int p = s0;
+      int pend_p = 0, pend_e = 0;  // the chunk whose results wait in `o` (pend_e = 0: none)
+      f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (;;) {  // wave-uniform trip count
+        const bool more = __builtin_amdgcn_ballot_w64(p + 16 < e0) != 0;
+        store_chunk(pend_p, pend_e, o);
+        issue_chunk(more ? p + 16 : s1, rn);
+        finish_chunk(p, e0, r0);
+        const int left = e0 - p;
+        static_for<4>([&](auto b_) {
+          constexpr int b = 4 * decltype(b_)::value;
+          if (b == 0 || __builtin_amdgcn_ballot_w64(b < left) != 0) {  // wave-uniform
+            static_for<4>([&](auto e_) {
+              constexpr int e = b + decltype(e_)::value;
+              constexpr int src = e >> 2, comp = e & 3;
+              const unsigned off = (unsigned)group_lane<4, src, true>(r0[comp]);
+              f32x4 y[Q];
+#pragma unroll
+              for (int j = 0; j < Q; ++j) y[j] = *(LdsRow)(unsigned long)(off + lb[j]);
+              float part[Q];
+#pragma unroll
+              for (int j = 0; j < Q; ++j) {
+                float a = __builtin_fmaf(x0[j].x, y[j].x, 0.f);
+                a = __builtin_fmaf(x0[j].y, y[j].y, a);
+                a = __builtin_fmaf(x0[j].z, y[j].z, a);
+                part[j] = __builtin_fmaf(x0[j].w, y[j].w, a);
+              }
+              float t = (part[0] + part[2]) + (part[1] + part[3]);                                   // levels 8, 4
+              t = t + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4e, 0xf, 0xf, true));  // 2
+              t = t + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xb1, 0xf, 0xf, true));  // 1
+              if (gl == src) o[comp] = t + 0.0f;
+              if constexpr ((e & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            });
+          }
+        });
+        pend_p = p;
+        pend_e = e0;
+        r0 = rn;
+        p += 16;
+        if (!more) break;
+      }
+      store_chunk(pend_p, pend_e, o);
+      c0 = c1, c1 = c2;
+      s0 = s1, e0 = e1;
+      s1 = s2, e1 = e2;
+#pragma unroll
+      for (int j = 0; j < Q; ++j) x0[j] = x1[j];
+    }
+  }
+}
+
 }  // namespace
 
 namespace mi {
@@ -650,8 +832,9 @@ bool sddmm_ldsb_fits(int32_t K, int32_t N) { return N >= 4 && N <= 64 && N % 4 =
 
 int launch_sddmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* dC, const float* B, float* out,
                       int32_t batch, int32_t M, int32_t K, int32_t N, int64_t lddc, int64_t strideDC, int64_t ldb,
-                      int64_t strideB, hipStream_t s) {
+                      int64_t strideB, hipStream_t s, int64_t nnz_total) {
   if (!sddmm_ldsb_fits(K, N)) return MI_EINVAL;
+  const int form = g_ldsb_form.load(std::memory_order_relaxed);
   static const int cus = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
@@ -660,6 +843,22 @@ int launch_sddmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* dC
     }
     return n;
   }();
+  if (form != 0 && N == 64 && K <= 512 && nnz_total >= 4 && nnz_total < (1LL << 29) && (int64_t)M * lddc < (1LL << 29)) {
+    int upi = 1;  // the quad form (sddmm_ldsq_kernel): units of whole 256-row steps, as launch_spmm_ldsb sizes them
+    while ((long)batch * upi < 3L * cus && ((long)M + upi * 2 - 1) / (upi * 2) >= 256) upi *= 2;
+    const int rpu = (int)((((long)M + upi - 1) / upi + 255) / 256 * 256);
+    upi = (int)(((long)M + rpu - 1) / rpu);
+    const long total = (long)batch * upi;
+    if (total > 0x7fffffffL) return MI_ERANGE;
+    const long per = (total + cus - 1) / cus;
+    const unsigned grid = (unsigned)((total + per - 1) / per);
+    const size_t lds = (size_t)K * 64 * 4;
+    if (lds > 64 * 1024)
+      MI_HIP_TRY(hipFuncSetAttribute((const void*)sddmm_ldsq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(sddmm_ldsq_kernel, dim3(grid), dim3(kWaves * 64), lds, s, rowptr, col, dC, B, out, M, K, (long)lddc,
+                       (long)strideDC, (long)ldb, (long)strideB, upi, rpu, (unsigned)total, (int)(nnz_total - 4));
+    return check_launch();
+  }
   int units_per_item = 1;
   while ((long)batch * units_per_item < 3L * cus && ((long)M + units_per_item * 2 - 1) / (units_per_item * 2) >= 64)
     units_per_item *= 2;
@@ -724,7 +923,7 @@ int mi_sddmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col, int64_t 
   // taken where the forward's LDS-resident-B plan is (enough rows to fill the chip, rows of a few non-zeros at least)
   if (!vec || !mi::sddmm_ldsb_fits(K, N) || (long)batch * M < 16384 || nnz_total < 4L * batch * M) return 1;
   return mi::launch_sddmm_ldsb(rowptr, col, dC, B, out_val, batch, M, K, N, lddc, strideDC, ldb, strideB,
-                               static_cast<hipStream_t>(stream));
+                               static_cast<hipStream_t>(stream), nnz_total);
 }
 
 }  // extern "C"

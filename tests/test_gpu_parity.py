@@ -2609,7 +2609,7 @@ def test_lds_resident_b_keeps_negative_zero_and_reads_values_through_a_permutati
 
 
 @pytest.mark.parametrize("N,shared", [(64, False), (64, True), (32, False), (48, False), (16, False), (8, True), (4, False)])
-def test_sddmm_batched_lds_resident_form_bit_exact(cmm, dev, oracle_mod, N, shared):
+def test_sddmm_batched_lds_resident_form_bit_exact(capi, cmm, dev, oracle_mod, N, shared):
     """Round 4: custom_mm.sddmm_batched — the gradient of a batched CSR tensor's stored values with the item's dense
     operand resident in LDS — against the oracle's SDDMM per item and, bit for bit, against custom_mm.sddmm on the
     block-diagonal matrix of the batch (what matmuls ran before and still runs where the form does not apply): rows of
@@ -2643,6 +2643,27 @@ def test_sddmm_batched_lds_resident_form_bit_exact(cmm, dev, oracle_mod, N, shar
     ref = cmm.sddmm(t(diag_col, dev), t(flat_off, dev), len(col), batch * M, batch * K, t(dC.reshape(batch * M, N), dev),
                     t(b_stack, dev))
     assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+    if N == 64:
+        # the default above was the quad form (sddmm_ldsq_kernel: N = 64, K ≤ 512); the 16-lane form pinned beside it,
+        # and a batch whose last row holds the arrays' last 1 … 3 entries (the lane whose 16-byte load is clamped)
+        capi.mi_spmm_ldsb_set_form.argtypes = [ctypes.c_int]
+        try:
+            capi.mi_spmm_ldsb_set_form(0)
+            out16 = torch.full((len(col),), float("nan"), device=dev)
+            assert cmm.sddmm_batched(t(col, dev), t(off, dev), len(col), batch, M, K, t(dC, dev), t(B, dev), out16) is True
+            assert torch.equal(out.view(torch.int32), out16.view(torch.int32))
+            for tail in (1, 2, 3):
+                cut = len(col) - int(lens[-1]) + tail if lens[-1] >= tail else None
+                if cut is None:
+                    continue
+                off2 = off.copy()
+                off2[-1, -1] = cut
+                capi.mi_spmm_ldsb_set_form(1)
+                o1 = torch.full((cut,), float("nan"), device=dev)
+                assert cmm.sddmm_batched(t(col[:cut], dev), t(off2, dev), cut, batch, M, K, t(dC, dev), t(B, dev), o1) is True
+                assert torch.equal(o1.view(torch.int32), out[:cut].view(torch.int32)), tail
+        finally:
+            capi.mi_spmm_ldsb_set_form(-1)
     # not taken: too few rows / an operand beyond the LDS image
     small = torch.full((6,), -7.0, device=dev)
     assert cmm.sddmm_batched(torch.zeros(6, dtype=torch.int32, device=dev),
