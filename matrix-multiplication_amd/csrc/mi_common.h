@@ -43,7 +43,8 @@ int spmm_ldsb_tiles(int32_t K, int32_t N);  // column tiles the plan cuts N into
 int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val, const float* B, float* C,
                      int32_t batch, int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t ldc, int64_t strideB,
                      int64_t strideC, const float* bias, int long_thresh, hipStream_t s, const int32_t* perm = nullptr,
-                     int64_t nnz_total = -1);  // nnz_total (≥ 4): lets the quad form clamp its 16-byte loads of col / val
+                     int64_t nnz_total = -1);  // nnz_total (≥ 4): lets the quad form clamp its 16-byte loads of col / val;
+                                               // returns 1 (nothing launched) when only that form covers the shape and it cannot run
 
 // the same kernel on column-major operands (X = Bᵀ [N, ldx], Y = Cᵀ [N, ldy]); caller checks the requirements
 int launch_spmm_slab_colmajor(const int32_t* rowptr, const int32_t* col, const float* val, const float* X, float* Y,

@@ -1114,8 +1114,12 @@ int launch_variant(int variant, const Shape& sh, const int32_t* rowptr, const in
       return mi::launch_spmm_slab(rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la.thresh, s);
     case MI_SPMM_LDS_B:
       if (!(vec4_ok && mi::spmm_ldsb_fits(K, N))) return MI_EINVAL;
-      return mi::launch_spmm_ldsb(rowptr, col, val, B, C, batch, M, K, N, ldb, ldc, strideB, strideC, bias, la.thresh, s,
-                                  nullptr, nnz);
+    {
+      const int st = mi::launch_spmm_ldsb(rowptr, col, val, B, C, batch, M, K, N, ldb, ldc, strideB, strideC, bias, la.thresh,
+                                          s, nullptr, nnz);
+      if (st != 1) return st;  // 1: a shape only the quad form covers, with that form unavailable → same bits from the L2s
+      return dispatch_group<4>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, la, s);
+    }
     case MI_SPMM_NARROW: {
       if (N >= 4) return MI_EINVAL;
       const long blocks = ((long)M + 3) / 4;

@@ -234,7 +234,8 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_ldsq_kernel(
   // last4 = nnz_total − 4 (≥ 0): the last index a 16-byte load of col / val may start at; 1 << ctile_shift column tiles
   extern __shared__ __attribute__((aligned(16))) f32x4 Bs[];  // [K + 1][W / 4]
   constexpr int W = 16 * Q, ROWB = 4 * W, RPW = 16, STRIDE = kWaves * RPW;
-  static_assert((Q & (Q - 1)) == 0 && Q >= 4, "the rotation needs Q = 4, 8, …");
+  static_assert((Q & (Q - 1)) == 0, "the rotation needs a power of two");  // (Q < 4: rows narrower than the 64 banks —
+  // the quads of a service group meet on a bank quarter when their rows' offsets agree mod 256 B: up to 4-way, by the data)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qd = lane >> 2, gl = lane & 3;
@@ -749,9 +750,22 @@ static int ldsb_column_tiles(int32_t K, int32_t N) {
   return 0;
 }
 
+// Quad form (spmm_ldsq_kernel): column tiles of 64, 32 or 16 — the widest whose image (K + 1 rows) fits — whatever the
+// 16-lane form's tiling: 512 rows of B at 64 columns, 1024 at 32, 2048 at 16 (attention over 2048 tokens: four tiles of
+// 16, a shape the 16-lane form leaves to the L2 gathers); at most 8 tiles.  0: the form does not cover the shape.
+static int ldsq_tile_width(int32_t K, int32_t N) {
+  if (N < 16 || N % 16 != 0 || K < 1) return 0;
+  for (int w = 64; w >= 16; w /= 2)
+    if (N % w == 0 && N / w <= 8 && ((N / w) & (N / w - 1)) == 0 && ((long)K + 1) * w * 4 <= 132L * 1024) return w;
+  return 0;
+}
+
 // whether the plan can take the problem at all (shape only; the caller checked the vec4 requirements)
-bool spmm_ldsb_fits(int32_t K, int32_t N) { return ldsb_column_tiles(K, N) > 0; }
-int spmm_ldsb_tiles(int32_t K, int32_t N) { return ldsb_column_tiles(K, N); }
+bool spmm_ldsb_fits(int32_t K, int32_t N) { return ldsb_column_tiles(K, N) > 0 || ldsq_tile_width(K, N) > 0; }
+int spmm_ldsb_tiles(int32_t K, int32_t N) {
+  const int w = ldsq_tile_width(K, N);
+  return w > 0 ? N / w : ldsb_column_tiles(K, N);
+}
 
 // 0: the 16-lane form only, 1: the quad form wherever it covers the shape, -1 (default): by rule (developer A/B and tests)
 static std::atomic<int> g_ldsb_form{-1};
@@ -760,9 +774,6 @@ int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val
                      int32_t batch, int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t ldc, int64_t strideB,
                      int64_t strideC, const float* bias, int long_thresh, hipStream_t s, const int32_t* perm,
                      int64_t nnz_total) {
-  const int ctiles = ldsb_column_tiles(K, N);
-  if (ctiles == 0) return MI_EINVAL;
-  const int W = N / ctiles;
   static const int cus = [] {  // thread-safe one-time query (every device of a node has the same CU count)
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
@@ -771,12 +782,11 @@ int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val
     }
     return n;
   }();
-  // Quad form (spmm_ldsq_kernel): tiles of 64 or 128 columns, 256-row steps.  Units of whole steps, as many as keep
-  // every CU at work; taken by rule when that split leaves at most a tenth of the persistent grid's time idle.
+  // Quad form (spmm_ldsq_kernel): units of whole 256-row steps, as many as keep every CU at work.
   const int form = g_ldsb_form.load(std::memory_order_relaxed);
-  // quad form: column tiles of 64 whatever the 16-lane form's tiling (a 128-column tile — Q = 8 — spills registers)
-  const int qtiles = (N % 64 == 0 && (N == 64 || N == 128 || N == 256) && K <= 512) ? N / 64 : 0;
-  if (form != 0 && qtiles != 0 && qtiles <= 4 && nnz_total >= 4 && nnz_total < (1LL << 29) && (int64_t)M * ldc < (1LL << 29)) {
+  const int qw = ldsq_tile_width(K, N);
+  if (form != 0 && qw != 0 && nnz_total >= 4 && nnz_total < (1LL << 29) && (int64_t)M * ldc < (1LL << 29)) {
+    const int qtiles = N / qw;
     int upi = 1;
     while ((long)batch * qtiles * upi < 3L * cus && ((long)M + upi * 2 - 1) / (upi * 2) >= 256) upi *= 2;
     const int rpu = (int)((((long)M + upi - 1) / upi + 255) / 256 * 256);  // whole 256-row steps
@@ -785,14 +795,25 @@ int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val
     if (total > 0x7fffffffL) return MI_ERANGE;
     const long per = (total + cus - 1) / cus;
     const unsigned grid = (unsigned)((total + per - 1) / per);
-    const size_t lds = ((size_t)K + 1) * 64 * 4;
-    auto k = perm ? spmm_ldsq_kernel<4, true> : spmm_ldsq_kernel<4, false>;
-    if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kWaves * 64), lds, s, rowptr, col, val, B, C, M, K, (long)ldb, (long)ldc,
-                       (long)strideB, (long)strideC, bias, qtiles == 4 ? 2 : qtiles == 2 ? 1 : 0, upi, rpu, (unsigned)total,
-                       long_thresh, perm, (int)(nnz_total - 4));
+    const size_t lds = ((size_t)K + 1) * qw * 4;
+    const int shift = qtiles == 8 ? 3 : qtiles == 4 ? 2 : qtiles == 2 ? 1 : 0;
+#define MI_LDSQ(Q_)                                                                                                   \
+  do {                                                                                                                \
+    auto k = perm ? spmm_ldsq_kernel<Q_, true> : spmm_ldsq_kernel<Q_, false>;                                         \
+    if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kWaves * 64), lds, s, rowptr, col, val, B, C, M, K, (long)ldb, (long)ldc,  \
+                       (long)strideB, (long)strideC, bias, shift, upi, rpu, (unsigned)total, long_thresh, perm,         \
+                       (int)(nnz_total - 4));                                                                          \
+  } while (0)
+    if (qw == 64) MI_LDSQ(4);
+    else if (qw == 32) MI_LDSQ(2);
+    else MI_LDSQ(1);
+#undef MI_LDSQ
     return check_launch();
   }
+  const int ctiles = ldsb_column_tiles(K, N);
+  if (ctiles == 0) return 1;  // only the quad form covers the shape and it was pinned off / out of its index range: not taken
+  const int W = N / ctiles;
   // units: blocks of rows of one item, sized so that all CUs get work (two blocks per item for 384 items on 256 CUs),
   // never below 64 rows
   int units_per_item = 1;

@@ -2492,22 +2492,26 @@ def test_spmm_lds_resident_b_plan_bit_exact(capi, cmm, dev, oracle_mod, N):
         assert np.array_equal(outs[18], outs[5])
 
 
-@pytest.mark.parametrize("N", [64, 128, 256])
+@pytest.mark.parametrize("N", [16, 32, 64, 128, 256])
 def test_spmm_lds_resident_b_quad_form_bit_exact(capi, cmm, dev, oracle_mod, N):
     """The quad form of MI_SPMM_LDS_B (spmm_ldsq_kernel: four lanes per row, 16-byte loads of col / val clamped to the
     arrays' last 16 bytes, LDS-DMA staging, 256-row steps) pinned through mi_spmm_ldsb_set_form, beside the 16-lane
     form and the oracle: column tiles of 64 (N = 128, 256), K from a few rows to the 512 the image holds, row counts
     below / across / beyond a 256-row step, empty rows, duplicate and unsorted columns, a last row of 1 … 3 entries
     (the lane whose clamped load starts early), per-item and shared B; the values through a permutation; bias and the
-    long-row rule on one item.  Reference: the per-slice recursion of naive_matmul, matmuls.py:282-297."""
+    long-row rule on one item.  Column tiles of 64, 32 or 16 by the height of B (up to 2048 rows at 16 columns:
+    attention over 2048 tokens, which only this form keeps in LDS — pinned off, the product falls back to the L2
+    gathers with the same bits).  Reference: the per-slice recursion of naive_matmul, matmuls.py:282-297."""
     vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
     capi.mi_spmm_csr_batched_variant_f32.argtypes = [ctypes.c_int, vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp]
     capi.mi_spmm_ldsb_set_form.argtypes = [ctypes.c_int]
     stream = torch.cuda.current_stream().cuda_stream
     g = np.random.Generator(np.random.PCG64(1000 + N))
     try:
+        k_tall = {16: 2000, 32: 2000, 64: 2000, 128: 1000, 256: 509}[N]   # narrower tiles: 16 / 16 / 16 / 32 / 64 columns
         for case, (batch, M, K, share_b, tail) in enumerate(((1, 777, 512, False, 1), (5, 333, 300, False, 2), (7, 130, 17, True, 3),
-                                                             (3, 9, 512, False, 1), (2, 256, 64, False, 0), (40, 512, 128, False, 2))):
+                                                             (3, 9, 512, False, 1), (2, 256, 64, False, 0), (40, 512, 128, False, 2),
+                                                             (3, 300, k_tall, False, 3), (2, 515, 1024 if N <= 64 else 700, True, 1))):
             lens = g.integers(0, 70, size=batch * M)
             lens[g.integers(0, batch * M, size=5)] = 0
             lens[3] = 2 * K + 5                                     # longer than K: duplicate columns
@@ -2705,9 +2709,10 @@ def test_spmm_lds_resident_b_is_autos_choice_for_pruned_attention_and_keeps_the_
     capi.mi_spmm_csr_batched_f32_plan.argtypes = [i64, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64]
     capi.mi_spmm_csr_f32_plan.argtypes = [i64, i32, i32, i32, vp, i64, vp, i64]
     assert capi.mi_spmm_csr_batched_f32_plan(10_000_000, 384, 512, 512, 64, None, 64, 512 * 64, None, 64, 512 * 64) == 18
-    # 1024 tokens: B (256 KB) goes in as two column tiles of 32; 2048 tokens would need tiles of 16 columns: row-split
+    # 1024 tokens: B (256 KB) goes in as two column tiles of 32, 2048 tokens as four of 16 (the quad form); 4096: row-split
     assert capi.mi_spmm_csr_batched_f32_plan(10_000_000, 96, 1024, 1024, 64, None, 64, 1024 * 64, None, 64, 1024 * 64) == 18
-    assert capi.mi_spmm_csr_batched_f32_plan(10_000_000, 48, 2048, 2048, 64, None, 64, 2048 * 64, None, 64, 2048 * 64) != 18
+    assert capi.mi_spmm_csr_batched_f32_plan(10_000_000, 48, 2048, 2048, 64, None, 64, 2048 * 64, None, 64, 2048 * 64) == 18
+    assert capi.mi_spmm_csr_batched_f32_plan(10_000_000, 24, 4096, 4096, 64, None, 64, 4096 * 64, None, 64, 4096 * 64) != 18
     g = np.random.Generator(np.random.PCG64(18))
     M, K, N = 20000, 256, 64
     lens = g.integers(2, 12, size=M)

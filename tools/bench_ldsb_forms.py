@@ -53,9 +53,11 @@ for trial in range(60 if not quick else 20):
     items = int(torch.randint(1, 40, (1,), generator=cpu))
     M = int(torch.randint(1, 700, (1,), generator=cpu))
     K = int(torch.randint(1, 513, (1,), generator=cpu))
-    N = 64 if trial % 3 else 128
-    if K * N * 4 > 128 * 1024:
-        K = 128 * 1024 // (N * 4)
+    N = (64, 128, 32, 16, 64, 256)[trial % 6]
+    if trial % 7 == 0:
+        K = int(torch.randint(513, 2049, (1,), generator=cpu))  # narrower tiles
+    if (K + 1) * 16 * 4 > 132 * 1024 or N // 16 > 8 and K > 512:
+        K = 512
     kept = float(torch.rand(1, generator=cpu)) ** 2
     probs = torch.rand(items, M, K, device=dev, generator=g) * (torch.rand(items, M, K, device=dev, generator=g) < kept)
     if trial % 4 == 0:
@@ -88,7 +90,8 @@ print("# items x M x K x N   kept     nnz        group(L2)  16-lane   quad     b
 shapes = [(384, 512, 512, 64, (1.0, 0.5, 0.25, 0.1, 0.05, 0.02, 0.01)),
           (384, 128, 128, 64, (0.5, 0.1)), (384, 256, 256, 64, (0.5, 0.1)), (96, 1024, 512, 64, (0.1, 0.02)),
           (192, 512, 256, 128, (0.25, 0.05)), (96, 512, 512, 128, (0.1,)), (1, 131072, 512, 64, (0.1, 0.02)),
-          (4096, 64, 64, 64, (0.5,)), (1536, 197, 197, 64, (0.25,))]
+          (4096, 64, 64, 64, (0.5,)), (1536, 197, 197, 64, (0.25,)), (96, 1024, 1024, 64, (0.25, 0.1, 0.02)),
+          (48, 2048, 2048, 64, (0.1, 0.05, 0.02)), (96, 1024, 1024, 128, (0.1,)), (768, 512, 1024, 32, (0.1, 0.02))]
 if quick:
     shapes = shapes[:1]
 for items, M, K, N, kepts in shapes:
@@ -102,7 +105,7 @@ for items, M, K, N, kepts in shapes:
         nnz = val.numel()
         t_grp = timeit(lambda: run(GROUP, off, col, val, nnz, items, M, K, N, v, c1))
         lib.mi_spmm_ldsb_set_form(0)
-        t16 = timeit(lambda: run(LDSB, off, col, val, nnz, items, M, K, N, v, c2))
+        t16 = timeit(lambda: run(LDSB, off, col, val, nnz, items, M, K, N, v, c2))  # (a shape of the quad form only: the group kernel again)
         lib.mi_spmm_ldsb_set_form(1)
         tq = timeit(lambda: run(LDSB, off, col, val, nnz, items, M, K, N, v, c3))
         lib.mi_spmm_ldsb_set_form(-1)
