@@ -2535,7 +2535,9 @@ def test_spmm_lds_resident_b_quad_form_bit_exact(capi, cmm, dev, oracle_mod, N):
                                                           C.data_ptr(), N, M * N, stream)
                 assert st == 0, (form, batch, M, K, N)
                 assert np.array_equal(C.cpu().numpy().view(np.int32), want.view(np.int32)), (form, case, batch, M, K, N)
-            if not share_b and batch * M >= 16384:   # (what AUTO hands the permuted entry point)
+            capi.mi_spmm_csr_batched_f32_plan.argtypes = [i64, i32, i32, i32, i32, vp, i64, i64, vp, i64, i64]
+            if not share_b and capi.mi_spmm_csr_batched_f32_plan(len(col), batch, M, K, N, None, N, K * N, None, N, M * N) == 18:
+                # (what AUTO hands the permuted entry point)
                 capi.mi_spmm_ldsb_set_form(1)
                 shuffle = g.permutation(len(val))
                 stored = np.empty_like(val)
