@@ -1015,7 +1015,7 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
   // 65536 × 128 × 256 at 5 % 0.020 ms there vs 0.028 here, at 25 % 0.074 vs 0.046)
   // (a B that needs column tiles re-reads col / val per tile: rows must be that much longer)
   if (sh.vec4_ok && mi::spmm_ldsb_fits(K, N) && (long)batch * M >= 16384 &&
-      nnz >= (N > 128 ? 4 * MI_SPMM_LDSB_MIN_ROW : MI_SPMM_LDSB_MIN_ROW) * mi::spmm_ldsb_tiles(K, N) * (long)batch * M)
+      nnz >= (N > 128 ? 4 * MI_SPMM_LDSB_MIN_ROW : MI_SPMM_LDSB_MIN_ROW * mi::spmm_ldsb_tiles(K, N)) * (long)batch * M)
     return MI_SPMM_LDS_B;
   const int lp = (sh.wave_ok && batch == 1) ? l2_panels(M, K, N, ldb, nnz) : 0;
   // Moderate density: stage B through LDS (spmm_slab.hip) when its cost model beats the L2-blocked
