@@ -43,6 +43,14 @@ __device__ __forceinline__ f32x4 fma4(float a, f32x4 x, f32x4 acc) {
 
 constexpr int kWaves = 16;
 
+#ifndef MI_LDSQ_FMAC_DPP
+#define MI_LDSQ_FMAC_DPP 0
+#endif
+#ifndef MI_LDSQ_BATCH_MASK
+#define MI_LDSQ_BATCH_MASK 3  // entries whose LDS reads the scheduler may batch, minus one (A/B in one process, tools/probes/ldsb_ab.py:
+                              // 0 / 1 / 3 within 1 % of each other, 3 ahead by 0.5 %)
+#endif
+
 #ifdef MI_LDSB_TIMING
 // developer build (tools/probes/ldsb_timing.py): wave 0 of every workgroup stamps the 100 MHz wall clock at its phase
 // boundaries — entry, after each staging, after each unit, exit — into g_ldsq_stamps[workgroup][slot]
@@ -389,14 +397,29 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_ldsq_kernel(
               constexpr int e = b + decltype(e_)::value;
               constexpr int src = e >> 2, comp = e & 3;
               const unsigned off = (unsigned)group_lane<4, src, true>(r0.c[comp]);
-              const float v = group_lane<4, src, true>(r0.v[comp]);
               f32x4 x[Q];
 #pragma unroll
               for (int j = 0; j < Q; ++j) x[j] = *(LdsRow)(unsigned long)(off + lb[j]);
+#if MI_LDSQ_FMAC_DPP
+              // developer A/B: the value's quad broadcast as a DPP modifier of sixteen v_fmac_f32 instead of one
+              // v_mov_b32_dpp + eight v_pk_fma_f32 — measured 15 % SLOWER (0.340 vs 0.297 ms at 100 % kept): the packed
+              // FMA issues at full rate (SQ_ACTIVE_INST_VALU counts one quad-cycle for it)
+#pragma unroll
+              for (int j = 0; j < Q; ++j) {
+                float a0 = acc[j].x, a1 = acc[j].y, a2 = acc[j].z, a3 = acc[j].w;
+                asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a0) : "v"(r0.v[comp]), "v"(x[j].x), "n"(src));
+                asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a1) : "v"(r0.v[comp]), "v"(x[j].y), "n"(src));
+                asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a2) : "v"(r0.v[comp]), "v"(x[j].z), "n"(src));
+                asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[%3,%3,%3,%3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a3) : "v"(r0.v[comp]), "v"(x[j].w), "n"(src));
+                acc[j] = f32x4{a0, a1, a2, a3};
+              }
+#else
+              const float v = group_lane<4, src, true>(r0.v[comp]);
 #pragma unroll
               for (int j = 0; j < Q; ++j) acc[j] = fma4(v, x[j], acc[j]);
-              // two entries' reads in flight, not sixteen: the workgroup's 128 VGPRs per lane also hold two chunks
-              if constexpr ((e & 1) == 1 || Q > 4) __builtin_amdgcn_sched_barrier(0);
+#endif
+              // (a fence for the scheduler every MI_LDSQ_BATCH_MASK + 1 entries: left alone it hoists sixteen entries' reads and spills)
+              if constexpr ((e & MI_LDSQ_BATCH_MASK) == MI_LDSQ_BATCH_MASK) __builtin_amdgcn_sched_barrier(0);
             });
           }
         });
@@ -911,17 +934,20 @@ int launch_sddmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* dC
 
 extern "C" {
 
-#ifdef MI_LDSB_TIMING
+#if defined(MI_LDSB_TIMING) || defined(MI_LDSB_PROBE)
+// developer builds of this file alone (tools/probes/ldsb_timing.py, tools/probes/ldsb_ab.py): the plan's launcher without
+// the dispatcher; stamps_out = null: no synchronisation, nothing read back
 int mi_ldsb_probe(const int32_t* rowptr, const int32_t* col, const float* val, const float* B, float* C, int32_t batch,
                   int32_t M, int32_t K, int32_t N, int64_t nnz, void* stamps_out) {
   const int st = mi::launch_spmm_ldsb(rowptr, col, val, B, C, batch, M, K, N, N, N, (int64_t)K * N, (int64_t)M * N, nullptr,
                                       0x7fffffff, nullptr, nullptr, nnz);
-  if (st != MI_OK) return st;
+  if (st != MI_OK || !stamps_out) return st;
   MI_HIP_TRY(hipDeviceSynchronize());
-  if (stamps_out) MI_HIP_TRY(hipMemcpyFromSymbol(stamps_out, HIP_SYMBOL(g_ldsq_stamps), sizeof(g_ldsq_stamps)));
-  if (stamps_out)
-    MI_HIP_TRY(hipMemcpyFromSymbol(static_cast<char*>(stamps_out) + sizeof(g_ldsq_stamps), HIP_SYMBOL(g_ldsq_wave_end),
-                                   sizeof(g_ldsq_wave_end)));
+#ifdef MI_LDSB_TIMING
+  MI_HIP_TRY(hipMemcpyFromSymbol(stamps_out, HIP_SYMBOL(g_ldsq_stamps), sizeof(g_ldsq_stamps)));
+  MI_HIP_TRY(hipMemcpyFromSymbol(static_cast<char*>(stamps_out) + sizeof(g_ldsq_stamps), HIP_SYMBOL(g_ldsq_wave_end),
+                                 sizeof(g_ldsq_wave_end)));
+#endif
   return MI_OK;
 }
 #endif
