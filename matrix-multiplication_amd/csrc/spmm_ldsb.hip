@@ -588,8 +588,10 @@ __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsb_kernel(
 __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsq_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dC,
     const float* __restrict__ B, float* __restrict__ out, int M, int K, long lddc, long strideDC, long ldb,
-    long strideB, int units_per_item, int rows_per_unit, unsigned total_units, int last4) {
-  extern __shared__ __attribute__((aligned(16))) f32x4 Bs[];  // [K][16]
+    long strideB, int units_per_item, int rows_per_unit, unsigned total_units, int last4, int ktile_shift, int ktile_rows) {
+  // 1 << ktile_shift tiles of ktile_rows rows of B per item (K beyond the 512 rows the image holds: an entry needs ONE row of
+  // B, so a pass per tile computes the entries whose column lies in it — exact whatever the order of columns inside a row)
+  extern __shared__ __attribute__((aligned(16))) f32x4 Bs[];  // [min(K, ktile_rows)][16]
   constexpr int Q = 4, W = 64, ROWB = 4 * W, RPW = 16, STRIDE = kWaves * RPW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsq_kernel(
   auto issue_bounds = [&](const Cursor& c, int& st, int& en) {
     const bool unit = c.u < u1;
     const bool there = unit && c.rb + qd < unit_r1(c.part);
-    const char* rp = reinterpret_cast<const char*>(rowptr + (unit ? (long)c.slice * ((long)M + 1) : 0L));
+    const char* rp = reinterpret_cast<const char*>(rowptr + (unit ? (long)(c.slice >> ktile_shift) * ((long)M + 1) : 0L));
     const unsigned o = there ? 4u * (unsigned)(c.rb + qd) : 0u;
     st = *reinterpret_cast<const int*>(rp + o);
     en = *reinterpret_cast<const int*>(rp + (there ? o + 4u : 0u));
@@ -629,8 +631,8 @@ __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsq_kernel(
   auto issue_x = [&](const Cursor& c, f32x4 (&x)[Q]) {
     const bool unit = c.u < u1;
     const bool there = unit && c.rb + qd < unit_r1(c.part);
-    const __amdgpu_buffer_rsrc_t xr =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dC + (unit ? (long)c.slice * strideDC : 0L)), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(dC + (unit ? (long)(c.slice >> ktile_shift) * strideDC : 0L)), 0, 0x7fffffff, 0x00020000);
     const unsigned xo = (there ? (unsigned)(c.rb + qd) * (unsigned)lddc * 4u : 0u) - lds0;
 #pragma unroll
     for (int j = 0; j < Q; ++j) x[j] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(xr, (int)(xo + lb[j]), 0, 0));
@@ -639,24 +641,34 @@ __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsq_kernel(
     const int idx = p + 4 * gl;
     c = *reinterpret_cast<const i32x4_u*>(reinterpret_cast<const char*>(col) + 4u * (unsigned)(idx < last4 ? idx : last4));
   };
-  auto finish_chunk = [&](int p, int en, i32x4& c) {  // → byte offsets of the B rows in LDS
-    const int idx = p + 4 * gl;
-    const int sh = idx - last4;  // see spmm_ldsq_kernel
-    if (__builtin_amdgcn_ballot_w64(en - idx > 0 && sh > 0) != 0) {
-      if (sh > 0) c = sh == 1 ? i32x4{c.y, c.z, c.w, 0} : sh == 2 ? i32x4{c.z, c.w, 0, 0} : i32x4{c.w, 0, 0, 0};
-    }
-    c *= ROWB;  // (positions past the row's end hold some column of the arrays: a row of the image, its sum is not stored)
-  };
-  auto store_chunk = [&](int p, int en, const f32x4& o) {
+  // → byte offsets of the B rows in the staged tile + which of the lane's four entries are computed in this pass (inside
+  // the row and, with tiles, a column of this tile); the others read row 0 of the image and their sum is not stored
+  auto finish_chunk = [&](int p, int en, int tile_lo, int tile_n, i32x4& c) -> unsigned {
     const int idx = p + 4 * gl;
     const int left = en - idx;
-    char* dst = reinterpret_cast<char*>(out) + 4u * (unsigned)idx;
-    if (left >= 4) {
+    const int sh = idx - last4;  // see spmm_ldsq_kernel
+    if (__builtin_amdgcn_ballot_w64(left > 0 && sh > 0) != 0) {
+      if (sh > 0) c = sh == 1 ? i32x4{c.y, c.z, c.w, 0} : sh == 2 ? i32x4{c.z, c.w, 0, 0} : i32x4{c.w, 0, 0, 0};
+    }
+    unsigned vm = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int rel = c[t] - tile_lo;
+      const bool ok = left > t && (unsigned)rel < (unsigned)tile_n;
+      c[t] = ok ? rel * ROWB : 0;
+      vm |= ok ? 1u << t : 0u;
+    }
+    return vm;
+  };
+  auto store_chunk = [&](int p, unsigned vm, const f32x4& o) {
+    char* dst = reinterpret_cast<char*>(out) + 4u * (unsigned)(p + 4 * gl);
+    if (vm == 15u) {
       *reinterpret_cast<f32x4_u*>(dst) = o;
-    } else if (left > 0) {
-      *reinterpret_cast<float*>(dst) = o.x;
-      if (left > 1) *reinterpret_cast<float*>(dst + 4) = o.y;
-      if (left > 2) *reinterpret_cast<float*>(dst + 8) = o.z;
+    } else if (vm != 0u) {
+      if (vm & 1u) *reinterpret_cast<float*>(dst) = o.x;
+      if (vm & 2u) *reinterpret_cast<float*>(dst + 4) = o.y;
+      if (vm & 4u) *reinterpret_cast<float*>(dst + 8) = o.z;
+      if (vm & 8u) *reinterpret_cast<float*>(dst + 12) = o.w;
     }
   };
 
@@ -679,12 +691,15 @@ __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsq_kernel(
 
   long staged = -1;
   for (unsigned u = u0; u < u1; ++u) {  // workgroup-uniform
-    const long item = u / (unsigned)units_per_item;
-    if (item != staged) {
+    const long slice = u / (unsigned)units_per_item;
+    const long item = slice >> ktile_shift;
+    const int tile_lo = (int)(slice & ((1 << ktile_shift) - 1)) * ktile_rows;
+    const int tile_n = K - tile_lo < ktile_rows ? (K - tile_lo > 0 ? K - tile_lo : 0) : ktile_rows;
+    if (slice != staged) {
       if (staged >= 0) __syncthreads();
-      const float* Bi = B + item * strideB;
+      const float* Bi = B + item * strideB + (long)tile_lo * ldb;
       constexpr int nq = W / 4;
-      const int total4 = K * nq;
+      const int total4 = tile_n * nq;
       for (int f0 = wave * 64; f0 < total4; f0 += kWaves * 64) {  // wave-uniform; LDS-DMA, see spmm_ldsq_kernel
         const int f = f0 + lane;
         if (f < total4)
@@ -694,7 +709,7 @@ __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsq_kernel(
       }
       __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
       __syncthreads();
-      staged = item;
+      staged = slice;
     }
     while (c0.u == u) {  // wave-uniform: this wave's row steps inside the unit
       // the bounds of the step two ahead and the dC row of the next step go out first
@@ -704,17 +719,19 @@ __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsq_kernel(
       issue_bounds(c2, s2, e2);
       issue_x(c1, x1);
       int p = s0;
-      int pend_p = 0, pend_e = 0;  // the chunk whose results wait in `o` (pend_e = 0: none)
+      int pend_p = 0;
+      unsigned pend_vm = 0;  // the chunk whose results wait in `o` (no bit set: none)
       f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
       for (;;) {  // wave-uniform trip count
         const bool more = __builtin_amdgcn_ballot_w64(p + 16 < e0) != 0;
-        store_chunk(pend_p, pend_e, o);
+        store_chunk(pend_p, pend_vm, o);
         issue_chunk(more ? p + 16 : s1, rn);
-        finish_chunk(p, e0, r0);
-        const int left = e0 - p;
+        const unsigned vm = finish_chunk(p, e0, tile_lo, tile_n, r0);
         static_for<4>([&](auto b_) {
           constexpr int b = 4 * decltype(b_)::value;
-          if (b == 0 || __builtin_amdgcn_ballot_w64(b < left) != 0) {  // wave-uniform
+          // wave-uniform: some quad's lane b / 4 holds an entry of this pass (a row's entries of one tile are a run when
+          // its columns ascend, so a pass skips most steps of the other tiles' entries)
+          if (__builtin_amdgcn_ballot_w64(gl == b / 4 && vm != 0u) != 0) {
             static_for<4>([&](auto e_) {
               constexpr int e = b + decltype(e_)::value;
               constexpr int src = e >> 2, comp = e & 3;
@@ -739,12 +756,12 @@ __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsq_kernel(
           }
         });
         pend_p = p;
-        pend_e = e0;
+        pend_vm = vm;
         r0 = rn;
         p += 16;
         if (!more) break;
       }
-      store_chunk(pend_p, pend_e, o);
+      store_chunk(pend_p, pend_vm, o);
       c0 = c1, c1 = c2;
       s0 = s1, e0 = e1;
       s1 = s2, e1 = e2;
@@ -872,7 +889,9 @@ int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val
 
 // whether the LDS-resident SDDMM takes a batched problem (shape only; the caller checked alignment): what
 // sddmm_group_kernel covers (N ≤ 64, N % 4 == 0) with an item's B fitting the LDS image
-bool sddmm_ldsb_fits(int32_t K, int32_t N) { return N >= 4 && N <= 64 && N % 4 == 0 && K >= 1 && (long)K * N * 4 <= 128L * 1024; }
+bool sddmm_ldsb_fits(int32_t K, int32_t N) {
+  return N >= 4 && N <= 64 && N % 4 == 0 && K >= 1 && ((long)K * N * 4 <= 128L * 1024 || (N == 64 && K <= 4096));
+}
 
 int launch_sddmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* dC, const float* B, float* out,
                       int32_t batch, int32_t M, int32_t K, int32_t N, int64_t lddc, int64_t strideDC, int64_t ldb,
@@ -887,22 +906,27 @@ int launch_sddmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* dC
     }
     return n;
   }();
-  if (form != 0 && N == 64 && K <= 512 && nnz_total >= 4 && nnz_total < (1LL << 29) && (int64_t)M * lddc < (1LL << 29)) {
-    int upi = 1;  // the quad form (sddmm_ldsq_kernel): units of whole 256-row steps, as launch_spmm_ldsb sizes them
-    while ((long)batch * upi < 3L * cus && ((long)M + upi * 2 - 1) / (upi * 2) >= 256) upi *= 2;
+  if (form != 0 && N == 64 && K <= 4096 && nnz_total >= 4 && nnz_total < (1LL << 29) && (int64_t)M * lddc < (1LL << 29)) {
+    // the quad form (sddmm_ldsq_kernel): units of whole 256-row steps, as launch_spmm_ldsb sizes them; B beyond the 512 rows
+    // the image holds goes in as 2 / 4 / 8 tiles of 512 rows, a pass each
+    const int ktiles = K <= 512 ? 1 : K <= 1024 ? 2 : K <= 2048 ? 4 : 8;
+    int upi = 1;
+    while ((long)batch * ktiles * upi < 3L * cus && ((long)M + upi * 2 - 1) / (upi * 2) >= 256) upi *= 2;
     const int rpu = (int)((((long)M + upi - 1) / upi + 255) / 256 * 256);
     upi = (int)(((long)M + rpu - 1) / rpu);
-    const long total = (long)batch * upi;
+    const long total = (long)batch * ktiles * upi;
     if (total > 0x7fffffffL) return MI_ERANGE;
     const long per = (total + cus - 1) / cus;
     const unsigned grid = (unsigned)((total + per - 1) / per);
-    const size_t lds = (size_t)K * 64 * 4;
+    const size_t lds = (size_t)(K < 512 ? K : 512) * 64 * 4;
     if (lds > 64 * 1024)
       MI_HIP_TRY(hipFuncSetAttribute((const void*)sddmm_ldsq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(sddmm_ldsq_kernel, dim3(grid), dim3(kWaves * 64), lds, s, rowptr, col, dC, B, out, M, K, (long)lddc,
-                       (long)strideDC, (long)ldb, (long)strideB, upi, rpu, (unsigned)total, (int)(nnz_total - 4));
+                       (long)strideDC, (long)ldb, (long)strideB, upi, rpu, (unsigned)total, (int)(nnz_total - 4),
+                       ktiles == 8 ? 3 : ktiles == 4 ? 2 : ktiles == 2 ? 1 : 0, 512);
     return check_launch();
   }
+  if ((long)K * N * 4 > 128L * 1024) return 1;  // only the quad form's tiles cover this B, and it cannot run: not taken
   int units_per_item = 1;
   while ((long)batch * units_per_item < 3L * cus && ((long)M + units_per_item * 2 - 1) / (units_per_item * 2) >= 64)
     units_per_item *= 2;

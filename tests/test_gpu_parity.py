@@ -2670,6 +2670,32 @@ def test_sddmm_batched_lds_resident_form_bit_exact(capi, cmm, dev, oracle_mod, N
                 assert torch.equal(o1.view(torch.int32), out[:cut].view(torch.int32)), tail
         finally:
             capi.mi_spmm_ldsb_set_form(-1)
+        # B beyond the 512 rows the image holds (attention over 1024 / 2048 tokens): 2 / 4 / 8 row tiles of B, a pass each —
+        # an entry needs one row of B, so this is exact for any order of columns inside a row (sorted and shuffled rows below)
+        for K2 in (1000, 2049, 3000):
+            b2, M2 = 66, 257
+            lens2 = g.integers(0, 120, size=b2 * M2)
+            cols2 = [g.integers(0, K2, size=int(n)).astype(np.int32) for n in lens2]
+            cols2 = [c if i % 4 == 0 else np.sort(c) for i, c in enumerate(cols2)]
+            col2 = np.concatenate(cols2)
+            off2 = np.zeros((b2, M2 + 1), np.int64)
+            off2[:, 1:] = np.cumsum(lens2).reshape(b2, M2)
+            off2[1:, 0] = off2[:-1, M2]
+            off2 = off2.astype(np.int32)
+            dC2 = g.random((b2, M2, N), dtype=np.float32) - 0.5
+            B2 = g.random((K2, N) if shared else (b2, K2, N), dtype=np.float32) - 0.5
+            out2 = torch.full((len(col2),), float("nan"), device=dev)
+            assert cmm.sddmm_batched(t(col2, dev), t(off2, dev), len(col2), b2, M2, K2, t(dC2, dev), t(B2, dev), out2) is True
+            got2 = out2.cpu().numpy()
+            for b in (0, b2 - 1):
+                a0, a1 = int(off2[b, 0]), int(off2[b, M2])
+                want = oracle_mod.sddmm((off2[b] - a0).astype(np.int32), col2[a0:a1], M2, dC2[b], B2 if shared else B2[b])
+                assert np.array_equal(got2[a0:a1].view(np.int32), want.view(np.int32)), (K2, b)
+            flat2 = np.concatenate([off2[:, :-1].reshape(-1), off2[-1:, -1]]).astype(np.int32)
+            diag2 = (col2.astype(np.int64) + np.repeat(np.arange(b2), np.diff(off2, axis=1).sum(1)) * K2).astype(np.int32)
+            stack2 = np.ascontiguousarray(np.broadcast_to(B2, (b2, K2, N)).reshape(b2 * K2, N))
+            ref2 = cmm.sddmm(t(diag2, dev), t(flat2, dev), len(col2), b2 * M2, b2 * K2, t(dC2.reshape(b2 * M2, N), dev), t(stack2, dev))
+            assert torch.equal(out2.view(torch.int32), ref2.view(torch.int32)), K2
     # not taken: too few rows / an operand beyond the LDS image
     small = torch.full((6,), -7.0, device=dev)
     assert cmm.sddmm_batched(torch.zeros(6, dtype=torch.int32, device=dev),

@@ -1,11 +1,17 @@
 """Developer probe: pruned BERT-base attention probs·V with the probabilities as a batched CSR TENSOR through
 matmuls.cusparseMM.apply — forward and forward + backward (both gradients), beside the dense cublasMM.apply."""
+import os
 import sys
 from pathlib import Path
 import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "matrix-multiplication_amd"))
 import matmuls  # noqa: E402
 dev = torch.device("cuda")
+if "MI_LDSB_FORM" in os.environ:  # developer A/B: pin the 16-lane (0) / quad (1) form of the LDS-resident kernels
+    import ctypes
+    _lib = ctypes.CDLL(str(Path(__file__).resolve().parent.parent / "matrix-multiplication_amd" / "libmi_spmm.so"))
+    _lib.mi_spmm_ldsb_set_form.argtypes = [ctypes.c_int]
+    _lib.mi_spmm_ldsb_set_form(int(os.environ["MI_LDSB_FORM"]))
 
 
 def timeit(fn, iters=10):
@@ -22,11 +28,11 @@ def timeit(fn, iters=10):
 
 
 g = torch.Generator(device=dev).manual_seed(0)
-items, S, D = 384, 512, 64
+S = int(os.environ.get('MI_SEQ', '512'))
+items, D = 384 * 512 * 512 // (S * S), 64  # (the same number of score entries at every length)
 v = torch.rand(items, S, D, device=dev, generator=g, requires_grad=True)
 dctx = torch.rand(items, S, D, device=dev, generator=g)
-print("# tools/bench_attn_csr_bwd.py on MI355X: 384 x (512x512 . 512x64), ms")
-import os
+print(f"# tools/bench_attn_csr_bwd.py on MI355X: {items} x ({S}x{S} . {S}x{D}), ms")
 for kept in tuple(float(x) for x in os.environ.get('MI_KEPT','0.25,0.1,0.05').split(',')):
     per_item = int(S * S * kept)
     # equal non-zero counts per item (torch's batched CSR layout)
