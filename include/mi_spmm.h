@@ -412,6 +412,11 @@ int mi_sddmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col, int64_t 
                              int64_t strideDC, const float* B, int64_t ldb, int64_t strideB,
                              float* out_val, mi_stream_t stream);
 
+/* dst[p] = src[perm[p]], p < n: the stored values of a CSR tensor carried into its cached transposed pattern by the
+ * permutation mi_csr_transpose_* produced for the values 0, 1, 2, … (matmuls' backward; replaces the reference-side
+ * `index_select`).  perm entries must lie in [0, length of src). */
+int mi_gather_f32(const float* src, const int32_t* perm, int64_t n, float* dst, mi_stream_t stream);
+
 /* Column sums dst[j] = Σ_r src[r, j] (src rows×n, leading dimension ld): the bias gradient of
  * the FC layers (autograd of `output += self.bias`, reference benchmarks/cublas_fc_layer.py:44-45).
  * Fixed summation order (per row chunk: 4 waves × 4 interleaved row chains, added in a fixed

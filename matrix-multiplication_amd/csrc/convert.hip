@@ -527,6 +527,25 @@ __global__ __launch_bounds__(256) void sddmm_group_kernel(const int* __restrict_
   }
 }
 
+
+// dst[p] = src[perm[p]] — the values of a CSR tensor carried into its cached transposed pattern (matmuls' backward where the
+// product's plan takes no permutation itself).  Four entries per lane: the perm words and the results move as 16-byte
+// vectors, the gathers are single dwords (a permutation has no locality to offer).
+template <bool VEC>
+__global__ __launch_bounds__(256) void gather_perm_kernel(const float* __restrict__ src, const int* __restrict__ perm, long n,
+                                                          float* __restrict__ dst) {
+  const long p = 4 * ((long)blockIdx.x * 256 + threadIdx.x);
+  if (p >= n) return;
+  if (VEC && p + 4 <= n) {
+    const int4 q = *reinterpret_cast<const int4*>(perm + p);
+    float4 v;
+    v.x = src[q.x], v.y = src[q.y], v.z = src[q.z], v.w = src[q.w];
+    *reinterpret_cast<float4*>(dst + p) = v;
+  } else {
+    for (long i = p; i < n && i < p + 4; ++i) dst[i] = src[perm[i]];
+  }
+}
+
 }  // namespace
 
 
@@ -708,6 +727,19 @@ int mi_colsum_f32(const float* src, int32_t rows, int32_t n, int64_t ld, float* 
     hipLaunchKernelGGL(colsum_partial_kernel<false>, dim3((unsigned)((n + 63) / 64), (unsigned)chunks), dim3(256), 0,
                        s, src, rows, n, (long)ld, cr, partial);
   hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, partial, chunks, n, dst);
+  return mi::check_launch();
+}
+
+int mi_gather_f32(const float* src, const int32_t* perm, int64_t n, float* dst, mi_stream_t stream) {
+  if (n < 0) return MI_EINVAL;
+  if (n == 0) return MI_OK;
+  if (!src || !perm || !dst) return MI_EINVAL;
+  const long quads = (n + 3) / 4;
+  const long blocks = (quads + 255) / 256;
+  if (blocks > 0x7fffffffL) return MI_ERANGE;
+  const bool vec = mi::aligned16(perm) && mi::aligned16(dst);
+  if (vec) hipLaunchKernelGGL(gather_perm_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, perm, (long)n, dst);
+  else hipLaunchKernelGGL(gather_perm_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, perm, (long)n, dst);
   return mi::check_launch();
 }
 

@@ -411,6 +411,22 @@ torch::Tensor column_sums(torch::Tensor src) {
   return out;
 }
 
+// values[perm] as a new tensor (perm int32, values f32, both contiguous and on one device): torch's index_select on the
+// same operands takes ≈3× as long at 10 M entries
+torch::Tensor gather_perm(torch::Tensor values, torch::Tensor perm) {
+  check_device_f32(values, "values");
+  check_device_i32(perm, "perm");
+  check_same_device(values, perm, "gather_perm");
+  TORCH_CHECK(values.dim() == 1 && perm.dim() == 1 && values.is_contiguous() && perm.is_contiguous(),
+              "gather_perm: expected contiguous 1-d tensors");
+  c10::hip::HIPGuard guard(values.device().index());
+  torch::Tensor out = torch::empty({perm.numel()}, values.options());
+  check_status(mi_gather_f32(values.data_ptr<float>(), perm.data_ptr<int32_t>(), perm.numel(), out.data_ptr<float>(),
+                             stream_of(values)),
+               "gather_perm");
+  return out;
+}
+
 // ---- additions to the reference surface (used by matmuls.py) -----------------
 // The reference batches by Python recursion + torch.stack with one
 // to_sparse_csr() per slice (matmuls.py:289-297) and has no working backward
@@ -1206,6 +1222,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         "dA = dC.B and dB = dC^T.A in one launch that reads dC once; (dC, B, A, dA, dB) -> launched?");
   m.def("sddmm_batched", &sddmm_batched,
         "SDDMM on a batched CSR pattern into out[nnz]; False (nothing launched) if the LDS-resident form does not take it");
+  m.def("gather_perm", &gather_perm, "values[perm] (int32 perm) as a new tensor");
   m.def("naive_spmm_batched_perm", &naive_spmm_batched_perm,
         "naive_spmm_batched with entry p's value = A_values[perm[p]]; False (nothing launched) if the plan takes no permutation");
   m.def("naive_spmm_dense", &naive_spmm_dense,

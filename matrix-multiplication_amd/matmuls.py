@@ -701,7 +701,9 @@ def _csr_cached(m1: torch.Tensor):
             m1._mi_csr_cache = hit
         except (AttributeError, RuntimeError):
             pass  # a tensor type that takes no attributes: just no caching
-    return props, (values.index_select(0, hit[1]), hit[2], hit[3])
+    t_val = custom_mm.gather_perm(values, hit[1]) if hasattr(custom_mm, 'gather_perm') and values.is_contiguous() \
+        else values.index_select(0, hit[1])
+    return props, (t_val, hit[2], hit[3])
 
 
 def _batched_csr_backward(ctx, m1, m2, grad_output):
@@ -750,7 +752,8 @@ def _batched_csr_backward(ctx, m1, m2, grad_output):
                     custom_mm.naive_spmm_batched_perm(flat_val, t_perm, t_col, off_c, total, hi - lo, cols, rows, g_c, gb[lo:hi]):
                 continue
             if t_val is None:
-                t_val = flat_val.index_select(0, t_perm)
+                t_val = custom_mm.gather_perm(flat_val, t_perm) if hasattr(custom_mm, 'gather_perm') \
+                    else flat_val.index_select(0, t_perm)
             custom_mm.naive_spmm_batched(t_val, t_col, off_c, total, hi - lo, cols, rows, g_c, gb[lo:hi])
         grad_m2 = gb.sum(0) if shared else gb.reshape(m2.shape)
         if vec:

@@ -2614,6 +2614,32 @@ def test_lds_resident_b_keeps_negative_zero_and_reads_values_through_a_permutati
     assert took is False and bool((small == -7.0).all())
 
 
+def test_gather_perm_is_index_select(capi, cmm, dev):
+    """custom_mm.gather_perm / mi_gather_f32: values[perm] — what carries a CSR tensor's values into its cached transposed
+    pattern in matmuls' backward (the reference has no such step: its backward densifies, matmuls.py:245-256).  Any
+    length (the last lanes take single entries), any alignment of the operands, −0 / inf / nan moved as bits."""
+    g = torch.Generator(device=dev).manual_seed(5)
+    for n in (1, 3, 4, 5, 1023, 1024, 100_003):
+        src = torch.randn(n + 7, device=dev, generator=g)
+        src[0], src[-1] = float("inf"), -0.0
+        if n > 4:
+            src[2] = float("nan")
+        perm = torch.randint(0, n + 7, (n,), device=dev, generator=g, dtype=torch.int32)
+        got = cmm.gather_perm(src, perm)
+        assert torch.equal(got.view(torch.int32), src.index_select(0, perm.long()).view(torch.int32))
+        # through the C-ABI with operands that are not 16-byte aligned (the scalar form of the kernel)
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        capi.mi_gather_f32.argtypes = [vp, vp, i64, vp, vp]
+        buf_p = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        buf_p[1:] = perm
+        out = torch.full((n + 1,), 7.0, device=dev)
+        st = capi.mi_gather_f32(src.data_ptr(), buf_p.data_ptr() + 4, n, out.data_ptr() + 4,
+                                torch.cuda.current_stream().cuda_stream)
+        assert st == 0 and float(out[0]) == 7.0
+        assert torch.equal(out[1:].view(torch.int32), got.view(torch.int32))
+    assert capi.mi_gather_f32(None, None, 0, None, None) == 0 and capi.mi_gather_f32(None, None, 5, None, None) < 0
+
+
 @pytest.mark.parametrize("N,shared", [(64, False), (64, True), (32, False), (48, False), (16, False), (8, True), (4, False)])
 def test_sddmm_batched_lds_resident_form_bit_exact(capi, cmm, dev, oracle_mod, N, shared):
     """Round 4: custom_mm.sddmm_batched — the gradient of a batched CSR tensor's stored values with the item's dense
