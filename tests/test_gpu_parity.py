@@ -2545,7 +2545,14 @@ def test_spmm_lds_resident_b_quad_form_bit_exact(capi, cmm, dev, oracle_mod, N):
                 C = torch.full((batch, M, N), float("nan"), device=dev)
                 took = cmm.naive_spmm_batched_perm(t(stored, dev), t(shuffle.astype(np.int32), dev), d_col, d_off, len(col),
                                                    batch, M, K, d_B, C)
-                assert took is True and np.array_equal(C.cpu().numpy().view(np.int32), want.view(np.int32))
+                # (taken where B goes in as ONE tile; a column-tiled B would gather every value once per tile: declined,
+                # matmuls then gathers once — custom_mm.gather_perm — and runs the plain product)
+                assert took is (N <= 64 and K <= 512)
+                if took:
+                    assert np.array_equal(C.cpu().numpy().view(np.int32), want.view(np.int32))
+                else:
+                    gathered = cmm.gather_perm(t(stored, dev), t(shuffle.astype(np.int32), dev))
+                    assert torch.equal(gathered, d_val)
         # one item, a row beyond the long-row threshold (skipped by the kernel, summed by the follow-up), fused bias
         capi.mi_spmm_ldsb_set_form(1)
         M, K = 20000, 256
