@@ -9,7 +9,9 @@ Produces, next to this file:
 hipcc cross-compiles gfx950 without a GPU, so this runs in the CPU-only build
 container; the built files travel to the GPU box with the tree.
 
-    python matrix-multiplication_amd/build.py [--force] [--verbose]
+    python matrix-multiplication_amd/build.py [--force] [--verbose]        (MI_BUILD_FORCE=1 = --force, also through
+                                                                            __graft_entry__.build(): objects are otherwise
+                                                                            reused when their sources' hashes match)
 """
 from __future__ import annotations
 
@@ -118,6 +120,8 @@ def build_extension(force=False, verbose=False) -> Path:
 
 
 def build_all(force=False, verbose=False):
+    # MI_BUILD_FORCE=1: recompile everything whatever the stamps say (a driver that wants the build exercised, not reused)
+    force = force or os.environ.get("MI_BUILD_FORCE", "") == "1"
     lib = build_library(force, verbose)
     ext = build_extension(force, verbose)
     return lib, ext
