@@ -411,8 +411,8 @@ torch::Tensor column_sums(torch::Tensor src) {
   return out;
 }
 
-// values[perm] as a new tensor (perm int32, values f32, both contiguous and on one device): torch's index_select on the
-// same operands takes ≈3× as long at 10 M entries
+// values[perm] as a new tensor (perm int32, values f32, both contiguous and on one device); what torch's index_select
+// does, without its index conversion (bound by one line request per value either way: tools/probes/gather_bench.py)
 torch::Tensor gather_perm(torch::Tensor values, torch::Tensor perm) {
   check_device_f32(values, "values");
   check_device_i32(perm, "perm");
