@@ -49,9 +49,14 @@ print("# tools/bench_ldsb_forms.py on MI355X (ms; best of 3 blocks of 20)")
 # ---- fuzz first: a wrong kernel should not get to print timings
 cpu = torch.Generator().manual_seed(1)
 cases = 0
-for trial in range(60 if not quick else 20):
+n_fuzz = 60 if not quick else 20
+if "--fuzz" in sys.argv:
+    n_fuzz = int(sys.argv[sys.argv.index("--fuzz") + 1])
+for trial in range(n_fuzz):
     items = int(torch.randint(1, 40, (1,), generator=cpu))
     M = int(torch.randint(1, 700, (1,), generator=cpu))
+    if trial % 5 == 1:
+        items, M = int(torch.randint(30, 90, (1,), generator=cpu)), int(torch.randint(250, 600, (1,), generator=cpu))
     K = int(torch.randint(1, 513, (1,), generator=cpu))
     N = (64, 128, 32, 16, 64, 256)[trial % 6]
     if trial % 7 == 0:
@@ -83,8 +88,21 @@ for trial in range(60 if not quick else 20):
         cases += 1
     if ok0:
         assert torch.equal(c1.view(torch.int32), c3.view(torch.int32)), ("16-lane form differs", items, M, K, N, kept)
+    if N == 64 and items * M >= 16384 and nnz >= 4 * items * M:
+        # the batched SDDMM (quad form, row tiles of B beyond 512 rows) against the block-diagonal kernel
+        dc = torch.rand(items, M, N, device=dev, generator=g) - 0.5
+        o1 = torch.full((nnz,), 7.0, device=dev)
+        if custom_mm.sddmm_batched(col, off, nnz, items, M, K, dc, v, o1):
+            flat = torch.cat([off[:, :-1].reshape(-1), off[-1:, -1]])
+            counts = (off[:, -1] - off[:, 0]).long()
+            diag = (col.long() + torch.repeat_interleave(torch.arange(items, device=dev), counts) * K).to(torch.int32)
+            ref = custom_mm.sddmm(diag, flat, nnz, items * M, items * K, dc.reshape(items * M, N), v.reshape(items * K, N))
+            assert torch.equal(o1.view(torch.int32), ref.view(torch.int32)), ("sddmm quad form differs", items, M, K, kept)
+            sddmm_cases = globals().get("sddmm_cases", 0) + 1
     del probs, val, col, off
-print(f"# fuzz: {cases} ragged cases, quad form == group kernel bit for bit")
+print(f"# fuzz: {cases} ragged cases, quad form == group kernel bit for bit ({globals().get('sddmm_cases', 0)} of them also through the batched SDDMM)")
+if "--fuzz" in sys.argv:
+    sys.exit(0)
 
 print("# items x M x K x N   kept     nnz        group(L2)  16-lane   quad     by rule")
 shapes = [(384, 512, 512, 64, (1.0, 0.5, 0.25, 0.1, 0.05, 0.02, 0.01)),
