@@ -411,16 +411,6 @@ int mi_sddmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col, int64_t 
                              int32_t M, int32_t K, int32_t N, const float* dC, int64_t lddc,
                              int64_t strideDC, const float* B, int64_t ldb, int64_t strideB,
                              float* out_val, mi_stream_t stream);
-/* The same, and on the side val_t[inv_perm[p]] = val[p] for every entry p: the matrix's values carried into the order of
- * its transposed pattern (inv_perm = the inverse of the permutation a transpose of 0, 1, 2, … gives), so that a backward
- * that wants both gradients runs the transposed product on a plain value array — no gather through the permutation.
- * val_t must hold nnz_total + 1 floats (the last one is a dump slot).  All three of val / inv_perm / val_t or none.
- * Returns 1 — nothing launched, val_t untouched — where the scattering form (N = 64, K ≤ 4096) does not take the problem. */
-int mi_sddmm_csr_batched_scatter_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz_total, int32_t batch,
-                                     int32_t M, int32_t K, int32_t N, const float* dC, int64_t lddc,
-                                     int64_t strideDC, const float* B, int64_t ldb, int64_t strideB,
-                                     float* out_val, const float* val, const int32_t* inv_perm, float* val_t,
-                                     mi_stream_t stream);
 
 /* dst[p] = src[perm[p]], p < n: the stored values of a CSR tensor carried into its cached transposed pattern by the
  * permutation mi_csr_transpose_* produced for the values 0, 1, 2, … (matmuls' backward; replaces the reference-side

@@ -802,28 +802,9 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> csr_transpose_batched(to
 // The same on a batched CSR pattern (offsets [batch, A_rows + 1], global), dC [batch, A_rows, N], B [batch, A_cols, N] or
 // [A_cols, N] (shared), into the caller's out [nnzA]; False (nothing launched) when the LDS-resident form does not take
 // the problem: run sddmm on the block-diagonal matrix of the batch instead (same bits).
-// values / inv_perm / values_t (all three or none): on the side values_t[inv_perm[p]] = values[p] — the values in the order
-// of the cached transposed pattern for the transposed product that follows in the same backward (values_t: nnz + 1 floats).
-// Returns 0 (nothing launched), 1 (launched) or 2 (launched, values_t written).
-int64_t sddmm_batched(torch::Tensor A_columns, torch::Tensor A_offsets, int64_t nnzA, int64_t batch, int64_t A_rows,
-                      int64_t A_cols, torch::Tensor dC, torch::Tensor B, torch::Tensor out,
-                      c10::optional<torch::Tensor> values, c10::optional<torch::Tensor> inv_perm,
-                      c10::optional<torch::Tensor> values_t) {
+bool sddmm_batched(torch::Tensor A_columns, torch::Tensor A_offsets, int64_t nnzA, int64_t batch, int64_t A_rows,
+                   int64_t A_cols, torch::Tensor dC, torch::Tensor B, torch::Tensor out) {
   const char* what = "sddmm_batched";
-  const bool scatter = values.has_value() || inv_perm.has_value() || values_t.has_value();
-  if (scatter) {
-    TORCH_CHECK(values.has_value() && inv_perm.has_value() && values_t.has_value(), what,
-                ": values, inv_perm and values_t go together");
-    check_device_f32(*values, "values");
-    check_device_i32(*inv_perm, "inv_perm");
-    check_device_f32(*values_t, "values_t");
-    check_same_device(*values, out, what);
-    check_same_device(*inv_perm, out, what);
-    check_same_device(*values_t, out, what);
-    TORCH_CHECK(values->is_contiguous() && inv_perm->is_contiguous() && values_t->is_contiguous() &&
-                    values->numel() >= nnzA && inv_perm->numel() >= nnzA && values_t->numel() >= nnzA + 1,
-                what, ": values / inv_perm hold nnz entries, values_t nnz + 1");
-  }
   check_device_i32(A_columns, "A_columns");
   check_device_i32(A_offsets, "A_offsets");
   check_device_f32(dC, "dC");
@@ -851,23 +832,13 @@ int64_t sddmm_batched(torch::Tensor A_columns, torch::Tensor A_offsets, int64_t 
     TORCH_CHECK(Bc.dim() == 2 && Bc.size(0) == A_cols && Bc.size(1) == N, what, ": B must be [A_cols, N]");
   }
   c10::hip::HIPGuard guard(out.device().index());
-  if (scatter) {
-    const int st = mi_sddmm_csr_batched_scatter_f32(
-        A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(), nnzA, (int32_t)batch, (int32_t)A_rows, (int32_t)A_cols,
-        (int32_t)N, dCc.data_ptr<float>(), std::max<int64_t>(N, 1), A_rows * N, Bc.data_ptr<float>(), std::max<int64_t>(N, 1),
-        strideB, out.data_ptr<float>(), values->data_ptr<float>(), inv_perm->data_ptr<int32_t>(), values_t->data_ptr<float>(),
-        stream_of(out));
-    if (st == MI_OK) return 2;
-    if (st != 1) check_status(st, what);
-    // the scattering form does not take the problem: the plain one may
-  }
   const int st = mi_sddmm_csr_batched_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(), nnzA, (int32_t)batch,
                                           (int32_t)A_rows, (int32_t)A_cols, (int32_t)N, dCc.data_ptr<float>(),
                                           std::max<int64_t>(N, 1), A_rows * N, Bc.data_ptr<float>(),
                                           std::max<int64_t>(N, 1), strideB, out.data_ptr<float>(), stream_of(out));
-  if (st == 1) return 0;
+  if (st == 1) return false;
   check_status(st, what);
-  return 1;
+  return true;
 }
 
 // out[p] = <dC[row(p), :], B[col[p], :]> on A's pattern: d(A·B)/d(A values).
@@ -1250,12 +1221,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("cublas_bmm_pair", &cublas_bmm_pair,
         "dA = dC.B and dB = dC^T.A in one launch that reads dC once; (dC, B, A, dA, dB) -> launched?");
   m.def("sddmm_batched", &sddmm_batched,
-        "SDDMM on a batched CSR pattern into out[nnz]; 0 (nothing launched) if the LDS-resident form does not take it, 1 launched, "
-        "2 launched and values_t[inv_perm[p]] = values[p] written on the side",
-        pybind11::arg("A_columns"), pybind11::arg("A_offsets"), pybind11::arg("nnzA"), pybind11::arg("batch"),
-        pybind11::arg("A_rows"), pybind11::arg("A_cols"), pybind11::arg("dC"), pybind11::arg("B"), pybind11::arg("out"),
-        pybind11::arg("values") = pybind11::none(), pybind11::arg("inv_perm") = pybind11::none(),
-        pybind11::arg("values_t") = pybind11::none());
+        "SDDMM on a batched CSR pattern into out[nnz]; False (nothing launched) if the LDS-resident form does not take it");
   m.def("gather_perm", &gather_perm, "values[perm] (int32 perm) as a new tensor");
   m.def("naive_spmm_batched_perm", &naive_spmm_batched_perm,
         "naive_spmm_batched with entry p's value = A_values[perm[p]]; False (nothing launched) if the plan takes no permutation");

@@ -585,17 +585,10 @@ __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsb_kernel(
 // Results of a chunk are held until the next chunk's loads are out: a store between a load and its wait would make the
 // wait cover the store.
 // ---------------------------------------------------------------------------------------------
-template <bool SCATTER>
 __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsq_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dC,
     const float* __restrict__ B, float* __restrict__ out, int M, int K, long lddc, long strideDC, long ldb,
-    long strideB, int units_per_item, int rows_per_unit, unsigned total_units, int last4, int ktile_shift, int ktile_rows,
-    const float* __restrict__ sval, const int* __restrict__ sinv, float* __restrict__ sdst) {
-  // SCATTER (the caller's backward also wants the transposed product): sdst[sinv[p]] = sval[p] for every entry p, i.e. the
-  // matrix's values carried into the order of its cached transposed pattern on the side — this kernel walks the entries
-  // anyway and leaves the memory pipes idle, and a store has no consumer to wait for it, where the transposed product's
-  // own gather through the permutation (spmm_ldsq_kernel<…, true>) costs it 0.05 ms.  sdst holds one element more than
-  // the arrays: the dump slot of the positions that are not this pass's (every store is issued, see below).
+    long strideB, int units_per_item, int rows_per_unit, unsigned total_units, int last4, int ktile_shift, int ktile_rows) {
   // 1 << ktile_shift tiles of ktile_rows rows of B per item (K beyond the 512 rows the image holds: an entry needs ONE row of
   // B, so a pass per tile computes the entries whose column lies in it — exact whatever the order of columns inside a row)
   extern __shared__ __attribute__((aligned(16))) f32x4 Bs[];  // [min(K, ktile_rows)][16]
@@ -644,29 +637,18 @@ __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsq_kernel(
 #pragma unroll
     for (int j = 0; j < Q; ++j) x[j] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(xr, (int)(xo + lb[j]), 0, 0));
   };
-  auto issue_chunk = [&](int p, i32x4& c, f32x4& sv, i32x4& si) {
+  auto issue_chunk = [&](int p, i32x4& c) {
     const int idx = p + 4 * gl;
-    const unsigned a = 4u * (unsigned)(idx < last4 ? idx : last4);
-    c = *reinterpret_cast<const i32x4_u*>(reinterpret_cast<const char*>(col) + a);
-    if (SCATTER) {
-      sv = *reinterpret_cast<const f32x4_u*>(reinterpret_cast<const char*>(sval) + a);
-      si = *reinterpret_cast<const i32x4_u*>(reinterpret_cast<const char*>(sinv) + a);
-    }
+    c = *reinterpret_cast<const i32x4_u*>(reinterpret_cast<const char*>(col) + 4u * (unsigned)(idx < last4 ? idx : last4));
   };
   // → byte offsets of the B rows in the staged tile + which of the lane's four entries are computed in this pass (inside
   // the row and, with tiles, a column of this tile); the others read row 0 of the image and their sum is not stored
-  auto finish_chunk = [&](int p, int en, int tile_lo, int tile_n, i32x4& c, f32x4& sv, i32x4& si) -> unsigned {
+  auto finish_chunk = [&](int p, int en, int tile_lo, int tile_n, i32x4& c) -> unsigned {
     const int idx = p + 4 * gl;
     const int left = en - idx;
     const int sh = idx - last4;  // see spmm_ldsq_kernel
     if (__builtin_amdgcn_ballot_w64(left > 0 && sh > 0) != 0) {
-      if (sh > 0) {
-        c = sh == 1 ? i32x4{c.y, c.z, c.w, 0} : sh == 2 ? i32x4{c.z, c.w, 0, 0} : i32x4{c.w, 0, 0, 0};
-        if (SCATTER) {
-          sv = sh == 1 ? f32x4{sv.y, sv.z, sv.w, 0.f} : sh == 2 ? f32x4{sv.z, sv.w, 0.f, 0.f} : f32x4{sv.w, 0.f, 0.f, 0.f};
-          si = sh == 1 ? i32x4{si.y, si.z, si.w, 0} : sh == 2 ? i32x4{si.z, si.w, 0, 0} : i32x4{si.w, 0, 0, 0};
-        }
-      }
+      if (sh > 0) c = sh == 1 ? i32x4{c.y, c.z, c.w, 0} : sh == 2 ? i32x4{c.z, c.w, 0, 0} : i32x4{c.w, 0, 0, 0};
     }
     unsigned vm = 0;
 #pragma unroll
@@ -705,9 +687,7 @@ __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsq_kernel(
   issue_bounds(c1, s1, e1);
   issue_x(c0, x0);
   i32x4 r0, rn;
-  f32x4 v0 = f32x4{0.f, 0.f, 0.f, 0.f}, vn = v0;  // SCATTER: the chunk's values and where they go
-  i32x4 i0 = i32x4{0, 0, 0, 0}, in_ = i0;
-  issue_chunk(s0, r0, v0, i0);
+  issue_chunk(s0, r0);
 
   long staged = -1;
   for (unsigned u = u0; u < u1; ++u) {  // workgroup-uniform
@@ -745,17 +725,8 @@ __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsq_kernel(
       for (;;) {  // wave-uniform trip count
         const bool more = __builtin_amdgcn_ballot_w64(p + 16 < e0) != 0;
         store_chunk(pend_p, pend_vm, o);
-        issue_chunk(more ? p + 16 : s1, rn, vn, in_);
-        const unsigned vm = finish_chunk(p, e0, tile_lo, tile_n, r0, v0, i0);
-        if (SCATTER) {
-          // four stores per lane whatever the mask (a position that is not this pass's goes to the dump slot): issued on
-          // every path, they leave the wait for the next chunk's loads counted
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const unsigned at = (vm >> t) & 1u ? (unsigned)i0[t] : (unsigned)last4 + 4u;
-            *reinterpret_cast<float*>(reinterpret_cast<char*>(sdst) + 4u * at) = v0[t];
-          }
-        }
+        issue_chunk(more ? p + 16 : s1, rn);
+        const unsigned vm = finish_chunk(p, e0, tile_lo, tile_n, r0);
         static_for<4>([&](auto b_) {
           constexpr int b = 4 * decltype(b_)::value;
           // wave-uniform: some quad's lane b / 4 holds an entry of this pass (a row's entries of one tile are a run when
@@ -787,7 +758,6 @@ __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsq_kernel(
         pend_p = p;
         pend_vm = vm;
         r0 = rn;
-        if (SCATTER) v0 = vn, i0 = in_;
         p += 16;
         if (!more) break;
       }
@@ -925,8 +895,7 @@ bool sddmm_ldsb_fits(int32_t K, int32_t N) {
 
 int launch_sddmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* dC, const float* B, float* out,
                       int32_t batch, int32_t M, int32_t K, int32_t N, int64_t lddc, int64_t strideDC, int64_t ldb,
-                      int64_t strideB, hipStream_t s, int64_t nnz_total, const float* sc_val, const int32_t* sc_inv,
-                      float* sc_dst) {
+                      int64_t strideB, hipStream_t s, int64_t nnz_total) {
   if (!sddmm_ldsb_fits(K, N)) return MI_EINVAL;
   const int form = g_ldsb_form.load(std::memory_order_relaxed);
   static const int cus = [] {
@@ -950,15 +919,13 @@ int launch_sddmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* dC
     const long per = (total + cus - 1) / cus;
     const unsigned grid = (unsigned)((total + per - 1) / per);
     const size_t lds = (size_t)(K < 512 ? K : 512) * 64 * 4;
-    auto kern = sc_dst ? sddmm_ldsq_kernel<true> : sddmm_ldsq_kernel<false>;
     if (lds > 64 * 1024)
-      MI_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaves * 64), lds, s, rowptr, col, dC, B, out, M, K, (long)lddc,
+      MI_HIP_TRY(hipFuncSetAttribute((const void*)sddmm_ldsq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(sddmm_ldsq_kernel, dim3(grid), dim3(kWaves * 64), lds, s, rowptr, col, dC, B, out, M, K, (long)lddc,
                        (long)strideDC, (long)ldb, (long)strideB, upi, rpu, (unsigned)total, (int)(nnz_total - 4),
-                       ktiles == 8 ? 3 : ktiles == 4 ? 2 : ktiles == 2 ? 1 : 0, 512, sc_val, sc_inv, sc_dst);
+                       ktiles == 8 ? 3 : ktiles == 4 ? 2 : ktiles == 2 ? 1 : 0, 512);
     return check_launch();
   }
-  if (sc_dst) return 1;  // (only the quad form scatters)
   if ((long)K * N * 4 > 128L * 1024) return 1;  // only the quad form's tiles cover this B, and it cannot run: not taken
   int units_per_item = 1;
   while ((long)batch * units_per_item < 3L * cus && ((long)M + units_per_item * 2 - 1) / (units_per_item * 2) >= 64)
@@ -1015,28 +982,19 @@ int mi_spmm_ldsb_set_form(int form) {
   return MI_OK;
 }
 
-int mi_sddmm_csr_batched_scatter_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz_total, int32_t batch,
-                                     int32_t M, int32_t K, int32_t N, const float* dC, int64_t lddc, int64_t strideDC,
-                                     const float* B, int64_t ldb, int64_t strideB, float* out_val, const float* val,
-                                     const int32_t* inv_perm, float* val_t, mi_stream_t stream) {
+int mi_sddmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz_total, int32_t batch, int32_t M,
+                             int32_t K, int32_t N, const float* dC, int64_t lddc, int64_t strideDC, const float* B,
+                             int64_t ldb, int64_t strideB, float* out_val, mi_stream_t stream) {
   if (batch < 0 || M < 0 || K < 0 || N < 0 || nnz_total < 0 || strideDC < 0 || strideB < 0) return MI_EINVAL;
   if (nnz_total > 0x7fffffffLL) return MI_ERANGE;
-  if ((val_t != nullptr) != (val != nullptr) || (val_t != nullptr) != (inv_perm != nullptr)) return MI_EINVAL;
-  if (batch == 0 || M == 0 || nnz_total == 0) return val_t ? 1 : MI_OK;
+  if (batch == 0 || M == 0 || nnz_total == 0) return MI_OK;
   if (!rowptr || !col || !out_val || !dC || !B || lddc < N || ldb < N) return MI_EINVAL;
   const bool vec = N % 4 == 0 && lddc % 4 == 0 && ldb % 4 == 0 && strideDC % 4 == 0 && strideB % 4 == 0 &&
                    mi::aligned16(dC) && mi::aligned16(B);
   // taken where the forward's LDS-resident-B plan is (enough rows to fill the chip, rows of a few non-zeros at least)
   if (!vec || !mi::sddmm_ldsb_fits(K, N) || (long)batch * M < 16384 || nnz_total < 4L * batch * M) return 1;
   return mi::launch_sddmm_ldsb(rowptr, col, dC, B, out_val, batch, M, K, N, lddc, strideDC, ldb, strideB,
-                               static_cast<hipStream_t>(stream), nnz_total, val, inv_perm, val_t);
-}
-
-int mi_sddmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz_total, int32_t batch, int32_t M,
-                             int32_t K, int32_t N, const float* dC, int64_t lddc, int64_t strideDC, const float* B,
-                             int64_t ldb, int64_t strideB, float* out_val, mi_stream_t stream) {
-  return mi_sddmm_csr_batched_scatter_f32(rowptr, col, nnz_total, batch, M, K, N, dC, lddc, strideDC, B, ldb, strideB, out_val,
-                                          nullptr, nullptr, nullptr, stream);
+                               static_cast<hipStream_t>(stream), nnz_total);
 }
 
 }  // extern "C"

@@ -128,7 +128,6 @@ To add another, just change the mm/bmm operation
 
 
 _fused_pair = os.environ.get('MI_GEMM_PAIR', '1') != '0'  # 0: the two plain products (developer A/B)
-_sddmm_scatter = os.environ.get('MI_SDDMM_SCATTER', '1') != '0'  # 0: the transposed product gathers its values itself (A/B)
 
 
 def _dense_backward(ctx, grad_output, transa, transb):
@@ -376,11 +375,7 @@ def _batched_csr_pattern(a: torch.Tensor, dev, transposed: bool = False):
                 parts.append((tp, tc, to + p0))
             t_perm, t_col, t_off = (torch.cat([x[i] for x in parts]) for i in range(3))
         t_perm = t_perm.view(torch.int32)
-        # the inverse permutation (entry p of the matrix → its place in the transposed pattern): what lets the SDDMM of a
-        # backward carry the values there on the side (custom_mm.sddmm_batched(..., values, inv_perm, values_t))
-        t_inv = torch.empty_like(t_perm)
-        t_inv[t_perm.long()] = torch.arange(total, device=dev, dtype=torch.int32)
-        hit[3] = (flat_off, columns + shift, t_perm, t_col, t_off, t_inv)
+        hit[3] = (flat_off, columns + shift, t_perm, t_col, t_off)
     return hit[1], hit[2], hit[3]
 
 
@@ -728,29 +723,17 @@ def _batched_csr_backward(ctx, m1, m2, grad_output):
     nb = torch.Tensor.crow_indices(m1).reshape(-1, rows + 1).shape[0]
     total = val.numel()
     dev = grad_output.device
-    offsets, columns, (flat_off, diag_columns, t_perm, t_col, t_off, t_inv) = _batched_csr_pattern(m1, dev, transposed=True)
+    offsets, columns, (flat_off, diag_columns, t_perm, t_col, t_off) = _batched_csr_pattern(m1, dev, transposed=True)
     g = grad_output.reshape(nb, rows, n).contiguous()
     shared = m2.dim() == 2
     grad_m1 = grad_m2 = None
-    t_val = None  # the values in the transposed pattern's order, once some step has produced them
     if ctx.needs_input_grad[0]:
-        # the batched form keeps an item's m2 in LDS where that fits (pruned attention); else (0: nothing ran) ONE
-        # SDDMM on the block-diagonal matrix of the batch — the same sums, bit for bit.  When the other gradient is
-        # wanted too, the batched form carries the values into the transposed pattern's order on the side (returns 2):
-        # the transposed product below then needs no gather through the permutation
+        # the batched form keeps an item's m2 in LDS where that fits (pruned attention); else (False: nothing ran) ONE
+        # SDDMM on the block-diagonal matrix of the batch — the same sums, bit for bit
         gvals = torch.empty(total, device=dev, dtype=torch.float32)
-        took = 0
-        if hasattr(custom_mm, 'sddmm_batched'):
-            b_arg = m2.to(dev) if shared else m2.reshape(nb, cols, n).to(dev)
-            if ctx.needs_input_grad[1] and nb <= 65535 and _sddmm_scatter:
-                scat = torch.empty(total + 1, device=dev, dtype=torch.float32)
-                took = custom_mm.sddmm_batched(columns, offsets, total, nb, rows, cols, g, b_arg, gvals,
-                                               val.reshape(-1).to(dev).contiguous(), t_inv, scat)
-                if took == 2:
-                    t_val = scat[:total]
-            else:
-                took = custom_mm.sddmm_batched(columns, offsets, total, nb, rows, cols, g, b_arg, gvals)
-        if not took:
+        if not (hasattr(custom_mm, 'sddmm_batched') and
+                custom_mm.sddmm_batched(columns, offsets, total, nb, rows, cols, g,
+                                        m2.to(dev) if shared else m2.reshape(nb, cols, n).to(dev), gvals)):
             b_stack = (m2.unsqueeze(0).expand(nb, cols, n) if shared else m2.reshape(nb, cols, n)).reshape(nb * cols, n)
             gvals = custom_mm.sddmm(diag_columns, flat_off, total, nb * rows, nb * cols, g.reshape(nb * rows, n),
                                     b_stack.contiguous())
@@ -760,11 +743,12 @@ def _batched_csr_backward(ctx, m1, m2, grad_output):
         # m1[i]ᵀ·dC[i] on the cached transposed pattern; the values travel through the cached permutation INSIDE the
         # kernel where its plan allows (the LDS-resident-B kernel: pruned attention), else as one gathered copy
         flat_val = val.reshape(-1).to(dev).contiguous()
+        t_val = None
         gb = torch.empty((nb, cols, n), device=dev, dtype=torch.float32)
         for lo in range(0, nb, 65535):  # (items per launch, as in the forward)
             hi = min(nb, lo + 65535)
             off_c, g_c = t_off[lo:hi].contiguous(), g[lo:hi]
-            if t_val is None and hasattr(custom_mm, 'naive_spmm_batched_perm') and \
+            if hasattr(custom_mm, 'naive_spmm_batched_perm') and \
                     custom_mm.naive_spmm_batched_perm(flat_val, t_perm, t_col, off_c, total, hi - lo, cols, rows, g_c, gb[lo:hi]):
                 continue
             if t_val is None:

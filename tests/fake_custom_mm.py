@@ -129,10 +129,10 @@ def sddmm(cols, offs, nnz, rows, kcols, dC, B):
 batched_sddmm = True  # tests flip this: the LDS-resident batched form may or may not take a problem
 
 
-def sddmm_batched(cols, offs, nnz, batch, rows, kcols, dC, B, out, values=None, inv_perm=None, values_t=None):
+def sddmm_batched(cols, offs, nnz, batch, rows, kcols, dC, B, out):
     calls.append(("sddmm_batched", (batch, rows, kcols)))
     if not batched_sddmm:
-        return 0
+        return False
     o, c = _np(offs).reshape(batch, rows + 1), _np(cols)[:nnz]
     res = np.empty(nnz, np.float32)
     for b in range(batch):
@@ -140,10 +140,7 @@ def sddmm_batched(cols, offs, nnz, batch, rows, kcols, dC, B, out, values=None, 
         Bb = _np(B) if B.dim() == 2 else _np(B)[b]
         res[s0:s1] = oracle.sddmm((o[b] - s0).astype(np.int32), c[s0:s1], rows, _np(dC)[b], Bb)
     out[:nnz] = torch.from_numpy(res)
-    if values_t is not None:   # the values carried into the transposed pattern's order on the side
-        values_t[inv_perm[:nnz].long()] = values[:nnz]
-        return 2
-    return 1
+    return True
 
 
 fused_dense = True  # tests flip this to exercise the CSR route as well

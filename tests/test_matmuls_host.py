@@ -251,40 +251,20 @@ def test_batched_csr_operand_backward_and_pattern_cache(mm):
     # (no gathered copy); where it does not, one index_select + the plain batched product — same gradients either way
     a = dense.to_sparse_csr().requires_grad_(True)
     grads = []
-    matmuls._sddmm_scatter = False
-    try:
-        for take in (True, False):
-            fake.perm_plan = take
-            try:
-                del fake.calls[:]
-                a.grad = None
-                b1 = rand(torch.Generator().manual_seed(5), nb, K, 5).requires_grad_(True)
-                matmuls.cusparseMM.apply(a, b1).backward(torch.ones(nb, M, 5))
-                names = [c[0] for c in fake.calls]
-                assert "naive_spmm_batched_perm" in names
-                assert (names.count("naive_spmm_batched") == 1) == take  # forward only / forward + the gathered fallback
-                grads.append(b1.grad.clone())
-            finally:
-                fake.perm_plan = True
-    finally:
-        matmuls._sddmm_scatter = True
+    for take in (True, False):
+        fake.perm_plan = take
+        try:
+            del fake.calls[:]
+            a.grad = None
+            b1 = rand(torch.Generator().manual_seed(5), nb, K, 5).requires_grad_(True)
+            matmuls.cusparseMM.apply(a, b1).backward(torch.ones(nb, M, 5))
+            names = [c[0] for c in fake.calls]
+            assert "naive_spmm_batched_perm" in names
+            assert (names.count("naive_spmm_batched") == 1) == take  # forward only / forward + the gathered fallback
+            grads.append(b1.grad.clone())
+        finally:
+            fake.perm_plan = True
     assert torch.equal(grads[0], grads[1])
-    # with both gradients wanted (the default): the batched SDDMM carries the values into the transposed pattern's order on
-    # the side, and the transposed product is the plain one — no permuted product, no gather; same gradient
-    del fake.calls[:]
-    a.grad = None
-    b1 = rand(torch.Generator().manual_seed(5), nb, K, 5).requires_grad_(True)
-    matmuls.cusparseMM.apply(a, b1).backward(torch.ones(nb, M, 5))
-    names = [c[0] for c in fake.calls]
-    assert "sddmm_batched" in names and "naive_spmm_batched_perm" not in names and names.count("naive_spmm_batched") == 2
-    assert torch.equal(b1.grad, grads[0])
-    # … and with only the dense operand's gradient wanted there is no SDDMM to ride on: the permuted product again
-    del fake.calls[:]
-    b1 = rand(torch.Generator().manual_seed(5), nb, K, 5).requires_grad_(True)
-    matmuls.cusparseMM.apply(dense.to_sparse_csr(), b1).backward(torch.ones(nb, M, 5))
-    names = [c[0] for c in fake.calls]
-    assert "sddmm_batched" not in names and "naive_spmm_batched_perm" in names
-    assert torch.equal(b1.grad, grads[0])
     # the gradient of the stored values: the batched SDDMM where it takes the problem, else the block-diagonal one
     grads = []
     for take in (True, False):
