@@ -2556,13 +2556,15 @@ def test_spmm_lds_resident_b_quad_form_bit_exact(capi, cmm, dev, oracle_mod, N):
         # one item, a row beyond the long-row threshold (skipped by the kernel, summed by the follow-up), fused bias
         capi.mi_spmm_ldsb_set_form(1)
         M, K = 20000, 256
-        lens = g.integers(2, 12, size=M)
+        lens = g.integers(10, 40, size=M)   # (long enough for AUTO to keep the LDS plan at every N here: bias + column tiles)
         lens[77], lens[19999] = 9000, 3
         col = np.concatenate([g.integers(0, K, size=int(n)).astype(np.int32) for n in lens])
         rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
         val = g.random(len(col), dtype=np.float32) - 0.5
         B, bias = g.random((K, N), dtype=np.float32) - 0.5, g.random(N, dtype=np.float32)
         want = oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B)
+        capi.mi_spmm_csr_f32_plan.argtypes = [i64, i32, i32, i32, vp, i64, vp, i64]
+        assert capi.mi_spmm_csr_f32_plan(len(col), M, K, N, None, N, None, N) == 18
         C = torch.full((M, N), float("nan"), device=dev)
         cmm.naive_spmm_bias(t(val, dev), t(col, dev), t(rowptr, dev), len(col), M, K, t(B, dev), t(bias, dev), C)
         assert np.array_equal(C.cpu().numpy(), want + bias[None, :])
