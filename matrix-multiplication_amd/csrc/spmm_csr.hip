@@ -1378,7 +1378,7 @@ const char* mi_spmm_variant_name(int variant) {
       return "spmm_group_kernel";
     case MI_SPMM_NARROW: return "spmm_narrow_kernel";
     case MI_SPMM_SLAB: return "spmm_slab_kernel";
-    case MI_SPMM_LDS_B: return "spmm_ldsb_kernel";
+    case MI_SPMM_LDS_B: return "spmm_ldsq_kernel";  // (its quad form; spmm_ldsb_kernel where only the 16-lane form covers the shape)
     case MI_SPMM_PANELS_2: case MI_SPMM_PANELS_3: case MI_SPMM_PANELS_4: case MI_SPMM_PANELS_5:
     case MI_SPMM_PANELS_6: case MI_SPMM_PANELS_8: case MI_SPMM_COLTILE_PANELS:
       return "spmm_wave_row_panel_kernel";

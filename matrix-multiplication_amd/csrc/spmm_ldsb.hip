@@ -233,15 +233,17 @@ struct QuadChunk {  // 16 entries of a row as its quad holds them: lane e >> 2, 
   f32x4 v;
 };
 
-template <int Q, bool PERM>
-__global__ __launch_bounds__(kWaves * 64) void spmm_ldsq_kernel(
+template <int Q, bool PERM, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void spmm_ldsq_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ B, float* __restrict__ C, int M, int K, long ldb, long ldc, long strideB,
     long strideC, const float* __restrict__ bias, int ctile_shift, int units_per_item, int rows_per_unit,
     unsigned total_units, int long_thresh, const int* __restrict__ perm, int last4) {
   // last4 = nnz_total − 4 (≥ 0): the last index a 16-byte load of col / val may start at; 1 << ctile_shift column tiles
   extern __shared__ __attribute__((aligned(16))) f32x4 Bs[];  // [K + 1][W / 4]
-  constexpr int W = 16 * Q, ROWB = 4 * W, RPW = 16, STRIDE = kWaves * RPW;
+  constexpr int W = 16 * Q, ROWB = 4 * W, RPW = 16, STRIDE = WAVES * RPW;
+  // WAVES: 16 at Q = 4; the narrow tiles (Q = 2, 1) run 6–11 % faster as 8-wave workgroups (two 128-row steps per unit:
+  // 96 × 1024² × 64 at 10 % kept 0.0577 → 0.0543 ms, 48 × 2048² × 64 0.154 → 0.137), Q = 4 does not (100 % kept 0.299 → 0.315)
   static_assert((Q & (Q - 1)) == 0, "the rotation needs a power of two");  // (Q < 4: rows narrower than the 64 banks —
   // the quads of a service group meet on a bank quarter when their rows' offsets agree mod 256 B: up to 4-way, by the data)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_ldsq_kernel(
       const float* Bi = B + item * strideB + col0;
       constexpr int nq = W / 4;
       const int total4 = K * nq;
-      for (int f0 = wave * 64; f0 < total4; f0 += kWaves * 64) {  // wave-uniform
+      for (int f0 = wave * 64; f0 < total4; f0 += WAVES * 64) {  // wave-uniform
         const int f = f0 + lane;
         if (f < total4)
           __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void*>(
@@ -837,17 +839,17 @@ int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val
     const unsigned grid = (unsigned)((total + per - 1) / per);
     const size_t lds = ((size_t)K + 1) * qw * 4;
     const int shift = qtiles == 8 ? 3 : qtiles == 4 ? 2 : qtiles == 2 ? 1 : 0;
-#define MI_LDSQ(Q_)                                                                                                   \
+#define MI_LDSQ(Q_, WAVES_)                                                                                           \
   do {                                                                                                                \
-    auto k = perm ? spmm_ldsq_kernel<Q_, true> : spmm_ldsq_kernel<Q_, false>;                                         \
+    auto k = perm ? spmm_ldsq_kernel<Q_, true, WAVES_> : spmm_ldsq_kernel<Q_, false, WAVES_>;                         \
     if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kWaves * 64), lds, s, rowptr, col, val, B, C, M, K, (long)ldb, (long)ldc,  \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(WAVES_ * 64), lds, s, rowptr, col, val, B, C, M, K, (long)ldb, (long)ldc,  \
                        (long)strideB, (long)strideC, bias, shift, upi, rpu, (unsigned)total, long_thresh, perm,         \
                        (int)(nnz_total - 4));                                                                          \
   } while (0)
-    if (qw == 64) MI_LDSQ(4);
-    else if (qw == 32) MI_LDSQ(2);
-    else MI_LDSQ(1);
+    if (qw == 64) MI_LDSQ(4, 16);
+    else if (qw == 32) MI_LDSQ(2, 8);
+    else MI_LDSQ(1, 8);
 #undef MI_LDSQ
     return check_launch();
   }
