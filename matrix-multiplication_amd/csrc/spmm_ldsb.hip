@@ -824,18 +824,37 @@ int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val
     }
     return n;
   }();
-  // Quad form (spmm_ldsq_kernel): units of whole 256-row steps, as many as keep every CU at work.
+  // Quad form (spmm_ldsq_kernel)
   const int form = g_ldsb_form.load(std::memory_order_relaxed);
   const int qw = ldsq_tile_width(K, N);
   if (form != 0 && qw != 0 && nnz_total >= 4 && nnz_total < (1LL << 29) && (int64_t)M * ldc < (1LL << 29)) {
     const int qtiles = N / qw;
-    int upi = 1;
-    while ((long)batch * qtiles * upi < 3L * cus && ((long)M + upi * 2 - 1) / (upi * 2) >= 256) upi *= 2;
-    const int rpu = (int)((((long)M + upi - 1) / upi + 255) / 256 * 256);  // whole 256-row steps
-    upi = (int)(((long)M + rpu - 1) / rpu);
-    const long total = (long)batch * qtiles * upi;
+    // Units of whole row steps (256 rows with 16 waves, 128 with 8), as many as keep every CU at work.  The narrow tiles
+    // run 8 waves (see the kernel); the 64-column tile takes 8 where the finer units fill the persistent grid better
+    // (96 items of 1024 rows: 384 units of 256 rows leave a quarter of the CUs idle, 768 of 128 rows none) — its 8-wave
+    // build is ≈5 % slower per row, which the comparison prices in.
+    struct Units {
+      int upi, rpu;
+      long total, per;
+      double span;  // rows the busiest workgroup walks, priced
+    };
+    auto plan_units = [&](int step, double price) {
+      Units u;
+      u.upi = 1;
+      while ((long)batch * qtiles * u.upi < 3L * cus && ((long)M + u.upi * 2 - 1) / (u.upi * 2) >= step) u.upi *= 2;
+      u.rpu = (int)((((long)M + u.upi - 1) / u.upi + step - 1) / step * step);
+      u.upi = (int)(((long)M + u.rpu - 1) / u.rpu);
+      u.total = (long)batch * qtiles * u.upi;
+      u.per = (u.total + cus - 1) / cus;
+      u.span = (double)u.per * u.rpu * price;
+      return u;
+    };
+    const Units u16 = plan_units(256, 1.0), u8 = plan_units(128, qw == 64 ? 1.05 : 0.9);
+    const bool eight = qw != 64 || u8.span < u16.span;
+    const Units& un = eight ? u8 : u16;
+    const int upi = un.upi, rpu = un.rpu;
+    const long total = un.total, per = un.per;
     if (total > 0x7fffffffL) return MI_ERANGE;
-    const long per = (total + cus - 1) / cus;
     const unsigned grid = (unsigned)((total + per - 1) / per);
     const size_t lds = ((size_t)K + 1) * qw * 4;
     const int shift = qtiles == 8 ? 3 : qtiles == 4 ? 2 : qtiles == 2 ? 1 : 0;
@@ -847,7 +866,8 @@ int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val
                        (long)strideB, (long)strideC, bias, shift, upi, rpu, (unsigned)total, long_thresh, perm,         \
                        (int)(nnz_total - 4));                                                                          \
   } while (0)
-    if (qw == 64) MI_LDSQ(4, 16);
+    if (qw == 64 && !eight) MI_LDSQ(4, 16);
+    else if (qw == 64) MI_LDSQ(4, 8);
     else if (qw == 32) MI_LDSQ(2, 8);
     else MI_LDSQ(1, 8);
 #undef MI_LDSQ
