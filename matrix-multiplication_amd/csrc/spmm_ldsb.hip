@@ -830,14 +830,18 @@ int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val
   if (form != 0 && qw != 0 && nnz_total >= 4 && nnz_total < (1LL << 29) && (int64_t)M * ldc < (1LL << 29)) {
     const int qtiles = N / qw;
     // Units of whole row steps (256 rows with 16 waves, 128 with 8), as many as keep every CU at work.  The narrow tiles
-    // run 8 waves (see the kernel); the 64-column tile takes 8 where the finer units fill the persistent grid better
-    // (96 items of 1024 rows: 384 units of 256 rows leave a quarter of the CUs idle, 768 of 128 rows none) — its 8-wave
-    // build is ≈5 % slower per row, which the comparison prices in.
+    // run 8 waves (see the kernel); the 64-column tile takes 8 where the finer units suit the persistent grid better —
+    // priced as the busiest workgroup's rows (≈3 ns + 0.66 ns per non-zero each; the 8-wave build ≈5 % more) plus its
+    // stagings (≈35 ns per KB of image), from tools/bench_ldsb_forms.py: 384 items of 256 rows run 3 units of 128 rows per
+    // CU instead of 2 of 256 on three quarters of the CUs (0.053 → 0.047 ms at 50 % kept), 96 items of 1024 × 512 keep
+    // their 2 units of 256 rows — one staging per workgroup instead of two (0.013 against 0.018 ms at 2 % kept).
     struct Units {
       int upi, rpu;
       long total, per;
-      double span;  // rows the busiest workgroup walks, priced
+      double span;  // ns, the busiest workgroup
     };
+    const double row_ns = 3.0 + 0.66 * (double)nnz_total / ((double)batch * (double)M);
+    const double stage_ns = 35.0 * ((double)K + 1) * qw * 4 / 1024.0;
     auto plan_units = [&](int step, double price) {
       Units u;
       u.upi = 1;
@@ -846,10 +850,17 @@ int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val
       u.upi = (int)(((long)M + u.rpu - 1) / u.rpu);
       u.total = (long)batch * qtiles * u.upi;
       u.per = (u.total + cus - 1) / cus;
-      u.span = (double)u.per * u.rpu * price;
+      long stagings = 1;  // the most slices a workgroup's contiguous units touch
+      const long groups = (u.total + u.per - 1) / u.per;
+      for (long w = 0; w < groups && w < 4096; ++w) {
+        const long a = w * u.per, b = a + u.per < u.total ? a + u.per : u.total;
+        const long n = (b - 1) / u.upi - a / u.upi + 1;
+        stagings = n > stagings ? n : stagings;
+      }
+      u.span = (double)u.per * u.rpu * row_ns * price + (double)stagings * stage_ns;
       return u;
     };
-    const Units u16 = plan_units(256, 1.0), u8 = plan_units(128, qw == 64 ? 1.05 : 0.9);
+    const Units u16 = plan_units(256, 1.0), u8 = plan_units(128, 1.05);
     const bool eight = qw != 64 || u8.span < u16.span;
     const Units& un = eight ? u8 : u16;
     const int upi = un.upi, rpu = un.rpu;
