@@ -1010,10 +1010,11 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
   if (N < 4) return MI_SPMM_NARROW;
   // Many small products (or one tall one) whose B fits a CU's LDS: gather from LDS instead of from the L2s
   // (spmm_ldsb.hip).  It pays once rows are long enough to amortise copying B per workgroup.
-  // (tools/bench_attn_csr.py, profiles/r03_attention_csr.log: 384 × 512² × 64 at 10 % kept 0.125 → 0.058 ms, at
-  // 1 % 0.038 → 0.032; N = 256 has the one-wave-per-row kernels, whose col / val travel through scalar registers:
-  // 65536 × 128 × 256 at 5 % 0.020 ms there vs 0.028 here, at 25 % 0.074 vs 0.046)
-  // (a B that needs column tiles re-reads col / val per tile: rows must be that much longer)
+  // (tools/bench_attn_csr.py, profiles/r04_attention_csr.log: 384 × 512² × 64 at 10 % kept 0.121 → 0.050 ms, at
+  // 1 % 0.038 → 0.026; N = 256 has the one-wave-per-row kernels, whose col / val travel through scalar registers:
+  // 65536 × 128 × 256 at 5 % 0.020 ms there vs 0.026 here, at 25 % 0.069 (0.055 as the slab plan) vs 0.035)
+  // (a B that needs column tiles re-reads col / val per tile: rows must be that much longer — up to N = 128; beyond,
+  // 16 non-zeros per row whatever the number of tiles)
   if (sh.vec4_ok && mi::spmm_ldsb_fits(K, N) && (long)batch * M >= 16384 &&
       nnz >= (N > 128 ? 4 * MI_SPMM_LDSB_MIN_ROW : MI_SPMM_LDSB_MIN_ROW * mi::spmm_ldsb_tiles(K, N)) * (long)batch * M)
     return MI_SPMM_LDS_B;

@@ -203,9 +203,9 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // The same product with FOUR lanes per row (a DPP quad) and Q float4 of the output row per lane (tile width W = 16·Q:
-// 64 or 128 columns) — "quad form", what AUTO runs at BERT's head size.  Why a second form: in spmm_ldsb_kernel a
-// 16-lane group pays two DPP moves (column, value) per non-zero and ONE ds_read_b128; a quad pays them once per
-// non-zero for Q reads, a wave carries 16 rows instead of 4, and a row's col / val arrive as 16-byte vector loads
+// 64, 32 or 16 columns) — "quad form", what AUTO runs at BERT's head size.  Why a second form: in spmm_ldsb_kernel a
+// 16-lane group pays two DPP moves (column, value) per non-zero and ONE ds_read_b128; a quad pays one DPP move and Q
+// DPP adds for Q reads, a wave carries 16 rows instead of 4, and a row's col / val arrive as 16-byte vector loads
 // (16 entries per quad and instruction instead of 16 dwords), so the bookkeeping per non-zero — loads, bounds, row
 // steps, stores — shrinks fourfold: a workgroup of 16 waves covers a 256-row unit in ONE row step (the 16-lane form:
 // four, each waiting for its own bounds → col / val chain).  Same arithmetic: one fmaf chain per output element over
@@ -221,7 +221,12 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
 //     last 16 bytes; the one lane in the whole launch that this shifts rotates its components back;
 //   * bounds two row steps ahead, the first chunk of the next row step one ahead, chunk k + 1 of a row while chunk k is
 //     processed (16 entry steps of four waves per SIMD: ≈1.5 µs) — all of it ACROSS units and stagings (registers
-//     only), so the staging of B hides the first trip to memory for col / val.  (Two chunks ahead spilled: 128 VGPRs.)
+//     only), so the staging of B hides the first trip to memory for col / val.  ONE look-ahead register set serves
+//     both: behind a row's last chunk it holds the next row step's first one (a wave-uniform choice of the address,
+//     the same load sequence on either path).  (Separate sets for the row's next chunks and the next row's spilled.)
+//   * B is staged by LDS-DMA, C rows leave as buffer stores, every global load is unconditional on a clamped address:
+//     see the comments at those places — each was measured (the first version, with predicated loads, ran at half the
+//     16-lane form's speed).
 // ---------------------------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
