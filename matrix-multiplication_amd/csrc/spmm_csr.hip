@@ -1013,10 +1013,13 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
   // (tools/bench_attn_csr.py, profiles/r04_attention_csr.log: 384 × 512² × 64 at 10 % kept 0.121 → 0.050 ms, at
   // 1 % 0.038 → 0.026; N = 256 has the one-wave-per-row kernels, whose col / val travel through scalar registers:
   // 65536 × 128 × 256 at 5 % 0.020 ms there vs 0.026 here, at 25 % 0.069 (0.055 as the slab plan) vs 0.035)
-  // (a B that needs column tiles re-reads col / val per tile: rows must be that much longer — up to N = 128; beyond,
-  // 16 non-zeros per row whatever the number of tiles)
+  // With the quad form the plan pays from ≈4 non-zeros per row whatever the number of column tiles (tools/bench_plans.py,
+  // one tall matrix: 65536 × 256 × 128 at 3 % — 7.7 per row, two tiles — 0.014 ms against 0.025 for the group kernel;
+  // 65536 × 128 × 256 at 5 % — 6.4 per row, four tiles — 0.021 against 0.025 for the one-wave-per-row kernel and at 10 %
+  // 0.025 against 0.040 for the slab plan; 32768 × 512 × 128 at 1 %: 0.010 against 0.014; 131072 × 512 × 64 at 0.5 % — 2.6
+  // per row — level with the group kernel)
   if (sh.vec4_ok && mi::spmm_ldsb_fits(K, N) && (long)batch * M >= 16384 &&
-      nnz >= (N > 128 ? 4 * MI_SPMM_LDSB_MIN_ROW : MI_SPMM_LDSB_MIN_ROW * mi::spmm_ldsb_tiles(K, N)) * (long)batch * M)
+      nnz >= MI_SPMM_LDSB_MIN_ROW * (long)batch * M)
     return MI_SPMM_LDS_B;
   const int lp = (sh.wave_ok && batch == 1) ? l2_panels(M, K, N, ldb, nnz) : 0;
   // Moderate density: stage B through LDS (spmm_slab.hip) when its cost model beats the L2-blocked

@@ -2776,10 +2776,11 @@ def test_spmm_lds_resident_b_is_autos_choice_for_pruned_attention_and_keeps_the_
     assert capi.mi_spmm_csr_batched_f32_plan(10_000_000, 96, 1024, 1024, 64, None, 64, 1024 * 64, None, 64, 1024 * 64) == 18
     assert capi.mi_spmm_csr_batched_f32_plan(10_000_000, 48, 2048, 2048, 64, None, 64, 2048 * 64, None, 64, 2048 * 64) == 18
     assert capi.mi_spmm_csr_batched_f32_plan(10_000_000, 24, 4096, 4096, 64, None, 64, 4096 * 64, None, 64, 4096 * 64) != 18
-    # wide N (four column tiles of 64): from 16 non-zeros per row, whatever the number of tiles (tools/bench_attn_csr.py:
-    # 65536 × 128 × 256 at 25 % kept 0.035 ms here against 0.055 for the slab plan; at 5 % the one-wave-per-row kernel wins)
+    # from 4 non-zeros per row whatever the number of column tiles (tools/bench_plans.py: 65536 × 128 × 256 — four tiles of
+    # 64 — at 25 / 10 / 5 % kept 0.039 / 0.025 / 0.021 ms here against 0.058 / 0.040 / 0.025 for the plans AUTO took before)
     assert capi.mi_spmm_csr_f32_plan(2_097_040, 65536, 128, 256, None, 256, None, 256) == 18
-    assert capi.mi_spmm_csr_f32_plan(418_690, 65536, 128, 256, None, 256, None, 256) != 18
+    assert capi.mi_spmm_csr_f32_plan(418_690, 65536, 128, 256, None, 256, None, 256) == 18
+    assert capi.mi_spmm_csr_f32_plan(3 * 65536, 65536, 128, 256, None, 256, None, 256) != 18
     g = np.random.Generator(np.random.PCG64(18))
     M, K, N = 20000, 256, 64
     lens = g.integers(2, 12, size=M)
