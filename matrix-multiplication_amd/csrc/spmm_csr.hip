@@ -1018,7 +1018,10 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
   // 65536 × 128 × 256 at 5 % — 6.4 per row, four tiles — 0.021 against 0.025 for the one-wave-per-row kernel and at 10 %
   // 0.025 against 0.040 for the slab plan; 32768 × 512 × 128 at 1 %: 0.010 against 0.014; 131072 × 512 × 64 at 0.5 % — 2.6
   // per row — level with the group kernel)
-  if (sh.vec4_ok && mi::spmm_ldsb_fits(K, N) && (long)batch * M >= 16384 &&
+  // (rows: enough 256-row units for the persistent grid — or, from 8192 rows, enough non-zeros that the gathers decide:
+  // 12 heads of 1024 tokens at 25 % kept 0.041 → 0.020 ms, 24 × 512² 0.024 → 0.017, tools/probes/small_batch_probe.py)
+  if (sh.vec4_ok && mi::spmm_ldsb_fits(K, N) &&
+      ((long)batch * M >= 16384 || ((long)batch * M >= 8192 && nnz >= 1500000)) &&
       nnz >= MI_SPMM_LDSB_MIN_ROW * (long)batch * M)
     return MI_SPMM_LDS_B;
   const int lp = (sh.wave_ok && batch == 1) ? l2_panels(M, K, N, ldb, nnz) : 0;
