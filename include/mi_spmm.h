@@ -53,6 +53,17 @@ const char* mi_last_hip_error_string(void);
  * Exception, N < 4 (SpMV-like): 64 lane-strided chains (lane l takes the row's
  * non-zeros l, l+64, …) combined by a xor-butterfly (32, 16, …, 1) — also a fixed,
  * launch-independent order, restated by the oracle.
+ *
+ * The `nnz` argument of every SpMM / SDDMM entry (nnz_total for the batched ones):
+ *   rowptr's last entry  ≤  nnz  ≤  the number of entries `col` / `val` hold.
+ * It picks the plan and sizes the long-row workspace; the kernels walk the rows through
+ * rowptr and never read col / val at an index ≥ max(nnz, rowptr's last entry), so a CAPACITY (arrays
+ * sized for every element of a dense operand, filled without a read-back) is a valid count
+ * and gives the same bits as the exact one.  A count BELOW rowptr's last entry is outside
+ * the contract wherever a long-row workspace is in use (its lists are sized from it); without
+ * one (mi_spmm_csr_f32, MI_LONG_ROWS_NONE, the batched forms) it only steers the plan — the
+ * 16-byte col / val loads of MI_SPMM_LDS_B take their clamp from max(nnz, rowptr's last entry),
+ * read on the device.  It must never exceed the array length.
  * ------------------------------------------------------------------------ */
 int mi_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                     int64_t nnz, int32_t M, int32_t K, int32_t N,

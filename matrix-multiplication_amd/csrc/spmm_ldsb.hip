@@ -243,8 +243,14 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_ldsq_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ B, float* __restrict__ C, int M, int K, long ldb, long ldc, long strideB,
     long strideC, const float* __restrict__ bias, int ctile_shift, int units_per_item, int rows_per_unit,
-    unsigned total_units, int long_thresh, const int* __restrict__ perm, int last4) {
-  // last4 = nnz_total − 4 (≥ 0): the last index a 16-byte load of col / val may start at; 1 << ctile_shift column tiles
+    unsigned total_units, int long_thresh, const int* __restrict__ perm, int last4_hint, long rp_last) {
+  // last4: the last index a 16-byte load of col / val may start at = (entries the arrays hold) − 4.  The caller's count
+  // (last4_hint = nnz_total − 4 ≥ 0) is an UPPER BOUND by contract (include/mi_spmm.h: rowptr's last entry ≤ nnz ≤ array
+  // length); a count BELOW the offsets' last entry (a stale estimate, a shard's local count) must not move the clamp into
+  // the data, so the clamp is taken from whichever is larger — the arrays hold at least rowptr[rp_last] entries.
+  // 1 << ctile_shift column tiles
+  const int true_last4 = rowptr[rp_last] - 4;
+  const int last4 = last4_hint > true_last4 ? last4_hint : true_last4;
   extern __shared__ __attribute__((aligned(16))) f32x4 Bs[];  // [K + 1][W / 4]
   constexpr int W = 16 * Q, ROWB = 4 * W, RPW = 16, STRIDE = WAVES * RPW;
   // WAVES: 16 at Q = 4; the narrow tiles (Q = 2, 1) run 6–11 % faster as 8-wave workgroups (two 128-row steps per unit:
@@ -595,7 +601,10 @@ __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsb_kernel(
 __global__ __launch_bounds__(kWaves * 64) void sddmm_ldsq_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ dC,
     const float* __restrict__ B, float* __restrict__ out, int M, int K, long lddc, long strideDC, long ldb,
-    long strideB, int units_per_item, int rows_per_unit, unsigned total_units, int last4, int ktile_shift, int ktile_rows) {
+    long strideB, int units_per_item, int rows_per_unit, unsigned total_units, int last4_hint, long rp_last, int ktile_shift,
+    int ktile_rows) {
+  const int true_last4 = rowptr[rp_last] - 4;  // see spmm_ldsq_kernel: the caller's count is an upper bound, never a clamp below the data
+  const int last4 = last4_hint > true_last4 ? last4_hint : true_last4;
   // 1 << ktile_shift tiles of ktile_rows rows of B per item (K beyond the 512 rows the image holds: an entry needs ONE row of
   // B, so a pass per tile computes the entries whose column lies in it — exact whatever the order of columns inside a row)
   extern __shared__ __attribute__((aligned(16))) f32x4 Bs[];  // [min(K, ktile_rows)][16]
@@ -880,7 +889,7 @@ int launch_spmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* val
     if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL(k, dim3(grid), dim3(WAVES_ * 64), lds, s, rowptr, col, val, B, C, M, K, (long)ldb, (long)ldc,  \
                        (long)strideB, (long)strideC, bias, shift, upi, rpu, (unsigned)total, long_thresh, perm,         \
-                       (int)(nnz_total - 4));                                                                          \
+                       (int)(nnz_total - 4), (long)batch * ((long)M + 1) - 1);                                         \
   } while (0)
     if (qw == 64 && !eight) MI_LDSQ(4, 16);
     else if (qw == 64) MI_LDSQ(4, 8);
@@ -961,7 +970,7 @@ int launch_sddmm_ldsb(const int32_t* rowptr, const int32_t* col, const float* dC
       MI_HIP_TRY(hipFuncSetAttribute((const void*)sddmm_ldsq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(sddmm_ldsq_kernel, dim3(grid), dim3(kWaves * 64), lds, s, rowptr, col, dC, B, out, M, K, (long)lddc,
                        (long)strideDC, (long)ldb, (long)strideB, upi, rpu, (unsigned)total, (int)(nnz_total - 4),
-                       ktiles == 8 ? 3 : ktiles == 4 ? 2 : ktiles == 2 ? 1 : 0, 512);
+                       (long)batch * ((long)M + 1) - 1, ktiles == 8 ? 3 : ktiles == 4 ? 2 : ktiles == 2 ? 1 : 0, 512);
     return check_launch();
   }
   if ((long)K * N * 4 > 128L * 1024) return 1;  // only the quad form's tiles cover this B, and it cannot run: not taken

@@ -117,7 +117,11 @@ class _SparseLinearBias(InplaceFunction):
             if sparse_forward_pays(est * x2.numel(), tokens, fin, fout):
                 offsets = custom_mm.dense_row_offsets(x2)
                 if fin <= custom_mm.long_row_threshold():
-                    # no read-back: room for every element; the count the kernels are told is the estimate (plan choice only)
+                    # no read-back: room for every element.  The count the kernels are told is the estimate — possibly
+                    # BELOW the true count (stale or sampled): allowed here because rule 0 runs without the long-row
+                    # workspace, the only thing sized from it (include/mi_spmm.h); MI_SPMM_LDS_B takes the clamp of its
+                    # 16-byte loads from max(count, offsets' last entry) on the device, every other plan reads through
+                    # the offsets alone (tests: test_spmm_count_as_bound_or_estimate_same_bits, test_cusparse_linear_lds_fit_…)
                     values, columns = custom_mm.dense_to_csr_fill(x2, offsets, x2.numel())
                     csr = (values, columns, offsets.view(-1))
                     nnz_arg = min(x2.numel(), max(1, int(est * x2.numel())))

@@ -283,8 +283,9 @@ def _dense_to_csr(a: torch.Tensor):
     '''(values, columns, offsets, nnz) of a dense tensor's last two dims (batched: the "rowptr of rowptrs" layout).
     Outside stream capture: the exact arrays (one read-back of the count sizes them; the kernels' plan choice sees the
     true number of non-zeros).  Under capture nothing may be read back: the arrays get room for EVERY element
-    (capacity = a.numel(): the fill cannot overflow) and `nnz` is that bound — the product kernels walk the rows through
-    `offsets`, the count only steers their choice of plan, so the result is the same bits.'''
+    (capacity = a.numel(): the fill cannot overflow) and `nnz` is that bound — an upper bound no larger than the arrays,
+    which is what include/mi_spmm.h asks of the count: the product kernels walk the rows through `offsets`, the bound
+    steers their choice of plan (and is the clamp of MI_SPMM_LDS_B's 16-byte loads), so the result is the same bits.'''
     if a.is_cuda and torch.cuda.is_current_stream_capturing():
         offsets = custom_mm.dense_row_offsets(a)
         values, columns = custom_mm.dense_to_csr_fill(a, offsets, a.numel())

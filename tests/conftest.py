@@ -53,3 +53,39 @@ def oracle_mod():
     import oracle
     oracle.build()
     return oracle
+
+
+# ---- fixtures of the GPU parity modules (tests/test_gpu_*.py); module scope: each module imports the product afresh ----
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need the MI355X; the HIP path has no fallback"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def cmm(built):
+    for k in ("custom_mm", "matmuls"):
+        sys.modules.pop(k, None)
+    import custom_mm
+    assert custom_mm.__file__.endswith(".so") and "matrix-multiplication_amd" in custom_mm.__file__
+    custom_mm.init_cublas()
+    custom_mm.init_cusparse()
+    return custom_mm
+
+
+@pytest.fixture(scope="module")
+def mm(cmm):
+    import matmuls
+    assert matmuls.custom_mm is cmm
+    return matmuls
+
+
+@pytest.fixture(scope="module")
+def capi(built, cmm):
+    import ctypes
+    lib = ctypes.CDLL(str(built / "libmi_spmm.so"))
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    lib.mi_spmm_csr_f32_variant.argtypes = [ctypes.c_int, vp, vp, vp, i64, i32, i32, i32, vp, i64, vp, i64, vp]
+    return lib

@@ -40,7 +40,7 @@ def _spmm(name, vals, cols, offs, nnz, rows, kcols, B, C):
     calls.append((name, (rows, kcols)))
     assert offs.dtype == torch.int32 and cols.dtype == torch.int32 and vals.dtype == torch.float32
     assert offs.numel() == rows + 1 and B.shape[0] == kcols
-    # `nnz` may be a bound or an estimate (arrays sized for every element, no read-back): the rows are walked through offs
+    # `nnz` may be a bound (or, without a long-row workspace, an estimate): include/mi_spmm.h — the rows are walked through offs
     true_nnz = int(offs[-1]) if offs.numel() else 0
     assert vals.numel() >= max(nnz, true_nnz) and cols.numel() >= max(nnz, true_nnz)
     return _write(C, oracle.spmm_csr(_np(offs), _np(cols)[:true_nnz], _np(vals)[:true_nnz], rows, kcols, _np(B)))

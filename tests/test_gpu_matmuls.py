@@ -1,0 +1,590 @@
+"""The autograd classes of matmuls.py and fc_layers.py on the device.
+
+Parity of the HIP path with the oracle — needs the MI355X (`-m gpu`).  Everything here calls the product path
+(custom_mm → libmi_spmm.so → HIP kernels, or the C-ABI directly through ctypes) and compares with the CPU oracle on the
+same seeded inputs: bit-exact where the oracle states the same summation order, rtol 1e-5 / atol 1e-8 (the reference
+tests' torch.allclose defaults, tests/naive_kernel_test.py:36-37) against torch expectations and the golden fixtures.
+"""
+import ctypes
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_helpers import *  # noqa: F401,F403
+
+pytestmark = pytest.mark.gpu
+
+
+def test_matmuls_csr_times_batched_operand_on_device(mm, dev):
+    """naiveSpMM / cusparseMM with a CSR m1 and a batched m2: forward + both gradients vs torch
+    autograd of the dense product; the cached transpose is reused across backward passes."""
+    g = torch.Generator().manual_seed(5)
+    a = torch.rand(70, 90, generator=g) * (torch.rand(70, 90, generator=g) < 0.1)
+    for cls in (mm.naiveSpMM, mm.cusparseMM):
+        for bshape in ((4, 90, 32), (2, 3, 90, 20), (90, 64)):
+            b = torch.rand(*bshape, generator=g)
+            a_csr = a.to(dev).to_sparse_csr().requires_grad_(True)
+            b1 = b.to(dev).requires_grad_(True)
+            out = cls.apply(a_csr, b1)
+            a2, b2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            ref = torch.matmul(a2, b2)
+            assert torch.allclose(ref, out.cpu(), rtol=RTOL, atol=1e-6)
+            dc = torch.rand(ref.shape, generator=g)
+            for _ in range(2):   # second pass: transpose from the cache on the tensor
+                b1.grad = None
+                a_csr.grad = None
+                cls.apply(a_csr, b1).backward(dc.to(dev))
+            ref.backward(dc)
+            assert torch.allclose(b2.grad, b1.grad.cpu(), rtol=RTOL, atol=1e-5)
+            assert torch.allclose(a2.grad * (a != 0), a_csr.grad.to_dense().cpu(), rtol=RTOL, atol=1e-5)
+            assert getattr(a_csr, "_mi_csr_cache", None) is not None
+
+
+def test_matmuls_dense_classes_on_device(mm, dev):
+    g = torch.Generator().manual_seed(21)
+    for cls, ta, tb in [("cublasMM", 0, 0), ("cublasTransaMM", 1, 0), ("cublasTransbMM", 0, 1), ("cublasTransabMM", 1, 1)]:
+        for batch in [(), (3,), (2, 3), (2, 1, 2, 3)]:
+            m, n, k = 33, 65, 47
+            a = torch.rand(*batch, *((k, m) if ta else (m, k)), generator=g)
+            b = torch.rand(*batch, *((n, k) if tb else (k, n)), generator=g)
+            fwd_bwd_device(getattr(mm, cls).apply,
+                           lambda x, y: torch.matmul(x.transpose(-1, -2) if ta else x, y.transpose(-1, -2) if tb else y),
+                           a, b, dev)
+    # FC-layer call shape with a .t() weight view (reference benchmarks/cublas_fc_layer.py:41)
+    w = torch.rand(96, 80, generator=g)
+    fwd_bwd_device(lambda x, wt: mm.cublasMM.apply(x, wt.t()), lambda x, wt: x @ wt.t(), torch.rand(4, 10, 80, generator=g), w, dev)
+    fwd_bwd_device(mm.cublasMM.apply, torch.matmul, torch.rand(50, generator=g), torch.rand(50, 20, generator=g), dev)
+
+
+def test_matmuls_sparse_classes_on_device(mm, dev):
+    g = torch.Generator().manual_seed(22)
+
+    def sp(*shape, density=0.2):
+        return torch.rand(*shape, generator=g) * (torch.rand(*shape, generator=g) < density)
+    for cls in (mm.naiveSpMM, mm.cusparseMM):
+        fwd_bwd_device(cls.apply, torch.matmul, sp(70, 90), torch.rand(90, 256, generator=g), dev)
+        fwd_bwd_device(cls.apply, torch.matmul, sp(70, 90), torch.rand(3, 90, 33, generator=g), dev)
+        fwd_bwd_device(cls.apply, torch.matmul, sp(2, 5, 90), torch.rand(90, 64, generator=g), dev)      # FC layer shape
+        fwd_bwd_device(cls.apply, torch.matmul, sp(2, 3, 64, 64), torch.rand(2, 3, 64, 16, generator=g), dev)
+    # reference tests/naive_kernel_test.py:62-64 (torch.rand "sparse" inputs, 100 % dense)
+    fwd_bwd_device(mm.naiveSpMM.apply, torch.matmul, torch.rand(4, 2, generator=g), torch.rand(2, 3, generator=g), dev)
+    fwd_bwd_device(mm.naiveSpMM.apply, torch.matmul, torch.rand(2, 4, 2, generator=g), torch.rand(2, 2, 3, generator=g), dev)
+    fwd_bwd_device(mm.naiveSpMM.apply, lambda x, y: x @ y, torch.rand(2, 4, 2, generator=g),
+                   torch.rand(2, 4, 2, generator=g).transpose(-1, -2).contiguous(), dev)
+
+
+def test_matmuls_csr_tensor_input_on_device(mm, dev):
+    """reference tests/cusparse_kernel_test.py:46-58 incl. the (512,1024)×(1024,256) case."""
+    g = torch.Generator().manual_seed(23)
+    for (ar, ac), bshape in [((10, 10), (10, 10)), ((10, 20), (20, 10)), ((10, 10), (10, 5)), ((20, 10), (10, 5)),
+                             ((512, 1024), (1024, 256))]:
+        a = torch.rand(ar, ac, generator=g) * (torch.rand(ar, ac, generator=g) < 0.1)
+        b = torch.rand(bshape, generator=g)
+        exp = a @ b
+        a_csr = a.to(dev).to_sparse_csr().requires_grad_(True)
+        b1 = b.to(dev).requires_grad_(True)
+        our = mm.cusparseMM.apply(a_csr, b1)
+        assert torch.allclose(exp, our.cpu(), rtol=RTOL, atol=ATOL)
+        dc = torch.rand(exp.shape, generator=g)
+        our.backward(dc.to(dev))
+        a2, b2 = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        (a2 @ b2).backward(dc)
+        assert torch.allclose(b2.grad, b1.grad.cpu(), rtol=RTOL, atol=ATOL)
+        assert a_csr.grad.is_sparse_csr
+        assert torch.allclose(a2.grad * (a != 0), a_csr.grad.to_dense().cpu(), rtol=RTOL, atol=ATOL)
+
+
+def test_bert_large_reference_shapes(mm, dev):
+    """reference tests/naive_kernel_test.py:67-68 / tests/cublas_kernel_test.py:68-69, batch 256·16 cut to 16·16."""
+    g = torch.Generator(device=dev).manual_seed(1)
+    a = torch.rand(16, 16, 512, 512, device=dev, generator=g)
+    b = torch.rand(16, 16, 512, 64, device=dev, generator=g)
+    exp = torch.matmul(a, b)
+    assert torch.allclose(exp, mm.naiveSpMM.apply(a, b), rtol=RTOL, atol=ATOL)   # 100 % dense CSR, one launch
+    assert torch.allclose(exp, mm.cublasMM.apply(a, b), rtol=RTOL, atol=ATOL)
+    q = torch.rand(16, 16, 512, 64, device=dev, generator=g)
+    assert torch.allclose(torch.matmul(q, b.transpose(-1, -2)), mm.cublasTransbMM.apply(q, b), rtol=RTOL, atol=ATOL)
+    assert torch.allclose(torch.matmul(q, b.transpose(-1, -2)),
+                          mm.naiveSpMM.apply(q, b.transpose(-1, -2).contiguous()), rtol=RTOL, atol=ATOL)
+
+
+def test_fc_layer_modules_on_device(mm, dev):
+    """reference benchmarks/cublas_fc_layer.py / cusparse_fc_layer.py call sites vs nn.Linear."""
+    sys.modules.pop("fc_layers", None)
+    import fc_layers
+    g = torch.Generator().manual_seed(41)
+    for cls in (fc_layers.cublasLinear, fc_layers.cusparseLinear):
+        for bias in (True, False):
+            layer = cls(768, 256, bias=bias).to(dev)
+            ref = torch.nn.Linear(768, 256, bias=bias)
+            ref.load_state_dict({k: v.cpu() for k, v in layer.state_dict().items()})
+            x = torch.relu(torch.rand(4, 32, 768, generator=g) - 0.5)   # half the activations are exact zeros
+            x1, x2 = x.to(dev).requires_grad_(True), x.clone().requires_grad_(True)
+            y, yr = layer(x1), ref(x2)
+            assert y.is_cuda and torch.allclose(yr, y.cpu(), rtol=RTOL, atol=1e-6)
+            dy = torch.rand(yr.shape, generator=g)
+            y.backward(dy.to(dev))
+            yr.backward(dy)
+            assert torch.allclose(x2.grad, x1.grad.cpu(), rtol=RTOL, atol=1e-6)
+            assert torch.allclose(ref.weight.grad, layer.weight.grad.cpu(), rtol=1e-4, atol=1e-5)
+            if bias:
+                assert torch.allclose(ref.bias.grad, layer.bias.grad.cpu(), rtol=RTOL, atol=1e-5)
+
+
+def test_dense_inputs_of_the_sparse_classes_take_the_matrix_cores_above_the_crossover(mm, cmm, dev, monkeypatch):
+    """Round 3: naiveSpMM / cusparseMM on a DENSE tensor that is not sparse enough run the exact-fp32 MFMA product
+    (the reference's own naive test feeds torch.rand, tests/naive_kernel_test.py:48-49,62-68).  With finite operands
+    every route returns the same bits: the skipped terms are exact zeros.  The route is decided from a sampled
+    density that comes back without stalling the stream (the most recent count that has landed for operands of the
+    same shapes, or this very tensor's own).  THE RULE for non-finite operands (round 4, advisor): in the default
+    'auto' mode the route has NO semantic effect — a gated launch of the zero-skipping kernel recomputes the product
+    on the device iff `b` holds an inf / nan, so a zero of `a` never meets `b`, as with `to_sparse_csr()` (reference
+    matmuls.py:295-296), whatever ran before; dense_route='always' pins torch.matmul's semantics (0·inf = nan),
+    'never' pins the zero-skipping kernels."""
+    g = torch.Generator(device=dev).manual_seed(5)
+    calls = []
+    real = mm._on_matrix_cores
+
+    def spy(*a, **k):
+        took = real(*a, **k)
+        if took:
+            calls.append("dense")
+        return took
+    monkeypatch.setattr(mm, "_on_matrix_cores", spy)
+    mm._density_of_shape.clear()
+    mm._density_of_tensor.clear()
+    for kept, expect_dense in ((1.0, True), (0.1, True), (0.005, False)):
+        probs = torch.rand(8, 12, 512, 512, device=dev, generator=g)
+        probs = probs * (torch.rand(probs.shape, device=dev, generator=g) < kept)
+        v = torch.rand(8, 12, 512, 64, device=dev, generator=g) - 0.5
+        out = mm.naiveSpMM.apply(probs, v)   # may still run on the previous density's route …
+        torch.cuda.synchronize()
+        del calls[:]
+        out2 = mm.naiveSpMM.apply(probs, v)  # … this one knows the operand's own density
+        assert bool(calls) == expect_dense, (kept, calls)
+        assert torch.equal(out, out2), "the route must not change a bit"
+        assert torch.allclose(out, torch.matmul(probs, v), rtol=RTOL, atol=1e-4)
+        # the CSR route on the same data, bit for bit
+        values, columns, offsets = cmm.dense_to_csr(probs.reshape(-1, 512, 512))
+        c = torch.empty(96, 512, 64, device=dev)
+        cmm.naive_spmm_batched(values, columns, offsets, values.numel(), 96, 512, 512, v.reshape(96, 512, 64), c)
+        assert torch.equal(out.reshape(96, 512, 64), c), kept
+    # one large matrix (the FC-layer call shape), dense → one MFMA launch
+    x, w = torch.rand(4, 1024, 768, device=dev, generator=g), torch.rand(768, 512, device=dev, generator=g)
+    del calls[:]
+    out = mm.cusparseMM.apply(x, w)
+    assert calls and torch.allclose(out, x @ w, rtol=RTOL, atol=1e-4)
+    # the rule for a non-finite entry of b facing zeros of a: same shapes, different densities, back to back —
+    # in 'auto' the result never depends on the route nor on what ran before
+    b = torch.rand(512, 256, device=dev, generator=g)
+    b[7, 3] = float("inf")
+    b[7, 5] = float("nan")
+    b[9, 11] = float("-inf")   # faces non-zeros of a: a genuine -inf in column 11 on every route
+    b0 = b.clone()
+    b0[7] = 0.0
+    a_dense = torch.rand(16384, 512, device=dev, generator=g) + 0.1
+    a_dense[:, 7] = 0.0
+    a_sparse = a_dense * (torch.rand(16384, 512, device=dev, generator=g) < 0.004)
+    a_sparse[:, 9] = a_dense[:, 9]
+    for order in ((a_dense, a_sparse, a_dense), (a_sparse, a_dense, a_sparse)):
+        mm._density_of_shape.clear()
+        mm._density_of_tensor.clear()
+        for a in order:
+            del calls[:]
+            out = mm.naiveSpMM.apply(a, b)
+            skip = mm.naive_matmul(a, b, dense_route="never")
+            assert torch.equal(out.view(torch.int32), skip.view(torch.int32)), "auto must keep the zero-skipping result"
+            # the zero in column 7 of a is not a term of the sum: columns 3 and 5 stay finite, column 11 is -inf
+            assert bool(torch.isfinite(out[:, [3, 5]]).all()) and bool((out[:, 11] == float("-inf")).all())
+            ref0 = mm.naive_matmul(a, b0, dense_route="never")
+            keep = [c for c in range(256) if c != 11]
+            assert torch.equal(out[:, keep], ref0[:, keep])
+    # the dense operand did take the matrix cores (its own density is known by now), the sparse one did not
+    del calls[:]
+    mm.naiveSpMM.apply(a_dense, b)
+    assert calls
+    del calls[:]
+    mm.naiveSpMM.apply(a_sparse, b)
+    assert not calls
+    # pinned modes: 'always' = torch.matmul (0·inf = nan in columns 3 and 5), 'never' = no MFMA product
+    del calls[:]
+    out = mm.naive_matmul(a_sparse, b, dense_route="always")
+    assert calls
+    ref = torch.matmul(a_sparse, b)
+    assert torch.equal(torch.isnan(out), torch.isnan(ref)) and bool(torch.isnan(out[:, 3]).all())
+    prev = mm.set_dense_route("never")
+    try:
+        del calls[:]
+        mm.naiveSpMM.apply(a_dense, b)
+        assert not calls
+    finally:
+        mm.set_dense_route(prev)
+    with pytest.raises(ValueError):
+        mm.naive_matmul(a_dense, b, dense_route="sometimes")
+    # the gated launch by itself: runs iff the flag is set; covers N beyond 256 in one launch
+    x = torch.rand(300, 96, device=dev, generator=g) * (torch.rand(300, 96, device=dev, generator=g) < 0.3)
+    w = torch.rand(96, 1300 * 4, device=dev, generator=g) - 0.5
+    want = torch.empty(300, 5200, device=dev)
+    for n0 in range(0, 5200, 1024):
+        n1 = min(5200, n0 + 1024)
+        blk = torch.empty(300, n1 - n0, device=dev)
+        assert cmm.naive_spmm_dense(x, w[:, n0:n1].contiguous(), blk)
+        want[:, n0:n1] = blk
+    c = torch.full((300, 5200), -7.0, device=dev)
+    flag = cmm.nonfinite_flag(w)
+    assert int(flag) == 0
+    assert cmm.naive_spmm_dense_gated(x, w, c, flag, False) and bool((c == -7.0).all())
+    w2 = w.clone()
+    w2[95, 5199] = float("nan")
+    flag = cmm.nonfinite_flag(w2)
+    assert int(flag) == 1
+    assert cmm.naive_spmm_dense_gated(x, w, c, flag, False) and torch.equal(c, want)
+
+
+def test_naive_matmul_of_a_dense_matrix_is_graph_capturable(mm, dev):
+    """Advisor (round 2): under stream capture nothing may be read back — dense inputs take the in-kernel
+    zero-skipping route whenever it covers the shape, whatever the regime model says; replay follows new data."""
+    g = torch.Generator(device=dev).manual_seed(6)
+    a = torch.rand(2048, 1024, device=dev, generator=g) * (torch.rand(2048, 1024, device=dev, generator=g) < 0.05)
+    b = torch.rand(1024, 256, device=dev, generator=g)
+    mm.naive_matmul(a, b)  # warm-up outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = mm.naive_matmul(a, b)
+    a.copy_(torch.rand(2048, 1024, device=dev, generator=g) * (torch.rand(2048, 1024, device=dev, generator=g) < 0.05))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.allclose(out, a @ b, rtol=RTOL, atol=1e-4)
+
+
+def test_dense_inputs_beyond_the_fused_shapes_are_graph_capturable_and_fc_layers_read_nothing_back(mm, cmm, dev, monkeypatch):
+    """Round 4 (review item 7).  (1) A dense-with-zeros operand whose shape the in-kernel zero-skipping product does not
+    cover (1030 output columns: not a multiple of 4) takes dense→CSR + the CSR kernels; under stream capture the
+    conversion may not read the count back, so the arrays get room for every element and the kernels walk the rows
+    through the offsets: the capture goes through, the replay follows new data — a different number of non-zeros
+    included — and the bits equal the uncaptured call's.  (2) cusparseLinear's forward: its density comes from the
+    stream-ordered sample (matmuls.sampled_density) and its conversion is sized the same way — after the first forward
+    of a shape no `.item()` / int() read-back happens (checked by forbidding synchronisation)."""
+    g = torch.Generator(device=dev).manual_seed(16)
+
+    def sparse(shape, p):
+        return torch.rand(shape, device=dev, generator=g) * (torch.rand(shape, device=dev, generator=g) < p)
+    a = sparse((1500, 700), 0.05)
+    b = torch.rand(700, 1030, device=dev, generator=g) - 0.5
+    mm.naive_matmul(a, b, dense_route="never")  # warm-up outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = mm.naive_matmul(a, b, dense_route="never")
+    for p in (0.05, 0.3, 0.0):
+        a.copy_(sparse((1500, 700), p))
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = mm.naive_matmul(a, b, dense_route="never")
+        assert torch.equal(out, ref), p
+        assert torch.allclose(out, a @ b, rtol=RTOL, atol=1e-4)
+    # (2) a ReLU-sparse FC layer: first forward of the shape may wait for its own sample, later ones may not wait at all
+    import fc_layers
+    layer = fc_layers.cusparseLinear(3072, 768).to(dev)
+    x = sparse((4, 4096, 3072), 0.01)
+    y0 = layer(x)
+    torch.cuda.synchronize()
+    calls = []
+    real_fill = cmm.dense_to_csr_fill
+    monkeypatch.setattr(fc_layers.custom_mm, "dense_to_csr_fill",
+                        lambda d, o, n: (calls.append(n), real_fill(d, o, n))[1])
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        y1 = layer(x)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert calls == [x.numel()], "the sparse route ran with arrays sized for every element"
+    ref = torch.nn.functional.linear(x, layer.weight, layer.bias)
+    assert torch.equal(y0, y1) and torch.allclose(y1, ref, rtol=RTOL, atol=1e-5)
+    x.requires_grad_(True)
+    y2 = layer(x)
+    y2.backward(torch.ones_like(y2))
+    xr = x.detach().clone().requires_grad_(True)
+    wr = layer.weight.detach().clone().requires_grad_(True)
+    torch.nn.functional.linear(xr, wr, layer.bias.detach()).backward(torch.ones_like(y2))
+    assert torch.allclose(layer.weight.grad, wr.grad, rtol=1e-4, atol=1e-4) and torch.allclose(x.grad, xr.grad, rtol=RTOL, atol=1e-5)
+
+
+def test_batched_csr_tensor_as_the_sparse_operand(mm, dev):
+    """Reference matmuls.py:289-293 recurses over the leading dimension of `a`; here a batched CSR tensor runs as one
+    launch of the batched kernel (shared or per-item b), for both classes."""
+    g = torch.Generator().manual_seed(8)
+    dense = torch.rand(6, 40, 50, generator=g)
+    keep = torch.zeros(6, 40, 50, dtype=torch.bool)
+    for i in range(6):  # torch's batched CSR wants the same number of non-zeros in every item
+        idx = torch.randperm(2000, generator=g)[:300]
+        keep[i].view(-1)[idx] = True
+    dense = dense * keep
+    a = dense.to(dev).to_sparse_csr()
+    assert a.dim() == 3 and a.is_sparse_csr
+    for b in (torch.rand(50, 36, generator=g), torch.rand(6, 50, 64, generator=g)):
+        exp = torch.matmul(dense, b)
+        for cls in (mm.naiveSpMM, mm.cusparseMM):
+            out = cls.apply(a, b.to(dev))
+            assert out.shape == exp.shape and torch.allclose(exp, out.cpu(), rtol=RTOL, atol=1e-5)
+    a4 = (dense.reshape(2, 3, 40, 50)).to(dev).to_sparse_csr()
+    out = mm.naiveSpMM.apply(a4, torch.rand(2, 3, 50, 8, generator=g).to(dev))
+    assert out.shape == (2, 3, 40, 8)
+    with pytest.raises(RuntimeError):
+        mm.naive_matmul(a, torch.rand(5, 50, 8).to(dev))  # batch dimensions differ
+
+
+def test_transpose_cache_keeps_the_pattern_not_the_values(mm, dev):
+    """Advisor (round 2): a write to the values that bypasses the version counter must not meet a stale copy — the
+    cache on the CSR tensor holds the transposed pattern and a permutation; values are gathered per backward."""
+    g = torch.Generator().manual_seed(9)
+    a = torch.rand(60, 80, generator=g) * (torch.rand(60, 80, generator=g) < 0.15)
+    b = torch.rand(80, 32, generator=g)
+    dc = torch.rand(60, 32, generator=g)
+    a_csr = a.to(dev).to_sparse_csr().requires_grad_(True)
+    b1 = b.to(dev).requires_grad_(True)
+    mm.naiveSpMM.apply(a_csr, b1).backward(dc.to(dev))
+    assert torch.allclose((a.t() @ dc), b1.grad.cpu(), rtol=RTOL, atol=1e-5)
+    a_csr.values().data.mul_(3.0)  # no version bump
+    b1.grad = None
+    mm.naiveSpMM.apply(a_csr, b1).backward(dc.to(dev))
+    assert torch.allclose(3.0 * (a.t() @ dc), b1.grad.cpu(), rtol=RTOL, atol=1e-4)
+
+
+def test_reference_test_shapes_at_full_size(mm, cmm, dev, oracle_mod):
+    """reference tests/naive_kernel_test.py:67-68 and tests/cublas_kernel_test.py:68-69 at their own size:
+    (256,16,512,512) × (256,16,512,64) through cublasMM, cublasTransbMM and naiveSpMM against torch.matmul at the
+    reference's tolerance, and the CSR route on the fully dense "sparse" input — 1.07 × 10⁹ non-zeros in one batched
+    CSR: the int32 index guard and the 64-bit offsets meet a shape the reference holds."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs ≈ 30 GB of device memory")
+    g = torch.Generator(device=dev).manual_seed(11)
+    a = torch.rand(256, 16, 512, 512, device=dev, generator=g)
+    b = torch.rand(256, 16, 512, 64, device=dev, generator=g)
+    exp = torch.matmul(a, b)
+    dense_out = mm.cublasMM.apply(a, b)
+    assert torch.allclose(exp, dense_out, rtol=RTOL, atol=ATOL)
+    out = mm.naiveSpMM.apply(a, b)  # dense input: the matrix cores
+    assert torch.allclose(exp, out, rtol=RTOL, atol=ATOL)
+    # sampled heads against the CPU oracle (bit-exact: same ascending-k fmaf chain) and against torch-CPU matmul —
+    # the reference tests' own expectation — so this test does not rest on hipBLASLt's GPU matmul alone
+    heads = [(0, 0), (131, 7), (255, 15)]
+    for (i, j) in heads:
+        ah, bh = a[i, j].cpu().numpy(), b[i, j].cpu().numpy()
+        want = oracle_mod.gemm(ah, bh)
+        assert np.array_equal(dense_out[i, j].cpu().numpy(), want), (i, j)
+        assert np.array_equal(out[i, j].cpu().numpy(), want), (i, j)
+        assert torch.allclose(torch.from_numpy(want), torch.matmul(a[i, j].cpu(), b[i, j].cpu()), rtol=RTOL, atol=ATOL)
+    del dense_out
+    # the CSR route at 2³⁰ non-zeros, in chunks of ≤ 65535 items as matmuls does
+    values, columns, offsets = cmm.dense_to_csr(a.reshape(-1, 512, 512))
+    # (torch.rand draws an exact 0 about once in 2²⁴ samples: a few dozen of the 2³⁰ entries)
+    assert values.numel() == int(torch.count_nonzero(a)) > 2 ** 30 - 4096 and int(offsets.view(-1)[-1]) == values.numel()
+    c = torch.empty(4096, 512, 64, device=dev)
+    cmm.naive_spmm_batched(values, columns, offsets, values.numel(), 4096, 512, 512, b.reshape(4096, 512, 64), c)
+    assert torch.equal(c.view_as(out), out)  # same chain either way
+    del values, columns, offsets, c, out
+    q = torch.rand(256, 16, 512, 64, device=dev, generator=g)
+    scores = mm.cublasTransbMM.apply(q, b)
+    ref = torch.matmul(q, b.transpose(-1, -2))
+    assert torch.allclose(ref, scores, rtol=RTOL, atol=ATOL)
+    for (i, j) in heads:
+        want = oracle_mod.gemm(q[i, j].cpu().numpy(), b[i, j].cpu().numpy(), False, True)
+        assert np.array_equal(scores[i, j].cpu().numpy(), want), (i, j)
+        assert torch.allclose(torch.from_numpy(want), torch.matmul(q[i, j].cpu(), b[i, j].cpu().t()), rtol=RTOL, atol=ATOL)
+
+
+def test_matmuls_broadcasting_fuzz_forward_and_backward(mm, dev):
+    """Random operand ranks and batch shapes as torch.matmul broadcasts them (dims of size 1, missing leading dims,
+    rank-1 operands for the dense classes, transposed and sliced views) through every autograd class of matmuls.py
+    (reference matmuls.py:75-327): forward and both gradients against torch.matmul and its autograd at the reference
+    tests' tolerance (rtol 1e-5)."""
+    import os
+    g = torch.Generator().manual_seed(int(os.environ.get("MI_FUZZ_SEED", "404")))
+    cases = int(os.environ.get("MI_FUZZ_CASES", "60"))
+    ri = lambda lo, hi: int(torch.randint(lo, hi, (1,), generator=g))
+    classes = [("cublasMM", 0, 0, False), ("cublasTransaMM", 1, 0, False), ("cublasTransbMM", 0, 1, False),
+               ("cublasTransabMM", 1, 1, False), ("naiveSpMM", 0, 0, True), ("cusparseMM", 0, 0, True)]
+
+    def operand(batch, rows, cols, density):
+        kind = ri(0, 3)
+        if kind == 0:
+            x = torch.rand(*batch, rows, cols, generator=g)
+        elif kind == 1:   # a transposed view
+            x = torch.rand(*batch, cols, rows, generator=g).transpose(-1, -2)
+        else:             # a slice of a wider tensor
+            x = torch.rand(*batch, rows, cols + 5, generator=g)[..., 2:cols + 2]
+        if density < 1.0:
+            x = x * (torch.rand(*batch, rows, cols, generator=g) < density)
+        return x
+
+    for case in range(cases):
+        name, ta, tb, sparse = classes[ri(0, len(classes))]
+        common = tuple(ri(1, 4) for _ in range(ri(0, 4)))
+        def batch_of():
+            keep = ri(0, len(common) + 1)
+            b = list(common[len(common) - keep:])
+            return tuple(1 if ri(0, 4) == 0 else d for d in b)
+        ba, bb = batch_of(), batch_of()
+        m, n, k = ri(1, 70), ri(1, 70), ri(1, 65)
+        density = (0.0, 0.1, 0.5, 1.0)[ri(0, 4)] if sparse else 1.0
+        a = operand(ba, *((k, m) if ta else (m, k)), density)
+        b = operand(bb, *((n, k) if tb else (k, n)), 1.0)
+        if not sparse and not ta and not tb and ri(0, 6) == 0:   # rank-1 operands
+            if ri(0, 2):
+                a = torch.rand(k, generator=g)
+            else:
+                b = torch.rand(k, generator=g)
+        ref = lambda x, y: torch.matmul(x.transpose(-1, -2) if ta and x.dim() > 1 else x,
+                                        y.transpose(-1, -2) if tb and y.dim() > 1 else y)
+        try:
+            fwd_bwd_device(getattr(mm, name).apply, ref, a, b, dev)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: {name} a{tuple(a.shape)} (strides {a.stride()}) b{tuple(b.shape)} "
+                                 f"(strides {b.stride()}) density {density}") from e
+
+
+def test_batched_csr_tensor_backward_beyond_65535_items(mm, dev):
+    """The reference's recursion takes any number of slices (matmuls.py:289-293); round 3's backward stopped at 65535 items
+    (the launch's grid.y).  Now chunked like the forward, the batched transpose included: 70 000 items of 3×5, both
+    gradients against torch autograd of the dense product."""
+    g = torch.Generator().manual_seed(12)
+    nb, M, K, N, per = 70_000, 3, 5, 4, 6
+    keep = torch.zeros(nb, M * K, dtype=torch.bool)
+    keep.scatter_(1, torch.rand(nb, M * K, generator=g).topk(per, dim=1).indices, True)
+    dense = (torch.rand(nb, M, K, generator=g) + 0.1) * keep.reshape(nb, M, K)
+    b = torch.rand(nb, K, N, generator=g)
+    a = dense.to(dev).to_sparse_csr().requires_grad_(True)
+    b1 = b.to(dev).requires_grad_(True)
+    out = mm.cusparseMM.apply(a, b1)
+    dc = torch.rand(nb, M, N, generator=g)
+    out.backward(dc.to(dev))
+    a2, b2 = dense.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.matmul(a2, b2)
+    ref.backward(dc)
+    assert torch.allclose(ref, out.detach().cpu(), rtol=RTOL, atol=1e-6)
+    assert torch.allclose(b2.grad, b1.grad.cpu(), rtol=RTOL, atol=1e-6)
+    assert torch.allclose(a2.grad * keep.reshape(nb, M, K), a.grad.to_dense().cpu(), rtol=RTOL, atol=1e-6)
+
+
+def test_batched_csr_tensor_backward(mm, dev):
+    """Both gradients of a product whose sparse operand is a batched CSR tensor (pruned attention probabilities × V,
+    BASELINE.json configs[4]): grad of the dense operand (per item, and summed for a shared one) against torch autograd
+    of the dense product; grad of the sparse operand comes back as a batched CSR tensor on the operand's pattern,
+    equal to the dense gradient sampled there.  The reference has no backward for this input (matmuls.py:250-254)."""
+    g = torch.Generator().manual_seed(9)
+    nb, M, K = 6, 40, 50
+    dense = torch.rand(nb, M, K, generator=g)
+    keep = torch.zeros(nb, M, K, dtype=torch.bool)
+    for i in range(nb):
+        keep[i].view(-1)[torch.randperm(M * K, generator=g)[:300]] = True
+    dense = dense * keep
+    for b in (torch.rand(nb, K, 64, generator=g), torch.rand(K, 36, generator=g), torch.rand(2, 3, K, 8, generator=g)):
+        a_shape = (2, 3, M, K) if b.dim() == 4 else (nb, M, K)
+        for cls in (mm.naiveSpMM, mm.cusparseMM):
+            a = dense.reshape(a_shape).to(dev).to_sparse_csr().requires_grad_(True)
+            b1 = b.to(dev).requires_grad_(True)
+            out = cls.apply(a, b1)
+            dc = torch.rand(out.shape, generator=torch.Generator().manual_seed(4))
+            out.backward(dc.to(dev))
+            a2, b2 = dense.reshape(a_shape).clone().requires_grad_(True), b.clone().requires_grad_(True)
+            torch.matmul(a2, b2).backward(dc)
+            assert torch.allclose(b2.grad, b1.grad.cpu(), rtol=RTOL, atol=1e-5)
+            assert a.grad.is_sparse_csr and a.grad.shape == a.shape
+            assert torch.equal(a.grad.col_indices().cpu(), a.col_indices().cpu())
+            assert torch.allclose((a2.grad * keep.reshape(a_shape)), a.grad.to_dense().cpu(), rtol=RTOL, atol=1e-5)
+
+
+@pytest.mark.parametrize("kept", [0.10, 0.25])
+def test_config_c5_pruned_attention_as_batched_csr_full_size_forward_and_backward(mm, cmm, dev, oracle_mod, kept):
+    """BASELINE.json configs[4], the SpMM leg at FULL size: attention probabilities (32, 12, 512, 512) pruned to the
+    top `kept` share of every row, handed over as ONE 4-d batched CSR tensor, times V (32, 12, 512, 64) through
+    cusparseMM.apply and naiveSpMM.apply, forward + both gradients (the reference reaches this through the per-slice
+    recursion matmuls.py:289-297 and has no working backward for it, :245-256).  Checked on sampled (b, h) items
+    against torch-CPU autograd of the dense product (the reference tests' criterion, tests/naive_kernel_test.py:30-37)
+    and bit-exact against the oracle: forward = oracle.spmm_csr_batched, grad of the values = oracle.sddmm,
+    grad of V = the oracle's CSR product with the oracle's transpose."""
+    Bz, H, S, D = 32, 12, 512, 64
+    g = torch.Generator(device=dev).manual_seed(21)
+    probs = torch.softmax(torch.rand(Bz, H, S, S, device=dev, generator=g) * 4, dim=-1)
+    keep_n = int(round(S * kept))
+    idx = probs.topk(keep_n, dim=-1).indices.sort(dim=-1).values           # [Bz, H, S, keep_n], ascending columns
+    vals = probs.gather(-1, idx)
+    crow = (torch.arange(S + 1, device=dev, dtype=torch.int64) * keep_n).expand(Bz, H, S + 1).contiguous()
+    v = torch.rand(Bz, H, S, D, device=dev, generator=g) - 0.5
+    d_ctx = torch.rand(Bz, H, S, D, device=dev, generator=g) - 0.5
+    items = [(0, 0), (17, 5), (31, 11)]
+    outs = {}
+    for cls in (mm.cusparseMM, mm.naiveSpMM):
+        a = torch.sparse_csr_tensor(crow, idx.reshape(Bz, H, -1), vals.reshape(Bz, H, -1), size=(Bz, H, S, S),
+                                    device=dev).requires_grad_(True)
+        v1 = v.clone().requires_grad_(True)
+        out = cls.apply(a, v1)
+        assert out.shape == (Bz, H, S, D)
+        out.backward(d_ctx)
+        assert a.grad.is_sparse_csr and a.grad.shape == a.shape and v1.grad.shape == v.shape
+        gvals = a.grad.values().reshape(Bz, H, S * keep_n)
+        outs[cls.__name__] = (out.detach(), v1.grad, gvals)
+        for (i, j) in items:
+            rp = (np.arange(S + 1) * keep_n).astype(np.int32)
+            col = idx[i, j].reshape(-1).cpu().numpy().astype(np.int32)
+            val = vals[i, j].reshape(-1).cpu().numpy()
+            vh, dh = v[i, j].cpu().numpy(), d_ctx[i, j].cpu().numpy()
+            # forward: the CSR-order chain
+            want = oracle_mod.spmm_csr_batched(rp.reshape(1, -1), col, val, 1, S, S, vh.reshape(1, S, D))[0]
+            assert np.array_equal(out[i, j].detach().cpu().numpy(), want), (cls.__name__, i, j)
+            # grad of the values on the pattern: <dC[row], V[col]>
+            assert np.array_equal(gvals[i, j].cpu().numpy(), oracle_mod.sddmm(rp, col, S, dh, vh)), (cls.__name__, i, j)
+            # grad of V = Aᵀ·dC, Aᵀ by the oracle's transpose (rows of Aᵀ keep A's row order: ascending columns)
+            t_rp, t_col, t_val = oracle_mod.csr_transpose(rp, col, val, S, S)
+            assert np.array_equal(v1.grad[i, j].cpu().numpy(), oracle_mod.spmm_csr(t_rp, t_col, t_val, S, S, dh)), \
+                (cls.__name__, i, j)
+            # torch-CPU autograd of the dense product on the same item
+            ad = torch.zeros(S, S)
+            ad[torch.arange(S).repeat_interleave(keep_n), torch.from_numpy(col.astype(np.int64))] = torch.from_numpy(val)
+            ad.requires_grad_(True)
+            vd = torch.from_numpy(vh).clone().requires_grad_(True)
+            ref = torch.matmul(ad, vd)
+            ref.backward(torch.from_numpy(dh))
+            assert torch.allclose(ref.detach(), out[i, j].detach().cpu(), rtol=RTOL, atol=1e-6)
+            assert torch.allclose(vd.grad, v1.grad[i, j].cpu(), rtol=RTOL, atol=1e-6)
+            picked = ad.grad[torch.arange(S).repeat_interleave(keep_n), torch.from_numpy(col.astype(np.int64))]
+            assert torch.allclose(picked, gvals[i, j].cpu(), rtol=RTOL, atol=1e-6)
+    # both classes run the same kernels: identical bits over the WHOLE batch
+    for x, y in zip(outs["cusparseMM"], outs["naiveSpMM"]):
+        assert torch.equal(x, y)
+    # whole-batch property: the product is linear in V — A·(2V) == 2·(A·V) exactly
+    a = torch.sparse_csr_tensor(crow, idx.reshape(Bz, H, -1), vals.reshape(Bz, H, -1), size=(Bz, H, S, S), device=dev)
+    assert torch.equal(mm.cusparseMM.apply(a, v * 2), outs["cusparseMM"][0] * 2)
+
+
+def test_cusparse_linear_lds_fit_layer_with_a_stale_low_density_estimate(mm, cmm, dev, monkeypatch):
+    """Round 5 (advisor, high): cusparseLinear's no-read-back route tells the kernels an ESTIMATED count, which may be below
+    the true one (a 512-row sample, or the previous step's).  At 65536 tokens × 1024 → 256 and ≈1 % non-zeros AUTO takes
+    MI_SPMM_LDS_B, whose quad form clamps its 16-byte col / val loads — from max(count, offsets' last entry) since this
+    round, so an estimate of half the true density must give the same bits as the exact count, and nn.Linear's values.
+    Reference call site: benchmarks/cusparse_fc_layer.py:41-45."""
+    sys.modules.pop("fc_layers", None)
+    import fc_layers
+    g = torch.Generator().manual_seed(5)
+    tokens, fin, fout = 65536, 1024, 256
+    x = torch.rand(tokens, fin, generator=g) * (torch.rand(tokens, fin, generator=g) < 0.01)
+    x[-1].zero_()
+    x[-1, 5], x[-1, 900] = 0.25, -0.5   # the arrays end inside a 16-byte load
+    layer = fc_layers.cusparseLinear(fin, fout, bias=True).to(dev)
+    xd = x.to(dev)
+    true_density = float(torch.count_nonzero(x)) / x.numel()
+    outs = {}
+    for name, est in (("exact", true_density), ("stale_low", 0.5 * true_density), ("high", 1.2 * true_density)):
+        monkeypatch.setattr(fc_layers, "sampled_density", lambda *a, _e=est, **k: _e)
+        nnz_arg = min(x.numel(), max(1, int(est * x.numel())))
+        assert cmm.spmm_plan(nnz_arg, tokens, fin, layer.weight.t().contiguous(), torch.empty(tokens, fout, device=dev))[0] == 18
+        y = layer(xd)
+        outs[name] = y.detach().cpu()
+    assert torch.equal(outs["exact"], outs["stale_low"]) and torch.equal(outs["exact"], outs["high"])
+    ref = torch.nn.functional.linear(x, layer.weight.detach().cpu(), layer.bias.detach().cpu())
+    assert torch.allclose(ref, outs["exact"], rtol=RTOL, atol=1e-6)

@@ -1,0 +1,183 @@
+"""The SpMM hot path across the HBM regime (B beyond the 256 MiB Infinity Cache), not on the one pinned C3 point.
+
+    python tools/bench_hbm_regime.py [--quick] [--variants] [--only TAG]
+
+Every row goes through `custom_mm.naive_spmm` (the reference's entry, src/custom_mm.cpp:166-179); the plan name comes from
+`custom_mm.spmm_plan`.  Per row: ms, algorithmic GB/s (`nnz·(4N+8) + 4(M+1) + 4MN`), the fraction of
+8 TB/s, and a bit-exact check of sampled rows against the oracle (the rows' sub-matrix with its columns renumbered in
+order — the per-element chain is unchanged — times the gathered rows of B, on the CPU).
+`--variants` also times the candidate plans pinned through the C-ABI (`mi_spmm_csr_f32_variant`), AUTO's starred.
+
+Patterns: `uniform` (the pinned generator's distribution: unique uniform keys in [0, M·K)), `banded` (columns within
+± 32 K of the diagonal), `powerlaw` (column popularity ∝ rank^-1.5 or so: col = ⌊K·u⁴⌋ scattered by an odd multiplier).
+Reference: src/naive_sparse_mm.cu:39,116 takes any N through one kernel.
+"""
+import argparse
+import ctypes
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "matrix-multiplication_amd"))
+sys.path.insert(0, str(ROOT))
+import custom_mm  # noqa: E402
+import oracle  # noqa: E402  (checker only)
+
+lib = ctypes.CDLL(str(Path(custom_mm.__file__).parent / "libmi_spmm.so"))
+vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+lib.mi_spmm_csr_f32_variant.argtypes = [ctypes.c_int, vp, vp, vp, i64, i32, i32, i32, vp, i64, vp, i64, vp]
+lib.mi_spmm_variant_name.restype = ctypes.c_char_p
+dev = torch.device("cuda")
+
+
+def make_csr(M, K, per_row, pattern, seed=0):
+    """(rowptr int32[M+1], col int32[nnz], val f32[nnz]) on the device; rows sorted, columns unique within a row."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    cols, counts = [], []
+    step = max(1, min(M, (1 << 28) // max(per_row, 1)))  # ≤ 2²⁸ keys per block of rows
+    for r0 in range(0, M, step):
+        rows = min(step, M - r0)
+        n = rows * per_row
+        if pattern == "uniform":
+            keys = torch.randint(0, rows * K, (n,), device=dev, generator=g, dtype=torch.int64)
+        else:
+            r = torch.randint(0, rows, (n,), device=dev, generator=g, dtype=torch.int64)
+            if pattern == "banded":
+                off = torch.randint(-32768, 32769, (n,), device=dev, generator=g, dtype=torch.int64)
+                c = (r + r0) * K // M + off
+                c = c.clamp_(0, K - 1)
+            elif pattern == "powerlaw":
+                u = torch.rand(n, device=dev, generator=g, dtype=torch.float64)
+                c = (u.pow_(4) * K).long().clamp_(0, K - 1)
+                c = (c * 2654435761) % K  # K a power of two: an odd multiplier is a bijection (hot columns scattered)
+            else:
+                raise ValueError(pattern)
+            keys = r * K + c
+            del r, c
+        keys = torch.unique(keys)  # sorted
+        cols.append((keys % K).to(torch.int32))
+        counts.append(torch.bincount(keys // K, minlength=rows))
+        del keys
+    col = torch.cat(cols)
+    cnt = torch.cat(counts)
+    rowptr = torch.zeros(M + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(cnt, 0)
+    assert int(rowptr[-1]) == col.numel() < 2**31
+    val = torch.rand(col.numel(), device=dev, generator=g)
+    return rowptr.to(torch.int32), col, val
+
+
+def check_rows(rowptr, col, val, B, C, K, n_rows=192, seed=0):
+    """Sampled rows of C bit-exact against the oracle."""
+    M = rowptr.numel() - 1
+    rs = np.unique(np.concatenate([[0, M - 1], np.random.default_rng(seed).integers(0, M, n_rows)]))
+    rp = rowptr.cpu().numpy().astype(np.int64)
+    segs = [np.arange(rp[r], rp[r + 1]) for r in rs]
+    idx = torch.from_numpy(np.concatenate(segs) if segs else np.zeros(0, np.int64)).to(dev)
+    c = col[idx].cpu().numpy()
+    v = val[idx].cpu().numpy()
+    sub_rp = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.int32)
+    uniq, inv = np.unique(c, return_inverse=True)
+    Bs = B[torch.from_numpy(uniq.astype(np.int64)).to(dev)].cpu().numpy()
+    want = oracle.spmm_csr(sub_rp, inv.astype(np.int32), v, len(rs), len(uniq), Bs)
+    got = C[torch.from_numpy(rs).to(dev)].cpu().numpy()
+    return np.array_equal(want.view(np.uint32), got.view(np.uint32)), len(rs)
+
+
+def timeit(fn, min_iters=3, budget_ms=1500.0):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    torch.cuda.synchronize()
+    one = e0.elapsed_time(e1)
+    iters = int(max(min_iters, min(50, budget_ms / max(one, 1e-3))))
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def run(tag, M, K, N, per_row, pattern, variants, out):
+    t0 = time.time()
+    rowptr, col, val = make_csr(M, K, per_row, pattern)
+    nnz = col.numel()
+    g = torch.Generator(device=dev).manual_seed(1)
+    B = torch.rand(K, N, device=dev, generator=g)
+    C = torch.empty(M, N, device=dev)
+    plan = custom_mm.spmm_plan(nnz, M, K, B, C)
+    ms = timeit(lambda: custom_mm.naive_spmm(val, col, rowptr, nnz, M, K, B, C))
+    ok, nr = check_rows(rowptr, col, val, B, C, K)
+    alg = nnz * (4 * N + 8) + 4 * (M + 1) + 4 * M * N
+    gbs = alg / ms / 1e6
+    line = (f"{tag:<28} M=K={M:>8} N={N:>4} nnz/row={nnz / M:7.1f} |B|={K * N * 4 / 2**20:6.0f} MiB  plan {plan[0]:>2} "
+            f"{plan[1]:<28} x{plan[2]}  {ms:9.3f} ms  {gbs:7.0f} GB/s  frac {gbs / 8000:.3f}  "
+            f"{2 * nnz * N / ms / 1e6:7.0f} GFLOP/s  rows {'bit-exact' if ok else 'MISMATCH'} ({nr})")
+    if variants:
+        st = torch.cuda.current_stream().cuda_stream
+        alt = []
+        for v in (2, 3, 4, 6, 7, 8, 14):
+            Cv = torch.empty_like(C)
+            args = (v, rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), nnz, M, K, N, B.data_ptr(), N, Cv.data_ptr(), N, st)
+            if lib.mi_spmm_csr_f32_variant(*args) != 0:
+                continue
+            t = timeit(lambda: lib.mi_spmm_csr_f32_variant(*args), budget_ms=600.0)
+            same = torch.equal(Cv.view(torch.int32), C.view(torch.int32))
+            alt.append(f"{v}{'*' if v == plan[0] else ''}:{t:.3f}{'' if same else '!'}")
+            del Cv
+        line += "   variants " + " ".join(alt)
+    line += f"   [{time.time() - t0:.0f} s]"
+    print(line, flush=True)
+    out.append(line)
+    assert ok, "sampled rows differ from the oracle"
+    del rowptr, col, val, B, C
+    torch.cuda.empty_cache()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true", help="1M rows only")
+    ap.add_argument("--variants", action="store_true")
+    ap.add_argument("--only", default="")
+    ap.add_argument("--log", default="")
+    a = ap.parse_args()
+    oracle.build()
+    print(f"# device {torch.cuda.get_device_name(0)}; ms per product through custom_mm.naive_spmm; frac = algorithmic GB/s / 8000",
+          flush=True)
+    out = []
+    sizes = [1 << 20] if a.quick else [1 << 20, 1 << 21, 1 << 22]
+    cases = []
+    for mk in sizes:
+        for n in (64, 128, 256, 512):
+            if mk * n * 4 < (512 << 20):
+                continue  # B inside the Infinity-Cache regime
+            for d in (20, 100, 400):
+                if mk * d >= 2**31 - 2**24:
+                    continue
+                cases.append((f"uniform/{mk >> 20}M/N{n}/d{d}", mk, mk, n, d, "uniform"))
+    for n in (256,):
+        for d in (20, 100):
+            cases.append((f"banded/1M/N{n}/d{d}", 1 << 20, 1 << 20, n, d, "banded"))
+            cases.append((f"powerlaw/1M/N{n}/d{d}", 1 << 20, 1 << 20, n, d, "powerlaw"))
+    for n in (128,):
+        cases.append((f"banded/4M/N{n}/d100", 1 << 22, 1 << 22, n, 100, "banded"))
+        cases.append((f"powerlaw/4M/N{n}/d100", 1 << 22, 1 << 22, n, 100, "powerlaw"))
+    for c in cases:
+        if a.only and a.only not in c[0]:
+            continue
+        run(*c, a.variants, out)
+    if a.log:
+        Path(a.log).parent.mkdir(parents=True, exist_ok=True)
+        Path(a.log).write_text("\n".join(out) + "\n")
+
+
+if __name__ == "__main__":
+    main()
