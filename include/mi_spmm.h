@@ -150,7 +150,10 @@ enum {
                                through LDS in 64-row slabs, one ds_read_b128 per non-zero           */
   MI_SPMM_LDS_B = 18,       /* K·N·4 ≤ 128 KB (N ≤ 256, N % 4 == 0): an item's whole B copied into LDS, rows
                                gather from there — batched products of small matrices (pruned attention) */
-  MI_SPMM_VARIANT_COUNT = 19
+  MI_SPMM_GROUP_PANELS_2 = 19, /* N ≤ 128 (float4 lanes), B beyond the Infinity Cache: the lane-group kernel in 2 column   */
+  MI_SPMM_GROUP_PANELS_3 = 20, /*   panels (3, 4), one launch per panel, C carried; a pass takes the entries whose running */
+  MI_SPMM_GROUP_PANELS_4 = 21, /*   maximum of the row's columns lies in its panel: CSR order kept for every legal input   */
+  MI_SPMM_VARIANT_COUNT = 22
 };
 /* The two forms of MI_SPMM_LDS_B (same bits): 16 lanes per row (any tile width), or — tiles of 64 / 128 columns — a
  * quad per row with 16-byte loads of col / val (what BERT's head size runs).  form: -1 by rule (default), 0 the 16-lane
@@ -160,6 +163,11 @@ int mi_spmm_csr_f32_variant(int variant, const int32_t* rowptr, const int32_t* c
                             const float* val, int64_t nnz, int32_t M, int32_t K,
                             int32_t N, const float* B, int64_t ldb, float* C,
                             int64_t ldc, mi_stream_t stream);
+/* mi_spmm_csr_ex_f32 with the plan pinned (benchmarks and tests: bias and the long-row rule on a chosen kernel). */
+int mi_spmm_csr_ex_variant_f32(int variant, const int32_t* rowptr, const int32_t* col, const float* val,
+                               int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,
+                               const float* bias, float* C, int64_t ldc, int long_rows, void* workspace,
+                               size_t workspace_bytes, mi_stream_t stream);
 
 /* What MI_SPMM_AUTO resolves to for this problem (no GPU work), how many kernel
  * launches a variant issues per product, and the kernel's name as profilers show

@@ -660,6 +660,132 @@ int launch_group(const int* rowptr, const int* col, const float* val, const floa
   return mi::check_launch();
 }
 
+// ---------------------------------------------------------------------------
+// Column-panel passes for the lane-group kernel (round 5): N ≤ 128 with B beyond the Infinity Cache (N = 64 at
+// K ≥ 3 M, N = 128 at K ≥ 1.5 M: a 256- or 512-byte row gathered at random from 1 GiB and more).  Same idea as
+// spmm_wave_row_panel_kernel — K cut into P panels whose slice of B the cache can hold, one launch per panel, all
+// CUs on the same panel at the same time, C carried through memory — with another way of staying exact: a pass
+// takes the entries whose RUNNING MAXIMUM of the columns so far (m_i = max_{j ≤ i} col_j, a prefix maximum over the
+// row) falls in its panel.  m is non-decreasing, so the passes cut every row into P contiguous index ranges in CSR
+// order, whatever the order of its columns: the per-element fmaf chain is the one-pass chain for every legal CSR
+// input, with no descent check and no recomputation (for a sorted row m_i = col_i and a pass gathers exactly its own
+// panel's rows of B; in an unsorted row an entry may be gathered in a later panel's pass — slower, same bits).
+// A pass scans the row's columns from its start (4 bytes per non-zero and pass against 4N + 8 of gathers) and stops
+// at the first chunk that ends beyond its panel.
+// G = 16 (N ≤ 64) or 32 (N ≤ 128) lanes per row, float4 per lane; grid = ⌈M / (4·64/G)⌉, block = 256.
+// ---------------------------------------------------------------------------
+constexpr int kIntMin = -0x7fffffff - 1;
+
+template <int G>
+__device__ __forceinline__ int group_prefix_max(int x, int gl) {
+#pragma unroll
+  for (int d = 1; d < G; d <<= 1) {
+    const int y = __shfl_up(x, d, G);
+    if (gl >= d) x = x > y ? x : y;
+  }
+  return x;
+}
+
+template <bool FIRST, int G>
+__global__ __launch_bounds__(256) void spmm_group_panel_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+    const float* __restrict__ B, float* __restrict__ C, int M, int N, long ldb, long ldc, int c_lo, int c_hi,
+    const float* __restrict__ bias, int last_pass, LongArg la) {
+  constexpr int RPW = 64 / G;
+  constexpr int UI = 4;
+  const int lane = threadIdx.x & 63;
+  const int gl = lane & (G - 1);
+  const int gshift = lane & ~(G - 1);  // first lane of this group inside the wave
+  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + (lane / G);
+  const int coff = gl * 4;
+  const bool on = coff < N;
+  int start = 0, end = 0;
+  if (row < M) {
+    start = rowptr[row];
+    end = rowptr[row + 1];
+  }
+  const bool skipped = end - start > la.thresh;  // left to spmm_long_rows_kernel (in every pass)
+  if (skipped) {
+    if (FIRST && gl == 0) long_list_append(la, (int)row, end - start);
+    end = start;
+  }
+  float* dst = C + row * ldc + coff;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (!FIRST && row < M && !skipped && on) acc = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dst));
+  int prev_max = kIntMin;  // running maximum of the columns of the chunks behind
+  constexpr unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+  for (int p = start; p < end; p += G) {  // trip count differs between groups
+    const int idx = p + gl;
+    const bool there = idx < end;
+    const int myc = there ? col[idx] : kIntMin;
+    int m = group_prefix_max<G>(myc, gl);
+    m = m > prev_max ? m : prev_max;
+    prev_max = __shfl(m, G - 1, G);
+    const bool below = there && m < c_lo;
+    const bool inq = there && m >= c_lo && m < c_hi;
+    const int i0 = __builtin_popcountll((__ballot(below) >> gshift) & gmask);       // group-uniform: first entry of this pass
+    const int i1 = i0 + __builtin_popcountll((__ballot(inq) >> gshift) & gmask);    // … one past its last
+    if (i1 > i0) {
+      const float myv = inq ? val[idx] : 0.f;
+      mi::static_for<G / UI>([&](auto b_) {
+        constexpr int b = UI * decltype(b_)::value;
+        if (b >= i0 && b + UI <= i1) {
+          f32x4 x[UI];
+          float v[UI];
+          mi::static_for<UI>([&](auto u_) {
+            constexpr int u = decltype(u_)::value;
+            const int c = mi::group_lane<G, b + u, false>(myc);
+            v[u] = mi::group_lane<G, b + u, false>(myv);
+            if (on) x[u] = *reinterpret_cast<const f32x4*>(B + (long)c * ldb + coff);
+          });
+#pragma unroll
+          for (int u = 0; u < UI; ++u)
+            if (on) acc = fma4(v[u], x[u], acc);
+        } else if (b + UI > i0 && b < i1) {
+          mi::static_for<UI>([&](auto u_) {
+            constexpr int u = decltype(u_)::value;
+            const int c = mi::group_lane<G, b + u, false>(myc);
+            const float v = mi::group_lane<G, b + u, false>(myv);
+            if (b + u >= i0 && b + u < i1 && on) acc = fma4(v, *reinterpret_cast<const f32x4*>(B + (long)c * ldb + coff), acc);
+          });
+        }
+      });
+    }
+    if (prev_max >= c_hi) break;  // every later entry belongs to a later pass
+  }
+  if (row < M && !skipped && on) {
+    if (bias && last_pass) acc += *reinterpret_cast<const f32x4*>(bias + coff);
+    __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(dst));
+  }
+}
+
+template <int G>
+int launch_group_panels_t(int panels, const int* rowptr, const int* col, const float* val, const float* B, float* C,
+                          int M, int K, int N, long ldb, long ldc, const float* bias, LongArg la, hipStream_t s) {
+  constexpr int rows_per_block = 4 * (64 / G);
+  const long blocks = ((long)M + rows_per_block - 1) / rows_per_block;
+  if (blocks > 0x7fffffffL) return MI_ERANGE;
+  const long kp = ((long)K + panels - 1) / panels;
+  for (int q = 0; q < panels; ++q) {
+    const int lo = (int)(q * kp);
+    // the last pass takes whatever is left (columns ≥ K of a lying matrix included: every entry is summed exactly once)
+    const int hi = q == panels - 1 ? 0x7fffffff : (int)((q + 1) * kp);
+    if (q == 0)
+      hipLaunchKernelGGL((spmm_group_panel_kernel<true, G>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, val, B, C,
+                         M, N, ldb, ldc, kIntMin, hi, bias, q == panels - 1 ? 1 : 0, la);  // (first pass: from the smallest int, as lo is unused)
+    else
+      hipLaunchKernelGGL((spmm_group_panel_kernel<false, G>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, val, B, C,
+                         M, N, ldb, ldc, lo, hi, bias, q == panels - 1 ? 1 : 0, la);
+  }
+  return mi::check_launch();
+}
+
+int launch_group_panels(int panels, const int* rowptr, const int* col, const float* val, const float* B, float* C, int M,
+                        int K, int N, long ldb, long ldc, const float* bias, LongArg la, hipStream_t s) {
+  if (N <= 64) return launch_group_panels_t<16>(panels, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
+  return launch_group_panels_t<32>(panels, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
+}
+
 // Column-tiled launch of the float4 group kernel: tile_cols = 4·G columns per tile.
 template <int G>
 int launch_coltile(const int* rowptr, const int* col, const float* val, const float* B, float* C, int M,
@@ -1094,6 +1220,9 @@ int launch_variant(int variant, const Shape& sh, const int32_t* rowptr, const in
       static const int kPanels[] = {2, 3, 4, 5, 6, 8};
       return launch_panels(kPanels[variant - MI_SPMM_PANELS_2], rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
     }
+    case MI_SPMM_GROUP_PANELS_2: case MI_SPMM_GROUP_PANELS_3: case MI_SPMM_GROUP_PANELS_4:
+      if (!(vec4_ok && batch == 1 && N <= 128)) return MI_EINVAL;
+      return launch_group_panels(2 + variant - MI_SPMM_GROUP_PANELS_2, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
     case MI_SPMM_COLTILE_PANELS: {
       if (!(vec4_ok && batch == 1 && N % 256 == 0 && N >= 256)) return MI_EINVAL;
       int panels = coltile_panels(M, K, N, ldb, nnz);
@@ -1316,6 +1445,14 @@ int mi_spmm_csr_f32_variant(int variant, const int32_t* rowptr, const int32_t* c
                        static_cast<hipStream_t>(stream));
 }
 
+int mi_spmm_csr_ex_variant_f32(int variant, const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
+                               int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb, const float* bias, float* C,
+                               int64_t ldc, int long_rows, void* workspace, size_t workspace_bytes, mi_stream_t stream) {
+  if (long_rows == MI_LONG_ROWS_SPLIT && workspace == nullptr && nnz > kLongRow) return MI_EINVAL;
+  return spmm_dispatch(variant, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0, bias, workspace, workspace_bytes,
+                       static_cast<hipStream_t>(stream), long_rows);
+}
+
 int mi_spmm_csr_batched_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                             int64_t nnz_total, int32_t batch, int32_t M, int32_t K, int32_t N,
                             const float* B, int64_t ldb, int64_t strideB, float* C, int64_t ldc,
@@ -1372,6 +1509,7 @@ int mi_spmm_csr_f32_plan(int64_t nnz, int32_t M, int32_t K, int32_t N, const flo
 int mi_spmm_variant_launches(int variant) {
   static const int kPanels[] = {2, 3, 4, 5, 6, 8};
   if (variant >= MI_SPMM_PANELS_2 && variant <= MI_SPMM_PANELS_8) return kPanels[variant - MI_SPMM_PANELS_2];
+  if (variant >= MI_SPMM_GROUP_PANELS_2 && variant <= MI_SPMM_GROUP_PANELS_4) return 2 + variant - MI_SPMM_GROUP_PANELS_2;
   if (variant == MI_SPMM_COLTILE_PANELS) return 0;  // one per row panel of B: depends on K
   return (variant > MI_SPMM_AUTO && variant < MI_SPMM_VARIANT_COUNT) ? 1 : MI_EINVAL;
 }
@@ -1389,6 +1527,7 @@ const char* mi_spmm_variant_name(int variant) {
     case MI_SPMM_PANELS_2: case MI_SPMM_PANELS_3: case MI_SPMM_PANELS_4: case MI_SPMM_PANELS_5:
     case MI_SPMM_PANELS_6: case MI_SPMM_PANELS_8: case MI_SPMM_COLTILE_PANELS:
       return "spmm_wave_row_panel_kernel";
+    case MI_SPMM_GROUP_PANELS_2: case MI_SPMM_GROUP_PANELS_3: case MI_SPMM_GROUP_PANELS_4: return "spmm_group_panel_kernel";
     default: return "unknown";
   }
 }

@@ -279,37 +279,54 @@ def _csr_props_cached(a: torch.Tensor):
     return props
 
 
-def _dense_to_csr(a: torch.Tensor):
+def _dense_to_csr(a: torch.Tensor, est_density=None):
     '''(values, columns, offsets, nnz) of a dense tensor's last two dims (batched: the "rowptr of rowptrs" layout).
-    Outside stream capture: the exact arrays (one read-back of the count sizes them; the kernels' plan choice sees the
-    true number of non-zeros).  Under capture nothing may be read back: the arrays get room for EVERY element
-    (capacity = a.numel(): the fill cannot overflow) and `nnz` is that bound — an upper bound no larger than the arrays,
-    which is what include/mi_spmm.h asks of the count: the product kernels walk the rows through `offsets`, the bound
-    steers their choice of plan (and is the clamp of MI_SPMM_LDS_B's 16-byte loads), so the result is the same bits.'''
+    With neither capture nor an estimate: the exact arrays (one read-back of the count sizes them; the kernels' plan
+    choice sees the true number of non-zeros).  Under capture nothing may be read back, and with `est_density` (a sampled
+    share of non-zeros, see sampled_density) nothing needs to be: the arrays get room for EVERY element (capacity =
+    a.numel(): the fill cannot overflow) and the product kernels walk the rows through `offsets`.  The count they are told
+    is then the capacity (capture) — an upper bound no larger than the arrays, which is what include/mi_spmm.h asks of it
+    — or the estimate, which only steers the plan and is allowed where no long-row workspace is sized from it (callers
+    pass an estimate only on those routes: rule 0 of naive_spmm_ex, the batched entry); either way the same bits.'''
     if a.is_cuda and torch.cuda.is_current_stream_capturing():
         offsets = custom_mm.dense_row_offsets(a)
         values, columns = custom_mm.dense_to_csr_fill(a, offsets, a.numel())
         return values, columns, offsets, a.numel()
+    if est_density is not None and a.is_cuda and 0 < a.numel() <= _NO_READBACK_MAX_ELEMS and hasattr(custom_mm, 'dense_row_offsets'):
+        offsets = custom_mm.dense_row_offsets(a)
+        values, columns = custom_mm.dense_to_csr_fill(a, offsets, a.numel())
+        return values, columns, offsets, min(a.numel(), max(1, int(est_density * a.numel())))
     values, columns, offsets = custom_mm.dense_to_csr(a)
     return values, columns, offsets, values.numel()
 
 
-def _csr_of(a: torch.Tensor):
+_NO_READBACK_MAX_ELEMS = 1 << 28  # capacity-sized CSR arrays (8 B per element of A) stay under 2 GiB
+
+
+def _csr_of(a: torch.Tensor, est_density=None):
     '''(values, columns, offsets, nnz, rows, cols) of a 2-d dense or CSR tensor.'''
     if a.is_sparse_csr:
         return _csr_props_cached(a)
-    values, columns, offsets, nnz = _dense_to_csr(a)
+    values, columns, offsets, nnz = _dense_to_csr(a, est_density)
     return values, columns, offsets.view(-1), nnz, a.shape[-2], a.shape[-1]
 
 
-def _csr_product(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, mm_op, default_op):
+def _csr_product(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, mm_op, default_op, owner=None):
     '''c = a·b for a 2-d CSR (or dense, converted) a through mm_op.  A matrix no wider than
     custom_mm.long_row_threshold() columns cannot hold an over-long row (columns are not repeated inside a row of a
     torch CSR or of a converted dense matrix), so the stock kernel then runs as ONE launch
     (custom_mm.naive_spmm_ex, rule 0: same bits); wider ones take the plain entry, which is the main kernel plus
-    one follow-up launch that finds its list of long rows empty.  No host read-back either way.'''
-    props = _csr_of(a)
-    if mm_op is default_op and hasattr(custom_mm, 'naive_spmm_ex') and a.shape[-1] <= custom_mm.long_row_threshold():
+    one follow-up launch that finds its list of long rows empty.  No host read-back either way for a CSR tensor; a DENSE
+    a on the one-launch route is converted without one too (round 5): the count the kernel is told is the sampled
+    density's (sampled_density — a count kernel whose result comes back behind an event, only the first call of a shape
+    waits), the arrays have room for every element.  The reference converts with `to_sparse_csr()` on every call, which
+    synchronises every time (matmuls.py:295-296).'''
+    one_launch = mm_op is default_op and hasattr(custom_mm, 'naive_spmm_ex') and a.shape[-1] <= custom_mm.long_row_threshold()
+    est = None
+    if one_launch and not a.is_sparse_csr and a.is_cuda and a.numel() > 0 and not torch.cuda.is_current_stream_capturing():
+        est = sampled_density(a, (tuple(a.shape), tuple(b.shape), a.device.index), a.shape[-1], owner)
+    props = _csr_of(a, est)
+    if one_launch:
         return custom_mm.naive_spmm_ex(*props, b, c, 0)
     return mm_op(*props, b, c)
 
@@ -527,11 +544,14 @@ def _dense_route(a: torch.Tensor, b: torch.Tensor, items: int, rows: int, cols: 
     sampled_density: nothing stalls the stream after the first call of a shape).  A stale estimate can only cost
     time: in 'auto' mode the result does not depend on the route (see _DENSE_ROUTE_MODES).  Under stream capture
     nothing is read back: the question is not asked.  Products whose dense form takes under ≈20 µs are not worth the
-    question either.'''
+    question either: they take the dense product unless the one-launch in-kernel skip applies.'''
     if not a.is_cuda or torch.cuda.is_current_stream_capturing() or a.numel() == 0 or b.numel() == 0:
         return False
     if 2.0 * items * rows * cols * width / 110e12 < 20e-6:
-        return False
+        # under the gate the dense product is bounded by 20 µs by construction; the dense→CSR route is not (1024² fully
+        # dense × 1024: 0.023 against 0.258 ms, profiles/r03_dense_input_routing.log) — so: the one-launch in-kernel skip
+        # where a matrix is tiny enough for it (fused_skip_pays), else the matrix cores
+        return not fused_skip_pays(items, rows, cols, width)
     est = sampled_density(a, (tuple(a.shape), tuple(b.shape), a.device.index), cols, owner)
     return dense_route_pays(est, items, rows, cols, width)
 
@@ -588,9 +608,9 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op, dense_ro
     capturing = b.is_cuda and torch.cuda.is_current_stream_capturing()
     # A dense matrix that is not sparse enough belongs on the matrix cores (same result, see _on_matrix_cores):
     # 6× faster on the reference's own naive test shapes (tests/naive_kernel_test.py:48-49 feeds torch.rand).
+    if dense_route is not None and dense_route not in _DENSE_ROUTE_MODES:  # (checked whatever the operands: a bad value never passes silently)
+        raise ValueError(f"dense_route must be one of {_DENSE_ROUTE_MODES}, not {dense_route!r}")
     mode = (dense_route or _dense_route_mode) if fused and a.is_cuda and b.is_cuda else 'never'
-    if mode not in _DENSE_ROUTE_MODES:
-        raise ValueError(f"dense_route must be one of {_DENSE_ROUTE_MODES}, not {mode!r}")
 
     if a.dim() == 2 and b.dim() == 2:
         c = torch.empty((c_rows, c_cols), device=dev, dtype=torch.float32)
@@ -599,7 +619,7 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op, dense_ro
         # (under capture the conversion's read-back of nnz is not possible: the in-kernel route whenever it applies)
         if fused and (capturing or fused_skip_pays(1, c_rows, a_shape[-1], c_cols)) and custom_mm.naive_spmm_dense(a, b, c):
             return c
-        return _csr_product(a, b, c, mm_op, default_op)
+        return _csr_product(a, b, c, mm_op, default_op, a)
 
     if a.dim() == 2:
         # one CSR × a batch of B: C[i] = A·B[i]  ==  A · [K, batch·N]
@@ -607,7 +627,7 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op, dense_ro
         _b = b.reshape((-1,) + tuple(b_shape[-2:])).permute(1, 0, 2).reshape(b_shape[-2], -1)
         c = torch.empty((c_rows, _b.shape[1]), device=dev, dtype=torch.float32)
         if not _on_matrix_cores(a, _b, c, mode, a):
-            c = _csr_product(a, _b, c, mm_op, default_op)
+            c = _csr_product(a, _b, c, mm_op, default_op, a)
         return c.view(c_rows, -1, c_cols).permute(1, 0, 2).reshape(batch + (c_rows, c_cols))
 
     if a.is_sparse_csr:
@@ -621,7 +641,7 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op, dense_ro
             return c.view(tuple(a_shape[:-1]) + (c_cols,))
         if not (fused and (capturing or fused_skip_pays(1, _a.shape[0], _a.shape[1], c_cols))
                 and custom_mm.naive_spmm_dense(_a, b, c)):
-            c = _csr_product(_a, b, c, mm_op, default_op)
+            c = _csr_product(_a, b, c, mm_op, default_op, a)
         return c.view(tuple(a_shape[:-1]) + (c_cols,))
 
     # batch × batch
@@ -636,9 +656,12 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op, dense_ro
         pass  # one launch, A read once, no CSR materialised
     elif mm_op is default_op:
         # one dense→CSR conversion and one launch for the whole batch
+        est = None
+        if _a.is_cuda and not capturing and _a.numel() > 0:  # (the batched entry has no long-row workspace: an estimate is a legal count)
+            est = sampled_density(_a, (tuple(_a.shape), tuple(_b.shape), _a.device.index), a_shape[-1], a)
         for lo in range(0, nb, 65535):
             hi = min(nb, lo + 65535)
-            values, columns, offsets, nnz = _dense_to_csr(_a[lo:hi])
+            values, columns, offsets, nnz = _dense_to_csr(_a[lo:hi], est)
             custom_mm.naive_spmm_batched(values, columns, offsets, nnz, hi - lo,
                                          c_rows, a_shape[-1], _b[lo:hi], c[lo:hi])
     else:

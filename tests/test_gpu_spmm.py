@@ -41,7 +41,7 @@ def test_spmm_every_variant_is_bit_identical(capi, dev, oracle_mod, M, K, N, den
     d = [t(x, dev) for x in (rowptr, col, val, B)]
     ran = 0
     chain = oracle_mod.spmm_csr_chain(rowptr, col, val, M, K, B)  # explicit group variants ignore the N < 4 rule
-    for variant in range(19):
+    for variant in range(22):
         C = torch.full((M, N), float("nan"), device=dev)
         st = capi.mi_spmm_csr_f32_variant(variant, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(val), M, K,
                                           N, d[3].data_ptr(), N, C.data_ptr(), N,
