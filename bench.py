@@ -298,6 +298,25 @@ def bench_c5(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     flops = 6 * 2.0 * Bz * H * S * S * D
+    single_ms = None
+    if world > 1:
+        # The whole matrix on rank 0's GPU alone (after every timed leg; the other ranks wait at the barrier): the
+        # N-GPU line then carries its own single-GPU time, speed-up and the exchange rate a 6x speed-up needs —
+        # self-judging, whatever box the driver's separate N = 1 run landed on.
+        if rank == 0:
+            s_rp, s_col, s_val = (torch.from_numpy(np.asarray(x)).to(dev) for x in (rowptr, col, val))
+            s_C = torch.empty(M, N, device=dev)
+            for _ in range(2):
+                custom_mm.naive_spmm(s_val, s_col, s_rp, nnz, M, K, B, s_C)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(max(3, min(args.steps, 10))):
+                custom_mm.naive_spmm(s_val, s_col, s_rp, nnz, M, K, B, s_C)
+            torch.cuda.synchronize()
+            single_ms = (time.perf_counter() - t1) / max(3, min(args.steps, 10)) * 1e3
+            assert torch.equal(s_C, C[:M]), "the gathered C differs from rank 0's single-GPU product"
+            del s_rp, s_col, s_val, s_C
+        barrier()
     step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     kern_ms = ev[0].elapsed_time(ev[-1]) / args.steps
     # light parity check against torch autograd of matmul on one head
@@ -421,7 +440,11 @@ def main():
         kernel_name, launches_per_step = spmm_plan(nnz, M, K, B, C)
         local_bytes_alg = bytes_alg
     else:
-        rp_t, col_t, val_t = torch.from_numpy(np.asarray(rowptr)), torch.from_numpy(col), torch.from_numpy(val)
+        # col / val go to the device ONCE (840 MB at C3: nothing on 288 GB): every ShardedSpMM below — up to six trial
+        # operators and the measured one — then cuts its blocks with device-side slices instead of uploading its share
+        # again (round-4 review); rowptr stays on the host, where the constructor computes the block boundaries
+        rp_t = torch.from_numpy(np.asarray(rowptr))
+        col_t, val_t = torch.from_numpy(col).to(dev), torch.from_numpy(val).to(dev)
         # Which exchange?  The in-place all-gather (RCCL picks rings / trees) and the list-form all_to_all (every block
         # straight to every peer: one xGMI link each) are both COLLECTIVES: every rank calls them alike, a build that
         # refuses one does so at an argument check on every rank, which ShardedSpMM probes at construction and settles
@@ -529,6 +552,25 @@ def main():
             custom_mm.naive_spmm(torch.from_numpy(np.array(val[p0:p1])).to(dev), torch.from_numpy(np.array(col[p0:p1])).to(dev),
                                  (rp_t[r0:r1 + 1] - rp_t[r0]).to(torch.int32).to(dev), p1 - p0, r1 - r0, K, B, chk)
             assert torch.equal(chk, C[r0:r1]), f"rank {rank}: gathered block of rank {peer} differs from a local recompute"
+    single_ms = None
+    if world > 1:
+        # The whole matrix on rank 0's GPU alone (after every timed leg; the other ranks wait at the barrier): the
+        # N-GPU line then carries its own single-GPU time, speed-up and the exchange rate a 6x speed-up needs —
+        # self-judging, whatever box the driver's separate N = 1 run landed on.
+        if rank == 0:
+            s_rp, s_col, s_val = (torch.from_numpy(np.asarray(x)).to(dev) for x in (rowptr, col, val))
+            s_C = torch.empty(M, N, device=dev)
+            for _ in range(2):
+                custom_mm.naive_spmm(s_val, s_col, s_rp, nnz, M, K, B, s_C)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(max(3, min(args.steps, 10))):
+                custom_mm.naive_spmm(s_val, s_col, s_rp, nnz, M, K, B, s_C)
+            torch.cuda.synchronize()
+            single_ms = (time.perf_counter() - t1) / max(3, min(args.steps, 10)) * 1e3
+            assert torch.equal(s_C, C[:M]), "the gathered C differs from rank 0's single-GPU product"
+            del s_rp, s_col, s_val, s_C
+        barrier()
     step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     # the step's launches run back to back on this stream: their durations sum to the step's event time
     kernels_ms_per_step = float(np.mean(step_ms))
@@ -586,6 +628,14 @@ def main():
                 # bytes every rank RECEIVES per step (the other ranks' rows of C) / the gather-only time
                 "gather_receive_GBps_per_rank": None if gather_only_ms is None else
                                                 round(4.0 * N * (op.padded_rows - op.local_rows) / (gather_only_ms * 1e-3) / 1e9, 1),
+                # self-judging fields for BASELINE's ">= 6x at 8 GPUs": rank 0's single-GPU time of the whole product
+                # (measured in this run, same box), the speed-up of this line over it, and the receive rate per rank the
+                # exchange needs for 6x even with perfect overlap (bytes a rank receives per step / (single / 6))
+                "single_gpu_ms_on_rank0": None if single_ms is None else round(single_ms, 4),
+                "speedup_vs_single_gpu_on_rank0": None if single_ms is None else round(single_ms / (elapsed / args.steps * 1e3), 3),
+                "gathered_C_equals_single_gpu_product": None if single_ms is None else True,
+                "gather_GBps_needed_for_6x": None if single_ms is None else
+                                             round(4.0 * N * (op.padded_rows - op.local_rows) / (single_ms / 6.0 * 1e-3) / 1e9, 1),
                 "gather_note": None if gather_only_ms is None else
                                "xGMI: 7 links x ~153 GB/s per GPU; a single ring is bound by ONE link, direct / multi-link "
                                "exchanges by several: compare gather_receive_GBps_per_rank with those",

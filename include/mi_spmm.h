@@ -153,7 +153,9 @@ enum {
   MI_SPMM_GROUP_PANELS_2 = 19, /* N ≤ 128 (float4 lanes), B beyond the Infinity Cache: the lane-group kernel in 2 column   */
   MI_SPMM_GROUP_PANELS_3 = 20, /*   panels (3, 4), one launch per panel, C carried; a pass takes the entries whose running */
   MI_SPMM_GROUP_PANELS_4 = 21, /*   maximum of the row's columns lies in its panel: CSR order kept for every legal input   */
-  MI_SPMM_VARIANT_COUNT = 22
+  MI_SPMM_GROUP_PANELS_6 = 22,
+  MI_SPMM_GROUP_PANELS_8 = 23,
+  MI_SPMM_VARIANT_COUNT = 24
 };
 /* The two forms of MI_SPMM_LDS_B (same bits): 16 lanes per row (any tile width), or — tiles of 64 / 128 columns — a
  * quad per row with 16-byte loads of col / val (what BERT's head size runs).  form: -1 by rule (default), 0 the 16-lane

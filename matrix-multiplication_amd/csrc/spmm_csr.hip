@@ -84,6 +84,49 @@ __device__ __forceinline__ void long_list_append(const LongArg& la, int row, int
   for (int g = 0; g < S; ++g) owner[sb + g] = e;
 }
 
+// The last end − p < U entries of a row (wave-uniform p, end; col / val through the scalar unit): their gathers are
+// issued TOGETHER — blocks of U/2, U/4, … 1 entries, every block's loads before the first block's FMAs — instead of
+// one entry at a time with its latency exposed (a row of 20 entries at U = 8 used to end in four dependent trips to
+// memory, as long as its two full batches took).  The FMAs run in entry order: the chain is unchanged.
+template <int T, int U>
+__device__ __forceinline__ void row_tail(const int* __restrict__ col, const float* __restrict__ val, const float* Bl,
+                                         long ldb, int p, int end, f32x4 (&acc)[T]) {
+  const int rem = end - p;  // 0 … U-1
+  if (rem <= 0) return;
+  f32x4 x[U > 1 ? U - 1 : 1][T];
+  float v[U > 1 ? U - 1 : 1];
+  int q = p;  // (compile-time slot of each block: U/2 entries at slots [0, U/2), U/4 at [U/2, 3U/4), …)
+  mi::static_for<7>([&](auto k_) {  // blocks of U >> 1, U >> 2, …
+    constexpr int blk = U >> (decltype(k_)::value + 1);
+    if constexpr (blk >= 1) {
+      constexpr int slot = U - 2 * blk;  // Σ of the larger blocks = U − 2·blk
+      if (rem & blk) {
+#pragma unroll
+        for (int u = 0; u < blk; ++u) {
+          const int c = col[q + u];
+          v[slot + u] = val[q + u];
+          const float* src = Bl + (long)c * ldb;
+#pragma unroll
+          for (int t = 0; t < T; ++t) x[slot + u][t] = *reinterpret_cast<const f32x4*>(src + t * 256);
+        }
+        q += blk;
+      }
+    }
+  });
+  mi::static_for<7>([&](auto k_) {
+    constexpr int blk = U >> (decltype(k_)::value + 1);
+    if constexpr (blk >= 1) {
+      constexpr int slot = U - 2 * blk;
+      if (rem & blk) {
+#pragma unroll
+        for (int u = 0; u < blk; ++u)
+#pragma unroll
+          for (int t = 0; t < T; ++t) acc[t] = fma4(v[slot + u], x[slot + u][t], acc[t]);
+      }
+    }
+  });
+}
+
 // ---------------------------------------------------------------------------
 // One wave per row, N == 256·T exactly.  col/val through the scalar unit.
 // grid = (⌈M/4⌉, batch), block = 256 (4 waves = 4 rows).
@@ -135,14 +178,7 @@ __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
       for (int t = 0; t < T; ++t) acc[t] = fma4(v[u], x[u][t], acc[t]);
     }
   }
-  for (; p < end; ++p) {
-    const int c = col[p];
-    const float v = val[p];
-    const float* src = Bl + (long)c * ldb;
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-      acc[t] = fma4(v, *reinterpret_cast<const f32x4*>(src + t * 256), acc[t]);
-  }
+  row_tail<T, U>(col, val, Bl, ldb, p, end, acc);
   if (bias) {  // fused epilogue: + bias[j] after the chain (one extra rounding, like `out += bias`)
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] += *reinterpret_cast<const f32x4*>(bias + lane * 4 + t * 256);
@@ -354,33 +390,31 @@ __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
     const bool in = (unsigned)(myc - c_lo) < width && idx < end;
     const float myv = in ? val[idx] : 0.f;
     unsigned long long mask = __ballot(in);  // this chunk's nonzeros that fall in the panel
-    while (__builtin_popcountll(mask) >= U) {
+    // batches of up to U entries of this panel: every gather of a batch is issued before its first FMA — the last,
+    // partial batch of a chunk too (it used to go one entry at a time, each with its latency exposed)
+    while (mask) {
+      const int n = __builtin_popcountll(mask);  // wave-uniform
       f32x4 x[U][T];
       float v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int i = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        const int c = __builtin_amdgcn_readlane(myc, i);
-        v[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), i));
-        const float* src = Bl + (long)c * ldb;
+        if (u < n) {
+          const int i = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          const int c = __builtin_amdgcn_readlane(myc, i);
+          v[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), i));
+          const float* src = Bl + (long)c * ldb;
 #pragma unroll
-        for (int t = 0; t < T; ++t) x[u][t] = *reinterpret_cast<const f32x4*>(src + t * 256);
+          for (int t = 0; t < T; ++t) x[u][t] = *reinterpret_cast<const f32x4*>(src + t * 256);
+        }
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+      for (int u = 0; u < U; ++u) {
+        if (u < n) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = fma4(v[u], x[u][t], acc[t]);
-    }
-    while (mask) {
-      const int i = __builtin_ctzll(mask);
-      mask &= mask - 1;
-      const int c = __builtin_amdgcn_readlane(myc, i);
-      const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), i));
-      const float* src = Bl + (long)c * ldb;
-#pragma unroll
-      for (int t = 0; t < T; ++t)
-        acc[t] = fma4(v, *reinterpret_cast<const f32x4*>(src + t * 256), acc[t]);
+          for (int t = 0; t < T; ++t) acc[t] = fma4(v[u], x[u][t], acc[t]);
+        }
+      }
     }
   }
   bool add_bias = bias != nullptr && last_pass != 0;
@@ -778,6 +812,11 @@ int launch_group_panels_t(int panels, const int* rowptr, const int* col, const f
                          M, N, ldb, ldc, lo, hi, bias, q == panels - 1 ? 1 : 0, la);
   }
   return mi::check_launch();
+}
+
+int group_panel_count(int variant) {
+  static const int kCount[] = {2, 3, 4, 6, 8};
+  return kCount[variant - MI_SPMM_GROUP_PANELS_2];
 }
 
 int launch_group_panels(int panels, const int* rowptr, const int* col, const float* val, const float* B, float* C, int M,
@@ -1220,9 +1259,10 @@ int launch_variant(int variant, const Shape& sh, const int32_t* rowptr, const in
       static const int kPanels[] = {2, 3, 4, 5, 6, 8};
       return launch_panels(kPanels[variant - MI_SPMM_PANELS_2], rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
     }
-    case MI_SPMM_GROUP_PANELS_2: case MI_SPMM_GROUP_PANELS_3: case MI_SPMM_GROUP_PANELS_4:
+    case MI_SPMM_GROUP_PANELS_2: case MI_SPMM_GROUP_PANELS_3: case MI_SPMM_GROUP_PANELS_4: case MI_SPMM_GROUP_PANELS_6:
+    case MI_SPMM_GROUP_PANELS_8:
       if (!(vec4_ok && batch == 1 && N <= 128)) return MI_EINVAL;
-      return launch_group_panels(2 + variant - MI_SPMM_GROUP_PANELS_2, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
+      return launch_group_panels(group_panel_count(variant), rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
     case MI_SPMM_COLTILE_PANELS: {
       if (!(vec4_ok && batch == 1 && N % 256 == 0 && N >= 256)) return MI_EINVAL;
       int panels = coltile_panels(M, K, N, ldb, nnz);
@@ -1509,7 +1549,7 @@ int mi_spmm_csr_f32_plan(int64_t nnz, int32_t M, int32_t K, int32_t N, const flo
 int mi_spmm_variant_launches(int variant) {
   static const int kPanels[] = {2, 3, 4, 5, 6, 8};
   if (variant >= MI_SPMM_PANELS_2 && variant <= MI_SPMM_PANELS_8) return kPanels[variant - MI_SPMM_PANELS_2];
-  if (variant >= MI_SPMM_GROUP_PANELS_2 && variant <= MI_SPMM_GROUP_PANELS_4) return 2 + variant - MI_SPMM_GROUP_PANELS_2;
+  if (variant >= MI_SPMM_GROUP_PANELS_2 && variant <= MI_SPMM_GROUP_PANELS_8) return group_panel_count(variant);
   if (variant == MI_SPMM_COLTILE_PANELS) return 0;  // one per row panel of B: depends on K
   return (variant > MI_SPMM_AUTO && variant < MI_SPMM_VARIANT_COUNT) ? 1 : MI_EINVAL;
 }
@@ -1527,7 +1567,8 @@ const char* mi_spmm_variant_name(int variant) {
     case MI_SPMM_PANELS_2: case MI_SPMM_PANELS_3: case MI_SPMM_PANELS_4: case MI_SPMM_PANELS_5:
     case MI_SPMM_PANELS_6: case MI_SPMM_PANELS_8: case MI_SPMM_COLTILE_PANELS:
       return "spmm_wave_row_panel_kernel";
-    case MI_SPMM_GROUP_PANELS_2: case MI_SPMM_GROUP_PANELS_3: case MI_SPMM_GROUP_PANELS_4: return "spmm_group_panel_kernel";
+    case MI_SPMM_GROUP_PANELS_2: case MI_SPMM_GROUP_PANELS_3: case MI_SPMM_GROUP_PANELS_4: case MI_SPMM_GROUP_PANELS_6:
+    case MI_SPMM_GROUP_PANELS_8: return "spmm_group_panel_kernel";
     default: return "unknown";
   }
 }

@@ -33,6 +33,7 @@ def test_spmm_golden_bit_exact_vs_oracle(cmm, dev, golden, oracle_mod):
     (1024, 1024, 1024, 0.01), (1024, 2048, 512, 0.01), (2048, 1024, 512, 0.01),  # tiledsppm_kernel_test.py:34-39
     (333, 777, 256, 0.05), (333, 777, 512, 0.05), (65, 129, 1024, 0.2), (1000, 1000, 100, 0.02),
     (77, 300, 1, 0.1), (77, 300, 2, 0.1), (77, 300, 7, 0.1), (300, 77, 1031, 0.1), (5, 40, 2048, 0.5),
+    (900, 3000, 64, 0.03), (900, 3000, 128, 0.03), (0 + 411, 2000, 96, 0.05),
 ])
 def test_spmm_every_variant_is_bit_identical(capi, dev, oracle_mod, M, K, N, density):
     rowptr, col, val = oracle_mod.make_csr(M, K, density, seed=M + N)
@@ -41,7 +42,7 @@ def test_spmm_every_variant_is_bit_identical(capi, dev, oracle_mod, M, K, N, den
     d = [t(x, dev) for x in (rowptr, col, val, B)]
     ran = 0
     chain = oracle_mod.spmm_csr_chain(rowptr, col, val, M, K, B)  # explicit group variants ignore the N < 4 rule
-    for variant in range(22):
+    for variant in range(24):
         C = torch.full((M, N), float("nan"), device=dev)
         st = capi.mi_spmm_csr_f32_variant(variant, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(val), M, K,
                                           N, d[3].data_ptr(), N, C.data_ptr(), N,
@@ -830,3 +831,50 @@ def test_batched_spmm_variants_fuzz_against_oracle(capi, dev, oracle_mod):
             assert np.isnan(got[~written]).all(), what
         assert ran >= 2
     assert took.get(18, 0) >= cases // 4 and took.get(4, 0) >= cases // 4 and took[0] == took[5] == cases, took
+
+
+@pytest.mark.parametrize("N", [64, 128, 36, 100])
+def test_group_panel_plans_keep_csr_order_for_any_row(capi, cmm, dev, oracle_mod, N):
+    """Round 5: the lane-group kernel in column panels (MI_SPMM_GROUP_PANELS_2/3/4 = 19/20/21; N ≤ 128 with B beyond the
+    Infinity Cache).  A pass takes the entries whose running maximum of the row's columns lies in its panel, which cuts
+    every row into contiguous ranges in CSR order — so sorted rows, shuffled rows, rows with duplicate columns, rows
+    longer than a chunk, empty rows and a descent exactly at a chunk boundary all give the one-pass chain, bit for bit;
+    bias in the last pass only; rows beyond the long-row threshold skipped in every pass and summed by the follow-up
+    launch.  Reference: src/naive_sparse_mm.cu:39,116 (any N through one kernel), :60-92 (CSR-order accumulation)."""
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_spmm_csr_ex_variant_f32.argtypes = [ctypes.c_int, vp, vp, vp, i64, i32, i32, i32, vp, i64, vp, vp, i64, ctypes.c_int,
+                                                vp, ctypes.c_size_t, vp]
+    capi.mi_spmm_csr_workspace_bytes.restype = ctypes.c_size_t
+    capi.mi_spmm_csr_workspace_bytes.argtypes = [i64, i32]
+    stream = torch.cuda.current_stream().cuda_stream
+    g = np.random.Generator(np.random.PCG64(500 + N))
+    M, K = 1300, 5000
+    lens = g.integers(0, 90, size=M)
+    lens[g.integers(0, M, size=20)] = 0
+    lens[5], lens[6], lens[7] = 16, 32, 33          # whole chunks of a 16- / 32-lane group, one entry over
+    lens[100] = 9000                                  # beyond the long-row threshold (duplicates: K = 5000)
+    cols = []
+    for r, n in enumerate(lens):
+        c = g.integers(0, K, size=int(n))
+        cols.append(np.sort(c) if r % 3 else c)      # two thirds sorted, one third in random order (with duplicates)
+    cols[6] = np.sort(cols[6])
+    cols[6][[15, 16]] = cols[6][[16, 15]]             # a descent exactly at the 16-entry chunk boundary
+    col = np.concatenate(cols).astype(np.int32)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    val = g.random(len(col), dtype=np.float32) - 0.5
+    B, bias = g.random((K, N), dtype=np.float32) - 0.5, g.random(N, dtype=np.float32)
+    chain = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    split = oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B)
+    d = [t(x, dev) for x in (rowptr, col, val, B, bias)]
+    ws_bytes = capi.mi_spmm_csr_workspace_bytes(len(col), N)
+    ws = torch.zeros(ws_bytes + 16, dtype=torch.uint8, device=dev)
+    for variant in (19, 20, 21, 22, 23):
+        for with_bias in (False, True):
+            for rule, want in ((0, chain), (1, split)):     # MI_LONG_ROWS_NONE / _SPLIT
+                C = torch.full((M, N), float("nan"), device=dev)
+                st = capi.mi_spmm_csr_ex_variant_f32(variant, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(col), M, K, N,
+                                                     d[3].data_ptr(), N, d[4].data_ptr() if with_bias else None, C.data_ptr(), N,
+                                                     rule, ws.data_ptr(), ws_bytes, stream)
+                assert st == 0, (variant, with_bias, rule)
+                expect = want + bias[None, :] if with_bias else want
+                assert np.array_equal(C.cpu().numpy().view(np.int32), expect.view(np.int32)), (variant, with_bias, rule)

@@ -106,6 +106,19 @@ def timeit(fn, min_iters=3, budget_ms=1500.0):
     return e0.elapsed_time(e1) / iters
 
 
+def time_interleaved(entries, rounds=3, budget_ms=300.0):
+    """{name: median ms}: the entries take turns (round-robin, `rounds` times), so that clock / power state — a burst
+    after an idle gap runs up to 15 % faster than the same kernel in a sustained run on this part — is shared evenly."""
+    times = {k: [] for k in entries}
+    for _ in range(rounds):
+        for k, fn in entries.items():
+            times[k].append(timeit(fn, budget_ms=budget_ms))
+    return {k: float(np.median(v)) for k, v in times.items()}
+
+
+VARIANTS = (2, 4, 7, 8, 9, 11, 12, 19, 20, 21, 22, 23)
+
+
 def run(tag, M, K, N, per_row, pattern, variants, out):
     t0 = time.time()
     rowptr, col, val = make_csr(M, K, per_row, pattern)
@@ -114,7 +127,24 @@ def run(tag, M, K, N, per_row, pattern, variants, out):
     B = torch.rand(K, N, device=dev, generator=g)
     C = torch.empty(M, N, device=dev)
     plan = custom_mm.spmm_plan(nnz, M, K, B, C)
-    ms = timeit(lambda: custom_mm.naive_spmm(val, col, rowptr, nnz, M, K, B, C))
+    entries = {"auto": lambda: custom_mm.naive_spmm(val, col, rowptr, nnz, M, K, B, C)}
+    same = {}
+    if variants:
+        st = torch.cuda.current_stream().cuda_stream
+        # every entry writes the SAME buffer: at multi-GiB sizes the placement of the output alone moved a plan by ± 10 %
+        custom_mm.naive_spmm(val, col, rowptr, nnz, M, K, B, C)
+        Cref = C.clone()
+        for v in VARIANTS:
+            args = (v, rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), nnz, M, K, N, B.data_ptr(), N, C.data_ptr(), N, st)
+            C.fill_(float("nan"))
+            if lib.mi_spmm_csr_f32_variant(*args) != 0:
+                continue
+            same[v] = torch.equal(C.view(torch.int32), Cref.view(torch.int32))
+            entries[v] = (lambda a: (lambda: lib.mi_spmm_csr_f32_variant(*a)))(args)
+        del Cref
+    ms_all = time_interleaved(entries)
+    ms = ms_all["auto"]
+    custom_mm.naive_spmm(val, col, rowptr, nnz, M, K, B, C)
     ok, nr = check_rows(rowptr, col, val, B, C, K)
     alg = nnz * (4 * N + 8) + 4 * (M + 1) + 4 * M * N
     gbs = alg / ms / 1e6
@@ -122,22 +152,13 @@ def run(tag, M, K, N, per_row, pattern, variants, out):
             f"{plan[1]:<28} x{plan[2]}  {ms:9.3f} ms  {gbs:7.0f} GB/s  frac {gbs / 8000:.3f}  "
             f"{2 * nnz * N / ms / 1e6:7.0f} GFLOP/s  rows {'bit-exact' if ok else 'MISMATCH'} ({nr})")
     if variants:
-        st = torch.cuda.current_stream().cuda_stream
-        alt = []
-        for v in (2, 3, 4, 6, 7, 8, 14):
-            Cv = torch.empty_like(C)
-            args = (v, rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), nnz, M, K, N, B.data_ptr(), N, Cv.data_ptr(), N, st)
-            if lib.mi_spmm_csr_f32_variant(*args) != 0:
-                continue
-            t = timeit(lambda: lib.mi_spmm_csr_f32_variant(*args), budget_ms=600.0)
-            same = torch.equal(Cv.view(torch.int32), C.view(torch.int32))
-            alt.append(f"{v}{'*' if v == plan[0] else ''}:{t:.3f}{'' if same else '!'}")
-            del Cv
-        line += "   variants " + " ".join(alt)
+        best = min((t, v) for v, t in ms_all.items() if v != "auto")
+        line += (f"   best pinned {best[1]}: {best[0]:.3f} ({alg / best[0] / 8e9:.3f})   variants " +
+                 " ".join(f"{v}{'*' if v == plan[0] else ''}:{t:.3f}{'' if same[v] else '!'}" for v, t in ms_all.items() if v != "auto"))
     line += f"   [{time.time() - t0:.0f} s]"
     print(line, flush=True)
     out.append(line)
-    assert ok, "sampled rows differ from the oracle"
+    assert ok and all(same.values()), "results differ (sampled rows vs the oracle, or a pinned plan vs AUTO)"
     del rowptr, col, val, B, C
     torch.cuda.empty_cache()
 
