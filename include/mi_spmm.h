@@ -212,6 +212,19 @@ int mi_spmm_csr_batched_variant_f32(int variant, const int32_t* rowptr, const in
                                     int32_t M, int32_t K, int32_t N, const float* B,
                                     int64_t ldb, int64_t strideB, float* C, int64_t ldc,
                                     int64_t strideC, mi_stream_t stream);
+/* Y[i] (K × N) = A[i]ᵀ · X[i] for a batched CSR A (rowptr [batch, M + 1] with base offsets, as above), X [batch, M, N],
+ * WITHOUT transposing A: the output tile is kept in registers, every wave walks the item's rows in ascending order and
+ * picks the entries of its columns (csrc/spmm_at.hip).  Per output element the terms arrive by ascending row, entries of
+ * one row in CSR order — the chain of csr_transpose + mi_spmm_csr_batched_f32, bit for bit.  N ≤ 64.  Returns 1 (nothing
+ * launched) for shapes it does not cover.  The gradient of V in pruned attention (reference matmuls.py:245-256 has no
+ * backward for a batched CSR operand; the forward's per-call conversion is :289-297). */
+int mi_spmm_csr_batched_at_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz_total,
+                               int32_t batch, int32_t M, int32_t K, int32_t N, const float* X, int64_t ldx,
+                               int64_t strideX, float* Y, int64_t ldy, int64_t strideY, mi_stream_t stream);
+/* torch's batched CSR indices (int64 crow [batch, M + 1] from 0 per item, int64 col [batch · per_item]) → int32 offsets
+ * with the items' bases added and int32 columns, in one launch. */
+int mi_batched_csr_narrow_i64(const int64_t* crow, const int64_t* col, int32_t batch, int32_t M, int64_t per_item,
+                              int32_t* offsets, int32_t* columns, mi_stream_t stream);
 int mi_spmm_csr_batched_f32_plan(int64_t nnz_total, int32_t batch, int32_t M, int32_t K, int32_t N,
                                  const float* B, int64_t ldb, int64_t strideB, const float* C,
                                  int64_t ldc, int64_t strideC);
@@ -406,6 +419,11 @@ int mi_csr_transpose_one_sweep_applies(int32_t batch, int32_t M, int32_t K, int6
 int mi_csr_transpose_check(const void* workspace, size_t workspace_bytes, int32_t batch, int32_t M,
                            int32_t K, int64_t nnz, mi_stream_t stream);
 size_t mi_csr_transpose_batched_workspace_bytes(int32_t batch, int32_t M, int32_t K, int64_t nnz);
+/* 1 when the batch is transposed by the one-workgroup-per-item plan (items small enough for a [waves][K] table in LDS,
+ * ≤ 256 K entries per item, ≥ 64 items or ≤ 128 K entries in all; plan AUTO): one launch, no workspace used, ≈ 20× faster
+ * than the general plan on pruned-attention batches — cheap enough to transpose the VALUES on every backward instead of
+ * keeping a permutation (matmuls._batched_csr_backward).  Same stable order, same bits. */
+int mi_csr_transpose_batched_in_lds(int64_t nnz, int32_t batch, int32_t M, int32_t K);
 int mi_csr_transpose_batched_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                                  int64_t nnz, int32_t batch, int32_t M, int32_t K,
                                  int32_t* t_rowptr, int32_t* t_col, float* t_val,

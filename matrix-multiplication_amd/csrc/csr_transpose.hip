@@ -1562,6 +1562,172 @@ int launch_scatter(const TrArgs& a, bool packed, bool staged, hipStream_t s) {
   return mi::check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batches of SMALL items (round 5): one workgroup transposes one item inside its LDS — pruned attention hands over a new
+// pattern on every step (384 items of 512 × 512 at 10 % kept: 10 M entries), and the general plan above, built for 10⁸
+// entries of one matrix, took 0.27 ms for them (tools/probes/attn_fresh_pieces.py) — more than the three products of the
+// step together.  Here: the item's rows are dealt to the WAVES waves in contiguous blocks; (1) every wave counts its block's
+// entries per column into its own row of an LDS table [WAVES][K] (ds_add); (2) one pass over the table turns it into
+// cursors — column k of wave w starts at (entries of columns < k) + (entries of column k in waves < w), the column starts
+// go out as the item's transposed offsets; (3) every wave walks its rows IN ORDER, a row's ≤ 64 entries per instruction:
+// position = cursor[w][col]++ (an LDS read and write — the columns of one instruction are distinct when the row ascends
+// strictly, which is checked on the spot; a chunk that does not — unsorted rows, duplicate columns — takes its positions
+// one lane after the other, in lane order), then t_col[position] = row, t_val[position] = value.  Entries of a column
+// therefore land by ascending row, ties in CSR order: the stable order of the general plan and of oracle_csr_transpose.
+// Loads travel eight rows (or eight 64-entry chunks) at a time.  No workspace, no inter-workgroup hand-off.
+// ---------------------------------------------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void tr_item_lds_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                                 const float* __restrict__ val, int M, int K,
+                                                                 int* __restrict__ t_rowptr, int* __restrict__ t_col,
+                                                                 float* __restrict__ t_val) {
+  extern __shared__ int tr_lds[];  // [WAVES][K] counters → cursors, then WAVES + 1 ints of scan scratch
+  constexpr int T = WAVES * 64;
+  int* cnt = tr_lds;
+  int* scratch = tr_lds + (long)WAVES * K;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long item = blockIdx.x;
+  const int* rp = rowptr + item * ((long)M + 1);
+  const int rows_per_wave = (M + WAVES - 1) / WAVES;
+  const int r0 = wave * rows_per_wave < M ? wave * rows_per_wave : M;
+  const int r1 = r0 + rows_per_wave < M ? r0 + rows_per_wave : M;
+  const int base = rp[0];
+  for (int i = tid; i < WAVES * K; i += T) cnt[i] = 0;
+  __syncthreads();
+  int* mine = cnt + (long)wave * K;
+  {  // (1) the wave's entries are contiguous: [rp[r0], rp[r1])
+    const int e0 = rp[r0], e1 = rp[r1];
+    for (int p = e0; p < e1; p += 8 * 64) {
+      int c[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = p + u * 64 + lane;
+        c[u] = idx < e1 ? col[idx] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if ((unsigned)c[u] < (unsigned)K) atomicAdd(&mine[c[u]], 1);  // (a column outside [0, K) is dropped here and below)
+    }
+  }
+  __syncthreads();
+  {  // (2) counters → cursors; a thread owns a contiguous range of columns
+    const int cpt = (K + T - 1) / T;
+    const int k_lo = tid * cpt < K ? tid * cpt : K, k_hi = k_lo + cpt < K ? k_lo + cpt : K;
+    int sum = 0;
+    for (int k = k_lo; k < k_hi; ++k)
+      for (int w = 0; w < WAVES; ++w) sum += cnt[(long)w * K + k];
+    // exclusive scan of `sum` over the workgroup's threads
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += y;
+    }
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+      int run = 0;
+      for (int w = 0; w < WAVES; ++w) {
+        const int x = scratch[w];
+        scratch[w] = run;
+        run += x;
+      }
+    }
+    __syncthreads();
+    int run = base + scratch[wave] + incl - sum;  // entries of the columns before k_lo, as a position in the item's arrays
+    int* t_rp = t_rowptr + item * ((long)K + 1);
+    for (int k = k_lo; k < k_hi; ++k) {
+      t_rp[k] = run;
+      for (int w = 0; w < WAVES; ++w) {
+        const int x = cnt[(long)w * K + k];
+        cnt[(long)w * K + k] = run;
+        run += x;
+      }
+    }
+    if (tid == T - 1) t_rp[K] = rp[M];  // (= base + every entry of the item when all columns are in range)
+  }
+  __syncthreads();
+  // (3) placement, rows in order, eight rows' first chunks in flight together
+  for (int r = r0; r < r1; r += 8) {
+    int b[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) b[u] = rp[r + u < r1 ? r + u : r1];
+    int c[8];
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = b[u] + lane;
+      const bool has = idx < b[u + 1];
+      c[u] = has ? col[idx] : -1;
+      v[u] = has ? val[idx] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int prev_last = -1;  // last column of the row's previous chunk
+      int cc = c[u];
+      float vv = v[u];
+      for (int p = b[u]; p < b[u + 1]; p += 64) {
+        const int idx = p + lane;
+        const bool has = idx < b[u + 1];
+        if (p > b[u]) {
+          cc = has ? col[idx] : -1;
+          vv = has ? val[idx] : 0.f;
+        }
+        const bool ok = has && (unsigned)cc < (unsigned)K;
+        int before = __shfl_up(cc, 1, 64);
+        if (lane == 0) before = prev_last;
+        int pos = 0;
+        if (__ballot(has && cc <= before) == 0ull) {  // strictly ascending: distinct cursors, one read and one write per lane
+          if (ok) {
+            pos = mine[cc];
+            mine[cc] = pos + 1;
+          }
+        } else {  // lane order by hand (wave-uniform loop; rare)
+          const int n = b[u + 1] - p < 64 ? b[u + 1] - p : 64;
+          for (int i = 0; i < n; ++i) {
+            const int ci = __builtin_amdgcn_readlane(cc, i);
+            if ((unsigned)ci >= (unsigned)K) continue;
+            const int pi = mine[ci];  // every lane reads the same word
+            if (lane == i) {
+              pos = pi;
+              mine[ci] = pi + 1;
+            }
+          }
+        }
+        if (ok) {
+          t_col[pos] = r + u;
+          t_val[pos] = vv;
+        }
+        prev_last = __builtin_amdgcn_readlane(cc, 63);
+      }
+    }
+  }
+}
+
+// Does the LDS plan take this batch?  Items small enough for one workgroup's table, and enough of them (or little enough
+// work) that one workgroup per item is not a serial tail.  Returns the number of waves (16, 8 or 4) or 0.
+int tr_item_lds_waves(int64_t nnz, int32_t batch, int32_t M, int32_t K) {
+  if (batch <= 0 || M <= 0 || K <= 0 || nnz <= 0) return 0;
+  if (nnz / batch > 262144 || (batch < 64 && nnz > 131072)) return 0;
+  for (int waves : {16, 8, 4})
+    if (((long)waves * K + waves + 1) * 4 <= 64L * 1024) return waves;  // ≤ 64 KiB: two workgroups per CU
+  return 0;
+}
+
+int launch_tr_item_lds(int waves, const int32_t* rowptr, const int32_t* col, const float* val, int32_t batch, int32_t M,
+                       int32_t K, int32_t* t_rowptr, int32_t* t_col, float* t_val, hipStream_t s) {
+  const size_t lds = ((size_t)waves * K + waves + 1) * sizeof(int);
+#define MI_TR_ITEM(W_)                                                                                                \
+  hipLaunchKernelGGL(tr_item_lds_kernel<W_>, dim3((unsigned)batch), dim3(W_ * 64), lds, s, rowptr, col, val, M, K, t_rowptr, \
+                     t_col, t_val)
+  if (waves == 16) MI_TR_ITEM(16);
+  else if (waves == 8) MI_TR_ITEM(8);
+  else MI_TR_ITEM(4);
+#undef MI_TR_ITEM
+  return mi::check_launch();
+}
+
 int transpose_impl(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz, int32_t batch, int32_t M,
                    int32_t K, int32_t* t_rowptr, int32_t* t_col, float* t_val, void* workspace, size_t workspace_bytes,
                    hipStream_t s) {
@@ -1576,6 +1742,12 @@ int transpose_impl(const int32_t* rowptr, const int32_t* col, const float* val, 
     return MI_OK;
   }
   if (!rowptr || !col || !val || !t_col || !t_val || M == 0) return MI_EINVAL;
+  // small items: one workgroup per item, inside its LDS (no workspace needed; the size query still covers the general plan,
+  // which MI_TRANSPOSE_PLAN_TABLES / _ONE_SWEEP pin)
+  if (g_tr_plan.load(std::memory_order_relaxed) == MI_TRANSPOSE_PLAN_AUTO) {
+    const int waves = tr_item_lds_waves(nnz, batch, M, K);
+    if (waves > 0) return launch_tr_item_lds(waves, rowptr, col, val, batch, M, K, t_rowptr, t_col, t_val, s);
+  }
   const TrPlan p = make_plan(batch, M, K, nnz);
   const TrWs w = ws_layout(p, nnz);
   if (workspace_bytes < w.total) return MI_ENOMEM;
@@ -1791,6 +1963,10 @@ int mi_csr_transpose_check(const void* workspace, size_t workspace_bytes, int32_
   MI_HIP_TRY(hipMemcpyAsync(&flag, static_cast<const char*>(workspace) + w.errflag, sizeof(int), hipMemcpyDeviceToHost, s));
   MI_HIP_TRY(hipStreamSynchronize(s));
   return flag == 0 ? MI_OK : MI_EHIP;
+}
+
+int mi_csr_transpose_batched_in_lds(int64_t nnz, int32_t batch, int32_t M, int32_t K) {
+  return g_tr_plan.load(std::memory_order_relaxed) == MI_TRANSPOSE_PLAN_AUTO && tr_item_lds_waves(nnz, batch, M, K) > 0 ? 1 : 0;
 }
 
 int mi_csr_transpose_batched_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,

@@ -583,6 +583,62 @@ bool naive_spmm_batched_perm(torch::Tensor A_values, torch::Tensor perm, torch::
   return true;
 }
 
+// C[i] (A_cols × N) = A[i]ᵀ · X[i] for a batched CSR A [batch, A_rows, A_cols] (offsets with base, as naive_spmm_batched)
+// and X [batch, A_rows, N] — no transpose of A is built (mi_spmm_csr_batched_at_f32).  Returns false (nothing launched)
+// when the shape is not covered (N > 64): transpose and call naive_spmm_batched.
+bool naive_spmm_batched_at(torch::Tensor A_values, torch::Tensor A_columns, torch::Tensor A_offsets, int64_t nnzA,
+                           int64_t batch, int64_t A_rows, int64_t A_cols, torch::Tensor X, torch::Tensor C) {
+  const char* what = "naive_spmm_batched_at";
+  check_device_f32(A_values, "A_values");
+  check_device_i32(A_columns, "A_columns");
+  check_device_i32(A_offsets, "A_offsets");
+  check_device_f32(X, "X");
+  check_device_f32(C, "C");
+  check_same_device(A_values, C, what);
+  check_same_device(A_columns, C, what);
+  check_same_device(A_offsets, C, what);
+  check_same_device(X, C, what);
+  TORCH_CHECK(batch >= 0 && A_rows >= 0 && A_cols >= 0 && nnzA >= 0, what, ": negative size");
+  TORCH_CHECK(A_rows <= INT32_MAX && A_cols <= INT32_MAX && batch <= INT32_MAX, what, ": dimension too large");
+  TORCH_CHECK(A_values.is_contiguous() && A_columns.is_contiguous() && A_offsets.is_contiguous(), what,
+              ": CSR arrays must be contiguous");
+  TORCH_CHECK(A_offsets.numel() == batch * (A_rows + 1), what, ": A_offsets must be [batch, A_rows + 1]");
+  TORCH_CHECK(A_columns.numel() >= nnzA && A_values.numel() >= nnzA, what, ": nnzA exceeds the CSR arrays");
+  TORCH_CHECK(C.dim() == 3 && C.is_contiguous() && C.size(0) == batch && C.size(1) == A_cols, what,
+              ": C must be contiguous [batch, A_cols, N]");
+  const int64_t N = C.size(2);
+  TORCH_CHECK(X.dim() == 3 && X.size(0) == batch && X.size(1) == A_rows && X.size(2) == N, what, ": X must be [batch, A_rows, N]");
+  torch::Tensor Xc = X.contiguous();
+  c10::hip::HIPGuard guard(C.device().index());
+  const int st = mi_spmm_csr_batched_at_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
+                                            A_values.data_ptr<float>(), nnzA, (int32_t)batch, (int32_t)A_rows, (int32_t)A_cols,
+                                            (int32_t)N, Xc.data_ptr<float>(), std::max<int64_t>(N, 1), A_rows * N,
+                                            C.data_ptr<float>(), std::max<int64_t>(N, 1), A_cols * N, stream_of(C));
+  if (st == 1) return false;
+  check_status(st, what);
+  return true;
+}
+
+// (offsets int32 [batch, rows + 1] with the items' bases added, columns int32 [batch · per_item]) of a batched torch CSR
+// tensor's int64 index tensors crow [batch, rows + 1] / col [batch, per_item], in one launch (mi_batched_csr_narrow_i64).
+std::tuple<torch::Tensor, torch::Tensor> batched_csr_narrow(torch::Tensor crow, torch::Tensor col) {
+  const char* what = "batched_csr_narrow";
+  TORCH_CHECK(crow.is_cuda() && col.is_cuda() && crow.scalar_type() == torch::kInt64 && col.scalar_type() == torch::kInt64,
+              what, ": int64 device tensors expected");
+  TORCH_CHECK(crow.dim() == 2 && col.dim() == 2 && crow.size(0) == col.size(0) && crow.size(1) >= 1, what,
+              ": crow [batch, rows + 1] and col [batch, per_item] expected");
+  TORCH_CHECK(crow.is_contiguous() && col.is_contiguous(), what, ": contiguous index tensors expected");
+  check_same_device(crow, col, what);
+  const int64_t batch = crow.size(0), rows = crow.size(1) - 1, per_item = col.size(1);
+  TORCH_CHECK(batch <= INT32_MAX && rows <= INT32_MAX && batch * per_item <= INT32_MAX, what, ": too large for int32 indices");
+  c10::hip::HIPGuard guard(crow.device().index());
+  torch::Tensor off = torch::empty({batch, rows + 1}, torch::dtype(torch::kInt32).device(crow.device()));
+  torch::Tensor c32 = torch::empty({batch * per_item}, torch::dtype(torch::kInt32).device(crow.device()));
+  check_status(mi_batched_csr_narrow_i64(crow.data_ptr<int64_t>(), col.data_ptr<int64_t>(), (int32_t)batch, (int32_t)rows, per_item,
+                                         off.data_ptr<int32_t>(), c32.data_ptr<int32_t>(), stream_of(off)), what);
+  return std::make_tuple(off, c32);
+}
+
 // C[b] = A[b]·B[b] (+ bias) with A DENSE [batch…, M, K]: exact zeros are skipped inside the
 // kernel (no CSR is built).  B is [batch…, K, N] or [K, N] (shared), C [batch…, M, N].
 // Returns false (and does nothing) when the fused kernel does not cover the shape, so the
@@ -789,7 +845,9 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> csr_transpose_batched(to
   torch::Tensor t_off = torch::empty({batch, A_cols + 1}, iopt);
   torch::Tensor t_col = torch::empty({nnzA}, iopt);
   torch::Tensor t_val = torch::empty({nnzA}, A_values.options());
-  const size_t ws_bytes = mi_csr_transpose_batched_workspace_bytes((int32_t)batch, (int32_t)A_rows, (int32_t)A_cols, nnzA);
+  // (the one-workgroup-per-item plan of small items uses no workspace)
+  const size_t ws_bytes = mi_csr_transpose_batched_in_lds(nnzA, (int32_t)batch, (int32_t)A_rows, (int32_t)A_cols) == 1
+                              ? 0 : mi_csr_transpose_batched_workspace_bytes((int32_t)batch, (int32_t)A_rows, (int32_t)A_cols, nnzA);
   torch::Tensor ws = torch::empty({(int64_t)std::max<size_t>(ws_bytes, 1)}, torch::dtype(torch::kUInt8).device(A_values.device()));
   check_status(mi_csr_transpose_batched_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
                                             A_values.data_ptr<float>(), nnzA, (int32_t)batch, (int32_t)A_rows,
@@ -1217,6 +1275,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("naive_spmm_batched", &naive_spmm_batched, "Batched CSR x dense in one launch");
   m.def("csr_transpose", &csr_transpose, "Device CSR transpose (values, columns, offsets)");
   m.def("csr_transpose_batched", &csr_transpose_batched, "Batched device CSR transpose (values, columns, offsets [batch, cols+1])");
+  m.def("csr_transpose_in_lds", [](int64_t nnz, int64_t batch, int64_t rows, int64_t cols) {
+          return rows <= INT32_MAX && cols <= INT32_MAX && batch <= INT32_MAX &&
+                 mi_csr_transpose_batched_in_lds(nnz, (int32_t)batch, (int32_t)rows, (int32_t)cols) == 1;
+        }, "does csr_transpose_batched run the one-workgroup-per-item LDS plan on this batch (cheap: transpose per backward)");
   m.def("sddmm", &sddmm, "Sampled dense-dense product on a CSR pattern");
   m.def("cublas_bmm_pair", &cublas_bmm_pair,
         "dA = dC.B and dB = dC^T.A in one launch that reads dC once; (dC, B, A, dA, dB) -> launched?");
@@ -1225,6 +1287,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("gather_perm", &gather_perm, "values[perm] (int32 perm) as a new tensor");
   m.def("naive_spmm_batched_perm", &naive_spmm_batched_perm,
         "naive_spmm_batched with entry p's value = A_values[perm[p]]; False (nothing launched) if the plan takes no permutation");
+  m.def("naive_spmm_batched_at", &naive_spmm_batched_at,
+        "C[i] = A[i]^T X[i] for a batched CSR A without transposing it; False (nothing launched) if the shape is not covered");
+  m.def("batched_csr_narrow", &batched_csr_narrow,
+        "(int32 offsets [batch, rows+1] with the items' bases, int32 columns) of int64 crow [batch, rows+1] / col [batch, per_item]");
   m.def("naive_spmm_dense", &naive_spmm_dense,
         "A·B with A dense, zeros skipped in the kernel; False if the shape is not covered");
   m.def("naive_spmm_dense_bias", &naive_spmm_dense_bias, "as naive_spmm_dense, + bias in the epilogue");

@@ -1140,6 +1140,28 @@ int l2_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
   return p >= 2 ? p : 0;
 }
 
+// Infinity-Cache panels for B beyond the cache (≥ 768 MiB): how many column panels K is cut into, or 0 for one pass.
+// Measured on MI355X over N 64 … 512, K = M 1 … 4 M, 20 / 100 / 400 non-zeros per row, every plan on the same operands and
+// the same output buffer (tools/bench_hbm_regime.py --variants, profiles/r05_hbm_regime.log): panels pay when a panel's
+// slice of B is ≈ 0.5–0.7 GiB — about twice the cache, so that about half of a pass's gathers hit it — i.e. P ≈ |B| / 683 MiB
+// (1 GiB: 2 panels −6 %; 2 GiB: 3–4 panels −5 … −11 %; 4 GiB: 6 panels −9 … −11 %; fewer, larger panels than that bring
+// nothing: 4 GiB in 2–3 panels +1 … +2 %), and when the rows are long enough to carry C through memory once more per
+// panel (2 (P − 1) row passes against nnz/M gathered rows per row: 20 per row never pays, 100 per row pays up to 6
+// panels).  Beyond ≈ 6 GiB no panel count helps (8 GiB in 8 panels: ± 1 %): one pass at the HBM random-row rate.
+// The launch must also re-touch a panel often enough to keep it resident (gathered bytes ≥ 8 × |B|), which excludes the
+// short row blocks of a sharded run.
+int ic_panels(int64_t nnz, int32_t M, int32_t K, int32_t N, int64_t ldb) {
+  const double b_bytes = (double)K * (double)ldb * 4.0;
+  if (b_bytes < 768.0 * 1048576.0 || M <= 0) return 0;
+  if ((double)nnz * (double)N < 8.0 * (double)K * (double)ldb) return 0;
+  const double want = b_bytes / (683.0 * 1048576.0);
+  if (want > 9.0) return 0;
+  int best = 2;
+  for (int p : {2, 3, 4, 6, 8})
+    if ((p - want < 0 ? want - p : p - want) <= (best - want < 0 ? want - best : best - want)) best = p;  // nearest, ties up
+  return nnz >= 16L * best * M ? best : 0;
+}
+
 struct Shape {
   bool vec4_ok, vec2_ok, wave_ok;
 };
@@ -1162,16 +1184,21 @@ Shape classify(int32_t N, int64_t ldb, int64_t ldc, int64_t strideB, int64_t str
 // The kernel AUTO resolves to.
 int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32_t K, int32_t N,
                    int64_t ldb) {
-  // B much larger than the 256 MiB Infinity Cache and rows long enough to pay for
-  // carrying C through memory once: two column panels (measured on MI355X at
-  // |B| = 1 GiB, 105 nnz/row: 15.5 ms vs 16.4 ms one-pass; 3+ panels lose, each
-  // extra pass costs a read + write of C).  The launch must also re-touch a panel
-  // often enough to keep it resident (gathered bytes >= 8x |B|), which excludes the
-  // short row blocks of a sharded run.
-  const long b_elems = (long)K * ldb;
-  if (sh.wave_ok && batch == 1 && b_elems * 4 >= (768L << 20) && nnz >= 32L * M &&
-      nnz * (long)N >= 8 * b_elems)
-    return MI_SPMM_PANELS_2;
+  // B beyond the 256 MiB Infinity Cache: K in column panels, one launch per panel (ic_panels: how many, fitted on
+  // tools/bench_hbm_regime.py, profiles/r05_hbm_regime.log) — the one-wave-per-row panel kernel for N = 256 / 512 / 1024,
+  // the lane-group panel kernel for N ≤ 128
+  if (batch == 1 && sh.vec4_ok) {
+    const int p = ic_panels(nnz, M, K, N, ldb);
+    if (p > 0 && sh.wave_ok) {
+      static const int kWave[9] = {0, 0, MI_SPMM_PANELS_2, MI_SPMM_PANELS_3, MI_SPMM_PANELS_4, 0, MI_SPMM_PANELS_6, 0, MI_SPMM_PANELS_8};
+      return kWave[p];
+    }
+    if (p > 0 && N >= 36 && N <= 128) {  // (narrower rows: 16-lane groups would idle half their lanes)
+      static const int kGroup[9] = {0, 0, MI_SPMM_GROUP_PANELS_2, MI_SPMM_GROUP_PANELS_3, MI_SPMM_GROUP_PANELS_4, 0,
+                                    MI_SPMM_GROUP_PANELS_6, 0, MI_SPMM_GROUP_PANELS_8};
+      return kGroup[p];
+    }
+  }
   if (N < 4) return MI_SPMM_NARROW;
   // Many small products (or one tall one) whose B fits a CU's LDS: gather from LDS instead of from the L2s
   // (spmm_ldsb.hip).  It pays once rows are long enough to amortise copying B per workgroup.

@@ -366,9 +366,16 @@ def _batched_csr_pattern(a: torch.Tensor, dev, transposed: bool = False):
     if hit is None or hit[0] != key:
         if total >= 2 ** 31 or nb * max(rows, cols) >= 2 ** 31:
             raise ValueError('sparse matmul: the batch holds too many non-zeros / rows for int32 indices')
-        base = torch.arange(nb, device=crow.device, dtype=crow.dtype).unsqueeze(1) * per_item
-        hit = [key, (crow + base).to(device=dev, dtype=torch.int32).contiguous(),
-               col.reshape(-1).to(device=dev, dtype=torch.int32).contiguous(), None]
+        if (hasattr(custom_mm, 'batched_csr_narrow') and crow.is_cuda and crow.device == torch.device(dev) and per_item > 0
+                and crow.dtype == torch.int64 and col.dtype == torch.int64):
+            # ONE launch for both index tensors (round 5: attention probabilities are a new pattern on every step, so
+            # this narrowing is per-step work, not a one-off — it used to be five torch kernels)
+            off32, col32 = custom_mm.batched_csr_narrow(crow.contiguous(), col.reshape(nb, per_item).contiguous())
+            hit = [key, off32, col32, None]
+        else:
+            base = torch.arange(nb, device=crow.device, dtype=crow.dtype).unsqueeze(1) * per_item
+            hit = [key, (crow + base).to(device=dev, dtype=torch.int32).contiguous(),
+                   col.reshape(-1).to(device=dev, dtype=torch.int32).contiguous(), None]
         try:
             a._mi_batched_pattern = hit
         except (AttributeError, RuntimeError):
@@ -746,8 +753,12 @@ def _batched_csr_backward(ctx, m1, m2, grad_output):
     val = torch.Tensor.values(m1)
     nb = torch.Tensor.crow_indices(m1).reshape(-1, rows + 1).shape[0]
     total = val.numel()
+    per_item = total // max(nb, 1)
     dev = grad_output.device
-    offsets, columns, (flat_off, diag_columns, t_perm, t_col, t_off) = _batched_csr_pattern(m1, dev, transposed=True)
+    # the transposed pattern (a batched device transpose + its permutation + the block-diagonal index arrays) is built only
+    # when a step below needs it: for pruned attention (n ≤ 64, an item's m2 in LDS) neither gradient does (round 5)
+    offsets, columns, _ = _batched_csr_pattern(m1, dev)
+    transposed = lambda: _batched_csr_pattern(m1, dev, transposed=True)[2]  # noqa: E731  (flat_off, diag_columns, t_perm, t_col, t_off)
     g = grad_output.reshape(nb, rows, n).contiguous()
     shared = m2.dim() == 2
     grad_m1 = grad_m2 = None
@@ -758,6 +769,7 @@ def _batched_csr_backward(ctx, m1, m2, grad_output):
         if not (hasattr(custom_mm, 'sddmm_batched') and
                 custom_mm.sddmm_batched(columns, offsets, total, nb, rows, cols, g,
                                         m2.to(dev) if shared else m2.reshape(nb, cols, n).to(dev), gvals)):
+            flat_off, diag_columns = transposed()[:2]
             b_stack = (m2.unsqueeze(0).expand(nb, cols, n) if shared else m2.reshape(nb, cols, n)).reshape(nb * cols, n)
             gvals = custom_mm.sddmm(diag_columns, flat_off, total, nb * rows, nb * cols, g.reshape(nb * rows, n),
                                     b_stack.contiguous())
@@ -769,7 +781,36 @@ def _batched_csr_backward(ctx, m1, m2, grad_output):
         flat_val = val.reshape(-1).to(dev).contiguous()
         t_val = None
         gb = torch.empty((nb, cols, n), device=dev, dtype=torch.float32)
-        for lo in range(0, nb, 65535):  # (items per launch, as in the forward)
+        # A tensor object seen for the FIRST time (attention probabilities: a new pattern on every step) gets its values
+        # transposed directly where the one-workgroup-per-item LDS transpose takes the batch: nothing is kept, no
+        # permutation, no block-diagonal index arrays are built (round 5: those cost a fresh pattern 0.39 ms per step,
+        # profiles/r05_attention_csr_fresh.log).  From the SECOND backward of the same object on (a static pattern:
+        # pruned weights) the transposed pattern and its permutation are kept on the tensor and the values travel
+        # through the permutation inside the product kernel, as before.  (The transpose-free product,
+        # custom_mm.naive_spmm_batched_at, was built and measured too: 0.54 ms at 10 % kept — its register-indexed FMA
+        # per entry and the 16-fold scan of the indices lose to transposing; it stays available as an entry point.)
+        launches = range(0, nb, 65535)  # (items per launch, as in the forward)
+        hit = getattr(m1, '_mi_batched_pattern', None)
+        seen = getattr(m1, '_mi_batched_backwards', 0)
+        try:
+            m1._mi_batched_backwards = seen + 1
+        except (AttributeError, RuntimeError):
+            pass
+        direct = seen == 0 and (hit is None or hit[3] is None) and hasattr(custom_mm, 'csr_transpose_in_lds') and \
+            all(custom_mm.csr_transpose_in_lds((min(nb, lo + 65535) - lo) * per_item, min(nb, lo + 65535) - lo, rows, cols)
+                for lo in launches)
+        if direct:
+            for lo in launches:
+                hi = min(nb, lo + 65535)
+                p0, p1 = lo * per_item, hi * per_item
+                tv, tc, to = custom_mm.csr_transpose_batched(flat_val[p0:p1], columns[p0:p1],
+                                                             offsets[lo:hi] if lo == 0 else (offsets[lo:hi] - p0).contiguous(),
+                                                             p1 - p0, hi - lo, rows, cols)
+                custom_mm.naive_spmm_batched(tv, tc, to, p1 - p0, hi - lo, cols, rows, g[lo:hi], gb[lo:hi])
+            launches = range(0)
+        else:
+            _, _, t_perm, t_col, t_off = transposed()
+        for lo in launches:
             hi = min(nb, lo + 65535)
             off_c, g_c = t_off[lo:hi].contiguous(), g[lo:hi]
             if hasattr(custom_mm, 'naive_spmm_batched_perm') and \

@@ -142,6 +142,16 @@ def test_every_variant_id_has_a_kernel_name_and_the_plan_query_needs_no_gpu(lib)
     assert plan(int(0.1 * 16384 * 16384), 16384, 16384, 256) == 9  # B = 16 MiB: four L2 panels beat the slab plan
     assert plan(40 * 16384, 16384, 16384, 256) == 9 and plan(20 * 16384, 16384, 16384, 256) == 7  # short rows: fewer passes
     assert plan(8 * 16384, 16384, 16384, 256) == 2                 # too short to carry C at all
+    # B beyond the Infinity Cache (round 5, fitted on tools/bench_hbm_regime.py): P ≈ |B| / 683 MiB panels when the rows
+    # are long enough (≥ 16 P non-zeros per row), the lane-group panel kernel for N ≤ 128; none beyond ≈ 6 GiB
+    m2, m4 = 1 << 21, 1 << 22
+    assert plan(100 * m2, m2, m2, 256) == 8                        # 2 GiB: three panels
+    assert plan(100 * m2, m2, m2, 512) == 11                       # 4 GiB: six panels
+    assert plan(20 * m2, m2, m2, 256) == 2                         # 20 per row: one pass
+    assert plan(100 * m2, m2, m2, 128) == 19                       # 1 GiB at N = 128: two group panels
+    assert plan(100 * m4, m4, m4, 128) == 20                       # 2 GiB at N = 128: three
+    assert plan(100 * m4, m4, m4, 64) == 19 and plan(20 * m4, m4, m4, 64) == 4   # N = 64: two panels / one pass for short rows
+    assert plan(100 * m4, m4, m4, 512) == 2                        # 8 GiB: no panel count pays
 
 
 def test_host_inspector_coo_to_csr(lib, golden, oracle_mod):

@@ -422,3 +422,51 @@ def test_spmm_count_as_bound_or_estimate_same_bits(capi, cmm, dev, oracle_mod, N
                 assert np.array_equal(C.cpu().numpy().view(np.int32), want[0].view(np.int32))
     finally:
         capi.mi_spmm_ldsb_set_form(-1)
+
+
+@pytest.mark.parametrize("batch,M,K,N", [(5, 333, 300, 64), (3, 700, 1100, 48), (2, 9, 17, 7), (40, 512, 512, 64), (1, 1, 1, 1),
+                                         (7, 130, 33, 20), (2, 1200, 40, 64), (300, 64, 64, 32)])
+def test_transpose_free_at_product_bit_exact(cmm, dev, oracle_mod, batch, M, K, N):
+    """Round 5: Y[i] = A[i]ᵀ·X[i] for batched CSR A WITHOUT a transpose (csrc/spmm_at.hip: output tile in registers, every
+    wave walks the item's rows in ascending order and picks the entries of its own columns) — the gradient of V in pruned
+    attention with a new pattern per step.  Bit-exact against oracle.csr_transpose + oracle.spmm_csr per item: rows longer
+    than a 64-entry chunk, duplicate and unsorted columns, empty rows and columns, items taller than one 512-row tile of
+    the staged operand, more columns than one workgroup owns, N not a multiple of 4 (scalar staging).  The index narrowing
+    of torch's int64 batched CSR (one launch) is checked on the way.  Reference: matmuls.py:245-256 (no backward for a
+    batched CSR operand), :289-297 (per-call conversion)."""
+    g = np.random.Generator(np.random.PCG64(batch * 1000 + M + K + N))
+    lens = g.integers(0, min(2 * K + 3, 150), size=batch * M)
+    lens[g.integers(0, batch * M, size=max(1, batch * M // 20))] = 0
+    if M > 3:
+        lens[2] = min(2 * K + 5, 300)          # longer than K: duplicate columns; longer than a chunk
+    cols = [g.integers(0, K, size=int(n)).astype(np.int32) for n in lens]
+    cols = [c if i % 3 == 0 else np.sort(c) for i, c in enumerate(cols)]
+    col = np.concatenate(cols) if len(cols) else np.zeros(0, np.int32)
+    val = (g.random(len(col), dtype=np.float32) - 0.5).astype(np.float32)
+    off = np.zeros((batch, M + 1), np.int64)
+    off[:, 1:] = np.cumsum(lens).reshape(batch, M)
+    off[1:, 0] = off[:-1, M]
+    off = off.astype(np.int32)
+    X = g.random((batch, M, N), dtype=np.float32) - 0.5
+    want = np.zeros((batch, K, N), np.float32)
+    for i in range(batch):
+        p0, p1 = off[i, 0], off[i, M]
+        t_rp, t_col, t_val = oracle_mod.csr_transpose(off[i] - p0, col[p0:p1], val[p0:p1], M, K)
+        want[i] = oracle_mod.spmm_csr(t_rp, t_col, t_val, K, M, X[i])
+    Y = torch.full((batch, K, N), float("nan"), device=dev)
+    took = cmm.naive_spmm_batched_at(t(val, dev), t(col, dev), t(off, dev), len(col), batch, M, K, t(X, dev), Y)
+    assert took
+    assert np.array_equal(Y.cpu().numpy().view(np.int32), want.view(np.int32))
+    # wider than 64 columns: declined, nothing written
+    Yw = torch.full((batch, K, 68), float("nan"), device=dev)
+    assert not cmm.naive_spmm_batched_at(t(val, dev), t(col, dev), t(off, dev), len(col), batch, M, K,
+                                         torch.zeros(batch, M, 68, device=dev), Yw)
+    assert bool(torch.isnan(Yw).all())
+    # the one-launch narrowing of torch's batched CSR indices (equal counts per item)
+    per_item = 11
+    crow = torch.arange(0, M + 1, dtype=torch.int64).clamp(max=per_item).repeat(batch, 1).to(dev)
+    ccol = torch.from_numpy(g.integers(0, K, size=(batch, per_item))).to(dev)
+    off32, col32 = cmm.batched_csr_narrow(crow, ccol)
+    base = torch.arange(batch, device=dev, dtype=torch.int64).unsqueeze(1) * per_item
+    assert off32.dtype == torch.int32 and torch.equal(off32.long(), crow + base)
+    assert col32.dtype == torch.int32 and torch.equal(col32.long(), ccol.reshape(-1))

@@ -507,7 +507,13 @@ def test_config_c5_pruned_attention_as_batched_csr_full_size_forward_and_backwar
     recursion matmuls.py:289-297 and has no working backward for it, :245-256).  Checked on sampled (b, h) items
     against torch-CPU autograd of the dense product (the reference tests' criterion, tests/naive_kernel_test.py:30-37)
     and bit-exact against the oracle: forward = oracle.spmm_csr_batched, grad of the values = oracle.sddmm,
-    grad of V = the oracle's CSR product with the oracle's transpose."""
+    grad of V = the oracle's CSR product with the oracle's transpose.
+    Every apply below gets a NEW tensor object — what matmuls keeps between calls lives on the object, so narrowing and
+    (where still needed) the transposed pattern are rebuilt per call, as with attention probabilities; the last block
+    runs a second, different top-k pattern through the same class (round 5: grad of V without any transpose,
+    csrc/spmm_at.hip).  The torch comparison uses atol 1e-6 rather than the reference tests' 1e-8: V and dC are signed
+    here (rand − 0.5), sums cancel to near zero and a relative criterion alone is then meaningless; the bit-exact oracle
+    checks beside it carry the parity claim."""
     Bz, H, S, D = 32, 12, 512, 64
     g = torch.Generator(device=dev).manual_seed(21)
     probs = torch.softmax(torch.rand(Bz, H, S, S, device=dev, generator=g) * 4, dim=-1)
@@ -560,6 +566,23 @@ def test_config_c5_pruned_attention_as_batched_csr_full_size_forward_and_backwar
     # whole-batch property: the product is linear in V — A·(2V) == 2·(A·V) exactly
     a = torch.sparse_csr_tensor(crow, idx.reshape(Bz, H, -1), vals.reshape(Bz, H, -1), size=(Bz, H, S, S), device=dev)
     assert torch.equal(mm.cusparseMM.apply(a, v * 2), outs["cusparseMM"][0] * 2)
+    # a second, DIFFERENT pattern through the same class: nothing of the first one may be reused
+    probs2 = torch.softmax(torch.rand(Bz, H, S, S, device=dev, generator=g) * 4, dim=-1)
+    idx2 = probs2.topk(keep_n, dim=-1).indices.sort(dim=-1).values
+    vals2 = probs2.gather(-1, idx2)
+    assert not torch.equal(idx2, idx)
+    a2 = torch.sparse_csr_tensor(crow, idx2.reshape(Bz, H, -1), vals2.reshape(Bz, H, -1), size=(Bz, H, S, S),
+                                 device=dev).requires_grad_(True)
+    v2 = v.clone().requires_grad_(True)
+    mm.cusparseMM.apply(a2, v2).backward(d_ctx)
+    for (i, j) in items[:2]:
+        rp = (np.arange(S + 1) * keep_n).astype(np.int32)
+        col = idx2[i, j].reshape(-1).cpu().numpy().astype(np.int32)
+        val = vals2[i, j].reshape(-1).cpu().numpy()
+        t_rp, t_col, t_val = oracle_mod.csr_transpose(rp, col, val, S, S)
+        assert np.array_equal(v2.grad[i, j].cpu().numpy(), oracle_mod.spmm_csr(t_rp, t_col, t_val, S, S, d_ctx[i, j].cpu().numpy()))
+        assert np.array_equal(a2.grad.values().reshape(Bz, H, -1)[i, j].cpu().numpy(),
+                              oracle_mod.sddmm(rp, col, S, d_ctx[i, j].cpu().numpy(), v[i, j].cpu().numpy()))
 
 
 def test_cusparse_linear_lds_fit_layer_with_a_stale_low_density_estimate(mm, cmm, dev, monkeypatch):
