@@ -1572,19 +1572,33 @@ int launch_scatter(const TrArgs& a, bool packed, bool staged, hipStream_t s) {
 // go out as the item's transposed offsets; (3) every wave walks its rows IN ORDER, a row's ≤ 64 entries per instruction:
 // position = cursor[w][col]++ (an LDS read and write — the columns of one instruction are distinct when the row ascends
 // strictly, which is checked on the spot; a chunk that does not — unsorted rows, duplicate columns — takes its positions
-// one lane after the other, in lane order), then t_col[position] = row, t_val[position] = value.  Entries of a column
-// therefore land by ascending row, ties in CSR order: the stable order of the general plan and of oracle_csr_transpose.
+// one lane after the other, in lane order).  Entries of a column therefore land by ascending row, ties in CSR order: the
+// stable order of the general plan and of oracle_csr_transpose.
+// The placed entries (row, value) do NOT go to memory one by one: a first version stored them straight to t_col / t_val —
+// 4-byte stores, 64 different lines per instruction, every 128-byte line completed by 32 stores spread over the whole sweep,
+// with 384 items' 80 MB of half-written lines thrashing the 4 MiB L2s: 0.24 ms, no faster than the general plan.  They
+// are STAGED in LDS and leave as whole lines: step (3) runs once per column PASS — the columns are cut into passes whose
+// entries fit the staging area (`cap` entries of 8 bytes), a pass places only its own columns' entries at
+// (position − the pass's first position) in the staging area, and after a barrier the workgroup copies the pass's
+// contiguous piece of t_col / t_val out with coalesced 16-byte stores.  A pass re-reads the item's col / val from the
+// L2s (they were read by step 1); two passes at 10 % kept.  A pass that does not fit its share of the staging area
+// (skewed columns) falls back to the direct stores for its entries: slower, same result.
 // Loads travel eight rows (or eight 64-entry chunks) at a time.  No workspace, no inter-workgroup hand-off.
 // ---------------------------------------------------------------------------------------------
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void tr_item_lds_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                                  const float* __restrict__ val, int M, int K,
                                                                  int* __restrict__ t_rowptr, int* __restrict__ t_col,
-                                                                 float* __restrict__ t_val) {
-  extern __shared__ int tr_lds[];  // [WAVES][K] counters → cursors, then WAVES + 1 ints of scan scratch
+                                                                 float* __restrict__ t_val, int cap) {
+  extern __shared__ __attribute__((aligned(16))) int tr_lds[];
+  // [cap] staged rows, [cap] staged values (both 16-byte aligned: cap % 4 == 0), [WAVES][K] counters → cursors,
+  // [K + 1] column starts of the item (relative), WAVES + 1 ints of scan scratch
   constexpr int T = WAVES * 64;
-  int* cnt = tr_lds;
-  int* scratch = tr_lds + (long)WAVES * K;
+  int* st_row = tr_lds;
+  float* st_val = reinterpret_cast<float*>(tr_lds + cap);
+  int* cnt = tr_lds + 2 * (long)cap;
+  int* starts = cnt + (long)WAVES * K;
+  int* scratch = starts + K + 1;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long item = blockIdx.x;
@@ -1611,14 +1625,13 @@ __global__ __launch_bounds__(WAVES * 64) void tr_item_lds_kernel(const int* __re
     }
   }
   __syncthreads();
-  {  // (2) counters → cursors; a thread owns a contiguous range of columns
+  {  // (2) counters → cursors (positions relative to the item); a thread owns a contiguous range of columns
     const int cpt = (K + T - 1) / T;
     const int k_lo = tid * cpt < K ? tid * cpt : K, k_hi = k_lo + cpt < K ? k_lo + cpt : K;
     int sum = 0;
     for (int k = k_lo; k < k_hi; ++k)
       for (int w = 0; w < WAVES; ++w) sum += cnt[(long)w * K + k];
-    // exclusive scan of `sum` over the workgroup's threads
-    int incl = sum;
+    int incl = sum;  // inclusive scan of `sum` over the wave, then over the workgroup
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const int y = __shfl_up(incl, d, 64);
@@ -1633,94 +1646,175 @@ __global__ __launch_bounds__(WAVES * 64) void tr_item_lds_kernel(const int* __re
         scratch[w] = run;
         run += x;
       }
+      scratch[WAVES] = run;  // entries of the item with a column in range
     }
     __syncthreads();
-    int run = base + scratch[wave] + incl - sum;  // entries of the columns before k_lo, as a position in the item's arrays
+    int run = scratch[wave] + incl - sum;  // entries of the columns before k_lo
     int* t_rp = t_rowptr + item * ((long)K + 1);
     for (int k = k_lo; k < k_hi; ++k) {
-      t_rp[k] = run;
+      t_rp[k] = base + run;
+      starts[k] = run;
       for (int w = 0; w < WAVES; ++w) {
         const int x = cnt[(long)w * K + k];
         cnt[(long)w * K + k] = run;
         run += x;
       }
     }
-    if (tid == T - 1) t_rp[K] = rp[M];  // (= base + every entry of the item when all columns are in range)
+    if (tid == T - 1) {
+      t_rp[K] = rp[M];  // (= base + every entry of the item when all columns are in range)
+      starts[K] = scratch[WAVES];
+    }
   }
   __syncthreads();
-  // (3) placement, rows in order, eight rows' first chunks in flight together
-  for (int r = r0; r < r1; r += 8) {
-    int b[9];
-#pragma unroll
-    for (int u = 0; u < 9; ++u) b[u] = rp[r + u < r1 ? r + u : r1];
-    int c[8];
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = b[u] + lane;
-      const bool has = idx < b[u + 1];
-      c[u] = has ? col[idx] : -1;
-      v[u] = has ? val[idx] : 0.f;
+  // (3) column passes: [ka, kb) = as many columns from ka on as fit the staging area (at least one)
+  const int total = starts[K];
+  int ka = 0;
+  while (ka < K) {  // workgroup-uniform
+    const int pa = starts[ka];
+    int lo = ka + 1, hi = K;  // the last kb in (ka, K] with starts[kb] − pa ≤ cap (kb = ka + 1 even if that column alone is too long)
+    while (lo < hi) {
+      const int mid = lo + ((hi - lo + 1) >> 1);
+      if (starts[mid] - pa <= cap) lo = mid; else hi = mid - 1;
     }
+    const int kb = lo;
+    const int pb = starts[kb];
+    const bool staged = pb - pa <= cap;  // false: one column longer than the staging area — its entries go out directly
+    if (pb > pa) {
+      for (int r = r0; r < r1; r += 8) {  // rows in order, eight rows' first chunks in flight together
+        int b[9];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      int prev_last = -1;  // last column of the row's previous chunk
-      int cc = c[u];
-      float vv = v[u];
-      for (int p = b[u]; p < b[u + 1]; p += 64) {
-        const int idx = p + lane;
-        const bool has = idx < b[u + 1];
-        if (p > b[u]) {
-          cc = has ? col[idx] : -1;
-          vv = has ? val[idx] : 0.f;
+        for (int u = 0; u < 9; ++u) b[u] = rp[r + u < r1 ? r + u : r1];
+        int c[8];
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = b[u] + lane;
+          const bool has = idx < b[u + 1];
+          c[u] = has ? col[idx] : -1;
+          v[u] = has ? val[idx] : 0.f;
         }
-        const bool ok = has && (unsigned)cc < (unsigned)K;
-        int before = __shfl_up(cc, 1, 64);
-        if (lane == 0) before = prev_last;
-        int pos = 0;
-        if (__ballot(has && cc <= before) == 0ull) {  // strictly ascending: distinct cursors, one read and one write per lane
-          if (ok) {
-            pos = mine[cc];
-            mine[cc] = pos + 1;
-          }
-        } else {  // lane order by hand (wave-uniform loop; rare)
-          const int n = b[u + 1] - p < 64 ? b[u + 1] - p : 64;
-          for (int i = 0; i < n; ++i) {
-            const int ci = __builtin_amdgcn_readlane(cc, i);
-            if ((unsigned)ci >= (unsigned)K) continue;
-            const int pi = mine[ci];  // every lane reads the same word
-            if (lane == i) {
-              pos = pi;
-              mine[ci] = pi + 1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          int prev_last = -1;  // last column of the row's previous chunk
+          int cc = c[u];
+          float vv = v[u];
+          for (int p = b[u]; p < b[u + 1]; p += 64) {
+            const int idx = p + lane;
+            const bool has = idx < b[u + 1];
+            if (p > b[u]) {
+              cc = has ? col[idx] : -1;
+              vv = has ? val[idx] : 0.f;
             }
+            const bool ok = has && cc >= ka && cc < kb;  // this pass's columns
+            int before = __shfl_up(cc, 1, 64);
+            if (lane == 0) before = prev_last;
+            int pos = 0;
+            if (__ballot(has && cc <= before) == 0ull) {  // strictly ascending: distinct cursors, one read and one write per lane
+              if (ok) {
+                pos = mine[cc];
+                mine[cc] = pos + 1;
+              }
+            } else {  // lane order by hand (wave-uniform loop; rare)
+              const int n = b[u + 1] - p < 64 ? b[u + 1] - p : 64;
+              for (int i = 0; i < n; ++i) {
+                const int ci = __builtin_amdgcn_readlane(cc, i);
+                if (ci < ka || ci >= kb) continue;
+                const int pi = mine[ci];  // every lane reads the same word
+                if (lane == i) {
+                  pos = pi;
+                  mine[ci] = pi + 1;
+                }
+              }
+            }
+            if (ok) {
+              if (staged) {
+                st_row[pos - pa] = r + u;
+                st_val[pos - pa] = vv;
+              } else {
+                t_col[base + pos] = r + u;
+                t_val[base + pos] = vv;
+              }
+            }
+            prev_last = __builtin_amdgcn_readlane(cc, 63);
           }
         }
-        if (ok) {
-          t_col[pos] = r + u;
-          t_val[pos] = vv;
-        }
-        prev_last = __builtin_amdgcn_readlane(cc, 63);
       }
     }
+    if (staged && pb > pa) {
+      __syncthreads();  // the pass's entries are all staged
+      // copy out: entries [pa, pb) of the item → t_col / t_val [base + pa, base + pb); 16-byte stores between aligned ends
+      const int n = pb - pa;
+      int* dc = t_col + base + pa;
+      float* dv = t_val + base + pa;
+      // entries up to the first 16-byte boundary; t_col and t_val normally share it (same offset into two aligned arrays) —
+      // if not, everything goes out as single entries
+      const bool vec = ((((unsigned long long)dc) ^ ((unsigned long long)dv)) & 15ull) == 0;
+      const int head = vec ? (int)((4 - (((unsigned long long)dc >> 2) & 3)) & 3) : n;
+      const int h = head < n ? head : n;
+      for (int i = tid + T; i < h; i += T) {  // (only without `vec`: the head is then the whole piece)
+        dc[i] = st_row[i];
+        dv[i] = st_val[i];
+      }
+      if (tid < h) {
+        dc[tid] = st_row[tid];
+        dv[tid] = st_val[tid];
+      }
+      const int quads = (n - h) >> 2;
+      for (int i = tid; i < quads; i += T) {
+        const int o = h + 4 * i;
+        int4 rq;
+        float4 vq;
+        rq.x = st_row[o], rq.y = st_row[o + 1], rq.z = st_row[o + 2], rq.w = st_row[o + 3];
+        vq.x = st_val[o], vq.y = st_val[o + 1], vq.z = st_val[o + 2], vq.w = st_val[o + 3];
+        *reinterpret_cast<int4*>(dc + o) = rq;
+        *reinterpret_cast<float4*>(dv + o) = vq;
+      }
+      const int done = h + 4 * quads;
+      if (tid < n - done) {
+        dc[done + tid] = st_row[done + tid];
+        dv[done + tid] = st_val[done + tid];
+      }
+      __syncthreads();  // the staging area is free for the next pass
+    }
+    ka = kb;
   }
+  (void)total;
 }
 
 // Does the LDS plan take this batch?  Items small enough for one workgroup's table, and enough of them (or little enough
 // work) that one workgroup per item is not a serial tail.  Returns the number of waves (16, 8 or 4) or 0.
+size_t tr_item_fixed_bytes(int waves, int32_t K) { return ((size_t)waves * K + K + 1 + waves + 1) * sizeof(int); }
+
 int tr_item_lds_waves(int64_t nnz, int32_t batch, int32_t M, int32_t K) {
   if (batch <= 0 || M <= 0 || K <= 0 || nnz <= 0) return 0;
   if (nnz / batch > 262144 || (batch < 64 && nnz > 131072)) return 0;
   for (int waves : {16, 8, 4})
-    if (((long)waves * K + waves + 1) * 4 <= 64L * 1024) return waves;  // ≤ 64 KiB: two workgroups per CU
+    if (tr_item_fixed_bytes(waves, K) <= 48u * 1024) return waves;  // table + column starts ≤ 48 KiB, the rest stages
   return 0;
 }
 
-int launch_tr_item_lds(int waves, const int32_t* rowptr, const int32_t* col, const float* val, int32_t batch, int32_t M,
-                       int32_t K, int32_t* t_rowptr, int32_t* t_col, float* t_val, hipStream_t s) {
-  const size_t lds = ((size_t)waves * K + waves + 1) * sizeof(int);
-#define MI_TR_ITEM(W_)                                                                                                \
-  hipLaunchKernelGGL(tr_item_lds_kernel<W_>, dim3((unsigned)batch), dim3(W_ * 64), lds, s, rowptr, col, val, M, K, t_rowptr, \
-                     t_col, t_val)
+int launch_tr_item_lds(int waves, int64_t nnz, const int32_t* rowptr, const int32_t* col, const float* val, int32_t batch,
+                       int32_t M, int32_t K, int32_t* t_rowptr, int32_t* t_col, float* t_val, hipStream_t s) {
+  // staging area: the whole (average) item where that fits 78 KiB per workgroup beside the table — two workgroups per CU,
+  // one pass; else 150 KiB per workgroup and as few passes as that allows (an item larger than the average just takes
+  // one pass more: the kernel cuts its passes from the item's own column starts)
+  const long per_item = (nnz + batch - 1) / batch;
+  const size_t fixed = tr_item_fixed_bytes(waves, K);
+  long cap = per_item + 64;
+  if ((long)fixed + cap * 8 > 78L * 1024) {
+    const long room = (150L * 1024 - (long)fixed) / 8;
+    const long passes = (cap + room - 1) / room;
+    cap = (per_item + passes - 1) / passes + 64;
+    if (cap > room) cap = room;
+  }
+  cap = (cap + 3) / 4 * 4;
+  const size_t lds = fixed + (size_t)cap * 8;
+#define MI_TR_ITEM(W_)                                                                                                       \
+  do {                                                                                                                       \
+    auto k = tr_item_lds_kernel<W_>;                                                                                         \
+    if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(W_ * 64), lds, s, rowptr, col, val, M, K, t_rowptr, t_col, t_val, (int)cap); \
+  } while (0)
   if (waves == 16) MI_TR_ITEM(16);
   else if (waves == 8) MI_TR_ITEM(8);
   else MI_TR_ITEM(4);
@@ -1746,7 +1840,7 @@ int transpose_impl(const int32_t* rowptr, const int32_t* col, const float* val, 
   // which MI_TRANSPOSE_PLAN_TABLES / _ONE_SWEEP pin)
   if (g_tr_plan.load(std::memory_order_relaxed) == MI_TRANSPOSE_PLAN_AUTO) {
     const int waves = tr_item_lds_waves(nnz, batch, M, K);
-    if (waves > 0) return launch_tr_item_lds(waves, rowptr, col, val, batch, M, K, t_rowptr, t_col, t_val, s);
+    if (waves > 0) return launch_tr_item_lds(waves, nnz, rowptr, col, val, batch, M, K, t_rowptr, t_col, t_val, s);
   }
   const TrPlan p = make_plan(batch, M, K, nnz);
   const TrWs w = ws_layout(p, nnz);

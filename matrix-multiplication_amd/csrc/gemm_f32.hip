@@ -268,7 +268,7 @@ __device__ __forceinline__ void gemm_epilogue_b(f32x16 (&acc)[TM][TN], float* __
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int row0 = m0 + wm * (BM / 2) + i * 32, col0 = n0 + wn * (BN / 2) + j * 32;  // uniform
+      const int row0 = m0 + wm * (TM * 32) + i * 32, col0 = n0 + wn * (TN * 32) + j * 32;  // uniform (a wave owns TM × TN blocks)
       const int col = col0 + l31;
       float bv = 0.f;
       if (HAS_BIAS && (MODE == 0 || col < n)) bv = bias[col];
@@ -457,13 +457,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI_GEMM_SHO
 // buffer t&1, the registers holding tile t+1 (loaded during tile t-1) are written to the other
 // buffer and the loads of tile t+2 are issued, so a global load has a whole MFMA phase to land and
 // a wave that is alone on its SIMD keeps the matrix pipe busy.
-template <int BM, int BN, bool TA, bool TB>
+// WN: waves along n — 2 (the 2 × 2 layout of every tile so far) or 1 (4 × 1: a wave owns 32 rows × the whole tile width,
+// which lets the width be any multiple of 32: the 96-column tile of head sizes 80 / 96, round 5).
+template <int BM, int BN, bool TA, bool TB, int WN = 2>
 __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int m, int n,
     int k, long lda, long ldb, long ldc, long strideA, long strideB, long strideC, int tiles_n,
     int tiles_per_item, bool vecA, bool vecB, bool vecC, const float* __restrict__ bias, int reverse) {
-  constexpr int TM = BM / 64;
-  constexpr int TN = BN / 64;
+  constexpr int WM = 4 / WN;
+  constexpr int TM = BM / (32 * WM);
+  constexpr int TN = BN / (32 * WN);
+  static_assert(TM * 32 * WM == BM && TN * 32 * WN == BN, "whole 32 x 32 blocks per wave");
   typedef TileLoader<BM, !TA> LA;
   typedef TileLoader<BN, TB> LB;
   constexpr int kStage = LA::LDS_FLOATS + LB::LDS_FLOATS;
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: the epilogue's descriptors stay scalar
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const unsigned total = gridDim.x, bid = blockIdx.x;
   const unsigned q = total / 8, rem = total % 8, xcd = bid % 8, pos = bid / 8;
   const unsigned work0 = xcd * q + (xcd < rem ? xcd : rem) + pos;
@@ -538,9 +542,9 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i) a[slot][h][i] = (MI_GEMM_ABL & 8) ? (float)(s + i) : LA::at(As, wm * (BM / 2) + i * 32 + l31, 4 * s + 2 * h + lhi);
+          for (int i = 0; i < TM; ++i) a[slot][h][i] = (MI_GEMM_ABL & 8) ? (float)(s + i) : LA::at(As, wm * (TM * 32) + i * 32 + l31, 4 * s + 2 * h + lhi);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) b[slot][h][j] = (MI_GEMM_ABL & 8) ? (float)(h + j) : LB::at(Bs, wn * (BN / 2) + j * 32 + l31, 4 * s + 2 * h + lhi);
+          for (int j = 0; j < TN; ++j) b[slot][h][j] = (MI_GEMM_ABL & 8) ? (float)(h + j) : LB::at(Bs, wn * (TN * 32) + j * 32 + l31, 4 * s + 2 * h + lhi);
         }
       };
       read_batch(0, 0);
@@ -609,9 +613,9 @@ __global__ __launch_bounds__(256) void gemm_f32_pipe_kernel(
       for (int kk = 0; kk < BK; kk += 2) {
         float a[TM], b[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = LA::at(As, wm * (BM / 2) + i * 32 + l31, kk + lhi);
+        for (int i = 0; i < TM; ++i) a[i] = LA::at(As, wm * (TM * 32) + i * 32 + l31, kk + lhi);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = LB::at(Bs, wn * (BN / 2) + j * 32 + l31, kk + lhi);
+        for (int j = 0; j < TN; ++j) b[j] = LB::at(Bs, wn * (TN * 32) + j * 32 + l31, kk + lhi);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1024,6 +1028,21 @@ int launch(const float* A, const float* B, float* C, int m, int n, int k, long l
   return mi::check_launch();
 }
 
+// 64 < n ≤ 96 with a long k (attention's probs·V and Pᵀ·dC at head sizes 80 / 96): ONE 96-column tile per 128 rows
+// instead of a 128-column one — the matrix pipe computes 96 columns for the 80 / 96 wanted, not 128 (round 4 measured
+// 1.17–1.41× torch's time on these products, profiles/r03_attention_shapes.log).  Same k order per element: same bits.
+template <bool TA, bool TB>
+int launch_n96(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb, long ldc, long sA, long sB,
+               long sC, int batch, bool vecA, bool vecB, bool vecC, const float* bias, hipStream_t s) {
+  const long tiles_m = (m + 127) / 128;
+  const long blocks = tiles_m * batch;
+  if (blocks > 0x7fffffffL) return MI_ERANGE;
+  const int rev = (int)(mi::g_gemm_launch_counter.fetch_add(1, std::memory_order_relaxed) & 1u);
+  hipLaunchKernelGGL((gemm_f32_pipe_kernel<128, 96, TA, TB, 1>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m, n, k, lda,
+                     ldb, ldc, sA, sB, sC, 1, (int)tiles_m, vecA, vecB, vecC, bias, rev);
+  return mi::check_launch();
+}
+
 template <bool TA, bool TB>
 int pick_tile(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb,
               long ldc, long sA, long sB, long sC, int batch, bool vecA, bool vecB, bool vecC,
@@ -1074,6 +1093,10 @@ int pick_tile(const float* A, const float* B, float* C, int m, int n, int k, lon
   if (MI_GEMM_FORCE_TILE == 2) MI_TILE(128, 64);
   if (MI_GEMM_FORCE_TILE == 3) MI_TILE(64, 128);
   if (MI_GEMM_FORCE_TILE == 4) MI_TILE(64, 64);
+#endif
+#ifndef MI_GEMM_NO_N96
+  if (n > 64 && n <= 96 && m > 64 && k >= MI_GEMM_PIPE_MIN_TILES * BK && vecA && vecB && k % BK == 0 && blocks_for(128, 96) >= 256)
+    return launch_n96<TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, vecC, bias, s);
 #endif
   if (m > 64 && n > 64 && blocks_for(128, 128) >= want) MI_TILE(128, 128);
   if (m > 64 && blocks_for(128, 64) >= want) MI_TILE(128, 64);

@@ -123,6 +123,29 @@ def test_gemm_bert_base_attention_shapes(cmm, dev, oracle_mod):
     assert np.array_equal(ctxt[3, 7].cpu().numpy(), oracle_mod.gemm(p, v[3, 7].numpy()))
 
 
+@pytest.mark.parametrize("items,S,D", [(96, 512, 80), (96, 512, 96), (24, 197, 64), (12, 577, 64), (6, 2048, 64), (24, 300, 72),
+                                       (3, 130, 96), (600, 256, 88)])
+def test_gemm_attention_products_at_other_head_sizes_and_lengths_bit_exact(cmm, dev, oracle_mod, items, S, D):
+    """Round 5: the four attention products (q·kᵀ, probs·V and the two transposed products of their backward) at head
+    sizes 80 / 96 / 72 / 88 — probs·V and Pᵀ·dC there run ONE 96-column tile per 128 rows (4 × 1 wave layout of the
+    pipelined kernel) instead of a 128-column one — and at ragged lengths (ViT's 197 / 577 tokens, 300, 130): bit-exact
+    against the oracle's k-ordered chain on sampled items, allclose against torch on all.  Reference: README.md:69-77,
+    tests/cublas_kernel_test.py:68-69."""
+    g = torch.Generator(device="cpu").manual_seed(S + D)
+    q, kk, v, dc = (torch.rand(items, S, D, generator=g) - 0.5 for _ in range(4))
+    p = torch.rand(items, S, S, generator=g) - 0.5
+    d = {n: x.to(dev) for n, x in (("q", q), ("k", kk), ("v", v), ("dc", dc), ("p", p))}
+    cases = [("q.kT", d["q"], d["k"], (S, S), False, True, q, kk), ("P.V", d["p"], d["v"], (S, D), False, False, p, v),
+             ("PT.dC", d["p"], d["dc"], (S, D), True, False, p, dc), ("dC.VT", d["dc"], d["v"], (S, S), False, True, dc, v)]
+    for name, a, b, shape, ta, tb, ah, bh in cases:
+        out = torch.full((items,) + shape, float("nan"), device=dev)
+        cmm.cublas_bmm(a, b, out, 3, ta, tb)
+        ref = torch.matmul(a.transpose(-1, -2) if ta else a, b.transpose(-1, -2) if tb else b)
+        assert torch.allclose(ref, out, rtol=1e-4, atol=1e-5), name   # (signed operands: sums cancel)
+        for i in sorted({0, items // 2, items - 1}):
+            assert np.array_equal(out[i].cpu().numpy(), oracle_mod.gemm(ah[i].numpy(), bh[i].numpy(), ta, tb)), (name, i)
+
+
 @pytest.mark.parametrize("batch,m,k", [((3, 2), 512, 512), ((5,), 256, 256), ((2, 3), 128, 512), ((9,), 512, 64), ((1,), 64, 128)])
 def test_fused_pair_of_products_sharing_an_operand_bit_exact(cmm, mm, dev, oracle_mod, batch, m, k):
     """Round 4: custom_mm.cublas_bmm_pair — dA = dC·B and dB = dCᵀ·A (the backward of cublasTransbMM, reference

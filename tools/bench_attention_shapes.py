@@ -28,7 +28,7 @@ def timeit(fn, iters=20):
 
 print("# tools/bench_attention_shapes.py on MI355X (ms per product, best of 3 blocks of 20; TFLOP/s of ours)")
 print("# items x S x D        product          ours     torch    ours/torch   TFLOP/s")
-for items, S, D in [(384, 128, 64), (384, 256, 64), (384, 384, 64), (384, 512, 64), (96, 1024, 64), (48, 2048, 64),
+for items, S, D in [(384, 512, 88), (384, 512, 72), (384, 128, 64), (384, 256, 64), (384, 384, 64), (384, 512, 64), (96, 1024, 64), (48, 2048, 64),
                     (512, 512, 64), (256, 512, 128), (384, 512, 96), (384, 512, 80), (384, 197, 64), (192, 577, 64)]:
     q = torch.rand(items, S, D, device=dev)
     kk = torch.rand(items, S, D, device=dev)
