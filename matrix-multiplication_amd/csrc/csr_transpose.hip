@@ -29,6 +29,8 @@
 // (row bits) > 32) or an 11-bit digit take a simpler path that scatters straight from registers.
 #include <atomic>
 
+#include <type_traits>
+
 #include "mi_common.h"
 
 namespace {
@@ -1585,11 +1587,27 @@ int launch_scatter(const TrArgs& a, bool packed, bool staged, hipStream_t s) {
 // (skewed columns) falls back to the direct stores for its entries: slower, same result.
 // Loads travel eight rows (or eight 64-entry chunks) at a time.  No workspace, no inter-workgroup hand-off.
 // ---------------------------------------------------------------------------------------------
+// lane l ← lane l − 1 (lane 0 keeps its own value): a DPP wave shift — no trip through the LDS crossbar, which the placement
+// loop below keeps busy enough
+__device__ __forceinline__ int wave_shr1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+
+#ifdef MI_TR_ITEM_TIMING  // developer probe (tools/probes/tr_item_timing.py): cycles per phase, summed over workgroups (thread 0)
+__device__ unsigned long long g_tr_item_stamp[8];
+#define TR_ITEM_STAMP(k)                                                                   \
+  do {                                                                                     \
+    const unsigned long long now_ = __builtin_readcyclecounter();                          \
+    if (threadIdx.x == 0) atomicAdd(&g_tr_item_stamp[k], now_ - stamp_);                   \
+    stamp_ = now_;                                                                         \
+  } while (0)
+#else
+#define TR_ITEM_STAMP(k) do {} while (0)
+#endif
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void tr_item_lds_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                                  const float* __restrict__ val, int M, int K,
                                                                  int* __restrict__ t_rowptr, int* __restrict__ t_col,
-                                                                 float* __restrict__ t_val, int cap) {
+                                                                 float* __restrict__ t_val, int cap, int nseg) {
   extern __shared__ __attribute__((aligned(16))) int tr_lds[];
   // [cap] staged rows, [cap] staged values (both 16-byte aligned: cap % 4 == 0), [WAVES][K] counters → cursors,
   // [K + 1] column starts of the item (relative), WAVES + 1 ints of scan scratch
@@ -1601,23 +1619,70 @@ __global__ __launch_bounds__(WAVES * 64) void tr_item_lds_kernel(const int* __re
   int* scratch = starts + K + 1;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long item = blockIdx.x;
+  // grid = items × nseg: workgroup (item, seg) counts the whole item (steps 1, 2 — it needs every column's start) and
+  // places the seg-th column pass; the last one also takes the passes beyond nseg, should the item need more than the
+  // launcher sized for (a larger or skewed item)
+  const long item = blockIdx.x / (unsigned)nseg;
+  const int seg = (int)(blockIdx.x % (unsigned)nseg);
   const int* rp = rowptr + item * ((long)M + 1);
   const int rows_per_wave = (M + WAVES - 1) / WAVES;
   const int r0 = wave * rows_per_wave < M ? wave * rows_per_wave : M;
   const int r1 = r0 + rows_per_wave < M ? r0 + rows_per_wave : M;
   const int base = rp[0];
+#ifdef MI_TR_ITEM_TIMING
+  unsigned long long stamp_ = __builtin_readcyclecounter();
+#endif
+  // The kernel is a chain of dependent trips to memory (row bounds → entries → … ) with the CU to itself, so the chain is
+  // kept short: the wave's row bounds arrive as ONE vector load, the counting pass's entries and the first placement
+  // group's entries are requested together right behind it.
+  const int last_e = rp[M] > base ? rp[M] - 1 : base;  // (an item without entries never dereferences it: every `has` is false … but the
+                                                       // load is issued: the caller's arrays hold ≥ 1 entry whenever nnz > 0)
+  const bool rp_in_reg = r1 - r0 <= 63;
+  const int rpv = rp_in_reg ? rp[r0 + lane <= r1 ? r0 + lane : r1] : 0;
+  auto bound = [&](int row) {  // rp[min(row, r1)], wave-uniform
+    const int rr = row < r1 ? row : r1;
+    return rp_in_reg ? __builtin_amdgcn_readlane(rpv, rr - r0) : rp[rr];
+  };
+  struct Group {
+    int b[9];
+    int c[8];
+    float v[8];
+  };
+  auto fetch = [&](int r, Group& gq) {
+#pragma unroll
+    for (int u = 0; u < 9; ++u) gq.b[u] = bound(r + u);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      // UNCONDITIONAL loads on an index clamped to the item's entries: a predicated load puts a branch round it, and the
+      // compiler then waits for EVERY outstanding load at the join — the next group's too, which were to stay in flight
+      const int idx = gq.b[u] + lane;
+      const int at = idx < last_e ? idx : last_e;
+      const int cl = col[at];
+      const float vl = val[at];
+      const bool has = idx < gq.b[u + 1];
+      gq.c[u] = has ? cl : -1;
+      gq.v[u] = has ? vl : 0.f;
+    }
+  };
+  Group g0, g1;
+  bool g0_ready = false;
+  if (r0 < r1) {
+    fetch(r0, g0);
+    g0_ready = true;
+  }
   for (int i = tid; i < WAVES * K; i += T) cnt[i] = 0;
   __syncthreads();
+  TR_ITEM_STAMP(0);  // bounds + first fetch issued, table zeroed
   int* mine = cnt + (long)wave * K;
   {  // (1) the wave's entries are contiguous: [rp[r0], rp[r1])
-    const int e0 = rp[r0], e1 = rp[r1];
+    const int e0 = bound(r0), e1 = bound(r1);
     for (int p = e0; p < e1; p += 8 * 64) {
       int c[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int idx = p + u * 64 + lane;
-        c[u] = idx < e1 ? col[idx] : -1;
+        const int cl = col[idx < last_e ? idx : last_e];
+        c[u] = idx < e1 ? cl : -1;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
@@ -1625,6 +1690,7 @@ __global__ __launch_bounds__(WAVES * 64) void tr_item_lds_kernel(const int* __re
     }
   }
   __syncthreads();
+  TR_ITEM_STAMP(1);  // counted
   {  // (2) counters → cursors (positions relative to the item); a thread owns a contiguous range of columns
     const int cpt = (K + T - 1) / T;
     const int k_lo = tid * cpt < K ? tid * cpt : K, k_hi = k_lo + cpt < K ? k_lo + cpt : K;
@@ -1652,7 +1718,7 @@ __global__ __launch_bounds__(WAVES * 64) void tr_item_lds_kernel(const int* __re
     int run = scratch[wave] + incl - sum;  // entries of the columns before k_lo
     int* t_rp = t_rowptr + item * ((long)K + 1);
     for (int k = k_lo; k < k_hi; ++k) {
-      t_rp[k] = base + run;
+      if (seg == 0) t_rp[k] = base + run;
       starts[k] = run;
       for (int w = 0; w < WAVES; ++w) {
         const int x = cnt[(long)w * K + k];
@@ -1661,124 +1727,173 @@ __global__ __launch_bounds__(WAVES * 64) void tr_item_lds_kernel(const int* __re
       }
     }
     if (tid == T - 1) {
-      t_rp[K] = rp[M];  // (= base + every entry of the item when all columns are in range)
+      if (seg == 0) t_rp[K] = rp[M];  // (= base + every entry of the item when all columns are in range)
       starts[K] = scratch[WAVES];
     }
   }
   __syncthreads();
-  // (3) column passes: [ka, kb) = as many columns from ka on as fit the staging area (at least one)
-  const int total = starts[K];
-  int ka = 0;
+  TR_ITEM_STAMP(2);  // cursors
+  // (3) column passes: [ka, kb) = as many columns from ka on as fit the staging area (at least one); this workgroup
+  // places pass number `seg` (and, if it is the last workgroup of the item, every pass behind it)
+  int ka = 0, pass = 0;
   while (ka < K) {  // workgroup-uniform
     const int pa = starts[ka];
     int lo = ka + 1, hi = K;  // the last kb in (ka, K] with starts[kb] − pa ≤ cap (kb = ka + 1 even if that column alone is too long)
     while (lo < hi) {
       const int mid = lo + ((hi - lo + 1) >> 1);
-      if (starts[mid] - pa <= cap) lo = mid; else hi = mid - 1;
+      if (starts[mid] - pa <= cap - 4) lo = mid; else hi = mid - 1;  // (− 4: the piece may start up to 3 entries into the area)
     }
     const int kb = lo;
     const int pb = starts[kb];
-    const bool staged = pb - pa <= cap;  // false: one column longer than the staging area — its entries go out directly
-    if (pb > pa) {
-      for (int r = r0; r < r1; r += 8) {  // rows in order, eight rows' first chunks in flight together
-        int b[9];
-#pragma unroll
-        for (int u = 0; u < 9; ++u) b[u] = rp[r + u < r1 ? r + u : r1];
-        int c[8];
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int idx = b[u] + lane;
-          const bool has = idx < b[u + 1];
-          c[u] = has ? col[idx] : -1;
-          v[u] = has ? val[idx] : 0.f;
+    const bool take = pass == seg || (seg == nseg - 1 && pass > seg);
+    // the staged piece starts `sh` entries into the staging area, sh = the destination's offset from a 16-byte boundary: an
+    // entry is then 16-byte aligned in LDS exactly when it is in memory, and the copy-out moves whole aligned quads
+    const int sh = (int)((((unsigned long long)(t_col + base + pa)) >> 2) & 3);
+    const bool staged = pb - pa <= cap - 4;  // false: one column longer than the staging area — its entries go out directly
+    // (the pass body is compiled twice, for staged and for direct output: with one body and a run-time choice of the
+    // destination hipcc merges the two stores of an entry into ONE flat store through a selected pointer — and a flat
+    // store into LDS is several times slower than a ds_write)
+    auto run_pass = [&](auto staged_c) {
+      constexpr bool kStaged = decltype(staged_c)::value;
+      auto emit = [&](bool ok, int pos, int row, float vv) {
+        if (!ok) return;
+        if constexpr (kStaged) {
+          st_row[pos - pa + sh] = row;
+          st_val[pos - pa + sh] = vv;
+        } else {
+          t_col[base + pos] = row;
+          t_val[base + pos] = vv;
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          int prev_last = -1;  // last column of the row's previous chunk
-          int cc = c[u];
-          float vv = v[u];
-          for (int p = b[u]; p < b[u + 1]; p += 64) {
-            const int idx = p + lane;
-            const bool has = idx < b[u + 1];
-            if (p > b[u]) {
-              cc = has ? col[idx] : -1;
-              vv = has ? val[idx] : 0.f;
+      };
+      // one ≤ 64-entry chunk of a row (prev_last: the last column of the row's previous chunk, −1 at its start)
+      auto place = [&](int cc, float vv, bool has, int n, int row, int prev_last) {
+        const bool ok = has && cc >= ka && cc < kb;  // this pass's columns
+        int before = __shfl_up(cc, 1, 64);
+        if (lane == 0) before = prev_last;
+        int pos = 0;
+        if (__ballot(has && cc <= before) == 0ull) {  // strictly ascending: the lanes' cursors are distinct words
+          if (ok) {
+            pos = mine[cc];
+            mine[cc] = pos + 1;
+          }
+        } else {  // lane order by hand (wave-uniform loop; rare)
+          for (int i = 0; i < n; ++i) {
+            const int ci = __builtin_amdgcn_readlane(cc, i);
+            if (ci < ka || ci >= kb) continue;
+            const int pi = mine[ci];  // every lane reads the same word
+            if (lane == i) {
+              pos = pi;
+              mine[ci] = pi + 1;
             }
-            const bool ok = has && cc >= ka && cc < kb;  // this pass's columns
-            int before = __shfl_up(cc, 1, 64);
-            if (lane == 0) before = prev_last;
-            int pos = 0;
-            if (__ballot(has && cc <= before) == 0ull) {  // strictly ascending: distinct cursors, one read and one write per lane
-              if (ok) {
-                pos = mine[cc];
-                mine[cc] = pos + 1;
-              }
-            } else {  // lane order by hand (wave-uniform loop; rare)
-              const int n = b[u + 1] - p < 64 ? b[u + 1] - p : 64;
-              for (int i = 0; i < n; ++i) {
-                const int ci = __builtin_amdgcn_readlane(cc, i);
-                if (ci < ka || ci >= kb) continue;
-                const int pi = mine[ci];  // every lane reads the same word
-                if (lane == i) {
-                  pos = pi;
-                  mine[ci] = pi + 1;
-                }
-              }
-            }
-            if (ok) {
-              if (staged) {
-                st_row[pos - pa] = r + u;
-                st_val[pos - pa] = vv;
-              } else {
-                t_col[base + pos] = r + u;
-                t_val[base + pos] = vv;
-              }
-            }
-            prev_last = __builtin_amdgcn_readlane(cc, 63);
           }
         }
+        emit(ok, pos, row, vv);
+      };
+      // Rows in order, eight rows per group, and the NEXT group's first chunks already in flight while a group is placed
+      // (two register sets, alternating): a pass is otherwise a chain of exposed memory latencies — with the staging area
+      // a workgroup has its CU to itself, so nothing else hides them.  The wave's row bounds sit in one register (lane j:
+      // rp[r0 + j]) where its block has ≤ 63 rows, so a group's bounds cost no memory access either.
+      auto settle = [&](int r, const Group& gq) {
+        const int* b = gq.b;
+        // Fast form: every row of the group fits one chunk and ascends strictly — straight-line code for the eight rows'
+        // cursor updates (the LDS executes a wave's instructions in order, so a column that two rows share gets its
+        // positions in row order; inside one instruction the columns are distinct).
+        bool fast = true;
+        unsigned long long bad = 0ull;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          fast = fast && (b[u + 1] - b[u] <= 64);
+          const int before = wave_shr1(gq.c[u]);
+          bad |= __ballot(gq.c[u] >= 0 && lane > 0 && gq.c[u] <= before);
+        }
+        if (fast && bad == 0ull) {
+          int pos[8];
+          bool ok[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            ok[u] = gq.c[u] >= ka && gq.c[u] < kb;  // (absent lanes carry −1)
+            pos[u] = 0;
+            // a plain read and a plain write (the lanes' words are distinct; the next row's read follows this row's write in
+            // the wave's LDS order): a RETURNING LDS atomic measured ≈ 1 lane per cycle for the whole CU — 64 cycles per
+            // instruction, 33 k cycles per pass and workgroup, four fifths of the kernel (tools/probes/tr_item_timing.py)
+            if (ok[u]) {
+              pos[u] = mine[gq.c[u]];
+              mine[gq.c[u]] = pos[u] + 1;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) emit(ok[u], pos[u], r + u, gq.v[u]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            int prev_last = -1;
+            int cc = gq.c[u];
+            float vv = gq.v[u];
+            for (int p = b[u]; p < b[u + 1]; p += 64) {
+              const int idx = p + lane;
+              const bool hh = idx < b[u + 1];
+              if (p > b[u]) {
+                cc = hh ? col[idx] : -1;
+                vv = hh ? val[idx] : 0.f;
+              }
+              place(cc, vv, hh, b[u + 1] - p < 64 ? b[u + 1] - p : 64, r + u, prev_last);
+              prev_last = __builtin_amdgcn_readlane(cc, 63);
+            }
+          }
+        }
+      };
+      if (r0 < r1 && !g0_ready) fetch(r0, g0);  // (a later pass of the same workgroup: the first group again)
+      g0_ready = false;
+      // (the fetches are UNCONDITIONAL — rows beyond the block read as empty, their loads are clamped: a fetch under a
+      // branch leaves the number of loads in flight unknown at the join and the compiler then drains them all, vmcnt(0),
+      // before the older group is used — which is exactly the overlap this loop exists for)
+      for (int r = r0; r < r1; r += 16) {
+        fetch(r + 8, g1);
+        settle(r, g0);
+        fetch(r + 16, g0);
+        settle(r + 8, g1);
       }
+    };
+    if (take && pb > pa) {
+      if (staged) run_pass(std::true_type{});
+      else run_pass(std::false_type{});
     }
-    if (staged && pb > pa) {
+    if (take && staged && pb > pa) {
       __syncthreads();  // the pass's entries are all staged
+      TR_ITEM_STAMP(3);  // placed
       // copy out: entries [pa, pb) of the item → t_col / t_val [base + pa, base + pb); 16-byte stores between aligned ends
       const int n = pb - pa;
-      int* dc = t_col + base + pa;
-      float* dv = t_val + base + pa;
-      // entries up to the first 16-byte boundary; t_col and t_val normally share it (same offset into two aligned arrays) —
-      // if not, everything goes out as single entries
+      int* dc = t_col + base + pa - sh;    // 16-byte aligned; entry j of the staging area ↔ dc[j], j in [sh, sh + n)
+      float* dv = t_val + base + pa - sh;  // aligned too when t_val shares t_col's alignment (two arrays at the same offset)
       const bool vec = ((((unsigned long long)dc) ^ ((unsigned long long)dv)) & 15ull) == 0;
-      const int head = vec ? (int)((4 - (((unsigned long long)dc >> 2) & 3)) & 3) : n;
-      const int h = head < n ? head : n;
-      for (int i = tid + T; i < h; i += T) {  // (only without `vec`: the head is then the whole piece)
-        dc[i] = st_row[i];
-        dv[i] = st_val[i];
-      }
-      if (tid < h) {
-        dc[tid] = st_row[tid];
-        dv[tid] = st_val[tid];
-      }
-      const int quads = (n - h) >> 2;
-      for (int i = tid; i < quads; i += T) {
-        const int o = h + 4 * i;
-        int4 rq;
-        float4 vq;
-        rq.x = st_row[o], rq.y = st_row[o + 1], rq.z = st_row[o + 2], rq.w = st_row[o + 3];
-        vq.x = st_val[o], vq.y = st_val[o + 1], vq.z = st_val[o + 2], vq.w = st_val[o + 3];
-        *reinterpret_cast<int4*>(dc + o) = rq;
-        *reinterpret_cast<float4*>(dv + o) = vq;
-      }
-      const int done = h + 4 * quads;
-      if (tid < n - done) {
-        dc[done + tid] = st_row[done + tid];
-        dv[done + tid] = st_val[done + tid];
+      if (vec) {
+        const int q0 = sh ? 1 : 0, q1 = (sh + n) >> 2;  // whole quads [q0, q1); entries before / behind them one by one
+        for (int i = q0 + tid; i < q1; i += T) {
+          *reinterpret_cast<int4*>(dc + 4 * i) = *reinterpret_cast<const int4*>(st_row + 4 * i);
+          *reinterpret_cast<float4*>(dv + 4 * i) = *reinterpret_cast<const float4*>(st_val + 4 * i);
+        }
+        const int head_end = q0 * 4 < sh + n ? q0 * 4 : sh + n;  // [sh, head_end)
+        if (tid < head_end - sh) {
+          dc[sh + tid] = st_row[sh + tid];
+          dv[sh + tid] = st_val[sh + tid];
+        }
+        const int tail0 = q1 * 4 > head_end ? q1 * 4 : head_end;  // [tail0, sh + n)
+        if (tid < sh + n - tail0) {
+          dc[tail0 + tid] = st_row[tail0 + tid];
+          dv[tail0 + tid] = st_val[tail0 + tid];
+        }
+      } else {
+        for (int i = sh + tid; i < sh + n; i += T) {
+          dc[i] = st_row[i];
+          dv[i] = st_val[i];
+        }
       }
       __syncthreads();  // the staging area is free for the next pass
+      TR_ITEM_STAMP(4);  // copied out
     }
     ka = kb;
+    ++pass;
   }
-  (void)total;
 }
 
 // Does the LDS plan take this batch?  Items small enough for one workgroup's table, and enough of them (or little enough
@@ -1789,7 +1904,12 @@ int tr_item_lds_waves(int64_t nnz, int32_t batch, int32_t M, int32_t K) {
   if (batch <= 0 || M <= 0 || K <= 0 || nnz <= 0) return 0;
   if (nnz / batch > 262144 || (batch < 64 && nnz > 131072)) return 0;
   for (int waves : {16, 8, 4})
-    if (tr_item_fixed_bytes(waves, K) <= 48u * 1024) return waves;  // table + column starts ≤ 48 KiB, the rest stages
+    if (tr_item_fixed_bytes(waves, K) <= 48u * 1024) {  // table + column starts ≤ 48 KiB, the rest stages
+      // every pass re-reads the item and every workgroup of an item re-counts it: beyond four passes the general plan is
+      // ahead (96 items of 1024² at 25 % kept — 19 passes — took 6.5 ms here)
+      const long room = (150L * 1024 - (long)tr_item_fixed_bytes(waves, K)) / 8;
+      return (nnz + batch - 1) / batch + 64 <= 4 * room ? waves : 0;
+    }
   return 0;
 }
 
@@ -1800,20 +1920,25 @@ int launch_tr_item_lds(int waves, int64_t nnz, const int32_t* rowptr, const int3
   // one pass more: the kernel cuts its passes from the item's own column starts)
   const long per_item = (nnz + batch - 1) / batch;
   const size_t fixed = tr_item_fixed_bytes(waves, K);
-  long cap = per_item + 64;
+  long cap = per_item + 64, passes = 1;
   if ((long)fixed + cap * 8 > 78L * 1024) {
     const long room = (150L * 1024 - (long)fixed) / 8;
-    const long passes = (cap + room - 1) / room;
+    passes = (cap + room - 1) / room;
     cap = (per_item + passes - 1) / passes + 64;
     if (cap > room) cap = room;
   }
   cap = (cap + 3) / 4 * 4;
   const size_t lds = fixed + (size_t)cap * 8;
+  // one workgroup per (item, pass): a pass re-counts the item (cheap) but the passes of an item run side by side, and the
+  // grid fills the CUs' rounds more evenly (384 items in 2 passes: 768 workgroups = 3 whole rounds of 256)
+  const int nseg = (int)(passes < 16 ? passes : 16);
+  if ((long)batch * nseg > 0x7fffffffL) return MI_ERANGE;
 #define MI_TR_ITEM(W_)                                                                                                       \
   do {                                                                                                                       \
     auto k = tr_item_lds_kernel<W_>;                                                                                         \
     if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(W_ * 64), lds, s, rowptr, col, val, M, K, t_rowptr, t_col, t_val, (int)cap); \
+    hipLaunchKernelGGL(k, dim3((unsigned)(batch * nseg)), dim3(W_ * 64), lds, s, rowptr, col, val, M, K, t_rowptr, t_col, t_val, \
+                       (int)cap, nseg);                                                                                      \
   } while (0)
   if (waves == 16) MI_TR_ITEM(16);
   else if (waves == 8) MI_TR_ITEM(8);
@@ -2058,6 +2183,16 @@ int mi_csr_transpose_check(const void* workspace, size_t workspace_bytes, int32_
   MI_HIP_TRY(hipStreamSynchronize(s));
   return flag == 0 ? MI_OK : MI_EHIP;
 }
+
+#ifdef MI_TR_ITEM_TIMING
+int mi_tr_item_stamps(unsigned long long* out8) {  // reads and clears the phase counters (synchronises the device)
+  MI_HIP_TRY(hipDeviceSynchronize());
+  MI_HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tr_item_stamp), 8 * sizeof(unsigned long long)));
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  MI_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_tr_item_stamp), zero, sizeof(zero)));
+  return MI_OK;
+}
+#endif
 
 int mi_csr_transpose_batched_in_lds(int64_t nnz, int32_t batch, int32_t M, int32_t K) {
   return g_tr_plan.load(std::memory_order_relaxed) == MI_TRANSPOSE_PLAN_AUTO && tr_item_lds_waves(nnz, batch, M, K) > 0 ? 1 : 0;
