@@ -298,25 +298,6 @@ def bench_c5(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     flops = 6 * 2.0 * Bz * H * S * S * D
-    single_ms = None
-    if world > 1:
-        # The whole matrix on rank 0's GPU alone (after every timed leg; the other ranks wait at the barrier): the
-        # N-GPU line then carries its own single-GPU time, speed-up and the exchange rate a 6x speed-up needs —
-        # self-judging, whatever box the driver's separate N = 1 run landed on.
-        if rank == 0:
-            s_rp, s_col, s_val = (torch.from_numpy(np.asarray(x)).to(dev) for x in (rowptr, col, val))
-            s_C = torch.empty(M, N, device=dev)
-            for _ in range(2):
-                custom_mm.naive_spmm(s_val, s_col, s_rp, nnz, M, K, B, s_C)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(max(3, min(args.steps, 10))):
-                custom_mm.naive_spmm(s_val, s_col, s_rp, nnz, M, K, B, s_C)
-            torch.cuda.synchronize()
-            single_ms = (time.perf_counter() - t1) / max(3, min(args.steps, 10)) * 1e3
-            assert torch.equal(s_C, C[:M]), "the gathered C differs from rank 0's single-GPU product"
-            del s_rp, s_col, s_val, s_C
-        barrier()
     step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     kern_ms = ev[0].elapsed_time(ev[-1]) / args.steps
     # light parity check against torch autograd of matmul on one head

@@ -55,7 +55,7 @@ def test_recorded_bench_lines_follow_the_contract(name):
         assert abs(roof["achieved"] - alg / (roof["kernel_ms_per_step"] * 1e-3) / 1e9) / roof["achieved"] < 0.01
 
 
-@pytest.mark.parametrize("rnd", ["r01", "r02", "r03", "r04"])
+@pytest.mark.parametrize("rnd", ["r01", "r02", "r03", "r04", "r05"])
 def test_c3_kernel_stats_agree_with_the_bench_line(rnd):
     """rocprofv3's average launch durations (same command) add up to bench.py's HIP-event time per product."""
     import csv
@@ -66,7 +66,7 @@ def test_c3_kernel_stats_agree_with_the_bench_line(rnd):
     total_ms = sum(float(r["AverageNs"]) for r in main) / 1e6
     assert abs(total_ms - rec["roofline"]["kernel_ms_per_step"]) / total_ms < 0.03
     traffic = json.loads((PROFILES / "pmc_traffic.json").read_text())["c3"]
-    assert traffic["round"] in ("r03", "r04")
+    assert traffic["round"] in ("r03", "r04", "r05")
     if rnd == traffic["round"]:
         # the bench line quotes the committed PMC record only while it was taken with the very sources that print it
         assert len(traffic["source_fingerprint"]) == 16
