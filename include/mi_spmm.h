@@ -416,6 +416,9 @@ int mi_csr_transpose_f32(const int32_t* rowptr, const int32_t* col, const float*
 #define MI_TRANSPOSE_PLAN_ONE_SWEEP 2
 int mi_csr_transpose_set_plan(int plan);
 int mi_csr_transpose_one_sweep_applies(int32_t batch, int32_t M, int32_t K, int64_t nnz);
+/* 1 when the next mi_csr_transpose*_f32 of this problem runs the one-sweep plan under the plan in force (the only plan
+ * whose give-up flag mi_csr_transpose_check can report). */
+int mi_csr_transpose_auto_takes_one_sweep(int32_t batch, int32_t M, int32_t K, int64_t nnz);
 int mi_csr_transpose_check(const void* workspace, size_t workspace_bytes, int32_t batch, int32_t M,
                            int32_t K, int64_t nnz, mi_stream_t stream);
 size_t mi_csr_transpose_batched_workspace_bytes(int32_t batch, int32_t M, int32_t K, int64_t nnz);

@@ -2170,6 +2170,15 @@ int mi_csr_transpose_one_sweep_applies(int32_t batch, int32_t M, int32_t K, int6
   return one_sweep_applies(make_plan(batch, M, K, nnz), batch, nnz) ? 1 : 0;
 }
 
+int mi_csr_transpose_auto_takes_one_sweep(int32_t batch, int32_t M, int32_t K, int64_t nnz) {
+  if (batch <= 0 || M <= 0 || K <= 0 || nnz <= 0 || nnz > 0x7fffffffLL) return 0;
+  const int plan = g_tr_plan.load(std::memory_order_relaxed);
+  if (plan == MI_TRANSPOSE_PLAN_TABLES) return 0;
+  if (plan == MI_TRANSPOSE_PLAN_AUTO && tr_item_lds_waves(nnz, batch, M, K) > 0) return 0;
+  const TrPlan p = make_plan(batch, M, K, nnz);
+  return one_sweep_applies(p, batch, nnz) && (plan == MI_TRANSPOSE_PLAN_ONE_SWEEP || p.ntiles0 >= 16 * TR_GRID) ? 1 : 0;
+}
+
 int mi_csr_transpose_check(const void* workspace, size_t workspace_bytes, int32_t batch, int32_t M, int32_t K,
                            int64_t nnz, mi_stream_t stream) {
   if (batch <= 0 || M < 0 || K < 0 || nnz < 0 || nnz > 0x7fffffffLL) return MI_EINVAL;

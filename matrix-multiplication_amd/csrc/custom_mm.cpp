@@ -812,11 +812,31 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> csr_transpose(torch::Ten
   torch::Tensor t_val = torch::empty({nnzA}, A_values.options());
   const size_t ws_bytes = mi_csr_transpose_workspace_bytes((int32_t)A_rows, (int32_t)A_cols, nnzA);
   torch::Tensor ws = torch::empty({(int64_t)std::max<size_t>(ws_bytes, 1)}, torch::dtype(torch::kUInt8).device(A_values.device()));
-  check_status(mi_csr_transpose_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
-                                    A_values.data_ptr<float>(), nnzA, (int32_t)A_rows, (int32_t)A_cols,
-                                    t_off.data_ptr<int32_t>(), t_col.data_ptr<int32_t>(), t_val.data_ptr<float>(),
-                                    ws.data_ptr(), ws_bytes, stream_of(A_values)),
-               what);
+  const mi_stream_t stream = stream_of(A_values);
+  auto run = [&]() {
+    check_status(mi_csr_transpose_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
+                                      A_values.data_ptr<float>(), nnzA, (int32_t)A_rows, (int32_t)A_cols,
+                                      t_off.data_ptr<int32_t>(), t_col.data_ptr<int32_t>(), t_val.data_ptr<float>(),
+                                      ws.data_ptr(), ws_bytes, stream),
+                 what);
+  };
+  run();
+  // The one-sweep plan (≥ 33 M non-zeros) hands offsets between workgroups by look-back; a poll that runs into its spin
+  // limit sets a flag and goes on with a wrong offset (never seen on a correct run).  Its callers keep what comes out of
+  // here for a tensor's or a handle's lifetime, so the flag is read here (one synchronisation behind a ≥ 1 ms launch; not
+  // under stream capture, where nothing may be read back) and a give-up re-runs the transpose on the table plan
+  // (advisor, round 4).
+  if (mi_csr_transpose_auto_takes_one_sweep(1, (int32_t)A_rows, (int32_t)A_cols, nnzA) == 1 && !stream_is_capturing(stream) &&
+      mi_csr_transpose_check(ws.data_ptr(), ws_bytes, 1, (int32_t)A_rows, (int32_t)A_cols, nnzA, stream) != MI_OK) {
+    mi_csr_transpose_set_plan(MI_TRANSPOSE_PLAN_TABLES);
+    try {
+      run();
+    } catch (...) {
+      mi_csr_transpose_set_plan(MI_TRANSPOSE_PLAN_AUTO);
+      throw;
+    }
+    mi_csr_transpose_set_plan(MI_TRANSPOSE_PLAN_AUTO);
+  }
   return std::make_tuple(t_val, t_col, t_off);
 }
 

@@ -251,6 +251,9 @@ int mi_gemm_pair_a_at_f32(const float* A, const float* B1, const float* B2, floa
   if (!A || !B1 || !B2 || !C1 || !C2) return MI_EINVAL;
   // the shapes the fused form covers (BERT-base / -large attention and their halves): n = 64, 64 | k ≤ 512, 64 | m
   if (n != 2 * FN || k % 64 != 0 || k > 512 || m % (2 * FR) != 0) return 1;
+  // the loaders form 32-bit byte offsets into one item's operands (raw buffer loads, 2 GiB records): beyond that the two
+  // plain products (advisor, round 4)
+  if ((int64_t)m * k * 4 >= (1LL << 31) || (int64_t)m * n * 4 >= (1LL << 31)) return 1;
   if (!mi::aligned16(A) || !mi::aligned16(B1) || !mi::aligned16(B2) || !mi::aligned16(C1) || !mi::aligned16(C2)) return 1;
   const long blocks = 8L * ((batch + 7) / 8) * 2;
   if (blocks > 0x7fffffffL) return 1;

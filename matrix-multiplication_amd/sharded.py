@@ -91,6 +91,9 @@ def shard_rowptr(rowptr: torch.Tensor, r0: int, r1: int, M: int) -> torch.Tensor
     return (rp - rp[0]).to(torch.int32)
 
 
+_P2P_PROBED = {}  # (world size, device) -> outcome of probe_p2p in this process
+
+
 def probe_p2p(device, timeout_s: float = 20.0, _fail_here: bool = False) -> bool:
     '''Can every rank exchange a tiny message with every peer by direct sends (the pattern of exchange="p2p")?
     Tried in its OWN process group with a short timeout, so a send that never completes cannot leave anything queued
@@ -100,7 +103,11 @@ def probe_p2p(device, timeout_s: float = 20.0, _fail_here: bool = False) -> bool
     import datetime
     world, rank = dist.get_world_size(), dist.get_rank()
     device = torch.device(device)
+    key = (world, str(device))
+    if key in _P2P_PROBED and not _fail_here:  # one probe (and one extra communicator) per process, not one per operator
+        return _P2P_PROBED[key]
     ok = True
+    pg = None
     try:
         pg = dist.new_group(timeout=datetime.timedelta(seconds=timeout_s))  # collective: every rank creates it
         if _fail_here:
@@ -123,11 +130,19 @@ def probe_p2p(device, timeout_s: float = 20.0, _fail_here: bool = False) -> bool
         ok = False
     flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    return bool(int(flag[0]))
+    if pg is not None:
+        try:
+            dist.destroy_process_group(pg)  # the probe's communicator is not kept (advisor, round 4)
+        except Exception:  # noqa: BLE001 — a group whose exchange hung may refuse; the probe's verdict stands
+            pass
+    _P2P_PROBED[key] = bool(int(flag[0]))
+    return _P2P_PROBED[key]
 
 
 class ShardedSpMM:
-    '''C = A·B with A row-sharded over the process group.
+    '''C = A·B with A row-sharded over the process group.  CONSTRUCTION IS COLLECTIVE when the group has more than one
+    rank: the chosen exchange is probed on a tiny tensor and the outcome agreed by all-reduce — every rank must build
+    the operator, with the same arguments, at the same point.
 
     :param rowptr, col, val: the FULL CSR of A (int32 / int32 / float32) on any
         device; only this rank's row blocks are kept (on `device`).
