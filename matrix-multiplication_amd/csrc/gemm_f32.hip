@@ -49,6 +49,9 @@
 
 #include "mi_common.h"
 
+#ifndef MI_GEMM_N16_ALL
+#define MI_GEMM_N16_ALL 0  // 1: the 16 × 16-block kernel for every 64 < n ≤ 96 (developer A/B; default: only where it computes fewer columns than the 96-wide tile, n ≤ 80)
+#endif
 #ifndef MI_GEMM_STORE_AUX
 #define MI_GEMM_STORE_AUX 2  // cache policy of the C stores: 2 = non-temporal, 0 = default (developer probes)
 #endif
@@ -947,6 +950,168 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_f32_t16_tn_kernel(
       __builtin_nontemporal_store(acc[nb][mb], reinterpret_cast<f32x4*>(Cp + (long)(16 * mb) * ldc + 16 * nb));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Head sizes that are not multiples of 32 (round 5): probs·V (NN) and Pᵀ·dC (TN) with 64 < n ≤ 96 — BERT / ViT variants
+// with 72, 80, 88, 96 columns per head.  32 × 32 blocks can only cover them with a 96- or 128-column tile (17 – 37 % of
+// the MFMA work thrown away: 1.09 – 1.41 × torch's time, profiles/r03 / r05_attention_shapes.log); 16 × 16 blocks
+// (v_mfma_f32_16x16x4_f32: the same k-ordered fmaf chain, the same rate per flop) tile 80 and 96 exactly.
+// One workgroup = 128 rows × 16·NB columns (NB = 5 or 6), 8 waves, a wave = 16 rows × all NB blocks, so a k-step of 4
+// costs a wave one A read and NB B reads from LDS for NB MFMAs.  Both operands go through LDS as [k][·] images
+// (B as it lies in memory; A as it lies for Aᵀ·B, transposed on the way for A·B: a [m][KC + 4] image, whose 36-float
+// row stride keeps the 16 rows × 4 k of an operand read on 64 distinct banks).  Two register sets of global loads, one
+// barrier per chunk of 32 k, operand reads one k-step ahead — the structure of gemm_f32_t16_tn_kernel.
+// Whole 128-row tiles, k % 64 == 0, n % 4 == 0, 16-byte aligned rows: pick_tile() checks.  Columns beyond n (n = 72 on the
+// 80-column tile, 88 on 96) read clamped addresses and are never stored.
+// ---------------------------------------------------------------------------------------------
+template <int NB, bool A_KCONTIG>
+__global__ __launch_bounds__(512) void gemm_f32_n16_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int n, int k, long lda, long ldb,
+    long ldc, long strideA, long strideB, long strideC, int tiles_per_item, int reverse) {
+  constexpr int KC = 32, TM_ = 128, TN_ = 16 * NB, THREADS = 512;
+  constexpr int LDA = A_KCONTIG ? KC + 4 : TM_ + 16;  // floats per LDS row of the A image ([m][k] or [k][m])
+  constexpr int A_FLOATS = A_KCONTIG ? TM_ * LDA : KC * LDA;
+  constexpr int LDB = TN_ + 16;
+  constexpr int B_FLOATS = KC * LDB;
+  constexpr int VA = TM_ * KC / 4 / THREADS;                      // float4 of A per thread and chunk (2)
+  constexpr int BQ = KC * (TN_ / 4);                              // float4 of B per chunk (640 / 768)
+  constexpr int VB = (BQ + THREADS - 1) / THREADS;                // per thread (2; the last ones clamped duplicates)
+  extern __shared__ __attribute__((aligned(16))) float n16_lds[];
+  float* As[2] = {n16_lds, n16_lds + A_FLOATS + B_FLOATS};
+  float* Bs[2] = {n16_lds + A_FLOATS, n16_lds + 2 * A_FLOATS + B_FLOATS};
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned total = gridDim.x, bid = blockIdx.x;
+  const unsigned q = total / 8, rem = total % 8, xcd = bid % 8, pos = bid / 8;
+  const unsigned work0 = xcd * q + (xcd < rem ? xcd : rem) + pos;
+  const unsigned work = reverse ? total - 1u - work0 : work0;
+  const long item = work / tiles_per_item;
+  const int tile_m = work % tiles_per_item;
+  const float* Ap = A + item * strideA + (A_KCONTIG ? (long)tile_m * TM_ * lda : (long)tile_m * TM_);
+  const float* Bp = B + item * strideB;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+  f32x4 acc[NB];  // register r of block nb ↔ row 4·(lane >> 4) + r of the wave's 16 rows … with the operands swapped (below):
+                  // r ↔ n = 16·nb + 4·(lane >> 4) + r, m = lane & 15 — four consecutive n per lane: 16-byte stores
+#pragma unroll
+  for (int i = 0; i < NB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // loop-invariant lane offsets (bytes); B's float4 index is clamped to the tile's last one that lies inside the row
+  unsigned a_off[VA], b_off[VB];
+  const int nq = n >> 2;  // float4 per row of B that exist
+#pragma unroll
+  for (int i = 0; i < VA; ++i) {
+    const int j = tid + THREADS * i;
+    if (A_KCONTIG) a_off[i] = (unsigned)((j / (KC / 4)) * (int)lda + 4 * (j % (KC / 4))) * 4u;   // row m, quad along k
+    else a_off[i] = (unsigned)((j / (TM_ / 4)) * (int)lda + 4 * (j % (TM_ / 4))) * 4u;           // row k, quad along m
+  }
+#pragma unroll
+  for (int i = 0; i < VB; ++i) {
+    int j = tid + THREADS * i;
+    j = j < BQ ? j : BQ - 1;
+    int c4 = j % (TN_ / 4);
+    c4 = c4 < nq ? c4 : nq - 1;
+    b_off[i] = (unsigned)((j / (TN_ / 4)) * (int)ldb + 4 * c4) * 4u;
+  }
+  f32x4 ra[2][VA], rb[2][VB];
+  const int chunks = k / KC;
+  auto load_chunk = [&](int set, int c) {
+    const int k0 = (c < chunks ? c : chunks - 1) * KC;
+    const __amdgpu_buffer_rsrc_t a_src = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(A_KCONTIG ? Ap + k0 : Ap + (long)k0 * lda), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Bp + (long)k0 * ldb), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < VA; ++i)
+      ra[set][i] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(a_src, (int)a_off[i], 0, 0));
+#pragma unroll
+    for (int i = 0; i < VB; ++i)
+      rb[set][i] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(b_src, (int)b_off[i], 0, 0));
+  };
+  auto store_chunk = [&](int set, int buf) {
+#pragma unroll
+    for (int i = 0; i < VA; ++i) {
+      const int j = tid + THREADS * i;
+      if (A_KCONTIG) *reinterpret_cast<f32x4*>(As[buf] + (j / (KC / 4)) * LDA + 4 * (j % (KC / 4))) = ra[set][i];
+      else *reinterpret_cast<f32x4*>(As[buf] + (j / (TM_ / 4)) * LDA + 4 * (j % (TM_ / 4))) = ra[set][i];
+    }
+#pragma unroll
+    for (int i = 0; i < VB; ++i) {
+      int j = tid + THREADS * i;
+      j = j < BQ ? j : BQ - 1;  // (a duplicate of the last float4: same value to the same place)
+      *reinterpret_cast<f32x4*>(Bs[buf] + (j / (TN_ / 4)) * LDB + 4 * (j % (TN_ / 4))) = rb[set][i];
+    }
+  };
+  const int lk = lane >> 4, lc = lane & 15;
+  const int m_w = wave * 16;
+  float a[2], b[2][NB];
+  auto read_ops = [&](int set, int buf, int kk) {
+    a[set] = A_KCONTIG ? As[buf][(m_w + lc) * LDA + kk * 4 + lk] : As[buf][(kk * 4 + lk) * LDA + m_w + lc];
+    const float* bs = Bs[buf] + (kk * 4 + lk) * LDB + lc;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b[set][i] = bs[16 * i];
+  };
+  auto mfmas = [&](int set) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[set][nb], a[set], acc[nb], 0, 0, 0);
+  };
+  auto half = [&](int buf, int next_chunk_to_load, int set_load, int set_store) {
+    load_chunk(set_load, next_chunk_to_load);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < KC / 4 - 1; ++kk) {
+      read_ops((kk + 1) & 1, buf, kk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(kk & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    store_chunk(set_store, buf ^ 1);
+    __syncthreads();
+    read_ops(0, buf ^ 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  load_chunk(0, 0);
+  store_chunk(0, 0);
+  load_chunk(1, 1);
+  __syncthreads();
+  read_ops(0, 0, 0);
+  for (int c = 0; c < chunks; c += 2) {
+    half(0, c + 2, 0, 1);
+    half(1, c + 3, 1, 0);
+  }
+  float* Cp = C + item * strideC + ((long)tile_m * TM_ + m_w + lc) * ldc + 4 * lk;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+    if (16 * nb + 4 * lk < n) __builtin_nontemporal_store(acc[nb], reinterpret_cast<f32x4*>(Cp + 16 * nb));
+}
+
+template <bool TA, bool TB>
+int launch_n16(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb, long ldc, long sA, long sB,
+               long sC, int batch, hipStream_t s) {
+  static_assert(!TB, "B as it lies in memory: [k][n]");
+  const long tiles_m = m / 128;
+  const long blocks = tiles_m * batch;
+  if (blocks > 0x7fffffffL) return MI_ERANGE;
+  const int rev = (int)(mi::g_gemm_launch_counter.fetch_add(1, std::memory_order_relaxed) & 1u);
+  const int nb = n <= 80 ? 5 : 6;
+  const size_t a_floats = TA ? 32 * (128 + 16) : 128 * (32 + 4);
+  const size_t lds = 2 * (a_floats + 32 * (16 * (size_t)nb + 16)) * sizeof(float);
+#define MI_N16(NB_)                                                                                                        \
+  do {                                                                                                                     \
+    auto kern = gemm_f32_n16_kernel<NB_, !TA>;                                                                             \
+    if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, A, B, C, n, k, lda, ldb, ldc, sA, sB, sC, (int)tiles_m, rev); \
+  } while (0)
+  if (nb == 5) MI_N16(5);
+#if MI_GEMM_N16_ALL
+  else MI_N16(6);
+#else
+  else return MI_EINVAL;  // (88 / 96 columns run the 96-wide tile of 32 × 32 blocks: pick_tile)
+#endif
+#undef MI_N16
+  return mi::check_launch();
+}
+
 template <int TILE, int WAVES>
 int launch_t16(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb, long ldc, long sA,
                long sB, long sC, int batch, int rev, hipStream_t s) {
@@ -1095,8 +1260,18 @@ int pick_tile(const float* A, const float* B, float* C, int m, int n, int k, lon
   if (MI_GEMM_FORCE_TILE == 4) MI_TILE(64, 64);
 #endif
 #ifndef MI_GEMM_NO_N96
-  if (n > 64 && n <= 96 && m > 64 && k >= MI_GEMM_PIPE_MIN_TILES * BK && vecA && vecB && k % BK == 0 && blocks_for(128, 96) >= 256)
+  if (n > 64 && n <= 96 && m > 64 && k >= MI_GEMM_PIPE_MIN_TILES * BK && vecA && vecB && k % BK == 0 && blocks_for(128, 96) >= 256) {
+#ifndef MI_GEMM_NO_N16
+    // exact 80- / 96-column tiles of 16 × 16 blocks where the shape is made of whole 128-row tiles (probs·V, Pᵀ·dC)
+    if constexpr (!TB) {
+      // (n ≤ 80: 384 × 512 × 80 probs·V 0.151 → 0.135 ms, × 72 0.159 → 0.142; at 88 / 96 columns the 96-wide tile of 32 × 32 blocks
+      // is ahead: 0.153 vs 0.162 ms)
+      if (bias == nullptr && vecC && m % 128 == 0 && k % 64 == 0 && n % 4 == 0 && (n <= 80 || MI_GEMM_N16_ALL))
+        return launch_n16<TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, s);
+    }
+#endif
     return launch_n96<TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, vecA, vecB, vecC, bias, s);
+  }
 #endif
   if (m > 64 && n > 64 && blocks_for(128, 128) >= want) MI_TILE(128, 128);
   if (m > 64 && blocks_for(128, 64) >= want) MI_TILE(128, 64);
