@@ -720,19 +720,27 @@ __device__ __forceinline__ int group_prefix_max(int x, int gl) {
   return x;
 }
 
-template <bool FIRST, int G>
+template <bool FIRST, int G, int T>
 __global__ __launch_bounds__(256) void spmm_group_panel_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ B, float* __restrict__ C, int M, int N, long ldb, long ldc, int c_lo, int c_hi,
     const float* __restrict__ bias, int last_pass, LongArg la) {
+  // T > 1 (G = 64 only): T tiles of 256 columns per lane — the widths between and beyond the one-wave-per-row panel kernel's
+  // 256 / 512 / 1024 (N = 160 … 1024, any multiple of 4): the same passes for every N the path takes
+  static_assert(T == 1 || G == 64, "column tiles only with a whole wave per row");
   constexpr int RPW = 64 / G;
-  constexpr int UI = 4;
+  constexpr int UI = T >= 3 ? 2 : 4;  // gathers in flight per group and batch (T float4 each)
   const int lane = threadIdx.x & 63;
   const int gl = lane & (G - 1);
   const int gshift = lane & ~(G - 1);  // first lane of this group inside the wave
   const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + (lane / G);
-  const int coff = gl * 4;
-  const bool on = coff < N;
+  int coff[T];
+  bool on[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    coff[t] = (t * G + gl) * 4;
+    on[t] = coff[t] < N;
+  }
   int start = 0, end = 0;
   if (row < M) {
     start = rowptr[row];
@@ -743,9 +751,13 @@ __global__ __launch_bounds__(256) void spmm_group_panel_kernel(
     if (FIRST && gl == 0) long_list_append(la, (int)row, end - start);
     end = start;
   }
-  float* dst = C + row * ldc + coff;
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (!FIRST && row < M && !skipped && on) acc = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dst));
+  float* dst = C + row * ldc;
+  f32x4 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!FIRST && row < M && !skipped && on[t]) acc[t] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dst + coff[t]));
+  }
   int prev_max = kIntMin;  // running maximum of the columns of the chunks behind
   constexpr unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
   for (int p = start; p < end; p += G) {  // trip count differs between groups
@@ -764,36 +776,50 @@ __global__ __launch_bounds__(256) void spmm_group_panel_kernel(
       mi::static_for<G / UI>([&](auto b_) {
         constexpr int b = UI * decltype(b_)::value;
         if (b >= i0 && b + UI <= i1) {
-          f32x4 x[UI];
+          f32x4 x[UI][T];
           float v[UI];
           mi::static_for<UI>([&](auto u_) {
             constexpr int u = decltype(u_)::value;
             const int c = mi::group_lane<G, b + u, false>(myc);
             v[u] = mi::group_lane<G, b + u, false>(myv);
-            if (on) x[u] = *reinterpret_cast<const f32x4*>(B + (long)c * ldb + coff);
+            const float* src = B + (long)c * ldb;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+              if (on[t]) x[u][t] = *reinterpret_cast<const f32x4*>(src + coff[t]);
           });
 #pragma unroll
           for (int u = 0; u < UI; ++u)
-            if (on) acc = fma4(v[u], x[u], acc);
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+              if (on[t]) acc[t] = fma4(v[u], x[u][t], acc[t]);
         } else if (b + UI > i0 && b < i1) {
           mi::static_for<UI>([&](auto u_) {
             constexpr int u = decltype(u_)::value;
             const int c = mi::group_lane<G, b + u, false>(myc);
             const float v = mi::group_lane<G, b + u, false>(myv);
-            if (b + u >= i0 && b + u < i1 && on) acc = fma4(v, *reinterpret_cast<const f32x4*>(B + (long)c * ldb + coff), acc);
+            if (b + u >= i0 && b + u < i1) {
+              const float* src = B + (long)c * ldb;
+#pragma unroll
+              for (int t = 0; t < T; ++t)
+                if (on[t]) acc[t] = fma4(v, *reinterpret_cast<const f32x4*>(src + coff[t]), acc[t]);
+            }
           });
         }
       });
     }
     if (prev_max >= c_hi) break;  // every later entry belongs to a later pass
   }
-  if (row < M && !skipped && on) {
-    if (bias && last_pass) acc += *reinterpret_cast<const f32x4*>(bias + coff);
-    __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(dst));
+  if (row < M && !skipped) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+      if (on[t]) {
+        if (bias && last_pass) acc[t] += *reinterpret_cast<const f32x4*>(bias + coff[t]);
+        __builtin_nontemporal_store(acc[t], reinterpret_cast<f32x4*>(dst + coff[t]));
+      }
   }
 }
 
-template <int G>
+template <int G, int T>
 int launch_group_panels_t(int panels, const int* rowptr, const int* col, const float* val, const float* B, float* C,
                           int M, int K, int N, long ldb, long ldc, const float* bias, LongArg la, hipStream_t s) {
   constexpr int rows_per_block = 4 * (64 / G);
@@ -805,10 +831,10 @@ int launch_group_panels_t(int panels, const int* rowptr, const int* col, const f
     // the last pass takes whatever is left (columns ≥ K of a lying matrix included: every entry is summed exactly once)
     const int hi = q == panels - 1 ? 0x7fffffff : (int)((q + 1) * kp);
     if (q == 0)
-      hipLaunchKernelGGL((spmm_group_panel_kernel<true, G>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, val, B, C,
+      hipLaunchKernelGGL((spmm_group_panel_kernel<true, G, T>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, val, B, C,
                          M, N, ldb, ldc, kIntMin, hi, bias, q == panels - 1 ? 1 : 0, la);  // (first pass: from the smallest int, as lo is unused)
     else
-      hipLaunchKernelGGL((spmm_group_panel_kernel<false, G>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, val, B, C,
+      hipLaunchKernelGGL((spmm_group_panel_kernel<false, G, T>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, val, B, C,
                          M, N, ldb, ldc, lo, hi, bias, q == panels - 1 ? 1 : 0, la);
   }
   return mi::check_launch();
@@ -821,8 +847,12 @@ int group_panel_count(int variant) {
 
 int launch_group_panels(int panels, const int* rowptr, const int* col, const float* val, const float* B, float* C, int M,
                         int K, int N, long ldb, long ldc, const float* bias, LongArg la, hipStream_t s) {
-  if (N <= 64) return launch_group_panels_t<16>(panels, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
-  return launch_group_panels_t<32>(panels, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
+  if (N <= 64) return launch_group_panels_t<16, 1>(panels, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
+  if (N <= 128) return launch_group_panels_t<32, 1>(panels, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
+  if (N <= 256) return launch_group_panels_t<64, 1>(panels, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
+  if (N <= 512) return launch_group_panels_t<64, 2>(panels, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
+  if (N <= 768) return launch_group_panels_t<64, 3>(panels, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
+  return launch_group_panels_t<64, 4>(panels, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
 }
 
 // Column-tiled launch of the float4 group kernel: tile_cols = 4·G columns per tile.
@@ -1193,7 +1223,7 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
       static const int kWave[9] = {0, 0, MI_SPMM_PANELS_2, MI_SPMM_PANELS_3, MI_SPMM_PANELS_4, 0, MI_SPMM_PANELS_6, 0, MI_SPMM_PANELS_8};
       return kWave[p];
     }
-    if (p > 0 && N >= 36 && N <= 128) {  // (narrower rows: 16-lane groups would idle half their lanes)
+    if (p > 0 && N >= 36 && N <= 1024) {  // every other width, N % 4 == 0 (narrower rows: 16-lane groups would idle half their lanes)
       static const int kGroup[9] = {0, 0, MI_SPMM_GROUP_PANELS_2, MI_SPMM_GROUP_PANELS_3, MI_SPMM_GROUP_PANELS_4, 0,
                                     MI_SPMM_GROUP_PANELS_6, 0, MI_SPMM_GROUP_PANELS_8};
       return kGroup[p];
@@ -1288,7 +1318,7 @@ int launch_variant(int variant, const Shape& sh, const int32_t* rowptr, const in
     }
     case MI_SPMM_GROUP_PANELS_2: case MI_SPMM_GROUP_PANELS_3: case MI_SPMM_GROUP_PANELS_4: case MI_SPMM_GROUP_PANELS_6:
     case MI_SPMM_GROUP_PANELS_8:
-      if (!(vec4_ok && batch == 1 && N <= 128)) return MI_EINVAL;
+      if (!(vec4_ok && batch == 1 && N <= 1024)) return MI_EINVAL;
       return launch_group_panels(group_panel_count(variant), rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
     case MI_SPMM_COLTILE_PANELS: {
       if (!(vec4_ok && batch == 1 && N % 256 == 0 && N >= 256)) return MI_EINVAL;

@@ -152,6 +152,8 @@ def test_every_variant_id_has_a_kernel_name_and_the_plan_query_needs_no_gpu(lib)
     assert plan(100 * m4, m4, m4, 128) == 20                       # 2 GiB at N = 128: three
     assert plan(100 * m4, m4, m4, 64) == 19 and plan(20 * m4, m4, m4, 64) == 4   # N = 64: two panels / one pass for short rows
     assert plan(100 * m4, m4, m4, 512) == 2                        # 8 GiB: no panel count pays
+    assert plan(100 * m2, m2, m2, 192) == 19 and plan(100 * m2, m2, m2, 320) == 21   # other widths: lane-group panels (whole wave, column tiles)
+    assert plan(100 * m2, m2, m2, 768) == 4 and plan(400 * m2, m2, m2, 768) == 23    # 6 GiB: eight panels need long rows
 
 
 def test_host_inspector_coo_to_csr(lib, golden, oracle_mod):

@@ -833,9 +833,10 @@ def test_batched_spmm_variants_fuzz_against_oracle(capi, dev, oracle_mod):
     assert took.get(18, 0) >= cases // 4 and took.get(4, 0) >= cases // 4 and took[0] == took[5] == cases, took
 
 
-@pytest.mark.parametrize("N", [64, 128, 36, 100])
+@pytest.mark.parametrize("N", [64, 128, 36, 100, 192, 320, 700, 1024])
 def test_group_panel_plans_keep_csr_order_for_any_row(capi, cmm, dev, oracle_mod, N):
-    """Round 5: the lane-group kernel in column panels (MI_SPMM_GROUP_PANELS_2/3/4 = 19/20/21; N ≤ 128 with B beyond the
+    """Round 5: the lane-group kernel in column panels (MI_SPMM_GROUP_PANELS_2/3/4/6/8 = 19 … 23; N ≤ 128 in lane groups, wider N as a whole wave per row with up to four column
+    tiles per lane; B beyond the
     Infinity Cache).  A pass takes the entries whose running maximum of the row's columns lies in its panel, which cuts
     every row into contiguous ranges in CSR order — so sorted rows, shuffled rows, rows with duplicate columns, rows
     longer than a chunk, empty rows and a descent exactly at a chunk boundary all give the one-pass chain, bit for bit;

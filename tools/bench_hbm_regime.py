@@ -169,6 +169,8 @@ def main():
     ap.add_argument("--variants", action="store_true")
     ap.add_argument("--only", default="")
     ap.add_argument("--log", default="")
+    ap.add_argument("--widths", default="", help="comma-separated N: a sweep over these widths instead (100 / 400 per row)")
+    ap.add_argument("--rows", type=int, default=1 << 21, help="M = K of the --widths sweep")
     a = ap.parse_args()
     oracle.build()
     print(f"# device {torch.cuda.get_device_name(0)}; ms per product through custom_mm.naive_spmm; frac = algorithmic GB/s / 8000",
@@ -191,6 +193,9 @@ def main():
     for n in (128,):
         cases.append((f"banded/4M/N{n}/d100", 1 << 22, 1 << 22, n, 100, "banded"))
         cases.append((f"powerlaw/4M/N{n}/d100", 1 << 22, 1 << 22, n, 100, "powerlaw"))
+    if a.widths:  # other widths than the sweep's powers of two (the reference kernel takes any N, src/naive_sparse_mm.cu:39,116)
+        cases = [(f"uniform/{a.rows >> 20}M/N{n}/d{d}", a.rows, a.rows, n, d, "uniform")
+                 for n in (int(x) for x in a.widths.split(",")) for d in (100, 400) if a.rows * d < 2**31 - 2**24]
     for c in cases:
         if a.only and a.only not in c[0]:
             continue
