@@ -155,7 +155,9 @@ enum {
   MI_SPMM_GROUP_PANELS_4 = 21, /*   maximum of the row's columns lies in its panel: CSR order kept for every legal input   */
   MI_SPMM_GROUP_PANELS_6 = 22,
   MI_SPMM_GROUP_PANELS_8 = 23,
-  MI_SPMM_VARIANT_COUNT = 24
+  MI_SPMM_GROUP_VEC4U = 24, /* any N ≥ 4 at any 4-byte alignment: four floats per lane on dword-aligned 16-byte accesses, a
+                               row's partial last quad shifted back onto its neighbour (same chain, same bits) */
+  MI_SPMM_VARIANT_COUNT = 25
 };
 /* The two forms of MI_SPMM_LDS_B (same bits): 16 lanes per row (any tile width), or — tiles of 64 / 128 columns — a
  * quad per row with 16-byte loads of col / val (what BERT's head size runs).  form: -1 by rule (default), 0 the 16-lane

@@ -506,6 +506,7 @@ template <int VEC>
 struct Vec;
 template <>
 struct Vec<4> {
+  static constexpr int width = 4;
   typedef f32x4 type;
   static __device__ __forceinline__ type zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
   static __device__ __forceinline__ type load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -514,8 +515,28 @@ struct Vec<4> {
   }
   static __device__ __forceinline__ type fma(float a, type x, type acc) { return fma4(a, x, acc); }
 };
+// 44: four floats per lane at ANY 4-byte alignment (rows of B / C that do not start on 16 bytes: N % 4 != 0, odd leading
+// dimensions, offset views) — dword-aligned global_load / store_dwordx4, which gfx950 serves (split where a request
+// crosses a line).  The kernel shifts a row's last, partial quad back to end at column N − 1: it overlaps its neighbour,
+// the shared columns are computed twice from the same chain and stored twice with the same bits.
+template <>
+struct Vec<44> {
+  static constexpr int width = 4;
+  typedef float type __attribute__((ext_vector_type(4), aligned(4)));
+  static __device__ __forceinline__ type zero() { return type{0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ type load(const float* p) { return *reinterpret_cast<const type*>(p); }
+  static __device__ __forceinline__ void store(float* p, type v) { __builtin_nontemporal_store(v, reinterpret_cast<type*>(p)); }
+  static __device__ __forceinline__ type fma(float a, type x, type acc) {
+    acc.x = __builtin_fmaf(a, x.x, acc.x);
+    acc.y = __builtin_fmaf(a, x.y, acc.y);
+    acc.z = __builtin_fmaf(a, x.z, acc.z);
+    acc.w = __builtin_fmaf(a, x.w, acc.w);
+    return acc;
+  }
+};
 template <>
 struct Vec<2> {
+  static constexpr int width = 2;
   typedef float type __attribute__((ext_vector_type(2)));
   static __device__ __forceinline__ type zero() { return type{0.f, 0.f}; }
   static __device__ __forceinline__ type load(const float* p) { return *reinterpret_cast<const type*>(p); }
@@ -530,6 +551,7 @@ struct Vec<2> {
 };
 template <>
 struct Vec<1> {
+  static constexpr int width = 1;
   typedef float type;
   static __device__ __forceinline__ type zero() { return 0.f; }
   static __device__ __forceinline__ type load(const float* p) { return *p; }
@@ -585,15 +607,17 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
     end = start;
   }
 
-  for (int n0 = 0; n0 < N; n0 += G * VEC * T) {  // wave-uniform pass loop
+  constexpr int W = V::width;  // floats per lane and tile
+  for (int n0 = 0; n0 < N; n0 += G * W * T) {  // wave-uniform pass loop
     vec_t acc[T];
     bool on[T];
     int coff[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       acc[t] = V::zero();
-      coff[t] = n0 + (t * G + gl) * VEC;
+      coff[t] = n0 + (t * G + gl) * W;
       on[t] = coff[t] < N;
+      if (VEC == 44 && on[t] && coff[t] + 4 > N) coff[t] = N - 4;  // the partial last quad, shifted back (N ≥ 4: the launcher checks)
     }
     if constexpr (G < 4) {
       // 1- or 2-lane groups: a chunk of G entries would leave only G gathers in flight, so take
@@ -909,6 +933,29 @@ int dispatch_group(const int* rowptr, const int* col, const float* val, const fl
   if (tiles == 2) MI_GROUP(64, 2);
   MI_GROUP(64, 4);
 #undef MI_GROUP
+}
+
+// any N ≥ 4 at any 4-byte alignment: quads per row = ⌈N / 4⌉ (the last one shifted back when N % 4 != 0)
+int dispatch_group_u4(const int* rowptr, const int* col, const float* val, const float* B, float* C, int M, int N, long ldb,
+                      long ldc, long strideB, long strideC, int batch, const float* bias, LongArg la, hipStream_t s) {
+  const int nv = (N + 3) / 4;
+  const int G = nv >= 64 ? 64 : mi::pow2_ceil(nv);
+#define MI_GROUP_U(G_, T_) \
+  return launch_group<G_, 44, T_>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, la, s)
+  switch (G) {
+    case 1: MI_GROUP_U(1, 1);
+    case 2: MI_GROUP_U(2, 1);
+    case 4: MI_GROUP_U(4, 1);
+    case 8: MI_GROUP_U(8, 1);
+    case 16: MI_GROUP_U(16, 1);
+    case 32: MI_GROUP_U(32, 1);
+    default: break;
+  }
+  const int tiles = (nv + 63) / 64;
+  if (tiles <= 1) MI_GROUP_U(64, 1);
+  if (tiles == 2) MI_GROUP_U(64, 2);
+  MI_GROUP_U(64, 4);
+#undef MI_GROUP_U
 }
 
 template <int T, int U>
@@ -1278,7 +1325,9 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
   if (sh.vec4_ok && batch == 1 && coltile_panels(M, K, N, ldb, nnz) > 0) return MI_SPMM_COLTILE_PANELS;
   if (sh.vec4_ok && batch == 1 && coltile_width(M, K, N, ldb) > 0) return MI_SPMM_COLTILE;
   if (sh.wave_ok) return MI_SPMM_WAVE_ROW_U8;
-  return sh.vec4_ok ? MI_SPMM_GROUP_VEC4 : MI_SPMM_GROUP_SCALAR;
+  // rows that do not start on 16 bytes (N % 4 != 0, odd leading dimensions, offset views): four floats per lane all the
+  // same, on dword-aligned 16-byte accesses (2 M rows, 100 per row: N = 77 0.38 → of 8 TB/s with one float per lane, 130: 0.35, 250: 0.49)
+  return sh.vec4_ok ? MI_SPMM_GROUP_VEC4 : (N >= 4 ? MI_SPMM_GROUP_VEC4U : MI_SPMM_GROUP_SCALAR);
 }
 
 size_t long_rows_workspace_bytes(int64_t nnz, int32_t N) { return long_ws_layout(nnz, N).bytes; }
@@ -1340,6 +1389,9 @@ int launch_variant(int variant, const Shape& sh, const int32_t* rowptr, const in
     case MI_SPMM_GROUP_VEC2:
       if (!vec2_ok) return MI_EINVAL;
       return dispatch_group<2>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, la, s);
+    case MI_SPMM_GROUP_VEC4U:
+      if (N < 4) return MI_EINVAL;
+      return dispatch_group_u4(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, la, s);
     case MI_SPMM_GROUP_SCALAR:
       return dispatch_group<1>(rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, batch, bias, la, s);
     case MI_SPMM_SLAB:
@@ -1616,7 +1668,7 @@ const char* mi_spmm_variant_name(int variant) {
     case MI_SPMM_AUTO: return "auto";
     case MI_SPMM_WAVE_ROW_U4: case MI_SPMM_WAVE_ROW_U8: case MI_SPMM_WAVE_ROW_U16: return "spmm_wave_row_kernel";
     case MI_SPMM_WAVE_ROW_VL: return "spmm_wave_row_vl_kernel";
-    case MI_SPMM_GROUP_VEC4: case MI_SPMM_GROUP_VEC2: case MI_SPMM_GROUP_SCALAR: case MI_SPMM_COLTILE:
+    case MI_SPMM_GROUP_VEC4: case MI_SPMM_GROUP_VEC2: case MI_SPMM_GROUP_SCALAR: case MI_SPMM_COLTILE: case MI_SPMM_GROUP_VEC4U:
       return "spmm_group_kernel";
     case MI_SPMM_NARROW: return "spmm_narrow_kernel";
     case MI_SPMM_SLAB: return "spmm_slab_kernel";

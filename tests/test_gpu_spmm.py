@@ -42,7 +42,7 @@ def test_spmm_every_variant_is_bit_identical(capi, dev, oracle_mod, M, K, N, den
     d = [t(x, dev) for x in (rowptr, col, val, B)]
     ran = 0
     chain = oracle_mod.spmm_csr_chain(rowptr, col, val, M, K, B)  # explicit group variants ignore the N < 4 rule
-    for variant in range(24):
+    for variant in range(25):
         C = torch.full((M, N), float("nan"), device=dev)
         st = capi.mi_spmm_csr_f32_variant(variant, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(val), M, K,
                                           N, d[3].data_ptr(), N, C.data_ptr(), N,
@@ -631,7 +631,7 @@ def test_spmm_shape_fuzz_against_oracle(cmm, capi, dev, oracle_mod):
         seen.add(capi.mi_spmm_csr_f32_plan(len(val), M, K, N, d_B.data_ptr(), N, C.data_ptr(), N))
         cmm.naive_spmm(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, d_B, C)
         assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr_omp(rowptr, col, val, M, K, B)), (M, K, N, density)
-    assert {2, 4, 5, 14, 15} <= seen, seen  # wave-row, group vec4 / scalar, column-tiled, tiles × panels all exercised
+    assert {2, 4, 14, 15, 24} <= seen, seen  # wave-row, group vec4 / unaligned quads (odd widths), column-tiled, tiles × panels all exercised
 
 
 @pytest.mark.gpu
@@ -879,3 +879,25 @@ def test_group_panel_plans_keep_csr_order_for_any_row(capi, cmm, dev, oracle_mod
                 assert st == 0, (variant, with_bias, rule)
                 expect = want + bias[None, :] if with_bias else want
                 assert np.array_equal(C.cpu().numpy().view(np.int32), expect.view(np.int32)), (variant, with_bias, rule)
+
+
+@pytest.mark.parametrize("N", [4, 5, 7, 30, 77, 130, 250, 257, 1031])
+def test_rows_off_16_byte_boundaries_take_unaligned_quads_bit_exact(capi, cmm, dev, oracle_mod, N):
+    """Round 5: N % 4 != 0 (or an offset view of B) used to fall to one float per lane (0.35 – 0.49 of the roofline at 2 M
+    rows); MI_SPMM_GROUP_VEC4U = 24 keeps four floats per lane on dword-aligned 16-byte accesses, the row's partial last quad
+    shifted back onto its neighbour — the shared columns are computed twice from the same chain.  Bit-exact against the
+    oracle for contiguous B and for a column-offset view with a padded leading dimension; AUTO picks it.
+    Reference: src/naive_sparse_mm.cu:39,116 (any N through one kernel)."""
+    M, K = 700, 900
+    rowptr, col, val = oracle_mod.make_csr(M, K, 0.03, seed=N)
+    g = np.random.Generator(np.random.PCG64(N))
+    Bpad = g.random((K, N + 7), dtype=np.float32) - 0.5
+    d_pad = t(Bpad, dev)
+    for B_host, d_B in ((np.ascontiguousarray(Bpad[:, 3:3 + N]), d_pad[:, 3:3 + N].contiguous()), (Bpad[:, 3:3 + N], d_pad[:, 3:3 + N])):
+        want = oracle_mod.spmm_csr_chain(rowptr, col, val, M, K, np.ascontiguousarray(B_host))
+        C = torch.full((M, N), float("nan"), device=dev)
+        plan = cmm.spmm_plan(len(val), M, K, d_B, C)
+        if N % 4 != 0 or not d_B.is_contiguous():
+            assert plan[0] == 24, plan
+        cmm.naive_spmm_ex(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, d_B, C, 0)
+        assert np.array_equal(C.cpu().numpy().view(np.int32), want.view(np.int32)), (N, d_B.is_contiguous())
