@@ -758,15 +758,26 @@ int mi_sddmm_csr_f32(const int32_t* rowptr, const int32_t* col, int64_t nnz, int
 #define MI_SDDMM(T_, V_)                                                                                    \
   hipLaunchKernelGGL((sddmm_kernel<T_, V_, false>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, M, N, dC, \
                      (long)lddc, B, (long)ldb, out_val, 0, 0)
-  // B far beyond the 256 MiB Infinity Cache and rows long enough to re-touch a panel (the conditions of the
-  // forward product's two-panel plan): two launches, one per half of K
-  if (vec && T == 1 && (long)K * ldb * 4 >= (768L << 20) && nnz >= 32L * M && nnz * (long)N >= 8L * K * ldb) {
-    const int half = (K + 1) / 2;
-    hipLaunchKernelGGL((sddmm_kernel<1, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, M, N, dC,
-                       (long)lddc, B, (long)ldb, out_val, 0, half);
-    hipLaunchKernelGGL((sddmm_kernel<1, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, M, N, dC,
-                       (long)lddc, B, (long)ldb, out_val, half, K);
-    return mi::check_launch();
+  // B far beyond the 256 MiB Infinity Cache and rows long enough to re-touch a panel: one launch per column panel of K,
+  // as many panels as the forward product's gate takes (spmm_csr.hip ic_panels, fitted in round 5: slices of ≈ 0.5 – 0.7 GiB,
+  // P ≈ |B| / 683 MiB from {2, 3, 4, 6, 8}; none beyond ≈ 6 GiB) — a pass here carries nothing through memory, it re-reads
+  // the row's col entries and its dC row, so 8 P entries per row suffice
+  // (N ≤ 64 stays with the lane-group kernel below: the one-wave-per-row kernel of the panel passes has columns for only
+  // N / 4 of its lanes — 4 M × 64 at 100 per row ran 30.7 ms in panels, half the forward product's rate)
+  if (vec && T == 1 && N > 64 && (long)K * ldb * 4 >= (768L << 20) && nnz * (long)N >= 8L * K * ldb) {
+    const double want = (double)K * (double)ldb * 4.0 / (683.0 * 1048576.0);
+    int panels = 2;
+    // (measured, tools/probes/sddmm_regime.py: three panels at 2 GiB −2 % against two, six at 4 GiB +1 %: beyond three nothing is gained here)
+    for (int p : {2, 3})
+      if ((p - want < 0 ? want - p : p - want) <= (panels - want < 0 ? want - panels : panels - want)) panels = p;
+    if (want <= 9.0 && nnz >= 8L * panels * M) {
+      for (int q = 0; q < panels; ++q) {
+        const int lo = (int)((long)K * q / panels), hi = (int)((long)K * (q + 1) / panels);
+        hipLaunchKernelGGL((sddmm_kernel<1, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, M, N, dC,
+                           (long)lddc, B, (long)ldb, out_val, lo, hi);
+      }
+      return mi::check_launch();
+    }
   }
   // B beyond the L2s but far from that regime (6 MiB < |B| ≤ 128 MiB): panels of ≈4 MiB keep the gathers in L2,
   // as in the forward product (spmm_csr.hip: l2_panels) — and here a pass carries nothing, it only re-reads the
