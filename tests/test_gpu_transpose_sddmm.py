@@ -304,3 +304,41 @@ def test_sddmm_mid_size_b_runs_in_l2_panels_bit_exact(cmm, dev, oracle_mod, M, K
     dC, B = g.random((M, N), dtype=np.float32) - 0.5, g.random((K, N), dtype=np.float32) - 0.5
     got = cmm.sddmm(t(col, dev), t(rowptr, dev), len(col), M, K, t(dC, dev), t(B, dev))
     assert np.array_equal(got.cpu().numpy(), oracle_mod.sddmm(rowptr, col, M, dC, B))
+
+
+def test_csr_transpose_small_items_lds_plan_skewed_batch_bit_exact(cmm, dev, oracle_mod):
+    """Round 5: the one-workgroup-per-item LDS transpose (tr_item_lds_kernel) on a batch it was NOT sized for: one item with
+    25 × the average number of entries (it needs many more column passes than the launch's workgroups per item: the last
+    workgroup of an item takes every pass behind its own), a column longer than the staging area (its entries go out
+    directly), rows longer than a 64-entry chunk, unsorted rows and duplicate columns (positions taken lane by lane),
+    empty items and empty rows.  Bit-exact against the oracle's stable transpose, item by item."""
+    g = np.random.Generator(np.random.PCG64(123))
+    batch, M, K = 96, 3000, 700
+    assert cmm.csr_transpose_in_lds(batch * 2000, batch, M, K)
+    lens = g.integers(0, 2, size=(batch, M))                      # ≈ 1.5 K entries per item on average
+    lens[0] = g.integers(8, 18, size=M)                            # item 0: ≈ 37 K entries
+    lens[0, 5] = 200                                               # a row of several chunks
+    lens[7] = 0                                                    # an empty item
+    cols = []
+    for i in range(batch):
+        for r in range(M):
+            n = int(lens[i, r])
+            c = g.integers(0, K, size=n)
+            if i == 0:
+                c[:1] = 5 if n else c[:1]                          # column 5 in every row of item 0: 3000 entries > the staging area
+            cols.append(c if (i + r) % 4 == 0 else np.sort(c))     # a quarter of the rows unsorted (duplicates possible anywhere)
+    col = np.concatenate(cols).astype(np.int32)
+    val = g.random(len(col), dtype=np.float32) - 0.5
+    off = np.zeros((batch, M + 1), np.int64)
+    off[:, 1:] = np.cumsum(lens.reshape(-1)).reshape(batch, M)
+    off[1:, 0] = off[:-1, M]
+    off = off.astype(np.int32)
+    assert cmm.csr_transpose_in_lds(len(col), batch, M, K)
+    t_val, t_col, t_off = cmm.csr_transpose_batched(t(val, dev), t(col, dev), t(off, dev), len(col), batch, M, K)
+    t_val, t_col, t_off = t_val.cpu().numpy(), t_col.cpu().numpy(), t_off.cpu().numpy()
+    for i in range(batch):
+        p0, p1 = off[i, 0], off[i, M]
+        w_rp, w_col, w_val = oracle_mod.csr_transpose(off[i] - p0, col[p0:p1], val[p0:p1], M, K)
+        assert np.array_equal(t_off[i] - p0, w_rp), i
+        assert np.array_equal(t_col[p0:p1], w_col), i
+        assert np.array_equal(t_val[p0:p1].view(np.int32), w_val.view(np.int32)), i
