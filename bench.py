@@ -336,7 +336,7 @@ def main():
     ap.add_argument("--split", choices=["rows", "nnz"], default="rows",
                     help="N > 1: equal-row blocks (one all_gather_into_tensor per step) or nnz-balanced split "
                          "points (one in-place broadcast per owner and step)")
-    ap.add_argument("--exchange", choices=["auto", "allgather", "allgather_copy", "alltoall", "p2p", "try-p2p"], default="auto",
+    ap.add_argument("--exchange", choices=["auto", "allgather", "allgather_copy", "alltoall", "p2p", "try-p2p", "push", "try-push"], default="auto",
                     help="N > 1: how a step's blocks reach the other ranks.  allgather: one in-place RCCL all-gather per "
                          "step (gather + copy if the build refuses the in-place form: allgather_copy pins that); alltoall: one "
                          "list-form all_to_all per step (every block straight to every peer: one xGMI link each, still a "
@@ -432,7 +432,11 @@ def main():
         # by agreement — so both are part of the default trial.  Independent direct sends (p2p) can fail on some ranks
         # only; they join the trial only on request AND after sharded.probe_p2p (own process group, short timeout,
         # outcome agreed over the main group) succeeded everywhere.  A failed probe costs nothing but the option.
-        exch_cands = {"auto": ("allgather", "alltoall"), "try-p2p": ("allgather", "alltoall")}.get(args.exchange, (args.exchange,))
+        # The IPC push exchange is part of the default trial too (round 5: peers' C mapped through CUDA IPC, blocks copied straight into them on
+        # a side stream, one tiny all-reduce as the fence — no RCCL data movement): also probed and agreed at construction,
+        # a refusal folds it into the all_to_all candidate.
+        exch_cands = {"auto": ("allgather", "alltoall", "push"), "try-p2p": ("allgather", "alltoall", "push"),
+                      "try-push": ("allgather", "alltoall", "push")}.get(args.exchange, (args.exchange,))
         if args.exchange == "try-p2p":
             p2p_probe = sharded.probe_p2p(dev, timeout_s=20.0)
             if p2p_probe:
@@ -591,7 +595,9 @@ def main():
                                                       "allgather_copy": "RCCL all-gather of C into a scratch span + copy",
                                                       "alltoall": "C exchanged by one list-form RCCL all_to_all per step (every block "
                                                                   "straight to every peer, in place)",
-                                                      "p2p": "C exchanged by direct RCCL sends to every peer"}[op.exchange if world > 1 else "allgather"],
+                                                      "p2p": "C exchanged by direct RCCL sends to every peer",
+                                                      "push": "C blocks copied straight into every peer's C through CUDA-IPC mappings "
+                                                              "(side-stream device copies, one tiny all-reduce as the fence)"}[op.exchange if world > 1 else "allgather"],
                 "rccl_ranks": world if world > 1 else None,
                 "chunks": None if world == 1 else args.chunks,
                 "exchange": None if world == 1 else op.exchange,

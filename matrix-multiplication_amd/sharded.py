@@ -45,6 +45,13 @@ Ways to exchange a step's blocks:
     send / recv pairs, i.e. the one-shard-per-link pattern below without leaving collective semantics (every rank
     calls it alike; nothing can half-fail the way independent sends can).  Probed and agreed like the in-place form;
     a build that refuses it (gloo has no list all_to_all) falls back to "allgather";
+  * exchange="push" (round 5): no RCCL data movement at all — every rank maps every peer's C buffer into its own address
+    space once (torch's CUDA IPC: `torch.multiprocessing.reductions.reduce_tensor`, handles exchanged with
+    `all_gather_object`) and, when a block is computed, COPIES it into its final position in every peer's C on a side
+    stream (device-to-device copies over xGMI, one shard per peer link, no collective kernel taking CUs from the
+    product); one tiny all-reduce behind the last copy is the completion fence (a rank's fence starts after its copies
+    and ends when every rank's has started: every push has landed everywhere).  Probed at construction on a tiny
+    buffer and agreed like the other forms; refused (CPU tensors, a build without CUDA IPC) → "alltoall";
   * exchange="p2p": every rank sends its block straight to every peer and receives each peer's block
     straight into its final position (one grouped batch of isend / irecv per step).  On a fully connected
     xGMI node that uses each of the 7 peer links for exactly one shard at a time — the pattern SURVEY.md
@@ -156,8 +163,8 @@ class ShardedSpMM:
                  layout=None, exchange="allgather"):
         if split not in ("rows", "nnz"):
             raise ValueError("split must be 'rows' or 'nnz'")
-        if exchange not in ("allgather", "allgather_copy", "alltoall", "p2p"):
-            raise ValueError("exchange must be 'allgather', 'allgather_copy', 'alltoall' or 'p2p'")
+        if exchange not in ("allgather", "allgather_copy", "alltoall", "p2p", "push"):
+            raise ValueError("exchange must be 'allgather', 'allgather_copy', 'alltoall', 'p2p' or 'push'")
         self.exchange = exchange
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -203,6 +210,9 @@ class ShardedSpMM:
         self._two_streams = {}  # N -> alternate the blocks over two streams?
         self._side = None
         self._scratch = {}     # (step, shape) -> out-of-place gather target (exchange="allgather_copy")
+        self._peer_out = {}    # (data_ptr, shape) of an output buffer -> every rank's view of it (exchange="push")
+        self._push_stream = None
+        self._fence = None
         self.fallbacks = []    # what was refused and replaced: reported by bench.py
         if self.world > 1 and not self.modelled and dist.is_initialized():
             self._probe_exchange()
@@ -219,6 +229,30 @@ class ShardedSpMM:
         enqueued, on every rank alike) moves every rank to the next form: alltoall → allgather → allgather_copy.  A
         DistBackendError (communicator, transport) is not a refusal: it is re-raised.'''
         refusals = (RuntimeError, ValueError, TypeError, NotImplementedError)
+        if self.exchange == "push":
+            ok, why = True, ""
+            try:
+                probe = torch.zeros((self.world, 4), device=self.device, dtype=torch.float32)
+                views = self._map_peers(probe)
+                for r in range(self.world):
+                    if r != self.rank:
+                        views[r][self.rank].copy_(torch.full((4,), float(self.rank + 1), device=self.device))
+                probe[self.rank] = float(self.rank + 1)
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize(self.device)
+                dist.barrier(group=self.group)
+                expect = torch.arange(1, self.world + 1, device=self.device, dtype=torch.float32)
+                if not torch.equal(probe, expect.unsqueeze(1).expand(self.world, 4)):
+                    ok, why = False, "pushed rows did not arrive"
+                self._peer_out.clear()
+                del views
+            except Exception as err:  # noqa: BLE001 — IPC is optional: whatever went wrong, the collectives remain
+                if isinstance(err, getattr(dist, "DistBackendError", ())):
+                    raise
+                ok, why = False, f"{type(err).__name__}: {str(err)[:120]}"
+            if not self._agreed(ok):
+                self.fallbacks.append(f"push refused on some rank ({why or 'on a peer'}): alltoall from now on")
+                self.exchange = "alltoall"
         while self.exchange == "alltoall" or (self.exchange == "allgather" and self.split == "rows"):
             ok, why = True, ""
             try:
@@ -249,6 +283,26 @@ class ShardedSpMM:
             nxt = "allgather" if self.exchange == "alltoall" else "allgather_copy"
             self.fallbacks.append(f"{self.exchange} refused on some rank ({why or 'on a peer'}): {nxt} from now on")
             self.exchange = nxt
+
+    def _map_peers(self, out: torch.Tensor):
+        '''Every rank's `out` as a tensor in THIS process (own entry: `out` itself), through torch's CUDA IPC; collective
+        (handles travel by all_gather_object), cached per output buffer.  CPU tensors have no such mapping: raises.'''
+        key = (out.data_ptr(), tuple(out.shape))
+        hit = self._peer_out.get(key)
+        if hit is not None:
+            return hit
+        if not out.is_cuda:
+            raise RuntimeError("push exchange needs device buffers (CUDA IPC)")
+        from torch.multiprocessing.reductions import reduce_tensor
+        fn, args = reduce_tensor(out)
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, (fn, args), group=self.group)
+        views = [out if r == self.rank else gathered[r][0](*gathered[r][1]) for r in range(self.world)]
+        for r, v in enumerate(views):
+            if tuple(v.shape) != tuple(out.shape):
+                raise RuntimeError(f"push exchange: rank {r}'s buffer has shape {tuple(v.shape)}, expected {tuple(out.shape)}")
+        self._peer_out[key] = views
+        return views
 
     def alloc_output(self, N: int) -> torch.Tensor:
         return torch.empty((self.padded_rows, N), device=self.device, dtype=torch.float32)
@@ -309,6 +363,13 @@ class ShardedSpMM:
         collective = gather and (self.world > 1 or force_collective)
         if collective and self.modelled:
             raise RuntimeError("a modelled layout has no process group: call forward(..., gather=False)")
+        peers = None
+        if collective and self.exchange == "push":
+            peers = self._map_peers(out)  # (collective on first use of this buffer)
+            if self._push_stream is None:
+                self._push_stream = torch.cuda.Stream(self.device)
+                self._fence = torch.zeros(1, device=self.device, dtype=torch.int32)
+            self._push_stream.wait_stream(torch.cuda.current_stream(self.device))  # `out` as the caller left it
         streams = None
         if compute and self._alternate(B, out):
             main = torch.cuda.current_stream(self.device)
@@ -325,6 +386,16 @@ class ShardedSpMM:
             if not collective:
                 return
             first = j * self.world
+            if self.exchange == "push":
+                if r1 > r0:
+                    done = torch.cuda.Event()
+                    done.record()  # the block is computed (current stream)
+                    with torch.cuda.stream(self._push_stream):
+                        self._push_stream.wait_event(done)
+                        for k in range(1, self.world):  # every rank starts with a different peer: one shard per link at a time
+                            r = (self.rank + k) % self.world
+                            peers[r][r0:r1].copy_(mine, non_blocking=True)
+                return
             if self.exchange == "p2p":
                 ops = []
                 for r in range(self.world):
@@ -374,6 +445,12 @@ class ShardedSpMM:
                     step(j, blk)
         if streams is not None:
             streams[0].wait_stream(streams[1])
+        if peers is not None:
+            # completion fence: a tiny all-reduce BEHIND this rank's copies on the push stream — it ends only once every
+            # rank's has started, i.e. once every rank's pushes are done: all blocks have landed in this rank's C
+            with torch.cuda.stream(self._push_stream):
+                dist.all_reduce(self._fence, op=dist.ReduceOp.MAX, group=self.group)  # (zeros stay zeros)
+            torch.cuda.current_stream(self.device).wait_stream(self._push_stream)
         for w in works:
             w.wait()
         for span, scratch in copies:

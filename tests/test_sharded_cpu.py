@@ -215,6 +215,20 @@ def test_all_to_all_refused_by_the_backend_falls_back_to_the_all_gather_by_agree
         assert np.array_equal(np.load(tmp_path / f"c_{r}.npy"), single), f"rank {r}"
 
 
+def test_push_exchange_without_device_buffers_falls_back_by_agreement(tmp_path, oracle_mod):
+    """exchange="push" (round 5: peers' C buffers mapped through CUDA IPC, blocks copied straight into them) needs device
+    buffers: on CPU tensors the construction-time probe refuses on every rank, the ranks agree and move to the list
+    all_to_all — which gloo refuses in turn — and end on the in-place all-gather, with the single-rank bits."""
+    M, K, N, world, chunks = 101, 64, 24, 2, 3
+    mp.spawn(_worker, args=(world, _free_port(), M, K, N, chunks, str(tmp_path), "rows", False, "push", False, False, None,
+                            "allgather"), nprocs=world, join=True)
+    rowptr, col, val = oracle_mod.make_csr(M, K, 0.05, seed=0)
+    B = np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32)
+    single = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"c_{r}.npy"), single), f"rank {r}"
+
+
 def test_probe_refused_on_one_rank_only_moves_every_rank_to_the_fallback(tmp_path, oracle_mod):
     """The probe's outcome is AGREED, not assumed identical on every rank: here rank 1 alone judges its probe of the
     in-place all_gather_into_tensor a failure (the collective went through, so nothing is left pending on rank 0); the
