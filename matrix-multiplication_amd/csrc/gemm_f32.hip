@@ -1093,7 +1093,7 @@ int launch_n16(const float* A, const float* B, float* C, int m, int n, int k, lo
   const long blocks = tiles_m * batch;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   const int rev = (int)(mi::g_gemm_launch_counter.fetch_add(1, std::memory_order_relaxed) & 1u);
-  const int nb = n <= 80 ? 5 : 6;
+  const int nb = n <= 64 ? 4 : (n <= 80 ? 5 : 6);
   const size_t a_floats = TA ? 32 * (128 + 16) : 128 * (32 + 4);
   const size_t lds = 2 * (a_floats + 32 * (16 * (size_t)nb + 16)) * sizeof(float);
 #define MI_N16(NB_)                                                                                                        \
@@ -1102,7 +1102,8 @@ int launch_n16(const float* A, const float* B, float* C, int m, int n, int k, lo
     if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, A, B, C, n, k, lda, ldb, ldc, sA, sB, sC, (int)tiles_m, rev); \
   } while (0)
-  if (nb == 5) MI_N16(5);
+  if (nb == 4) MI_N16(4);
+  else if (nb == 5) MI_N16(5);
 #if MI_GEMM_N16_ALL
   else MI_N16(6);
 #else
@@ -1196,14 +1197,14 @@ int launch(const float* A, const float* B, float* C, int m, int n, int k, long l
 // 64 < n ≤ 96 with a long k (attention's probs·V and Pᵀ·dC at head sizes 80 / 96): ONE 96-column tile per 128 rows
 // instead of a 128-column one — the matrix pipe computes 96 columns for the 80 / 96 wanted, not 128 (round 4 measured
 // 1.17–1.41× torch's time on these products, profiles/r03_attention_shapes.log).  Same k order per element: same bits.
-template <bool TA, bool TB>
+template <bool TA, bool TB, int BN_ = 96>
 int launch_n96(const float* A, const float* B, float* C, int m, int n, int k, long lda, long ldb, long ldc, long sA, long sB,
                long sC, int batch, bool vecA, bool vecB, bool vecC, const float* bias, hipStream_t s) {
   const long tiles_m = (m + 127) / 128;
   const long blocks = tiles_m * batch;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
   const int rev = (int)(mi::g_gemm_launch_counter.fetch_add(1, std::memory_order_relaxed) & 1u);
-  hipLaunchKernelGGL((gemm_f32_pipe_kernel<128, 96, TA, TB, 1>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m, n, k, lda,
+  hipLaunchKernelGGL((gemm_f32_pipe_kernel<128, BN_, TA, TB, 1>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m, n, k, lda,
                      ldb, ldc, sA, sB, sC, 1, (int)tiles_m, vecA, vecB, vecC, bias, rev);
   return mi::check_launch();
 }
@@ -1258,6 +1259,15 @@ int pick_tile(const float* A, const float* B, float* C, int m, int n, int k, lon
   if (MI_GEMM_FORCE_TILE == 2) MI_TILE(128, 64);
   if (MI_GEMM_FORCE_TILE == 3) MI_TILE(64, 128);
   if (MI_GEMM_FORCE_TILE == 4) MI_TILE(64, 64);
+#endif
+#ifndef MI_GEMM_NO_N16
+  // n = 64 with a LONG k (probs·V / Pᵀ·dC over 2048 tokens): the 16 × 16-block kernel's 128 × 64 tile — 8 waves of 16 rows,
+  // two workgroups per CU — is ahead of the 2 × 2-wave tile of 32 × 32 blocks there (48 × 2048² × 64: 0.2375 → 0.219 ms,
+  // torch 0.2305; at k = 512 / 1024 the 32 × 32 tiles stay ahead or level: tools/probes/gemm_n64_ab.py)
+  if constexpr (!TB) {
+    if (n == 64 && k >= 2048 && m % 128 == 0 && k % 64 == 0 && vecA && vecB && vecC && bias == nullptr && blocks_for(128, 64) >= 256)
+      return launch_n16<TA, TB>(A, B, C, m, n, k, lda, ldb, ldc, sA, sB, sC, batch, s);
+  }
 #endif
 #ifndef MI_GEMM_NO_N96
   if (n > 64 && n <= 96 && m > 64 && k >= MI_GEMM_PIPE_MIN_TILES * BK && vecA && vecB && k % BK == 0 && blocks_for(128, 96) >= 256) {

@@ -124,7 +124,7 @@ def test_gemm_bert_base_attention_shapes(cmm, dev, oracle_mod):
 
 
 @pytest.mark.parametrize("items,S,D", [(96, 512, 80), (96, 512, 96), (24, 197, 64), (12, 577, 64), (6, 2048, 64), (24, 300, 72),
-                                       (3, 130, 96), (600, 256, 88)])
+                                       (3, 130, 96), (600, 256, 88), (24, 2048, 64)])
 def test_gemm_attention_products_at_other_head_sizes_and_lengths_bit_exact(cmm, dev, oracle_mod, items, S, D):
     """Round 5: the four attention products (q·kᵀ, probs·V and the two transposed products of their backward) at head
     sizes 80 / 96 / 72 / 88 — probs·V and Pᵀ·dC there run ONE 96-column tile per 128 rows (4 × 1 wave layout of the
