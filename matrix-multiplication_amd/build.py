@@ -105,14 +105,14 @@ def build_extension(force=False, verbose=False) -> Path:
     out = ext_path()
     stamp = OBJ_DIR / "custom_mm.stamp"
     torch_lib = Path(torch.__file__).resolve().parent / "lib"
-    inc = [f"-I{p}" for p in ce.include_paths("cuda")] + [f"-I{INCLUDE}", f"-I{sysconfig.get_paths()['include']}"]
+    inc = [f"-I{p}" for p in ce.include_paths("cuda")] + [f"-I{INCLUDE}", f"-I{CSRC}", f"-I{sysconfig.get_paths()['include']}"]
     abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
     flags = ["-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
              "-DTORCH_EXTENSION_NAME=custom_mm", "-DTORCH_API_INCLUDE_EXTENSION_H",
              f"-D_GLIBCXX_USE_CXX11_ABI={abi}", "-Wno-deprecated-declarations"]
     link = [f"-L{PKG_DIR}", "-lmi_spmm", f"-L{torch_lib}", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip",
             "-ltorch", "-ltorch_python", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{torch_lib}"]
-    digest = _digest([src, INCLUDE / "mi_spmm.h"], " ".join(flags + link) + torch.__version__)
+    digest = _digest([src, *sorted(CSRC.glob("custom_mm_*.inc")), INCLUDE / "mi_spmm.h"], " ".join(flags + link) + torch.__version__)
     if force or _stale(out, stamp, digest):
         _run(["g++", *flags, *inc, src, "-o", out, *link], verbose)
         stamp.write_text(digest)

@@ -36,1202 +36,10 @@
 #include "mi_spmm.h"
 
 namespace {
-
-void check_status(int st, const char* what) {
-  if (st == MI_OK) return;
-  if (st == MI_EHIP)
-    TORCH_CHECK(false, what, ": HIP error: ", mi_last_hip_error_string());
-  if (st == MI_EINVAL) throw std::invalid_argument(std::string(what) + ": " + mi_status_string(st));
-  TORCH_CHECK(false, what, ": ", mi_status_string(st));
-}
-
-void check_device_f32(const torch::Tensor& t, const char* name) {
-  TORCH_CHECK(t.is_cuda(), name, " must be a device (HIP) tensor; custom_mm has no CPU path");
-  TORCH_CHECK(t.scalar_type() == torch::kFloat32, name, " must be float32, got ", t.scalar_type());
-}
-
-void check_device_i32(const torch::Tensor& t, const char* name) {
-  TORCH_CHECK(t.is_cuda(), name, " must be a device (HIP) tensor; custom_mm has no CPU path");
-  TORCH_CHECK(t.scalar_type() == torch::kInt32, name, " must be int32, got ", t.scalar_type());
-}
-
-void check_same_device(const torch::Tensor& a, const torch::Tensor& b, const char* what) {
-  TORCH_CHECK(a.device() == b.device(), what, ": tensors are on different devices (", a.device(),
-              " vs ", b.device(), ")");
-}
-
-mi_stream_t stream_of(const torch::Tensor& t) {
-  return static_cast<mi_stream_t>(c10::hip::getCurrentHIPStream(t.device().index()).stream());
-}
-
-// A dense operand as the C-ABI wants it: pointer, leading dimension, batch
-// stride, and whether the stored matrix is the transpose of the logical one.
-struct Operand {
-  torch::Tensor keep;  // owns the memory for the duration of the call
-  const float* ptr;
-  int64_t ld;
-  int64_t batch_stride;
-  bool stored_transposed;
-  int64_t rows, cols;  // logical (before `stored_transposed`)
-};
-
-// View the last two dims of `t` (after flattening the leading `nbatch` dims to
-// one) as row-major-with-ld, or as a transposed row-major matrix; copy only
-// when the strides fit neither.
-Operand as_operand(const torch::Tensor& t, int nbatch_dims) {
-  Operand o;
-  const int64_t d = t.dim();
-  TORCH_CHECK(d == nbatch_dims + 2, "expected a ", nbatch_dims + 2, "-d tensor, got ", d, "-d");
-  o.rows = t.size(d - 2);
-  o.cols = t.size(d - 1);
-  // Leading dims must flatten to ONE batch stride (nbatch_dims ≤ 2 here).
-  auto batch_stride_of = [&](const torch::Tensor& y, int64_t& stride) {
-    stride = 0;
-    if (nbatch_dims == 0) return true;
-    if (nbatch_dims == 1) {
-      stride = y.size(0) > 1 ? y.stride(0) : 0;
-      return stride >= 0;
-    }
-    const int64_t b0 = y.size(0), b1 = y.size(1), s0 = y.stride(0), s1 = y.stride(1);
-    if (b0 <= 1) stride = b1 > 1 ? s1 : 0;
-    else if (b1 <= 1) stride = s0;
-    else if (s0 == s1 * b1) stride = s1;
-    else return false;
-    return stride >= 0;
-  };
-  // Row-major with a leading dimension, or the transpose of one.
-  auto layout_of = [&](const torch::Tensor& y, bool& transposed, int64_t& ld) {
-    const int64_t sr = y.stride(d - 2), sc = y.stride(d - 1);
-    if ((sc == 1 || o.cols <= 1) && (o.rows <= 1 || sr >= std::max<int64_t>(o.cols, 1))) {
-      transposed = false;
-      ld = o.rows > 1 ? sr : std::max<int64_t>(o.cols, 1);
-      return true;
-    }
-    if ((sr == 1 || o.rows <= 1) && (o.cols <= 1 || sc >= std::max<int64_t>(o.rows, 1))) {
-      transposed = true;
-      ld = o.cols > 1 ? sc : std::max<int64_t>(o.rows, 1);
-      return true;
-    }
-    return false;
-  };
-  torch::Tensor x = t;
-  bool transposed = false;
-  int64_t ld = 0, bstride = 0;
-  if (!layout_of(x, transposed, ld) || !batch_stride_of(x, bstride)) {
-    x = t.contiguous();
-    TORCH_INTERNAL_ASSERT(layout_of(x, transposed, ld) && batch_stride_of(x, bstride));
-  }
-  o.keep = x;
-  o.ptr = x.data_ptr<float>();
-  o.stored_transposed = transposed;
-  o.ld = ld;
-  o.batch_stride = bstride;
-  return o;
-}
-
-int64_t batch_count(const torch::Tensor& t, int nbatch_dims) {
-  int64_t b = 1;
-  for (int i = 0; i < nbatch_dims; ++i) b *= t.size(i);
-  return b;
-}
-
-// C = op(A)·op(B) for `nbatch_dims` leading batch dims.
-torch::Tensor gemm_impl(const torch::Tensor& A, const torch::Tensor& B, torch::Tensor C,
-                        int nbatch_dims, bool transa, bool transb, const char* what,
-                        const torch::Tensor* bias = nullptr) {
-  check_device_f32(A, "A");
-  check_device_f32(B, "B");
-  check_device_f32(C, "C");
-  check_same_device(A, B, what);
-  check_same_device(A, C, what);
-  TORCH_CHECK(C.is_contiguous(), what, ": C must be contiguous");
-  TORCH_CHECK(C.dim() == nbatch_dims + 2, what, ": C has the wrong rank");
-  for (int i = 0; i < nbatch_dims; ++i)
-    TORCH_CHECK(A.size(i) == B.size(i) && A.size(i) == C.size(i), what,
-                ": batch dimensions of A, B and C differ");
-  Operand a = as_operand(A, nbatch_dims);
-  Operand b = as_operand(B, nbatch_dims);
-  const int64_t m = transa ? a.cols : a.rows, ka = transa ? a.rows : a.cols;
-  const int64_t kb = transb ? b.cols : b.rows, n = transb ? b.rows : b.cols;
-  TORCH_CHECK(ka == kb, what, ": inner dimensions differ (", ka, " vs ", kb, ")");
-  TORCH_CHECK(C.size(-2) == m && C.size(-1) == n, what, ": C must be ", m, "x", n, ", got ",
-              C.size(-2), "x", C.size(-1));
-  TORCH_CHECK(m <= INT32_MAX && n <= INT32_MAX && ka <= INT32_MAX, what, ": dimension too large");
-  const int64_t batch = batch_count(C, nbatch_dims);
-  const float* bias_ptr = nullptr;
-  torch::Tensor bias_keep;
-  if (bias != nullptr && bias->defined()) {
-    check_device_f32(*bias, "bias");
-    check_same_device(*bias, C, what);
-    TORCH_CHECK(bias->dim() == 1 && bias->size(0) == n, what, ": bias must have ", n, " entries");
-    bias_keep = bias->contiguous();
-    bias_ptr = bias_keep.data_ptr<float>();
-  }
-  c10::hip::HIPGuard guard(C.device().index());
-  const int st = mi_gemm_bias_f32(transa != a.stored_transposed, transb != b.stored_transposed,
-                                  (int32_t)m, (int32_t)n, (int32_t)ka, a.ptr, a.ld, a.batch_stride,
-                                  b.ptr, b.ld, b.batch_stride, bias_ptr, C.data_ptr<float>(),
-                                  std::max<int64_t>(n, 1), m * n, (int32_t)batch, stream_of(C));
-  check_status(st, what);
-  return C;
-}
-
-// ---- cuBLAS-named entry points (reference custom_mm.cpp:104-164) ------------
-
-torch::Tensor cublas_mmul(torch::Tensor A, torch::Tensor B, torch::Tensor C, bool transa,
-                          bool transb) {
-  return gemm_impl(A, B, C, 0, transa, transb, "cublas_mmul");
-}
-
-torch::Tensor cublas_bmm(torch::Tensor A, torch::Tensor B, torch::Tensor C, int dim, bool transa,
-                         bool transb) {
-  if (dim == 3) return gemm_impl(A, B, C, 1, transa, transb, "cublas_bmm");
-  if (dim == 4) return gemm_impl(A, B, C, 2, transa, transb, "cublas_bmm");
-  if (dim == 2) return cublas_mmul(A, B, C, transa, transb);
-  throw std::invalid_argument("Invalid dim argument.");  // reference custom_mm.cpp:162
-}
-
-// ---- CSR × dense, row-major (reference custom_mm.cpp:166-179, :203-217) -----
-
-// One long-row workspace per (device, stream), reused by every plain naive_spmm / cusparse_mmul on that stream
-// (products on one stream are ordered, so they can share it).  Invariant (MI_LONG_ROWS_AUTO_ZEROED, include/mi_spmm.h):
-// its first 16 bytes are zero whenever no product is in flight — zeroed once here, restored by each product's
-// follow-up kernel.  Not used under stream capture (the buffer would belong to the graph's pool).
-struct StreamWorkspace {
-  torch::Tensor buf;
-};
-std::mutex g_stream_ws_mutex;
-std::map<std::pair<int, mi_stream_t>, StreamWorkspace> g_stream_ws;
-
-bool stream_is_capturing(mi_stream_t stream) {
-  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &status) != hipSuccess) {
-    (void)hipGetLastError();
-    return true;  // be conservative: the per-call path is always valid
-  }
-  return status != hipStreamCaptureStatusNone;
-}
-
-torch::Tensor zeroed_stream_workspace(const torch::Device& dev, mi_stream_t stream, size_t bytes) {
-  std::lock_guard<std::mutex> lock(g_stream_ws_mutex);
-  const auto key = std::make_pair((int)dev.index(), stream);
-  if (g_stream_ws.size() >= 64 && g_stream_ws.find(key) == g_stream_ws.end())
-    g_stream_ws.clear();  // a program that keeps creating streams: start over (the allocator keeps freed blocks stream-ordered)
-  StreamWorkspace& w = g_stream_ws[key];
-  if (!w.buf.defined() || (size_t)w.buf.numel() < bytes) {
-    const int64_t cap = (int64_t)(bytes + bytes / 2 + 4096);
-    w.buf = torch::empty({cap}, torch::dtype(torch::kUInt8).device(dev));
-    w.buf.narrow(0, 0, 16).zero_();  // once per (re)allocation, on the current stream
-  }
-  return w.buf;
-}
-
-void drop_stream_workspace(const torch::Device& dev, mi_stream_t stream) {
-  std::lock_guard<std::mutex> lock(g_stream_ws_mutex);
-  g_stream_ws.erase(std::make_pair((int)dev.index(), stream));
-}
-
-torch::Tensor spmm_impl(const torch::Tensor& A_values, const torch::Tensor& A_columns,
-                        const torch::Tensor& A_offsets, int64_t nnzA, int64_t A_rows,
-                        int64_t A_cols, const torch::Tensor& B, torch::Tensor C, const char* what,
-                        const torch::Tensor* bias = nullptr, int long_rows = MI_LONG_ROWS_AUTO) {
-  check_device_f32(A_values, "A_values");
-  check_device_i32(A_columns, "A_columns");
-  check_device_i32(A_offsets, "A_offsets");
-  check_device_f32(B, "B");
-  check_device_f32(C, "C");
-  check_same_device(A_values, C, what);
-  check_same_device(A_columns, C, what);
-  check_same_device(A_offsets, C, what);
-  check_same_device(B, C, what);
-  TORCH_CHECK(A_rows >= 0 && A_cols >= 0 && nnzA >= 0, what, ": negative size");
-  TORCH_CHECK(A_rows <= INT32_MAX && A_cols <= INT32_MAX, what, ": dimension too large");
-  TORCH_CHECK(A_values.is_contiguous() && A_columns.is_contiguous() && A_offsets.is_contiguous(),
-              what, ": CSR arrays must be contiguous");
-  TORCH_CHECK(A_values.numel() >= nnzA && A_columns.numel() >= nnzA, what,
-              ": nnzA exceeds the CSR arrays");
-  TORCH_CHECK(A_offsets.numel() == A_rows + 1, what, ": A_offsets must have A_rows + 1 entries");
-  TORCH_CHECK(B.dim() == 2 && C.dim() == 2, what, ": B and C must be 2-d");
-  TORCH_CHECK(B.size(0) == A_cols, what, ": B must have A_cols = ", A_cols, " rows, got ", B.size(0));
-  TORCH_CHECK(C.size(0) == A_rows && C.size(1) == B.size(1), what, ": C must be ", A_rows, "x",
-              B.size(1));
-  TORCH_CHECK(C.is_contiguous(), what, ": C must be contiguous");
-  torch::Tensor Bc = (B.stride(1) == 1 || B.size(1) == 1) && (B.stride(0) >= B.size(1) || B.size(0) <= 1)
-                         ? B
-                         : B.contiguous();
-  const int64_t N = B.size(1);
-  const int64_t ldb = Bc.size(0) > 1 ? Bc.stride(0) : std::max<int64_t>(N, 1);
-  const float* bias_ptr = nullptr;
-  torch::Tensor bias_keep;
-  if (bias != nullptr && bias->defined()) {
-    check_device_f32(*bias, "bias");
-    check_same_device(*bias, C, what);
-    TORCH_CHECK(bias->dim() == 1 && bias->size(0) == N, what, ": bias must have ", N, " entries");
-    bias_keep = bias->contiguous();
-    bias_ptr = bias_keep.data_ptr<float>();
-  }
-  c10::hip::HIPGuard guard(C.device().index());
-  // workspace for the over-long rows (list + partial rows of the split ones);
-  // none when the caller pins "no row is split" (MI_LONG_ROWS_NONE: one launch, nothing else)
-  const size_t ws_bytes = long_rows == MI_LONG_ROWS_NONE ? 0 : mi_spmm_csr_workspace_bytes(nnzA, (int32_t)N);
-  torch::Tensor ws;
-  int mode = long_rows;
-  const mi_stream_t stream = stream_of(C);
-  if (ws_bytes > 0) {
-    if (long_rows == MI_LONG_ROWS_AUTO && !stream_is_capturing(stream)) {
-      // the plain entry points: one workspace per (device, stream), kept with a zero header between products, so a
-      // product is the main kernel (which lists the rows it skips) + one follow-up launch — no memset, no scan
-      ws = zeroed_stream_workspace(C.device(), stream, ws_bytes);
-      mode = MI_LONG_ROWS_AUTO_ZEROED;
-    } else {
-      ws = torch::empty({(int64_t)ws_bytes}, torch::dtype(torch::kUInt8).device(C.device()));  // caching allocator
-    }
-  }
-  const int st = mi_spmm_csr_ex_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
-                                    A_values.data_ptr<float>(), nnzA, (int32_t)A_rows, (int32_t)A_cols,
-                                    (int32_t)N, Bc.data_ptr<float>(), ldb, bias_ptr, C.data_ptr<float>(),
-                                    std::max<int64_t>(N, 1), mode, ws_bytes > 0 ? ws.data_ptr() : nullptr,
-                                    ws_bytes > 0 ? (size_t)ws.numel() : 0, stream);
-  if (st != MI_OK && mode == MI_LONG_ROWS_AUTO_ZEROED) drop_stream_workspace(C.device(), stream);  // its header may be dirty
-  check_status(st, what);
-  return C;
-}
-
-torch::Tensor naive_spmm(torch::Tensor A_values, torch::Tensor A_columns, torch::Tensor A_offsets,
-                         int nnzA, int A_rows, int A_cols, torch::Tensor B, torch::Tensor C) {
-  return spmm_impl(A_values, A_columns, A_offsets, nnzA, A_rows, A_cols, B, C, "naive_spmm");
-}
-
-torch::Tensor cusparse_mmul(torch::Tensor A_values, torch::Tensor A_columns, torch::Tensor A_offsets,
-                            int nnzA, int A_rows, int A_cols, torch::Tensor B, torch::Tensor C) {
-  return spmm_impl(A_values, A_columns, A_offsets, nnzA, A_rows, A_cols, B, C, "cusparse_mmul");
-}
-
-// Fused FC-layer forms (additions): C = op(A)·op(B) + bias and C = A_csr·B + bias, bias[n]
-// added to every row in the kernel epilogue — what cublasLinear / cusparseLinear.forward
-// compute with a clone and an in-place add (reference benchmarks/cublas_fc_layer.py:41-45).
-torch::Tensor cublas_mmul_bias(torch::Tensor A, torch::Tensor B, torch::Tensor bias, torch::Tensor C,
-                               bool transa, bool transb) {
-  return gemm_impl(A, B, C, 0, transa, transb, "cublas_mmul_bias", &bias);
-}
-
-torch::Tensor naive_spmm_bias(torch::Tensor A_values, torch::Tensor A_columns, torch::Tensor A_offsets,
-                              int64_t nnzA, int64_t A_rows, int64_t A_cols, torch::Tensor B,
-                              torch::Tensor bias, torch::Tensor C) {
-  return spmm_impl(A_values, A_columns, A_offsets, nnzA, A_rows, A_cols, B, C, "naive_spmm_bias", &bias);
-}
-
-// naive_spmm with the long-row rule pinned (include/mi_spmm.h, MI_LONG_ROWS_*): -1 = as naive_spmm,
-// 0 = plain CSR-order chain for every row, ONE launch and no workspace (also right when the caller
-// knows no row exceeds long_row_threshold() non-zeros), 1 = always split the long rows.  Used by
-// sharded.py so a row shard sums exactly as the whole matrix would.
-torch::Tensor naive_spmm_ex(torch::Tensor A_values, torch::Tensor A_columns, torch::Tensor A_offsets,
-                            int64_t nnzA, int64_t A_rows, int64_t A_cols, torch::Tensor B, torch::Tensor C,
-                            int long_rows) {
-  if (long_rows < MI_LONG_ROWS_AUTO || long_rows > MI_LONG_ROWS_SPLIT)
-    throw std::invalid_argument("naive_spmm_ex: long_rows must be -1, 0 or 1");
-  return spmm_impl(A_values, A_columns, A_offsets, nnzA, A_rows, A_cols, B, C, "naive_spmm_ex", nullptr, long_rows);
-}
-
-// … and with the fused bias (fc_layers: activations converted from a dense matrix have no row longer than
-// the layer is wide, so a layer of ≤ long_row_threshold() inputs needs neither workspace nor helper launches).
-torch::Tensor naive_spmm_bias_ex(torch::Tensor A_values, torch::Tensor A_columns, torch::Tensor A_offsets,
-                                 int64_t nnzA, int64_t A_rows, int64_t A_cols, torch::Tensor B, torch::Tensor bias,
-                                 torch::Tensor C, int long_rows) {
-  if (long_rows < MI_LONG_ROWS_AUTO || long_rows > MI_LONG_ROWS_SPLIT)
-    throw std::invalid_argument("naive_spmm_bias_ex: long_rows must be -1, 0 or 1");
-  return spmm_impl(A_values, A_columns, A_offsets, nnzA, A_rows, A_cols, B, C, "naive_spmm_bias_ex", &bias, long_rows);
-}
-
-// (variant id, kernel name, launches per product, splits_long_rows) of the AUTO plan for
-// C[M,N] = A[M,K]·B with nnz non-zeros and these operand buffers — no GPU work.
-std::tuple<int, std::string, int, bool> spmm_plan(int64_t nnz, int64_t M, int64_t K, torch::Tensor B, torch::Tensor C) {
-  check_device_f32(B, "B");
-  check_device_f32(C, "C");
-  TORCH_CHECK(B.dim() == 2 && C.dim() == 2 && B.size(1) == C.size(1), "spmm_plan: B [K,N] and C [M,N] expected");
-  TORCH_CHECK(M <= INT32_MAX && K <= INT32_MAX, "spmm_plan: dimension too large");
-  const int64_t N = B.size(1);
-  const int64_t ldb = B.size(0) > 1 ? B.stride(0) : std::max<int64_t>(N, 1);
-  const int64_t ldc = C.size(0) > 1 ? C.stride(0) : std::max<int64_t>(N, 1);
-  const int v = mi_spmm_csr_f32_plan(nnz, (int32_t)M, (int32_t)K, (int32_t)N, B.data_ptr<float>(), ldb,
-                                     C.data_ptr<float>(), ldc);
-  check_status(v < 0 ? v : MI_OK, "spmm_plan");
-  const int sp = mi_spmm_auto_splits_long_rows(nnz, (int32_t)M, (int32_t)K, (int32_t)N, B.data_ptr<float>(), ldb,
-                                               C.data_ptr<float>(), ldc);
-  return std::make_tuple(v, std::string(mi_spmm_variant_name(v)), mi_spmm_variant_launches(v), sp == 1);
-}
-
-int long_row_threshold() { return mi_spmm_long_row_threshold(); }
-
-// Opt-in check of a CSR's CONTENTS (the hot-path entry points validate sizes, dtypes, devices and
-// layout, but trust the indices like the reference does, src/naive_sparse_mm.cu:60-92: a column
-// outside [0, A_cols) or decreasing offsets read B out of bounds).  Raises on the first violation;
-// costs a few reductions and one host read-back, so call it where the matrix is built, not per product.
-// The inspector entry points (cusparse_inspect / tiledspmm_inspect_*) run the same checks once.
-void validate_csr(torch::Tensor A_values, torch::Tensor A_columns, torch::Tensor A_offsets, int64_t nnzA,
-                  int64_t A_rows, int64_t A_cols) {
-  const char* what = "validate_csr";
-  check_device_f32(A_values, "A_values");
-  check_device_i32(A_columns, "A_columns");
-  check_device_i32(A_offsets, "A_offsets");
-  check_same_device(A_values, A_columns, what);
-  check_same_device(A_values, A_offsets, what);
-  TORCH_CHECK(A_rows >= 0 && A_cols >= 0 && nnzA >= 0, what, ": negative size");
-  TORCH_CHECK(A_offsets.numel() == A_rows + 1, what, ": A_offsets must have A_rows + 1 entries");
-  TORCH_CHECK(A_values.numel() >= nnzA && A_columns.numel() >= nnzA, what, ": nnzA exceeds the CSR arrays");
-  torch::Tensor off = A_offsets.reshape({-1});
-  if (A_rows > 0) {
-    TORCH_CHECK(off[0].item<int32_t>() == 0 && off[A_rows].item<int32_t>() == nnzA, what,
-                ": offsets must start at 0 and end at nnz");
-    TORCH_CHECK((off.slice(0, 1) - off.slice(0, 0, A_rows)).min().item<int32_t>() >= 0, what,
-                ": offsets must not decrease");
-  } else {
-    TORCH_CHECK(nnzA == 0, what, ": a matrix without rows has no non-zeros");
-  }
-  if (nnzA > 0) {
-    torch::Tensor c = A_columns.reshape({-1}).slice(0, 0, nnzA);
-    TORCH_CHECK(c.min().item<int32_t>() >= 0 && c.max().item<int32_t>() < A_cols, what, ": column index out of range");
-  }
-}
-
-// Column sums of a 2-d tensor (bias gradient of the FC layers): returns a [n] tensor.
-torch::Tensor column_sums(torch::Tensor src) {
-  check_device_f32(src, "src");
-  TORCH_CHECK(src.dim() == 2, "column_sums: expected a 2-d tensor");
-  torch::Tensor x = src.stride(1) == 1 && src.stride(0) >= src.size(1) ? src : src.contiguous();
-  const int64_t rows = x.size(0), n = x.size(1);
-  TORCH_CHECK(rows <= INT32_MAX && n <= INT32_MAX, "column_sums: dimension too large");
-  c10::hip::HIPGuard guard(x.device().index());
-  torch::Tensor out = torch::empty({n}, x.options());
-  const size_t ws_bytes = mi_colsum_workspace_bytes((int32_t)rows, (int32_t)n);
-  torch::Tensor ws = torch::empty({(int64_t)std::max<size_t>(ws_bytes, 4)}, torch::dtype(torch::kUInt8).device(x.device()));
-  check_status(mi_colsum_f32(x.data_ptr<float>(), (int32_t)rows, (int32_t)n, rows > 1 ? x.stride(0) : std::max<int64_t>(n, 1),
-                             out.data_ptr<float>(), ws.data_ptr(), ws_bytes, stream_of(x)),
-               "column_sums");
-  return out;
-}
-
-// values[perm] as a new tensor (perm int32, values f32, both contiguous and on one device); what torch's index_select
-// does, without its index conversion (bound by one line request per value either way: tools/probes/gather_bench.py)
-torch::Tensor gather_perm(torch::Tensor values, torch::Tensor perm) {
-  check_device_f32(values, "values");
-  check_device_i32(perm, "perm");
-  check_same_device(values, perm, "gather_perm");
-  TORCH_CHECK(values.dim() == 1 && perm.dim() == 1 && values.is_contiguous() && perm.is_contiguous(),
-              "gather_perm: expected contiguous 1-d tensors");
-  c10::hip::HIPGuard guard(values.device().index());
-  torch::Tensor out = torch::empty({perm.numel()}, values.options());
-  check_status(mi_gather_f32(values.data_ptr<float>(), perm.data_ptr<int32_t>(), perm.numel(), out.data_ptr<float>(),
-                             stream_of(values)),
-               "gather_perm");
-  return out;
-}
-
-// ---- additions to the reference surface (used by matmuls.py) -----------------
-// The reference batches by Python recursion + torch.stack with one
-// to_sparse_csr() per slice (matmuls.py:289-297) and has no working backward
-// (SURVEY.md §8a defects 1-2); these four entry points give matmuls.py the
-// one-launch batched forward and the sparse backward.  They are extra names:
-// the 16 reference names keep their exact signatures.
-
-// dense [..., rows, cols] → (values f32[nnz], columns i32[nnz], offsets i32[batch, rows+1]);
-// offsets are global over the batch ("rowptr of rowptrs", include/mi_spmm.h).
-// Device counterpart of dense_to_csr (reference src/baseline_mm.cu:218-264).
-// Step 1 alone: the row offsets [batch, rows+1] (global over the batch; the last entry is the total
-// nnz) — no host read-back, so a caller can look at the density before paying for the fill.
-torch::Tensor dense_row_offsets(torch::Tensor dense) {
-  check_device_f32(dense, "dense");
-  TORCH_CHECK(dense.dim() >= 2, "dense_to_csr: expected at least a 2-d tensor");
-  torch::Tensor d = dense.contiguous();
-  const int64_t rows = d.size(-2), cols = d.size(-1);
-  const int64_t batch = rows * cols > 0 ? d.numel() / (rows * cols) : [&] {
-    int64_t b = 1;
-    for (int64_t i = 0; i + 2 < d.dim(); ++i) b *= d.size(i);
-    return b;
-  }();
-  TORCH_CHECK(rows <= INT32_MAX && cols <= INT32_MAX && batch <= INT32_MAX, "dense_to_csr: dimension too large");
-  TORCH_CHECK(d.numel() <= INT32_MAX, "dense_to_csr: more than 2^31-1 elements cannot be indexed by int32 offsets");
-  c10::hip::HIPGuard guard(d.device().index());
-  auto iopt = torch::dtype(torch::kInt32).device(d.device());
-  torch::Tensor offsets = torch::empty({batch, rows + 1}, iopt);
-  const size_t ws_bytes = mi_dense_to_csr_workspace_bytes((int32_t)batch, (int32_t)rows);
-  torch::Tensor ws = torch::empty({(int64_t)std::max<size_t>(ws_bytes, 1)}, torch::dtype(torch::kUInt8).device(d.device()));
-  check_status(mi_dense_to_csr_count(d.data_ptr<float>(), (int32_t)batch, (int32_t)rows, (int32_t)cols, cols,
-                                     rows * cols, offsets.data_ptr<int32_t>(), ws.data_ptr(), ws_bytes,
-                                     stream_of(d)),
-               "dense_to_csr(count)");
-  return offsets;
-}
-
-// Step 2: (values, columns) for offsets produced by dense_row_offsets on the same tensor; nnz is
-// the caller's host copy of offsets[-1, -1].
-std::tuple<torch::Tensor, torch::Tensor> dense_to_csr_fill(torch::Tensor dense, torch::Tensor offsets, int64_t nnz) {
-  check_device_f32(dense, "dense");
-  check_device_i32(offsets, "offsets");
-  check_same_device(dense, offsets, "dense_to_csr_fill");
-  TORCH_CHECK(dense.dim() >= 2 && nnz >= 0 && nnz <= dense.numel(), "dense_to_csr_fill: bad arguments");
-  torch::Tensor d = dense.contiguous();
-  const int64_t rows = d.size(-2), cols = d.size(-1);
-  const int64_t batch = rows * cols > 0 ? d.numel() / (rows * cols) : 0;
-  TORCH_CHECK(offsets.is_contiguous() && offsets.numel() == batch * (rows + 1) || nnz == 0,
-              "dense_to_csr_fill: offsets must be the [batch, rows + 1] tensor of dense_row_offsets");
-  c10::hip::HIPGuard guard(d.device().index());
-  torch::Tensor columns = torch::empty({nnz}, torch::dtype(torch::kInt32).device(d.device()));
-  torch::Tensor values = torch::empty({nnz}, torch::dtype(torch::kFloat32).device(d.device()));
-  if (nnz > 0)
-    check_status(mi_dense_to_csr_fill(d.data_ptr<float>(), (int32_t)batch, (int32_t)rows, (int32_t)cols, cols,
-                                      rows * cols, offsets.data_ptr<int32_t>(), columns.data_ptr<int32_t>(),
-                                      values.data_ptr<float>(), stream_of(d)),
-                 "dense_to_csr(fill)");
-  return std::make_tuple(values, columns);
-}
-
-std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> dense_to_csr(torch::Tensor dense) {
-  torch::Tensor offsets = dense_row_offsets(dense);
-  // one host read-back per call (not per slice) to size col / val
-  const int64_t nnz = offsets.numel() > 0 ? offsets.view({-1})[offsets.numel() - 1].item<int32_t>() : 0;
-  auto vc = dense_to_csr_fill(dense, offsets, nnz);
-  return std::make_tuple(std::get<0>(vc), std::get<1>(vc), offsets);
-}
-
-// C[b] = A[b]·B[b] for a batched CSR (offsets [batch, A_rows+1], global) in one
-// launch; B is [batch, K, N] or [K, N] (shared by every item), C is [batch, M, N].
-torch::Tensor naive_spmm_batched(torch::Tensor A_values, torch::Tensor A_columns, torch::Tensor A_offsets,
-                                 int64_t nnzA, int64_t batch, int64_t A_rows, int64_t A_cols,
-                                 torch::Tensor B, torch::Tensor C) {
-  const char* what = "naive_spmm_batched";
-  check_device_f32(A_values, "A_values");
-  check_device_i32(A_columns, "A_columns");
-  check_device_i32(A_offsets, "A_offsets");
-  check_device_f32(B, "B");
-  check_device_f32(C, "C");
-  check_same_device(A_values, C, what);
-  check_same_device(A_columns, C, what);
-  check_same_device(A_offsets, C, what);
-  check_same_device(B, C, what);
-  TORCH_CHECK(batch >= 0 && A_rows >= 0 && A_cols >= 0 && nnzA >= 0, what, ": negative size");
-  TORCH_CHECK(batch <= 65535, what, ": at most 65535 items per launch");
-  TORCH_CHECK(A_values.is_contiguous() && A_columns.is_contiguous() && A_offsets.is_contiguous(), what,
-              ": CSR arrays must be contiguous");
-  TORCH_CHECK(A_offsets.numel() == batch * (A_rows + 1), what, ": A_offsets must be [batch, A_rows + 1]");
-  TORCH_CHECK(A_values.numel() >= nnzA && A_columns.numel() >= nnzA, what, ": nnzA exceeds the CSR arrays");
-  TORCH_CHECK(C.dim() == 3 && C.is_contiguous() && C.size(0) == batch && C.size(1) == A_rows, what,
-              ": C must be contiguous [batch, A_rows, N]");
-  const int64_t N = C.size(2);
-  torch::Tensor Bc = B.contiguous();
-  int64_t strideB = 0;
-  if (Bc.dim() == 3) {
-    TORCH_CHECK(Bc.size(0) == batch && Bc.size(1) == A_cols && Bc.size(2) == N, what, ": B must be [batch, A_cols, N]");
-    strideB = A_cols * N;
-  } else {
-    TORCH_CHECK(Bc.dim() == 2 && Bc.size(0) == A_cols && Bc.size(1) == N, what, ": B must be [A_cols, N]");
-  }
-  c10::hip::HIPGuard guard(C.device().index());
-  check_status(mi_spmm_csr_batched_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
-                                       A_values.data_ptr<float>(), nnzA, (int32_t)batch, (int32_t)A_rows,
-                                       (int32_t)A_cols, (int32_t)N, Bc.data_ptr<float>(), std::max<int64_t>(N, 1),
-                                       strideB, C.data_ptr<float>(), std::max<int64_t>(N, 1), A_rows * N,
-                                       stream_of(C)),
-               what);
-  return C;
-}
-
-// naive_spmm_batched with the values read through a permutation (entry p has the value A_values[perm[p]]): the
-// transposed pattern of a batched CSR tensor in a backward, without a gathered copy of the values.  Returns false
-// (nothing launched) when the plan for the problem does not take a permutation: gather and call naive_spmm_batched.
-bool naive_spmm_batched_perm(torch::Tensor A_values, torch::Tensor perm, torch::Tensor A_columns, torch::Tensor A_offsets,
-                             int64_t nnzA, int64_t batch, int64_t A_rows, int64_t A_cols, torch::Tensor B,
-                             torch::Tensor C) {
-  const char* what = "naive_spmm_batched_perm";
-  check_device_f32(A_values, "A_values");
-  check_device_i32(perm, "perm");
-  check_device_i32(A_columns, "A_columns");
-  check_device_i32(A_offsets, "A_offsets");
-  check_device_f32(B, "B");
-  check_device_f32(C, "C");
-  check_same_device(A_values, C, what);
-  check_same_device(perm, C, what);
-  check_same_device(A_columns, C, what);
-  check_same_device(A_offsets, C, what);
-  check_same_device(B, C, what);
-  TORCH_CHECK(batch >= 0 && A_rows >= 0 && A_cols >= 0 && nnzA >= 0, what, ": negative size");
-  TORCH_CHECK(batch <= 65535, what, ": at most 65535 items per launch");
-  TORCH_CHECK(A_values.is_contiguous() && perm.is_contiguous() && A_columns.is_contiguous() && A_offsets.is_contiguous(),
-              what, ": CSR arrays must be contiguous");
-  TORCH_CHECK(A_offsets.numel() == batch * (A_rows + 1), what, ": A_offsets must be [batch, A_rows + 1]");
-  TORCH_CHECK(perm.numel() >= nnzA && A_columns.numel() >= nnzA && A_values.numel() >= nnzA, what,
-              ": nnzA exceeds the CSR arrays");
-  TORCH_CHECK(C.dim() == 3 && C.is_contiguous() && C.size(0) == batch && C.size(1) == A_rows, what,
-              ": C must be contiguous [batch, A_rows, N]");
-  const int64_t N = C.size(2);
-  torch::Tensor Bc = B.contiguous();
-  int64_t strideB = 0;
-  if (Bc.dim() == 3) {
-    TORCH_CHECK(Bc.size(0) == batch && Bc.size(1) == A_cols && Bc.size(2) == N, what, ": B must be [batch, A_cols, N]");
-    strideB = A_cols * N;
-  } else {
-    TORCH_CHECK(Bc.dim() == 2 && Bc.size(0) == A_cols && Bc.size(1) == N, what, ": B must be [A_cols, N]");
-  }
-  c10::hip::HIPGuard guard(C.device().index());
-  const int st = mi_spmm_csr_batched_perm_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
-                                              A_values.data_ptr<float>(), perm.data_ptr<int32_t>(), nnzA, (int32_t)batch,
-                                              (int32_t)A_rows, (int32_t)A_cols, (int32_t)N, Bc.data_ptr<float>(),
-                                              std::max<int64_t>(N, 1), strideB, C.data_ptr<float>(),
-                                              std::max<int64_t>(N, 1), A_rows * N, stream_of(C));
-  if (st == 1) return false;
-  check_status(st, what);
-  return true;
-}
-
-// C[i] (A_cols × N) = A[i]ᵀ · X[i] for a batched CSR A [batch, A_rows, A_cols] (offsets with base, as naive_spmm_batched)
-// and X [batch, A_rows, N] — no transpose of A is built (mi_spmm_csr_batched_at_f32).  Returns false (nothing launched)
-// when the shape is not covered (N > 64): transpose and call naive_spmm_batched.
-bool naive_spmm_batched_at(torch::Tensor A_values, torch::Tensor A_columns, torch::Tensor A_offsets, int64_t nnzA,
-                           int64_t batch, int64_t A_rows, int64_t A_cols, torch::Tensor X, torch::Tensor C) {
-  const char* what = "naive_spmm_batched_at";
-  check_device_f32(A_values, "A_values");
-  check_device_i32(A_columns, "A_columns");
-  check_device_i32(A_offsets, "A_offsets");
-  check_device_f32(X, "X");
-  check_device_f32(C, "C");
-  check_same_device(A_values, C, what);
-  check_same_device(A_columns, C, what);
-  check_same_device(A_offsets, C, what);
-  check_same_device(X, C, what);
-  TORCH_CHECK(batch >= 0 && A_rows >= 0 && A_cols >= 0 && nnzA >= 0, what, ": negative size");
-  TORCH_CHECK(A_rows <= INT32_MAX && A_cols <= INT32_MAX && batch <= INT32_MAX, what, ": dimension too large");
-  TORCH_CHECK(A_values.is_contiguous() && A_columns.is_contiguous() && A_offsets.is_contiguous(), what,
-              ": CSR arrays must be contiguous");
-  TORCH_CHECK(A_offsets.numel() == batch * (A_rows + 1), what, ": A_offsets must be [batch, A_rows + 1]");
-  TORCH_CHECK(A_columns.numel() >= nnzA && A_values.numel() >= nnzA, what, ": nnzA exceeds the CSR arrays");
-  TORCH_CHECK(C.dim() == 3 && C.is_contiguous() && C.size(0) == batch && C.size(1) == A_cols, what,
-              ": C must be contiguous [batch, A_cols, N]");
-  const int64_t N = C.size(2);
-  TORCH_CHECK(X.dim() == 3 && X.size(0) == batch && X.size(1) == A_rows && X.size(2) == N, what, ": X must be [batch, A_rows, N]");
-  torch::Tensor Xc = X.contiguous();
-  c10::hip::HIPGuard guard(C.device().index());
-  const int st = mi_spmm_csr_batched_at_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
-                                            A_values.data_ptr<float>(), nnzA, (int32_t)batch, (int32_t)A_rows, (int32_t)A_cols,
-                                            (int32_t)N, Xc.data_ptr<float>(), std::max<int64_t>(N, 1), A_rows * N,
-                                            C.data_ptr<float>(), std::max<int64_t>(N, 1), A_cols * N, stream_of(C));
-  if (st == 1) return false;
-  check_status(st, what);
-  return true;
-}
-
-// (offsets int32 [batch, rows + 1] with the items' bases added, columns int32 [batch · per_item]) of a batched torch CSR
-// tensor's int64 index tensors crow [batch, rows + 1] / col [batch, per_item], in one launch (mi_batched_csr_narrow_i64).
-std::tuple<torch::Tensor, torch::Tensor> batched_csr_narrow(torch::Tensor crow, torch::Tensor col) {
-  const char* what = "batched_csr_narrow";
-  TORCH_CHECK(crow.is_cuda() && col.is_cuda() && crow.scalar_type() == torch::kInt64 && col.scalar_type() == torch::kInt64,
-              what, ": int64 device tensors expected");
-  TORCH_CHECK(crow.dim() == 2 && col.dim() == 2 && crow.size(0) == col.size(0) && crow.size(1) >= 1, what,
-              ": crow [batch, rows + 1] and col [batch, per_item] expected");
-  TORCH_CHECK(crow.is_contiguous() && col.is_contiguous(), what, ": contiguous index tensors expected");
-  check_same_device(crow, col, what);
-  const int64_t batch = crow.size(0), rows = crow.size(1) - 1, per_item = col.size(1);
-  TORCH_CHECK(batch <= INT32_MAX && rows <= INT32_MAX && batch * per_item <= INT32_MAX, what, ": too large for int32 indices");
-  c10::hip::HIPGuard guard(crow.device().index());
-  torch::Tensor off = torch::empty({batch, rows + 1}, torch::dtype(torch::kInt32).device(crow.device()));
-  torch::Tensor c32 = torch::empty({batch * per_item}, torch::dtype(torch::kInt32).device(crow.device()));
-  check_status(mi_batched_csr_narrow_i64(crow.data_ptr<int64_t>(), col.data_ptr<int64_t>(), (int32_t)batch, (int32_t)rows, per_item,
-                                         off.data_ptr<int32_t>(), c32.data_ptr<int32_t>(), stream_of(off)), what);
-  return std::make_tuple(off, c32);
-}
-
-// C[b] = A[b]·B[b] (+ bias) with A DENSE [batch…, M, K]: exact zeros are skipped inside the
-// kernel (no CSR is built).  B is [batch…, K, N] or [K, N] (shared), C [batch…, M, N].
-// Returns false (and does nothing) when the fused kernel does not cover the shape, so the
-// caller can take the dense_to_csr + naive_spmm_batched route instead.
-bool spmm_dense_impl(const torch::Tensor& A, const torch::Tensor& B, const torch::Tensor* bias, torch::Tensor C,
-                     const char* what) {
-  check_device_f32(A, "A");
-  check_device_f32(B, "B");
-  check_device_f32(C, "C");
-  check_same_device(A, C, what);
-  check_same_device(B, C, what);
-  TORCH_CHECK(A.dim() >= 2 && C.dim() == A.dim(), what, ": A and C must have the same rank (>= 2)");
-  TORCH_CHECK(C.is_contiguous(), what, ": C must be contiguous");
-  torch::Tensor Ac = A.contiguous(), Bc = B.contiguous();
-  const int64_t M = Ac.size(-2), K = Ac.size(-1), N = C.size(-1);
-  const int64_t batch = M * K > 0 ? Ac.numel() / (M * K) : (C.numel() / std::max<int64_t>(C.size(-2) * N, 1));
-  TORCH_CHECK(C.size(-2) == M, what, ": C must have ", M, " rows");
-  int64_t strideB = 0;
-  if (Bc.dim() == 2) {
-    TORCH_CHECK(Bc.size(0) == K && Bc.size(1) == N, what, ": B must be [", K, ", ", N, "]");
-  } else {
-    TORCH_CHECK(Bc.dim() == Ac.dim() && Bc.size(-2) == K && Bc.size(-1) == N && Bc.numel() == batch * K * N, what,
-                ": B must be [batch…, ", K, ", ", N, "] with A's batch dims");
-    strideB = K * N;
-  }
-  TORCH_CHECK(C.numel() == batch * M * N, what, ": C must be [batch…, ", M, ", ", N, "]");
-  TORCH_CHECK(M <= INT32_MAX && K <= INT32_MAX && N <= INT32_MAX, what, ": dimension too large");
-  const float* bias_ptr = nullptr;
-  torch::Tensor bias_keep;
-  if (bias != nullptr && bias->defined()) {
-    check_device_f32(*bias, "bias");
-    check_same_device(*bias, C, what);
-    TORCH_CHECK(bias->dim() == 1 && bias->size(0) == N, what, ": bias must have ", N, " entries");
-    bias_keep = bias->contiguous();
-    bias_ptr = bias_keep.data_ptr<float>();
-  }
-  if (batch == 0 || M == 0 || N == 0) return true;
-  // The kernel covers up to 256 columns; wider products (up to 1024 columns) run as column tiles of
-  // 256 — every column of C is its own chain, so the bits are the same — at the price of scanning A once
-  // per tile.  That keeps them free of the CSR route's host read-back (nnz sizes the CSR arrays), i.e.
-  // stream-ordered and graph-capturable; beyond 1024 columns the L2-blocked CSR plans are the better tool.
-  constexpr int64_t kTile = 256, kMaxN = 1024;
-  if (N > kMaxN || N % 4 != 0 || (M * N) % 4 != 0 || (bias_ptr && (reinterpret_cast<uintptr_t>(bias_ptr) & 15u)))
-    return false;
-  for (int64_t n0 = 0; n0 < N; n0 += kTile)
-    if (!mi_spmm_dense_skip_supported((int32_t)std::min(kTile, N - n0), K, N, N, Ac.data_ptr<float>(),
-                                      Bc.data_ptr<float>() + n0, C.data_ptr<float>() + n0))
-      return false;
-  c10::hip::HIPGuard guard(C.device().index());
-  for (int64_t n0 = 0; n0 < N; n0 += kTile)
-    check_status(mi_spmm_dense_skip_f32(Ac.data_ptr<float>(), std::max<int64_t>(K, 1), M * K, (int32_t)batch,
-                                        (int32_t)M, (int32_t)K, (int32_t)std::min(kTile, N - n0),
-                                        Bc.data_ptr<float>() + n0, N, strideB, bias_ptr ? bias_ptr + n0 : nullptr,
-                                        C.data_ptr<float>() + n0, N, M * N, stream_of(C)),
-                 what);
-  return true;
-}
-
-bool naive_spmm_dense(torch::Tensor A, torch::Tensor B, torch::Tensor C) {
-  return spmm_dense_impl(A, B, nullptr, C, "naive_spmm_dense");
-}
-
-bool naive_spmm_dense_bias(torch::Tensor A, torch::Tensor B, torch::Tensor bias, torch::Tensor C) {
-  return spmm_dense_impl(A, B, &bias, C, "naive_spmm_dense_bias");
-}
-
-// dA = dC·B and dB = dCᵀ·A of C = A·Bᵀ (the backward of cublasTransbMM) in ONE launch that reads dC once:
-// dC [batch…, m, k], B [batch…, k, n], A [batch…, m, n] contiguous with equal batch dims → dA [batch…, m, n],
-// dB [batch…, k, n] (caller-allocated).  False (nothing launched) when the fused form does not cover the shapes.
-bool cublas_bmm_pair(torch::Tensor dC, torch::Tensor B, torch::Tensor A, torch::Tensor dA, torch::Tensor dB) {
-  const char* what = "cublas_bmm_pair";
-  for (const torch::Tensor* t : {&dC, &B, &A, &dA, &dB}) check_device_f32(*t, "operand");
-  check_same_device(dC, dA, what);
-  check_same_device(B, dA, what);
-  check_same_device(A, dA, what);
-  check_same_device(dB, dA, what);
-  if (dC.dim() < 2 || B.dim() != dC.dim() || A.dim() != dC.dim() || dA.dim() != dC.dim() || dB.dim() != dC.dim()) return false;
-  const int64_t m = dC.size(-2), k = dC.size(-1), n = B.size(-1);
-  const int64_t batch = m * k > 0 ? dC.numel() / (m * k) : 0;
-  if (!(dC.is_contiguous() && B.is_contiguous() && A.is_contiguous() && dA.is_contiguous() && dB.is_contiguous())) return false;
-  if (B.size(-2) != k || A.size(-2) != m || A.size(-1) != n || B.numel() != batch * k * n || A.numel() != batch * m * n ||
-      dA.numel() != batch * m * n || dB.numel() != batch * k * n || dA.size(-2) != m || dA.size(-1) != n ||
-      dB.size(-2) != k || dB.size(-1) != n)
-    return false;
-  if (batch <= 0 || batch > INT32_MAX || m > INT32_MAX || k > INT32_MAX || n > INT32_MAX) return false;
-  c10::hip::HIPGuard guard(dA.device().index());
-  const int st = mi_gemm_pair_a_at_f32(dC.data_ptr<float>(), B.data_ptr<float>(), A.data_ptr<float>(), dA.data_ptr<float>(),
-                                       dB.data_ptr<float>(), (int32_t)batch, (int32_t)m, (int32_t)k, (int32_t)n,
-                                       stream_of(dA));
-  if (st == 1) return false;
-  check_status(st, what);
-  return true;
-}
-
-// int32[1] on B's device: 1 when B holds an inf or a nan, else 0 (stream-ordered, nothing read back).
-torch::Tensor nonfinite_flag(torch::Tensor B) {
-  check_device_f32(B, "B");
-  torch::Tensor Bc = B.contiguous();
-  c10::hip::HIPGuard guard(B.device().index());
-  torch::Tensor flag = torch::empty({1}, torch::dtype(torch::kInt32).device(B.device()));
-  check_status(mi_nonfinite_flag_f32(Bc.data_ptr<float>(), 1, Bc.numel(), std::max<int64_t>(Bc.numel(), 1),
-                                     flag.data_ptr<int32_t>(), stream_of(B)),
-               "nonfinite_flag");
-  return flag;
-}
-
-// The zero-skipping product of naive_spmm_dense as a GATED launch: it runs only when flag[0] != 0 on the device
-// (see mi_spmm_dense_skip_gated_f32).  A [batch…, M, K] dense, B [K, N] or [batch…, K, N], C [batch…, M, N].
-// `dry_run` only answers whether the shape is covered (no launch).  Returns false when it is not.
-bool naive_spmm_dense_gated(torch::Tensor A, torch::Tensor B, torch::Tensor C, torch::Tensor flag, bool dry_run) {
-  const char* what = "naive_spmm_dense_gated";
-  check_device_f32(A, "A");
-  check_device_f32(B, "B");
-  check_device_f32(C, "C");
-  check_same_device(A, C, what);
-  check_same_device(B, C, what);
-  TORCH_CHECK(A.dim() >= 2 && C.dim() == A.dim(), what, ": A and C must have the same rank (>= 2)");
-  TORCH_CHECK(C.is_contiguous(), what, ": C must be contiguous");
-  const int64_t M = A.size(-2), K = A.size(-1), N = C.size(-1);
-  const int64_t batch = M * K > 0 ? A.numel() / (M * K) : (C.numel() / std::max<int64_t>(C.size(-2) * N, 1));
-  TORCH_CHECK(C.size(-2) == M, what, ": C must have ", M, " rows");
-  int64_t strideB = 0;
-  if (B.dim() == 2) {
-    TORCH_CHECK(B.size(0) == K && B.size(1) == N, what, ": B must be [", K, ", ", N, "]");
-  } else {
-    TORCH_CHECK(B.dim() == A.dim() && B.size(-2) == K && B.size(-1) == N && B.numel() == batch * K * N, what,
-                ": B must be [batch…, ", K, ", ", N, "] with A's batch dims");
-    strideB = K * N;
-  }
-  TORCH_CHECK(C.numel() == batch * M * N, what, ": C must be [batch…, ", M, ", ", N, "]");
-  TORCH_CHECK(M <= INT32_MAX && K <= INT32_MAX && N <= INT32_MAX && batch <= INT32_MAX, what, ": dimension too large");
-  if (N % 4 != 0 || (K * N) % 4 != 0 || (M * N) % 4 != 0 || N > 256 * 65535) return false;
-  if (dry_run) return true;
-  TORCH_CHECK(flag.defined() && flag.is_cuda() && flag.scalar_type() == torch::kInt32 && flag.numel() >= 1 &&
-                  flag.device() == C.device(),
-              what, ": flag must be an int32 device tensor on C's device");
-  if (batch == 0 || M == 0 || N == 0) return true;
-  torch::Tensor Ac = A.contiguous(), Bc = B.contiguous();
-  if ((reinterpret_cast<uintptr_t>(Bc.data_ptr<float>()) & 15u) || (reinterpret_cast<uintptr_t>(C.data_ptr<float>()) & 15u)) {
-    Bc = Bc.clone();  // a contiguous view at an odd offset: give the kernel an aligned copy
-    TORCH_CHECK((reinterpret_cast<uintptr_t>(C.data_ptr<float>()) & 15u) == 0, what, ": C must be 16-byte aligned");
-  }
-  c10::hip::HIPGuard guard(C.device().index());
-  check_status(mi_spmm_dense_skip_gated_f32(Ac.data_ptr<float>(), std::max<int64_t>(K, 1), M * K, (int32_t)batch,
-                                            (int32_t)M, (int32_t)K, (int32_t)N, Bc.data_ptr<float>(), N, strideB, nullptr,
-                                            C.data_ptr<float>(), N, M * N, flag.data_ptr<int32_t>(), stream_of(C)),
-               what);
-  return true;
-}
-
-// CSR of A (A_rows×A_cols) → CSR of Aᵀ: (values, columns, offsets[A_cols+1]).
-std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> csr_transpose(torch::Tensor A_values,
-                                                                      torch::Tensor A_columns,
-                                                                      torch::Tensor A_offsets, int64_t nnzA,
-                                                                      int64_t A_rows, int64_t A_cols) {
-  const char* what = "csr_transpose";
-  check_device_f32(A_values, "A_values");
-  check_device_i32(A_columns, "A_columns");
-  check_device_i32(A_offsets, "A_offsets");
-  check_same_device(A_values, A_columns, what);
-  check_same_device(A_values, A_offsets, what);
-  TORCH_CHECK(A_rows >= 0 && A_cols >= 0 && nnzA >= 0 && A_rows <= INT32_MAX && A_cols <= INT32_MAX, what, ": bad size");
-  TORCH_CHECK(A_values.is_contiguous() && A_columns.is_contiguous() && A_offsets.is_contiguous(), what,
-              ": CSR arrays must be contiguous");
-  TORCH_CHECK(A_offsets.numel() == A_rows + 1 && A_values.numel() >= nnzA && A_columns.numel() >= nnzA, what,
-              ": CSR array sizes do not match");
-  c10::hip::HIPGuard guard(A_values.device().index());
-  auto iopt = torch::dtype(torch::kInt32).device(A_values.device());
-  torch::Tensor t_off = torch::empty({A_cols + 1}, iopt);
-  torch::Tensor t_col = torch::empty({nnzA}, iopt);
-  torch::Tensor t_val = torch::empty({nnzA}, A_values.options());
-  const size_t ws_bytes = mi_csr_transpose_workspace_bytes((int32_t)A_rows, (int32_t)A_cols, nnzA);
-  torch::Tensor ws = torch::empty({(int64_t)std::max<size_t>(ws_bytes, 1)}, torch::dtype(torch::kUInt8).device(A_values.device()));
-  const mi_stream_t stream = stream_of(A_values);
-  auto run = [&]() {
-    check_status(mi_csr_transpose_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
-                                      A_values.data_ptr<float>(), nnzA, (int32_t)A_rows, (int32_t)A_cols,
-                                      t_off.data_ptr<int32_t>(), t_col.data_ptr<int32_t>(), t_val.data_ptr<float>(),
-                                      ws.data_ptr(), ws_bytes, stream),
-                 what);
-  };
-  run();
-  // The one-sweep plan (≥ 33 M non-zeros) hands offsets between workgroups by look-back; a poll that runs into its spin
-  // limit sets a flag and goes on with a wrong offset (never seen on a correct run).  Its callers keep what comes out of
-  // here for a tensor's or a handle's lifetime, so the flag is read here (one synchronisation behind a ≥ 1 ms launch; not
-  // under stream capture, where nothing may be read back) and a give-up re-runs the transpose on the table plan
-  // (advisor, round 4).
-  if (mi_csr_transpose_auto_takes_one_sweep(1, (int32_t)A_rows, (int32_t)A_cols, nnzA) == 1 && !stream_is_capturing(stream) &&
-      mi_csr_transpose_check(ws.data_ptr(), ws_bytes, 1, (int32_t)A_rows, (int32_t)A_cols, nnzA, stream) != MI_OK) {
-    mi_csr_transpose_set_plan(MI_TRANSPOSE_PLAN_TABLES);
-    try {
-      run();
-    } catch (...) {
-      mi_csr_transpose_set_plan(MI_TRANSPOSE_PLAN_AUTO);
-      throw;
-    }
-    mi_csr_transpose_set_plan(MI_TRANSPOSE_PLAN_AUTO);
-  }
-  return std::make_tuple(t_val, t_col, t_off);
-}
-
-// Batched CSR (offsets [batch, A_rows+1], global) → the batched CSR of the transposes
-// (values, columns, offsets [batch, A_cols+1]); one set of launches for the whole batch.
-std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> csr_transpose_batched(torch::Tensor A_values,
-                                                                              torch::Tensor A_columns,
-                                                                              torch::Tensor A_offsets, int64_t nnzA,
-                                                                              int64_t batch, int64_t A_rows,
-                                                                              int64_t A_cols) {
-  const char* what = "csr_transpose_batched";
-  check_device_f32(A_values, "A_values");
-  check_device_i32(A_columns, "A_columns");
-  check_device_i32(A_offsets, "A_offsets");
-  check_same_device(A_values, A_columns, what);
-  check_same_device(A_values, A_offsets, what);
-  TORCH_CHECK(batch >= 0 && A_rows >= 0 && A_cols >= 0 && nnzA >= 0 && A_rows <= INT32_MAX && A_cols <= INT32_MAX &&
-                  batch <= INT32_MAX,
-              what, ": bad size");
-  TORCH_CHECK(A_values.is_contiguous() && A_columns.is_contiguous() && A_offsets.is_contiguous(), what,
-              ": CSR arrays must be contiguous");
-  TORCH_CHECK(A_offsets.numel() == batch * (A_rows + 1) && A_values.numel() >= nnzA && A_columns.numel() >= nnzA, what,
-              ": CSR array sizes do not match");
-  c10::hip::HIPGuard guard(A_values.device().index());
-  auto iopt = torch::dtype(torch::kInt32).device(A_values.device());
-  torch::Tensor t_off = torch::empty({batch, A_cols + 1}, iopt);
-  torch::Tensor t_col = torch::empty({nnzA}, iopt);
-  torch::Tensor t_val = torch::empty({nnzA}, A_values.options());
-  // (the one-workgroup-per-item plan of small items uses no workspace)
-  const size_t ws_bytes = mi_csr_transpose_batched_in_lds(nnzA, (int32_t)batch, (int32_t)A_rows, (int32_t)A_cols) == 1
-                              ? 0 : mi_csr_transpose_batched_workspace_bytes((int32_t)batch, (int32_t)A_rows, (int32_t)A_cols, nnzA);
-  torch::Tensor ws = torch::empty({(int64_t)std::max<size_t>(ws_bytes, 1)}, torch::dtype(torch::kUInt8).device(A_values.device()));
-  check_status(mi_csr_transpose_batched_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(),
-                                            A_values.data_ptr<float>(), nnzA, (int32_t)batch, (int32_t)A_rows,
-                                            (int32_t)A_cols, t_off.data_ptr<int32_t>(), t_col.data_ptr<int32_t>(),
-                                            t_val.data_ptr<float>(), ws.data_ptr(), ws_bytes, stream_of(A_values)),
-               what);
-  return std::make_tuple(t_val, t_col, t_off);
-}
-
-// The same on a batched CSR pattern (offsets [batch, A_rows + 1], global), dC [batch, A_rows, N], B [batch, A_cols, N] or
-// [A_cols, N] (shared), into the caller's out [nnzA]; False (nothing launched) when the LDS-resident form does not take
-// the problem: run sddmm on the block-diagonal matrix of the batch instead (same bits).
-bool sddmm_batched(torch::Tensor A_columns, torch::Tensor A_offsets, int64_t nnzA, int64_t batch, int64_t A_rows,
-                   int64_t A_cols, torch::Tensor dC, torch::Tensor B, torch::Tensor out) {
-  const char* what = "sddmm_batched";
-  check_device_i32(A_columns, "A_columns");
-  check_device_i32(A_offsets, "A_offsets");
-  check_device_f32(dC, "dC");
-  check_device_f32(B, "B");
-  check_device_f32(out, "out");
-  check_same_device(A_columns, out, what);
-  check_same_device(A_offsets, out, what);
-  check_same_device(dC, out, what);
-  check_same_device(B, out, what);
-  TORCH_CHECK(batch >= 0 && A_rows >= 0 && A_cols >= 0 && nnzA >= 0 && batch <= INT32_MAX && A_rows <= INT32_MAX &&
-                  A_cols <= INT32_MAX,
-              what, ": bad size");
-  TORCH_CHECK(A_columns.is_contiguous() && A_offsets.is_contiguous() && out.is_contiguous(), what,
-              ": CSR arrays and out must be contiguous");
-  TORCH_CHECK(A_offsets.numel() == batch * (A_rows + 1) && A_columns.numel() >= nnzA && out.numel() >= nnzA, what,
-              ": CSR array sizes do not match");
-  TORCH_CHECK(dC.dim() == 3 && dC.size(0) == batch && dC.size(1) == A_rows, what, ": dC must be [batch, A_rows, N]");
-  const int64_t N = dC.size(2);
-  torch::Tensor dCc = dC.contiguous(), Bc = B.contiguous();
-  int64_t strideB = 0;
-  if (Bc.dim() == 3) {
-    TORCH_CHECK(Bc.size(0) == batch && Bc.size(1) == A_cols && Bc.size(2) == N, what, ": B must be [batch, A_cols, N]");
-    strideB = A_cols * N;
-  } else {
-    TORCH_CHECK(Bc.dim() == 2 && Bc.size(0) == A_cols && Bc.size(1) == N, what, ": B must be [A_cols, N]");
-  }
-  c10::hip::HIPGuard guard(out.device().index());
-  const int st = mi_sddmm_csr_batched_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(), nnzA, (int32_t)batch,
-                                          (int32_t)A_rows, (int32_t)A_cols, (int32_t)N, dCc.data_ptr<float>(),
-                                          std::max<int64_t>(N, 1), A_rows * N, Bc.data_ptr<float>(),
-                                          std::max<int64_t>(N, 1), strideB, out.data_ptr<float>(), stream_of(out));
-  if (st == 1) return false;
-  check_status(st, what);
-  return true;
-}
-
-// out[p] = <dC[row(p), :], B[col[p], :]> on A's pattern: d(A·B)/d(A values).
-torch::Tensor sddmm(torch::Tensor A_columns, torch::Tensor A_offsets, int64_t nnzA, int64_t A_rows,
-                    int64_t A_cols, torch::Tensor dC, torch::Tensor B) {
-  const char* what = "sddmm";
-  check_device_i32(A_columns, "A_columns");
-  check_device_i32(A_offsets, "A_offsets");
-  check_device_f32(dC, "dC");
-  check_device_f32(B, "B");
-  check_same_device(A_columns, dC, what);
-  check_same_device(A_offsets, dC, what);
-  check_same_device(B, dC, what);
-  TORCH_CHECK(A_columns.is_contiguous() && A_offsets.is_contiguous(), what, ": CSR arrays must be contiguous");
-  TORCH_CHECK(A_offsets.numel() == A_rows + 1 && A_columns.numel() >= nnzA, what, ": CSR array sizes do not match");
-  TORCH_CHECK(dC.dim() == 2 && B.dim() == 2 && dC.size(0) == A_rows && B.size(0) == A_cols &&
-                  dC.size(1) == B.size(1),
-              what, ": dC must be [A_rows, N] and B [A_cols, N]");
-  torch::Tensor dCc = dC.contiguous(), Bc = B.contiguous();
-  const int64_t N = Bc.size(1);
-  c10::hip::HIPGuard guard(dC.device().index());
-  torch::Tensor out = torch::empty({nnzA}, dCc.options());
-  check_status(mi_sddmm_csr_f32(A_offsets.data_ptr<int32_t>(), A_columns.data_ptr<int32_t>(), nnzA,
-                                (int32_t)A_rows, (int32_t)A_cols, (int32_t)N, dCc.data_ptr<float>(),
-                                std::max<int64_t>(N, 1), Bc.data_ptr<float>(), std::max<int64_t>(N, 1),
-                                out.data_ptr<float>(), stream_of(dCc)),
-               what);
-  return out;
-}
-
-// ---- inspector–executor registries -----------------------------------------
-// What `*_inspect` amortises here (reference: TiledSpMM_inspect builds its tiled-ELL image once,
-// src/sparse_mm.cu:137-368; cusparse_inspect caches descriptors, src/custom_mm.cpp:236-257):
-//   * the CSR arrays, owned (tensor references) and VALIDATED once (offsets monotone, columns in range);
-//   * Aᵀ in CSR — the backward product of a sparse-weight layer (`*_mmul_opt_t`) and any Aᵀ·G need it,
-//     and a transpose costs about a sixth of a product at the C3 shape;
-//   * the longest row of A and of Aᵀ, and — only when a row exceeds the split threshold — the prepared
-//     list of long rows (MI_LONG_ROWS_PREPARED: no per-call memset + list-building launch); without
-//     long rows every product is ONE kernel launch between the two operand transposes;
-//   * the executor's transposed-operand buffers (no allocation per call).
-// Calls on one handle must be ordered on one stream (they share those buffers), as with a cuSPARSE handle.
-
-struct CsrSide {
-  int64_t rows = 0, cols = 0;      // this side's matrix is rows × cols
-  torch::Tensor rowptr, col, val;  // device, int32 / int32 / float32 — owned references
-  int64_t max_row = 0;             // longest row (host-known since inspect)
-  torch::Tensor long_ws;           // prepared long-row list + partial rows (defined iff max_row > threshold)
-};
-
-struct CsrHandle {
-  int64_t M = 0, K = 0, N = 0;  // A is M×K, dense width N
-  int64_t nnz = 0;
-  CsrSide a, at;                // A and Aᵀ
-  torch::Tensor ws;             // executor workspace: Bt [K,N] | Ct [M,N] (either orientation)
-};
-
-std::mutex g_registry_mutex;
-std::unordered_map<std::string, CsrHandle> g_cusparse_layers;  // cusparse_inspect / _mmul_opt
-std::unordered_map<std::string, CsrHandle> g_tiled_layers;     // tiledspmm_*
-
-int64_t longest_row(const torch::Tensor& rowptr) {
-  if (rowptr.numel() < 2) return 0;
-  return (rowptr.slice(0, 1) - rowptr.slice(0, 0, rowptr.numel() - 1)).max().item<int32_t>();
-}
-
-void prepare_side(CsrSide& side, int64_t nnz, int64_t N, const char* what) {
-  side.max_row = longest_row(side.rowptr);
-  if (side.max_row > mi_spmm_long_row_threshold() && N > 0) {
-    const size_t bytes = mi_spmm_csr_workspace_bytes(nnz, (int32_t)N);
-    side.long_ws = torch::empty({(int64_t)bytes}, torch::dtype(torch::kUInt8).device(side.val.device()));
-    check_status(mi_spmm_long_rows_prepare(side.rowptr.data_ptr<int32_t>(), (int32_t)side.rows, nnz, (int32_t)N,
-                                           side.long_ws.data_ptr(), bytes, stream_of(side.val)),
-                 what);
-  }
-}
-
-// Shared inspector: device CSR (already int32 / float32, contiguous) → a complete handle.
-CsrHandle build_handle(int64_t M, int64_t K, int64_t N, int64_t nnz, torch::Tensor rowptr, torch::Tensor col,
-                       torch::Tensor val, const char* what) {
-  check_same_device(rowptr, val, what);
-  check_same_device(col, val, what);
-  c10::hip::HIPGuard guard(val.device().index());
-  // validate once what every later product trusts (the kernels index B with these columns)
-  if (M > 0) {
-    TORCH_CHECK(rowptr[0].item<int32_t>() == 0 && rowptr[M].item<int32_t>() == nnz, what,
-                ": offsets must start at 0 and end at nnz");
-    TORCH_CHECK((rowptr.slice(0, 1) - rowptr.slice(0, 0, M)).min().item<int32_t>() >= 0, what,
-                ": offsets must not decrease");
-  }
-  if (nnz > 0) {
-    torch::Tensor c = col.slice(0, 0, nnz);
-    TORCH_CHECK(c.min().item<int32_t>() >= 0 && c.max().item<int32_t>() < K, what, ": column index out of range");
-  }
-  CsrHandle h;
-  h.M = M;
-  h.K = K;
-  h.N = N;
-  h.nnz = nnz;
-  h.a.rows = M;
-  h.a.cols = K;
-  h.a.rowptr = rowptr;
-  h.a.col = col.slice(0, 0, nnz);
-  h.a.val = val.slice(0, 0, nnz);
-  // Aᵀ
-  auto iopt = torch::dtype(torch::kInt32).device(val.device());
-  h.at.rows = K;
-  h.at.cols = M;
-  h.at.rowptr = torch::empty({K + 1}, iopt);
-  h.at.col = torch::empty({nnz}, iopt);
-  h.at.val = torch::empty({nnz}, val.options());
-  {
-    const size_t bytes = mi_csr_transpose_workspace_bytes((int32_t)M, (int32_t)K, nnz);
-    torch::Tensor tws = torch::empty({(int64_t)std::max<size_t>(bytes, 1)}, torch::dtype(torch::kUInt8).device(val.device()));
-    check_status(mi_csr_transpose_f32(h.a.rowptr.data_ptr<int32_t>(), h.a.col.data_ptr<int32_t>(), h.a.val.data_ptr<float>(),
-                                      nnz, (int32_t)M, (int32_t)K, h.at.rowptr.data_ptr<int32_t>(),
-                                      h.at.col.data_ptr<int32_t>(), h.at.val.data_ptr<float>(), tws.data_ptr(), bytes,
-                                      stream_of(val)),
-                 what);
-  }
-  prepare_side(h.a, nnz, N, what);
-  prepare_side(h.at, nnz, N, what);
-  const size_t ws_bytes = mi_spmm_colmajor_workspace_bytes((int32_t)M, (int32_t)K, (int32_t)N);
-  h.ws = torch::empty({(int64_t)std::max<size_t>(ws_bytes, 16)}, torch::dtype(torch::kUInt8).device(val.device()));
-  return h;
-}
-
-// Column-major executor shared by cusparse_mmul_opt and tiledspmm_mm (and their `_t` forms on Aᵀ):
-// C (rows×N col-major) = S · B (cols×N col-major), S = A or Aᵀ; tensors of any shape with the
-// right element count are accepted, as in the reference (raw data_ptr()).
-void colmajor_mm(const CsrHandle& h, bool transposed, const torch::Tensor& B, torch::Tensor& C, const char* what) {
-  const CsrSide& s = transposed ? h.at : h.a;
-  check_device_f32(B, "B");
-  check_device_f32(C, "C");
-  check_same_device(B, C, what);
-  check_same_device(s.val, C, what);
-  TORCH_CHECK(B.is_contiguous() && C.is_contiguous(), what, ": B and C must be contiguous");
-  TORCH_CHECK(B.numel() == s.cols * h.N, what, ": B must hold ", s.cols * h.N, " elements, got ", B.numel());
-  TORCH_CHECK(C.numel() == s.rows * h.N, what, ": C must hold ", s.rows * h.N, " elements, got ", C.numel());
-  c10::hip::HIPGuard guard(C.device().index());
-  const size_t ws_bytes = mi_spmm_colmajor_workspace_bytes((int32_t)s.rows, (int32_t)s.cols, (int32_t)h.N);
-  TORCH_INTERNAL_ASSERT((size_t)h.ws.numel() >= ws_bytes);
-  // the same summation rule as cusparse_mmul / naive_spmm on this matrix: long rows are split iff the
-  // AUTO plan of the (row-major) product would split them — with the list prepared at inspect time
-  int mode = MI_LONG_ROWS_NONE;
-  if (s.long_ws.defined()) {
-    const float* bt = static_cast<const float*>(h.ws.data_ptr());
-    if (mi_spmm_auto_splits_long_rows(h.nnz, (int32_t)s.rows, (int32_t)s.cols, (int32_t)h.N, bt, h.N, bt, h.N) == 1)
-      mode = MI_LONG_ROWS_PREPARED;
-  }
-  const int st = mi_spmm_csr_colmajor_ex_f32(
-      s.rowptr.data_ptr<int32_t>(), s.col.data_ptr<int32_t>(), s.val.data_ptr<float>(), h.nnz, (int32_t)s.rows,
-      (int32_t)s.cols, (int32_t)h.N, B.data_ptr<float>(), s.cols, C.data_ptr<float>(), s.rows, mode,
-      mode == MI_LONG_ROWS_NONE ? nullptr : s.long_ws.data_ptr(), mode == MI_LONG_ROWS_NONE ? 0 : (size_t)s.long_ws.numel(),
-      h.ws.data_ptr(), (size_t)h.ws.numel(), stream_of(C));
-  check_status(st, what);
-}
-
-const CsrHandle& lookup(const std::unordered_map<std::string, CsrHandle>& reg,
-                        const std::string& layer, const char* what) {
-  auto it = reg.find(layer);
-  if (it == reg.end()) throw std::runtime_error(std::string(what) + ": Invalid handle_id! (unknown layer '" + layer + "')");
-  return it->second;
-}
-
-// reference custom_mm.cpp:236-257: (displ, colindex, value, nnz, M, N, K, layer);
-// A is M×K, dense operand width N (custom_mm.cpp:266-267 passes M, K, then K, N).
-void cusparse_inspect(torch::Tensor displ, torch::Tensor colindex, torch::Tensor value, int nnz,
-                      int M, int N, int K, std::string layer) {
-  check_device_i32(displ, "displ");
-  check_device_i32(colindex, "colindex");
-  check_device_f32(value, "value");
-  TORCH_CHECK(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "cusparse_inspect: negative size");
-  TORCH_CHECK(displ.numel() == (int64_t)M + 1, "cusparse_inspect: displ must have M + 1 entries");
-  TORCH_CHECK(colindex.numel() >= nnz && value.numel() >= nnz, "cusparse_inspect: nnz exceeds the CSR arrays");
-  CsrHandle h = build_handle(M, K, N, nnz, displ.contiguous(), colindex.contiguous(), value.contiguous(), "cusparse_inspect");
-  std::lock_guard<std::mutex> lock(g_registry_mutex);
-  g_cusparse_layers[layer] = std::move(h);
-}
-
-torch::Tensor cusparse_mmul_opt(torch::Tensor B, torch::Tensor C, std::string layer) {
-  CsrHandle h;
-  {
-    std::lock_guard<std::mutex> lock(g_registry_mutex);
-    h = lookup(g_cusparse_layers, layer, "cusparse_mmul_opt");
-  }
-  colmajor_mm(h, false, B, C, "cusparse_mmul_opt");
-  return C;
-}
-
-// Addition: C (K×N col-major) = Aᵀ · B (M×N col-major) with the Aᵀ cached by cusparse_inspect — the
-// input gradient of a sparse-weight layer (Y = X·Aᵀ  ⇒  dX = dY·A, i.e. dXᵀ = Aᵀ·dYᵀ).
-torch::Tensor cusparse_mmul_opt_t(torch::Tensor B, torch::Tensor C, std::string layer) {
-  CsrHandle h;
-  {
-    std::lock_guard<std::mutex> lock(g_registry_mutex);
-    h = lookup(g_cusparse_layers, layer, "cusparse_mmul_opt_t");
-  }
-  colmajor_mm(h, true, B, C, "cusparse_mmul_opt_t");
-  return C;
-}
-
-// What a handle holds (tests / diagnostics): sizes, longest rows, whether long-row lists were prepared.
-pybind11::dict inspect_info(const std::string& layer, bool tiled) {
-  CsrHandle h;
-  {
-    std::lock_guard<std::mutex> lock(g_registry_mutex);
-    h = lookup(tiled ? g_tiled_layers : g_cusparse_layers, layer, "inspect_info");
-  }
-  pybind11::dict d;
-  d["M"] = h.M;
-  d["K"] = h.K;
-  d["N"] = h.N;
-  d["nnz"] = h.nnz;
-  d["max_row"] = h.a.max_row;
-  d["max_row_transposed"] = h.at.max_row;
-  d["long_rows_prepared"] = h.a.long_ws.defined();
-  d["long_rows_prepared_transposed"] = h.at.long_ws.defined();
-  d["transpose"] = std::make_tuple(h.at.val, h.at.col, h.at.rowptr);
-  d["workspace_bytes"] = (int64_t)h.ws.numel();
-  return d;
-}
-
-void cusparse_clean() {
-  std::lock_guard<std::mutex> lock(g_registry_mutex);
-  g_cusparse_layers.clear();
-}
-
-// TiledSpMM convention (reference custom_mm.cpp:283-290): C[M×K] = A[M×N]·B[N×K],
-// B and C column-major.  In CsrHandle terms: inner dim = N, dense width = K.
-void register_tiled(int64_t M, int64_t N, int64_t K, torch::Tensor rowptr_cpu_i32,
-                    torch::Tensor col_cpu_i32, torch::Tensor val_cpu, const std::string& layer) {
-  const auto dev = torch::Device(torch::kCUDA, c10::hip::current_device());
-  // TiledSpMM convention: inner dimension = N, dense width = K (CsrHandle: K = inner, N = width)
-  CsrHandle h = build_handle(M, /*inner=*/N, /*width=*/K, val_cpu.numel(), rowptr_cpu_i32.to(dev), col_cpu_i32.to(dev),
-                             val_cpu.to(dev), "tiledspmm_inspect");
-  std::lock_guard<std::mutex> lock(g_registry_mutex);
-  g_tiled_layers[layer] = std::move(h);
-}
-
-void check_host(const torch::Tensor& t, torch::ScalarType ty, const char* name) {
-  TORCH_CHECK(t.device().is_cpu(), name, " must be a CPU tensor (host inspector input)");
-  TORCH_CHECK(t.scalar_type() == ty, name, " must be ", ty, ", got ", t.scalar_type());
-}
-
-// reference custom_mm.cpp:321-335: CSR with int64 displ / colindex on the host.
-void tiledspmm_inspect_csr(int M, int N, int K, torch::Tensor displ, torch::Tensor colindex,
-                           torch::Tensor value, std::string layer) {
-  check_host(displ, torch::kInt64, "displ");
-  check_host(colindex, torch::kInt64, "colindex");
-  check_host(value, torch::kFloat32, "value");
-  TORCH_CHECK(M >= 0 && N >= 0 && K >= 0, "tiledspmm_inspect_csr: negative size");
-  TORCH_CHECK(displ.numel() == (int64_t)M + 1, "tiledspmm_inspect_csr: displ must have M + 1 entries");
-  torch::Tensor d = displ.contiguous(), c = colindex.contiguous(), v = value.contiguous();
-  const int64_t nnz = M > 0 ? d.data_ptr<int64_t>()[M] : 0;
-  TORCH_CHECK(nnz >= 0 && nnz <= INT32_MAX, "tiledspmm_inspect_csr: nnz does not fit int32");
-  TORCH_CHECK(c.numel() >= nnz && v.numel() >= nnz, "tiledspmm_inspect_csr: nnz exceeds the CSR arrays");
-  if (nnz > 0) {
-    TORCH_CHECK(c.slice(0, 0, nnz).min().item<int64_t>() >= 0 &&
-                    c.slice(0, 0, nnz).max().item<int64_t>() < N,
-                "tiledspmm_inspect_csr: column index out of range");
-  }
-  register_tiled(M, N, K, d.to(torch::kInt32), c.slice(0, 0, nnz).to(torch::kInt32),
-                 v.slice(0, 0, nnz).contiguous(), layer);
-}
-
-// reference custom_mm.cpp:293-319: COO with int32 indices on the host, sorted by row.
-void tiledspmm_inspect_coo(int M, int N, int K, int64_t nnz, torch::Tensor rowidx,
-                           torch::Tensor colidx, torch::Tensor value, std::string layer) {
-  check_host(rowidx, torch::kInt32, "rowidx");
-  check_host(colidx, torch::kInt32, "colidx");
-  check_host(value, torch::kFloat32, "value");
-  TORCH_CHECK(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "tiledspmm_inspect_coo: negative size");
-  TORCH_CHECK(rowidx.numel() >= nnz && colidx.numel() >= nnz && value.numel() >= nnz,
-              "tiledspmm_inspect_coo: nnz exceeds the COO arrays");
-  torch::Tensor r = rowidx.contiguous(), c = colidx.contiguous(), v = value.contiguous();
-  if (nnz > 0) {
-    TORCH_CHECK(c.slice(0, 0, nnz).min().item<int32_t>() >= 0 &&
-                    c.slice(0, 0, nnz).max().item<int32_t>() < N,
-                "tiledspmm_inspect_coo: column index out of range");
-  }
-  torch::Tensor rowptr = torch::empty({(int64_t)M + 1}, torch::kInt32);
-  torch::Tensor col = torch::empty({nnz}, torch::kInt32);
-  torch::Tensor val = torch::empty({nnz}, torch::kFloat32);
-  int st;
-  {
-    pybind11::gil_scoped_release nogil;  // host inspector pass
-    st = mi_coo_to_csr_host(M, nnz, r.data_ptr<int32_t>(), c.data_ptr<int32_t>(), v.data_ptr<float>(),
-                            rowptr.data_ptr<int32_t>(), col.data_ptr<int32_t>(), val.data_ptr<float>());
-  }
-  check_status(st, "tiledspmm_inspect_coo");
-  register_tiled(M, N, K, rowptr, col, val, layer);
-}
-
-void tiledspmm_mm(torch::Tensor B, torch::Tensor C, std::string layer) {
-  CsrHandle h;
-  {
-    std::lock_guard<std::mutex> lock(g_registry_mutex);
-    h = lookup(g_tiled_layers, layer, "tiledspmm_mm");
-  }
-  colmajor_mm(h, false, B, C, "tiledspmm_mm");
-}
-
-void tiledspmm_mm_t(torch::Tensor B, torch::Tensor C, std::string layer) {
-  CsrHandle h;
-  {
-    std::lock_guard<std::mutex> lock(g_registry_mutex);
-    h = lookup(g_tiled_layers, layer, "tiledspmm_mm_t");
-  }
-  colmajor_mm(h, true, B, C, "tiledspmm_mm_t");
-}
-
-void tiledspmm_clean() {
-  std::lock_guard<std::mutex> lock(g_registry_mutex);
-  g_tiled_layers.clear();
-}
+#include "custom_mm_helpers.inc"
+#include "custom_mm_reference.inc"
+#include "custom_mm_extras.inc"
+#include "custom_mm_inspect.inc"
 
 // ---- handle init / destroy (reference custom_mm.cpp:361-391) ----------------
 // There are no vendor handles on this path; init checks that the C-ABI library
