@@ -901,3 +901,47 @@ def test_rows_off_16_byte_boundaries_take_unaligned_quads_bit_exact(capi, cmm, d
             assert plan[0] == 24, plan
         cmm.naive_spmm_ex(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, d_B, C, 0)
         assert np.array_equal(C.cpu().numpy().view(np.int32), want.view(np.int32)), (N, d_B.is_contiguous())
+
+
+@pytest.mark.parametrize("N,plan_id", [(128, 19), (320, 21)])
+def test_hbm_regime_panel_plans_at_full_size(capi, cmm, dev, oracle_mod, N, plan_id):
+    """Round 5, at the sizes of tools/bench_hbm_regime.py (2 M × 2 M, 100 per row: B = 1 / 2.5 GiB, beyond the Infinity
+    Cache): AUTO takes the lane-group panel kernel; the whole output equals the pinned one-pass kernel's bit for bit,
+    sampled rows equal the oracle bit for bit (the rows' sub-matrix with columns renumbered in order — the chain is
+    unchanged — times the gathered rows of B), and the product is exactly linear in B (×2 is exact in fp32).
+    Size-independent properties where the oracle cannot run the whole problem in seconds."""
+    M = K = 1 << 21
+    g = torch.Generator(device=dev).manual_seed(N)
+    keys = torch.unique(torch.randint(0, M * K, (M * 100,), device=dev, generator=g, dtype=torch.int64))
+    col = (keys % K).to(torch.int32)
+    rowptr = torch.zeros(M + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(torch.bincount(keys // K, minlength=M), 0)
+    rowptr = rowptr.to(torch.int32)
+    del keys
+    nnz = col.numel()
+    val = torch.rand(nnz, device=dev, generator=g) - 0.5
+    B = torch.rand(K, N, device=dev, generator=g) - 0.5
+    C = torch.full((M, N), float("nan"), device=dev)
+    assert cmm.spmm_plan(nnz, M, K, B, C)[0] == plan_id
+    cmm.naive_spmm(val, col, rowptr, nnz, M, K, B, C)
+    # (a) the pinned one-pass lane-group kernel: same bits on the whole output
+    C1 = torch.full((M, N), float("nan"), device=dev)
+    assert capi.mi_spmm_csr_f32_variant(4, rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), nnz, M, K, N, B.data_ptr(), N,
+                                        C1.data_ptr(), N, torch.cuda.current_stream().cuda_stream) == 0
+    assert torch.equal(C.view(torch.int32), C1.view(torch.int32))
+    # (b) linear in B, exactly
+    cmm.naive_spmm(val, col, rowptr, nnz, M, K, B * 2, C1)
+    assert torch.equal(C1, C * 2)
+    del C1
+    # (c) sampled rows against the oracle
+    rs = np.unique(np.concatenate([[0, M - 1], np.random.default_rng(N).integers(0, M, 160)]))
+    rp = rowptr.cpu().numpy().astype(np.int64)
+    segs = [np.arange(rp[r], rp[r + 1]) for r in rs]
+    idx = torch.from_numpy(np.concatenate(segs)).to(dev)
+    cs, vs = col[idx].cpu().numpy(), val[idx].cpu().numpy()
+    sub_rp = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.int32)
+    uniq, inv = np.unique(cs, return_inverse=True)
+    Bs = B[torch.from_numpy(uniq.astype(np.int64)).to(dev)].cpu().numpy()
+    want = oracle_mod.spmm_csr(sub_rp, inv.astype(np.int32), vs, len(rs), len(uniq), Bs)
+    got = C[torch.from_numpy(rs).to(dev)].cpu().numpy()
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
