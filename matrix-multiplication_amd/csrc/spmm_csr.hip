@@ -1239,6 +1239,25 @@ int ic_panels(int64_t nnz, int32_t M, int32_t K, int32_t N, int64_t ldb) {
   return nnz >= 16L * best * M ? best : 0;
 }
 
+// L2-level panels for the lane-group panel kernel: B beyond the L2s but inside the Infinity Cache (6 MiB < |B| ≤ 128 MiB).
+// Panels of ≈ 6 MiB measured best or within a few per cent of it over B = 8 … 128 MiB at N = 192 … 384 (B = 12 MiB: 2 panels,
+// 24 MiB: 3–4, 48 MiB: 8, 128 MiB: 8); every pass walks the row's columns up to its panel, which is why rows of thousands
+// of entries want half as many (8192 × 65536 × 256 at 5 %, 3277 per row: 4 panels 1.13 ms, 8 panels 1.19), and a pass needs
+// ≥ 32 entries per row to pay for carrying C (16384² × 256 with 82 per row: 2 panels 0.085 ms, 3 panels 0.096).
+// Returns 2, 3, 4, 6 or 8, or 0.  tools/probes/l2_regime_shapes*.sh, profiles/r05_l2_regime_plans.log.
+int l2_group_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
+  (void)N;
+  const double b_bytes = (double)K * (double)ldb * 4.0;
+  if (b_bytes <= 6.0 * 1048576.0 || b_bytes > 128.0 * 1048576.0 || M <= 0) return 0;
+  const double want = b_bytes / ((nnz >= 2048L * M ? 12.0 : 6.0) * 1048576.0);
+  int p = 2;
+  for (int c : {2, 3, 4, 6, 8})
+    if ((c < want ? want - c : c - want) < (p < want ? want - p : p - want)) p = c;
+  static const int kLower[9] = {0, 0, 0, 2, 3, 0, 4, 0, 6};
+  while (p >= 2 && nnz < 32L * p * M) p = kLower[p];
+  return p >= 2 ? p : 0;
+}
+
 struct Shape {
   bool vec4_ok, vec2_ok, wave_ok;
 };
@@ -1293,7 +1312,16 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
       ((long)batch * M >= 16384 || ((long)batch * M >= 8192 && nnz >= 1500000)) &&
       nnz >= MI_SPMM_LDSB_MIN_ROW * (long)batch * M)
     return MI_SPMM_LDS_B;
-  const int lp = (sh.wave_ok && batch == 1) ? l2_panels(M, K, N, ldb, nnz) : 0;
+  int lp = (sh.wave_ok && batch == 1) ? l2_panels(M, K, N, ldb, nnz) : 0;
+  // L2-level panels on the lane-group panel kernel (round 5): for the widths the one-wave-per-row panel kernel does not take
+  // (128 < N ≤ 1024 other than 256 / 512 / 1024) and, at N = 256, for long rows — it beats the wave-per-row panel kernel there
+  // (its passes stop at the first chunk behind their panel; 8192 × 131072 × 256 at 1 %: 0.99 → 0.58 ms, 16384² × 256 at 10 %:
+  // 1.04 → 0.96) and loses on short rows (65536 × 16384 at 0.3 %, 49 per row: 0.21 vs 0.24).  N ≤ 128 gains nothing from
+  // panels at this level (16384 × 65536 × 128: one pass 0.31 ms, two panels 0.37).  tools/probes/l2_regime_shapes*.sh,
+  // profiles/r05_l2_regime_plans.log.
+  int gp = 0;
+  if (sh.vec4_ok && batch == 1 && N > 128 && N <= 1024 && (N == 256 ? nnz >= 128L * M : !sh.wave_ok)) gp = l2_group_panels(M, K, N, ldb, nnz);
+  if (gp > 0) lp = 0;
   // Moderate density: stage B through LDS (spmm_slab.hip) when its cost model beats the L2-blocked
   // row-split plans.  Fitted on MI355X (tools/bench_density.py, tools/bench_plans.py): a slab
   // workgroup (128 rows × 256 columns) spends ≈2.35 µs + 34 µs × density per 64-row slab of B, one
@@ -1310,12 +1338,18 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
     // holds once B streams from the Infinity Cache or HBM (profiles/r02_plan_choice.log)
     const bool b_in_l2 = (double)K * (double)ldb * 4.0 <= 8.0 * 1024 * 1024;
     // with L2 panels the row-split plan gathers at the L2 rate and carries C (2·lp − 1) times
-    const double t_rows = lp > 0 ? 2.0 * (double)nnz * (double)N / 13e12 + (2.0 * lp - 1.0) * (double)M * (double)N * 4.0 / 4e12
+    const int panels = lp > 0 ? lp : gp;
+    const double t_rows = panels > 0 ? 2.0 * (double)nnz * (double)N / 13e12 + (2.0 * panels - 1.0) * (double)M * (double)N * 4.0 / 4e12
                                  : 2.0 * (double)nnz * (double)N /
                                        ((double)K * (double)ldb * 4.0 <= 2.0 * 1024 * 1024 ? 15e12  // B in every L2 at once
                                         : (N >= 512 || b_in_l2) ? 13e12 : 5e12);
     // below ≈100 workgroups too few CUs have work for the model to hold
     if (wgs >= 96.0 && t_slab < t_rows) return MI_SPMM_SLAB;
+  }
+  if (gp > 0) {
+    static const int kGroupOf[9] = {0, 0, MI_SPMM_GROUP_PANELS_2, MI_SPMM_GROUP_PANELS_3, MI_SPMM_GROUP_PANELS_4, 0,
+                                    MI_SPMM_GROUP_PANELS_6, 0, MI_SPMM_GROUP_PANELS_8};
+    return kGroupOf[gp];
   }
   if (lp > 0) {
     static const int kVariantOf[9] = {0, 0, MI_SPMM_PANELS_2, MI_SPMM_PANELS_3, MI_SPMM_PANELS_4, MI_SPMM_PANELS_5,

@@ -138,8 +138,11 @@ def test_every_variant_id_has_a_kernel_name_and_the_plan_query_needs_no_gpu(lib)
     assert plan(int(0.1 * 8192 * 8192), 8192, 8192, 8192) == 17   # pruned-weight density: LDS slabs
     assert plan(int(0.01 * 8192 * 8192), 8192, 8192, 8192) == 15  # 1 %: column tiles x row panels
     assert plan(int(0.1 * 8192 * 4096), 8192, 4096, 256) == 2     # too few 128 x 256 blocks for the slab kernel; B (4 MiB) in L2
-    assert plan(int(0.1 * 8192 * 8192), 8192, 8192, 256) == 7     # B = 8 MiB: two L2 panels
-    assert plan(int(0.1 * 16384 * 16384), 16384, 16384, 256) == 9  # B = 16 MiB: four L2 panels beat the slab plan
+    assert plan(int(0.1 * 8192 * 8192), 8192, 8192, 256) == 19    # B = 8 MiB, long rows: two L2 panels on the lane-group panel kernel
+    assert plan(int(0.1 * 16384 * 16384), 16384, 16384, 256) == 20  # B = 16 MiB: three of them beat the slab plan
+    assert plan(int(0.05 * 8192 * 65536), 8192, 65536, 256) == 22   # 64 MiB, 3277 per row: six (12 MiB panels for very long rows)
+    assert plan(int(0.01 * 32768 * 32768), 32768, 32768, 192) == 21 and plan(int(0.01 * 16384 * 32768), 16384, 32768, 384) == 23
+    assert plan(int(0.01 * 16384 * 65536), 16384, 65536, 128) == 4  # N ≤ 128: no L2-level panels
     assert plan(40 * 16384, 16384, 16384, 256) == 9 and plan(20 * 16384, 16384, 16384, 256) == 7  # short rows: fewer passes
     assert plan(8 * 16384, 16384, 16384, 256) == 2                 # too short to carry C at all
     # B beyond the Infinity Cache (round 5, fitted on tools/bench_hbm_regime.py): P ≈ |B| / 683 MiB panels when the rows

@@ -55,9 +55,14 @@ def test_spmm_every_variant_is_bit_identical(capi, dev, oracle_mod, M, K, N, den
     assert ran >= 2  # AUTO plus the generic kernel at least
 
 
-@pytest.mark.parametrize("M,K,N,density,panels", [(3000, 16384, 256, 0.01, 4), (2048, 24576, 256, 0.01, 6),
-                                                  (1500, 40000, 256, 0.004, 8), (4000, 8192, 256, 0.02, 2)])
-def test_spmm_auto_takes_l2_panels_for_mid_size_b(cmm, dev, oracle_mod, M, K, N, density, panels):
+@pytest.mark.parametrize("M,K,N,density,kernel,panels", [
+    (3000, 16384, 256, 0.004, "spmm_wave_row_panel_kernel", 4), (2048, 24576, 256, 0.004, "spmm_wave_row_panel_kernel", 6),
+    (1500, 40000, 256, 0.002, "spmm_wave_row_panel_kernel", 8), (4000, 8192, 256, 0.01, "spmm_wave_row_panel_kernel", 2),
+    # ≥ 128 per row at N = 256, and the other widths above 128: the lane-group panel kernel (round 5)
+    (3000, 16384, 256, 0.01, "spmm_group_panel_kernel", 3), (1500, 40000, 256, 0.004, "spmm_group_panel_kernel", 4),
+    (2048, 24576, 192, 0.01, "spmm_group_panel_kernel", 3), (1024, 16384, 384, 0.02, "spmm_group_panel_kernel", 4),
+    (1024, 16384, 640, 0.02, "spmm_group_panel_kernel", 6)])
+def test_spmm_auto_takes_l2_panels_for_mid_size_b(cmm, dev, oracle_mod, M, K, N, density, kernel, panels):
     """B beyond the L2s (> 8 MiB) but far from the Infinity-Cache regime: AUTO cuts K into panels of about
     4 MiB (one launch per panel, C carried) for N = 256 — still the CSR-order chain for every row,
     rows whose columns do not ascend included (detected in the kernel and recomputed in plain order)."""
@@ -72,7 +77,7 @@ def test_spmm_auto_takes_l2_panels_for_mid_size_b(cmm, dev, oracle_mod, M, K, N,
     d_B = t(B, dev)
     C = torch.full((M, N), float("nan"), device=dev)
     variant, name, launches, splits = cmm.spmm_plan(len(val), M, K, d_B, C)
-    assert name == "spmm_wave_row_panel_kernel" and launches == panels, (variant, name, launches)
+    assert name == kernel and launches == panels, (variant, name, launches)
     cmm.naive_spmm(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, d_B, C)
     assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr(rowptr, col, val, M, K, B))
 

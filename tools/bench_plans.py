@@ -38,7 +38,7 @@ def timeit(fn, iters=5):
 
 plan = lib.mi_spmm_csr_f32_plan(nnz, M, K, N, B.data_ptr(), N, C.data_ptr(), N)
 out = []
-for v in (2, 4, 7, 8, 9, 11, 12, 14, 15, 17, 18):
+for v in (2, 4, 7, 8, 9, 10, 11, 12, 14, 15, 17, 18, 19, 20, 21, 22, 23, 24):
     if lib.mi_spmm_csr_f32_variant(v, rp.data_ptr(), col.data_ptr(), val.data_ptr(), nnz, M, K, N, B.data_ptr(), N,
                                    C.data_ptr(), N, st) != 0:
         continue
