@@ -230,7 +230,10 @@ class ShardedSpMM:
         DistBackendError (communicator, transport) is not a refusal: it is re-raised.'''
         refusals = (RuntimeError, ValueError, TypeError, NotImplementedError)
         if self.exchange == "push":
+            # Every rank issues the SAME collectives whatever goes wrong on it (the handle exchange inside _map_peers, then
+            # two agreements): a rank that failed early must not leave its peers in a collective it never enters.
             ok, why = True, ""
+            probe = views = None
             try:
                 probe = torch.zeros((self.world, 4), device=self.device, dtype=torch.float32)
                 views = self._map_peers(probe)
@@ -240,17 +243,22 @@ class ShardedSpMM:
                 probe[self.rank] = float(self.rank + 1)
                 if self.device.type == "cuda":
                     torch.cuda.synchronize(self.device)
-                dist.barrier(group=self.group)
-                expect = torch.arange(1, self.world + 1, device=self.device, dtype=torch.float32)
-                if not torch.equal(probe, expect.unsqueeze(1).expand(self.world, 4)):
-                    ok, why = False, "pushed rows did not arrive"
-                self._peer_out.clear()
-                del views
             except Exception as err:  # noqa: BLE001 — IPC is optional: whatever went wrong, the collectives remain
                 if isinstance(err, getattr(dist, "DistBackendError", ())):
                     raise
                 ok, why = False, f"{type(err).__name__}: {str(err)[:120]}"
-            if not self._agreed(ok):
+            ok = self._agreed(ok)  # also the barrier behind every rank's pushes
+            if ok:
+                try:
+                    expect = torch.arange(1, self.world + 1, device=self.device, dtype=torch.float32)
+                    if not torch.equal(probe, expect.unsqueeze(1).expand(self.world, 4)):
+                        ok, why = False, "pushed rows did not arrive"
+                except Exception as err:  # noqa: BLE001
+                    ok, why = False, f"{type(err).__name__}: {str(err)[:120]}"
+                ok = self._agreed(ok)
+            self._peer_out.clear()
+            del views
+            if not ok:
                 self.fallbacks.append(f"push refused on some rank ({why or 'on a peer'}): alltoall from now on")
                 self.exchange = "alltoall"
         while self.exchange == "alltoall" or (self.exchange == "allgather" and self.split == "rows"):
@@ -291,12 +299,20 @@ class ShardedSpMM:
         hit = self._peer_out.get(key)
         if hit is not None:
             return hit
-        if not out.is_cuda:
-            raise RuntimeError("push exchange needs device buffers (CUDA IPC)")
-        from torch.multiprocessing.reductions import reduce_tensor
-        fn, args = reduce_tensor(out)
+        payload, failure = None, None
+        try:
+            if not out.is_cuda:
+                raise RuntimeError("push exchange needs device buffers (CUDA IPC)")
+            from torch.multiprocessing.reductions import reduce_tensor
+            payload = reduce_tensor(out)
+        except Exception as err:  # noqa: BLE001 — raised again below, AFTER the collective every peer is waiting in
+            failure = err
         gathered = [None] * self.world
-        dist.all_gather_object(gathered, (fn, args), group=self.group)
+        dist.all_gather_object(gathered, payload, group=self.group)
+        if failure is not None:
+            raise failure
+        if any(g is None for g in gathered):
+            raise RuntimeError("push exchange: a peer could not export its buffer")
         views = [out if r == self.rank else gathered[r][0](*gathered[r][1]) for r in range(self.world)]
         for r, v in enumerate(views):
             if tuple(v.shape) != tuple(out.shape):
@@ -365,7 +381,23 @@ class ShardedSpMM:
             raise RuntimeError("a modelled layout has no process group: call forward(..., gather=False)")
         peers = None
         if collective and self.exchange == "push":
-            peers = self._map_peers(out)  # (collective on first use of this buffer)
+            peers = self._peer_out.get((out.data_ptr(), tuple(out.shape)))
+            if peers is None:
+                # first use of this buffer: collective (handles exchanged), and agreed like the probe — a rank that cannot
+                # map a peer's buffer (IPC limits, a multi-GiB mapping refused) sends every rank to the all_to_all form
+                why = ""
+                try:
+                    peers = self._map_peers(out)
+                except Exception as err:  # noqa: BLE001
+                    if isinstance(err, getattr(dist, "DistBackendError", ())):
+                        raise
+                    peers, why = None, f"{type(err).__name__}: {str(err)[:120]}"
+                if not self._agreed(peers is not None):
+                    self._peer_out.pop((out.data_ptr(), tuple(out.shape)), None)
+                    self.fallbacks.append(f"push: output buffer not mappable on some rank ({why or 'on a peer'}): alltoall from now on")
+                    self.exchange = "alltoall"
+                    self._probe_exchange()  # (collective, on every rank alike) all_to_all itself may be refused: settles the form
+                    return self.forward(B, out=out, gather=gather, compute=compute, force_collective=force_collective)
             if self._push_stream is None:
                 self._push_stream = torch.cuda.Stream(self.device)
                 self._fence = torch.zeros(1, device=self.device, dtype=torch.int32)
