@@ -140,8 +140,8 @@ def test_self_launch_builds_a_torchrun_child_and_relays_rank0(monkeypatch, capsy
 
 
 def test_plain_multi_gpu_invocation_spawns_ranks_without_touching_hip():
-    """End to end in this GPU-less container: `python bench.py --gpus 2` must get as far as two child
-    ranks, each refusing loudly because there is no MI355X here (no CPU fallback), and hand their
+    """End to end in this GPU-less container: `python bench.py --gpus 2` must get as far as its child
+    ranks, which refuse loudly because there is no MI355X here (no CPU fallback), and hand their
     failure back as a non-zero exit code; the parent itself never imports torch."""
     import os
     import subprocess
@@ -150,6 +150,8 @@ def test_plain_multi_gpu_invocation_spawns_ranks_without_touching_hip():
     proc = subprocess.run([sys.executable, str(PROFILES.parent / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                            "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
     assert proc.returncode != 0
-    assert proc.stderr.count("bench.py needs an MI355X") >= 2, proc.stderr[-2000:]
+    # (torch.distributed.run stops the other ranks as soon as one has failed: a sibling that was still importing torch
+    # may never get to print its own refusal — one is the guaranteed count, two the usual one)
+    assert proc.stderr.count("bench.py needs an MI355X") >= 1, proc.stderr[-2000:]
     assert "parent: torch imported = False" in proc.stderr
     assert not [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
