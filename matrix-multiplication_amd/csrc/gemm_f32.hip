@@ -197,6 +197,37 @@ struct TileLoader {
       r[v] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off[v], 0, 0));
   }
 
+  // Operands whose rows are NOT 16-byte aligned (ld % 4 ≠ 0, a base or batch stride off 16 bytes — ViT's 197 / 577 tokens:
+  // probs is 197 × 197) take the same unconditional buffer loads: along k (KCONTIG) a float4 of a whole k-tile lies inside
+  // its row whatever the row's alignment, so load_clamped serves as it is (a dword-aligned 16-byte load); along ext a row's
+  // last quad would reach into the next row — or past the operand's end — so every ELEMENT is clamped to the extent and
+  // loaded as a dword (round 5; until then such products took the bounds-checked loader for every tile:
+  // 384 × (197 × 197)·(197 × 64) 0.040 ms against 0.029 at 200 tokens, torch 0.036).
+  static constexpr int DWV = KCONTIG ? 1 : VECS;
+  static __device__ __forceinline__ void lane_offsets_dw(unsigned (&off)[DWV][4], long ld, int tid, int left) {
+    if constexpr (!KCONTIG) {
+#pragma unroll
+      for (int v = 0; v < VECS; ++v) {
+        const int idx = v * 256 + tid;
+        const int row = idx / (EXT / 4), e = (idx % (EXT / 4)) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) off[v][c] = (unsigned)(row * (int)ld + (e + c < left ? e + c : left - 1)) * 4u;
+      }
+    }
+  }
+  static __device__ __forceinline__ void load_clamped_dw(f32x4 (&r)[VECS], const float* tile, const unsigned (&off)[DWV][4]) {
+    if constexpr (!KCONTIG) {
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tile), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int v = 0; v < VECS; ++v) {
+        r[v].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off[v][0], 0, 0));
+        r[v].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off[v][1], 0, 0));
+        r[v].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off[v][2], 0, 0));
+        r[v].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off[v][3], 0, 0));
+      }
+    }
+  }
+
   // Registers → LDS.
   static __device__ __forceinline__ void store(const f32x4 (&r)[VECS], float* lds, int tid) {
 #pragma unroll
@@ -377,7 +408,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI_GEMM_SHO
   // of its k-tiles (ViT's 197-token attention: 3 of 4 output tiles).
   // ALIGNED: the launcher saw that EVERY tile is whole, and the edge code is compiled out (it is what sets the
   // kernel's register count otherwise)
+  // (round 5) rows off 16-byte boundaries take them too — dword-aligned 16-byte loads along k, clamped dword loads along
+  // ext (TileLoader::load_clamped_dw) — as long as the 32-bit offsets hold (what vecA / vecB also stand for)
+#ifdef MI_GEMM_NO_UNALIGNED_FAST
   const bool fast = ALIGNED || (vecA && vecB);
+#else
+  const bool fast = ALIGNED || (lda < (1 << 21) && ldb < (1 << 21) && ldc < (1 << 24));
+#endif
   const bool whole = ALIGNED || (m0 + BM <= m && n0 + BN <= n);
 #ifndef MI_GEMM_KK_UNROLL
 #define MI_GEMM_KK_UNROLL 16
@@ -401,9 +438,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI_GEMM_SHO
   if (fast) {
     const unsigned a_lane = LA::lane_offset(lda, tid), b_lane = LB::lane_offset(ldb, tid);
     unsigned a_off[LA::VECS], b_off[LB::VECS];
+    unsigned a_dw[LA::DWV][4], b_dw[LB::DWV][4];
+    // an operand that is contiguous along ext with rows off 16-byte boundaries: element-wise clamped dword loads (uniform)
+    const bool a_by_dword = !ALIGNED && TA && !vecA, b_by_dword = !ALIGNED && !TB && !vecB;
     if (!ALIGNED) {
-      LA::lane_offsets(a_off, lda, tid, m - m0);
-      LB::lane_offsets(b_off, ldb, tid, n - n0);
+      if (a_by_dword) LA::lane_offsets_dw(a_dw, lda, tid, m - m0);
+      else LA::lane_offsets(a_off, lda, tid, m - m0);
+      if (b_by_dword) LB::lane_offsets_dw(b_dw, ldb, tid, n - n0);
+      else LB::lane_offsets(b_off, ldb, tid, n - n0);
     }
     auto load_tile = [&](int k0) {  // k-tile starting at k0 < k
       if (MI_GEMM_ABL & 4) return;
@@ -411,8 +453,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MI_GEMM_SHO
         LA::load_fast(ra, LA::origin(A, lda, m0, k0), lda, a_lane);
         LB::load_fast(rb, LB::origin(B, ldb, n0, k0), ldb, b_lane);
       } else if (k0 + BK <= k) {
-        LA::load_clamped(ra, LA::origin(A, lda, m0, k0), a_off);
-        LB::load_clamped(rb, LB::origin(B, ldb, n0, k0), b_off);
+        if (a_by_dword) LA::load_clamped_dw(ra, LA::origin(A, lda, m0, k0), a_dw);
+        else LA::load_clamped(ra, LA::origin(A, lda, m0, k0), a_off);
+        if (b_by_dword) LB::load_clamped_dw(rb, LB::origin(B, ldb, n0, k0), b_dw);
+        else LB::load_clamped(rb, LB::origin(B, ldb, n0, k0), b_off);
       } else {
         LA::load(ra, A, lda, m0, k0, m, k, vecA, tid);
         LB::load(rb, B, ldb, n0, k0, n, k, vecB, tid);
@@ -1149,7 +1193,15 @@ int launch(const float* A, const float* B, float* C, int m, int n, int k, long l
 #ifndef MI_GEMM_PIPE_MIN_TILES
 #define MI_GEMM_PIPE_MIN_TILES 8  // developer probes may override
 #endif
-  if (k >= MI_GEMM_PIPE_MIN_TILES * BK)
+  // (the pipelined kernel's fast loop wants whole k-tiles and 16-byte aligned rows; a long k that is ragged or unaligned —
+  // 577 tokens — is better off in the single-buffer kernel, whose whole k-tiles take unconditional loads whatever the
+  // alignment and only the ragged last one the bounds-checked loader, than in the pipelined kernel's bounds-checked loop)
+#ifdef MI_GEMM_NO_RAGGED_SHORTK
+  const bool pipe_ok = true;
+#else
+  const bool pipe_ok = (vecA && vecB && k % BK == 0) || !(lda < (1 << 21) && ldb < (1 << 21) && ldc < (1 << 24));
+#endif
+  if (k >= MI_GEMM_PIPE_MIN_TILES * BK && pipe_ok)
     hipLaunchKernelGGL((gemm_f32_pipe_kernel<BM, BN, TA, TB>), dim3((unsigned)blocks), dim3(256), 0, s, A, B, C, m,
                        n, k, lda, ldb, ldc, sA, sB, sC, (int)tiles_n, (int)(tiles_m * tiles_n), vecA, vecB, vecC,
                        bias, rev);

@@ -364,3 +364,44 @@ def test_gemm_short_k_chains_of_two_three_and_four_tiles(cmm, dev, oracle_mod, k
             C = torch.full((batch, m, n), float("nan"), device=dev)
             cmm.cublas_bmm(t(a, dev), t(b, dev), C, 3, ta, tb)
             assert np.array_equal(C.cpu().numpy(), gemm_ref(oracle_mod, a, b, ta, tb)), (n, ta, tb)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("m,n,k", [(197, 64, 197), (577, 64, 300), (130, 70, 333), (69, 197, 64), (5, 3, 40), (260, 129, 1031)])
+def test_gemm_rows_off_16_byte_boundaries_take_unconditional_loads_bit_exact(capi, dev, oracle_mod, ta, tb, m, n, k):
+    """Round 5: operands whose rows are not 16-byte aligned (ViT's 197 / 577 tokens: probs is 197 × 197; an odd leading
+    dimension, a base one float off) take the unconditional buffer loads too — dword-aligned 16-byte loads along k, clamped
+    dword loads along m / n — and a long ragged or unaligned k runs in the single-buffer kernel.  Every float around the
+    operands (row padding, the floats before and after) is NaN: a load that strayed outside an operand's extent, or a clamp
+    that duplicated the wrong element into a stored row / column, would show.  Bit-identical to the oracle, nothing but
+    C's m × n written.  Reference: src/custom_mm.cpp:104-164 (cublas_mmul / cublas_bmm take any shape)."""
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_gemm_f32.argtypes = [ctypes.c_int, ctypes.c_int, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, vp]
+    g = np.random.Generator(np.random.PCG64(m * 31 + n * 7 + k + 2 * ta + tb))
+    batch = 3
+    rows_a, cols_a = (k, m) if ta else (m, k)
+    rows_b, cols_b = (n, k) if tb else (k, n)
+    for pad_a, pad_b, pad_c, lead in ((0, 0, 0, 0), (1, 3, 1, 1), (2, 0, 5, 3)):
+        lda, ldb, ldc = cols_a + pad_a, cols_b + pad_b, n + pad_c
+        sa, sb, sc = rows_a * lda + pad_a, rows_b * ldb + pad_b, m * ldc + pad_c
+        a_buf = np.full(lead + batch * sa + 8, np.nan, dtype=np.float32)
+        b_buf = np.full(lead + batch * sb + 8, np.nan, dtype=np.float32)
+        view = lambda buf, i, stride, rows, cols, ld: np.lib.stride_tricks.as_strided(  # noqa: E731
+            buf[lead + i * stride:], shape=(rows, cols), strides=(ld * 4, 4))
+        want = np.empty((batch, m, n), dtype=np.float32)
+        for i in range(batch):
+            view(a_buf, i, sa, rows_a, cols_a, lda)[:] = g.random((rows_a, cols_a), dtype=np.float32) - 0.5
+            view(b_buf, i, sb, rows_b, cols_b, ldb)[:] = g.random((rows_b, cols_b), dtype=np.float32) - 0.5
+            want[i] = gemm_ref(oracle_mod, np.ascontiguousarray(view(a_buf, i, sa, rows_a, cols_a, lda)),
+                               np.ascontiguousarray(view(b_buf, i, sb, rows_b, cols_b, ldb)), ta, tb)
+        d_a, d_b = t(a_buf, dev), t(b_buf, dev)
+        C = torch.full((lead + batch * sc + 8,), float("nan"), device=dev)
+        st = capi.mi_gemm_f32(int(ta), int(tb), m, n, k, d_a.data_ptr() + 4 * lead, lda, sa, d_b.data_ptr() + 4 * lead, ldb, sb,
+                              C.data_ptr() + 4 * lead, ldc, sc, batch, torch.cuda.current_stream().cuda_stream)
+        assert st == 0
+        got = C.cpu().numpy()
+        written = np.zeros(got.shape, dtype=bool)
+        for i in range(batch):
+            assert np.array_equal(view(got, i, sc, m, n, ldc), want[i]), (pad_a, pad_b, pad_c, lead, i)
+            written[(lead + i * sc + np.arange(m)[:, None] * ldc + np.arange(n)[None, :]).ravel()] = True
+        assert np.isnan(got[~written]).all(), (pad_a, pad_b, pad_c, lead)

@@ -10,23 +10,35 @@ import custom_mm  # noqa: E402
 dev = torch.device("cuda")
 
 
-def timeit(fn, iters=20):
-    for _ in range(3):
+def block(fn, iters):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
         fn()
+    e1.record()
     torch.cuda.synchronize()
-    best = 1e9
-    for _ in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
+    return e0.elapsed_time(e1) / iters
+
+
+def time_pair(ours, ref, rounds=5):
+    """(median ms of ours, of ref): the two take turns, block by block (round 5) — a block that follows an idle gap runs up
+    to 15 % faster than the same kernel in a sustained run on this part, so timing one candidate after the other hands
+    whichever comes second a different clock state; blocks are sized to ≥ 4 ms so that short products see sustained clocks."""
+    for fn in (ours, ref):
+        for _ in range(3):
             fn()
-        e1.record()
-        torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) / iters)
-    return best
+    torch.cuda.synchronize()
+    iters = int(max(20, min(400, 4.0 / max(block(ours, 5), 1e-3))))
+    a, b = [], []
+    for _ in range(rounds):
+        a.append(block(ours, iters))
+        b.append(block(ref, iters))
+    a.sort()
+    b.sort()
+    return a[len(a) // 2], b[len(b) // 2]
 
 
-print("# tools/bench_attention_shapes.py on MI355X (ms per product, best of 3 blocks of 20; TFLOP/s of ours)")
+print("# tools/bench_attention_shapes.py on MI355X (ms per product: median of 5 blocks, ours and torch taking turns block by block; TFLOP/s of ours)")
 print("# items x S x D        product          ours     torch    ours/torch   TFLOP/s")
 for items, S, D in [(384, 512, 88), (384, 512, 72), (384, 128, 64), (384, 256, 64), (384, 384, 64), (384, 512, 64), (96, 1024, 64), (48, 2048, 64),
                     (512, 512, 64), (256, 512, 128), (384, 512, 96), (384, 512, 80), (384, 197, 64), (192, 577, 64)]:
@@ -45,5 +57,5 @@ for items, S, D in [(384, 512, 88), (384, 512, 72), (384, 128, 64), (384, 256, 6
         ("dC.VT  (NT, k=D)", lambda: custom_mm.cublas_bmm(dc, v, sc, 3, False, True), lambda: torch.matmul(dc, v.transpose(-1, -2), out=sc)),
     ]
     for name, ours, ref in rows:
-        t0, t1 = timeit(ours), timeit(ref)
+        t0, t1 = time_pair(ours, ref)
         print(f"{items:4d} x {S:4d} x {D:3d}   {name}   {t0:7.4f}  {t1:7.4f}   {t0 / t1:6.2f}     {flops / t0 / 1e9:6.1f}", flush=True)
