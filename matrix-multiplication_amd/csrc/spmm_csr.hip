@@ -1210,10 +1210,25 @@ int l2_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
   // 0.3 %: 0.64 ms with 8 panels vs 0.86 one-pass
   if (N != 256 && !((N == 512 || N == 1024) && coltile_width(M, K, N, ldb) == 0)) return 0;
   const double b_bytes = (double)K * (double)ldb * 4.0;
-  if (b_bytes <= (N == 256 ? 6.0 : 8.0) * 1024 * 1024 || b_bytes > 128.0 * 1024 * 1024) return 0;
+  // (from 32 Ki rows already at 4.5 MiB — B then fills the L2s to the brim and the many rows keep evicting it: 170752 × 2816 ×
+  // 512 with 129 per row, 5.5 MiB: one pass 1.90 ms, two panels 1.50; 134912 × 5376 × 256, 5.2 MiB: 0.74 → 0.63)
+  if (b_bytes <= (M >= 32768 ? 4.5 : (N == 256 ? 6.0 : 8.0)) * 1024 * 1024 || b_bytes > 192.0 * 1024 * 1024) return 0;
+  // panels turn re-gathers into L2 hits: below ≈ 32 gathers per row of B nothing is won (round 5, tools/plan_grid.py:
+  // 1280 × 14592 × 256 with 38 per row — 3.3 gathers per row of B — one pass 0.008 ms, the four panels taken until then 0.019)
+  // … and a launch of fewer waves than the chip holds is latency-bound: cutting it into passes multiplies that (1536 × 9728
+  // × 256 with 499 per row: one pass 0.044 ms, three panels 0.080) — unless B is far beyond the L2s (3328 × 27904 × 512 with 240 per
+  // row, 54 MiB: 0.170 → 0.129)
+  // (with a B that half fits the L2s as it is, up to ≈ 10 Ki rows: 4096 × 13056 × 256 with 393 per row one pass 0.065 ms, two
+  // panels 0.080 – 0.096; 8192 × 131072 × 256 with 1311 per row, 128 MiB: 1.27 → 0.58)
+  if (nnz < 24L * K || (M < 10240 && b_bytes < 32.0 * 1024 * 1024)) return 0;
   int p = (int)((b_bytes + (4 << 20) - 1) / (4 << 20));
   p = p > 6 ? 8 : p;
+  const int p_by_size = p;
   while (p >= 2 && nnz < 8L * p * M) p = p > 6 ? 6 : p - 1;  // each pass carries C once: it needs work to pay for that
+  // … and panels that short rows leave too large for the L2s only add passes (162560 × 106240 × 256 with 45 per row, 104 MiB:
+  // five panels of 21 MiB 1.11 ms, one pass 1.03; eight panels of 19 – 21 MiB for long rows pay: 19712 × 38400 × 1024 with 502
+  // per row 5.18 → 4.36 ms)
+  if (p >= 2 && p < p_by_size && b_bytes / p > 16.0 * 1024 * 1024) return 0;
   return p >= 2 ? p : 0;
 }
 
@@ -1240,21 +1255,60 @@ int ic_panels(int64_t nnz, int32_t M, int32_t K, int32_t N, int64_t ldb) {
 }
 
 // L2-level panels for the lane-group panel kernel: B beyond the L2s but inside the Infinity Cache (6 MiB < |B| ≤ 128 MiB).
-// Panels of ≈ 6 MiB measured best or within a few per cent of it over B = 8 … 128 MiB at N = 192 … 384 (B = 12 MiB: 2 panels,
-// 24 MiB: 3–4, 48 MiB: 8, 128 MiB: 8); every pass walks the row's columns up to its panel, which is why rows of thousands
-// of entries want half as many (8192 × 65536 × 256 at 5 %, 3277 per row: 4 panels 1.13 ms, 8 panels 1.19), and a pass needs
-// ≥ 32 entries per row to pay for carrying C (16384² × 256 with 82 per row: 2 panels 0.085 ms, 3 panels 0.096).
-// Returns 2, 3, 4, 6 or 8, or 0.  tools/probes/l2_regime_shapes*.sh, profiles/r05_l2_regime_plans.log.
+// Fitted on tools/probes/l2_regime_shapes*.sh (17 shapes) and tools/plan_grid.py (120 random shapes, every plan pinned;
+// profiles/r05_l2_regime_plans.log, r05_plan_grid.log):
+//   * panels of ≈ 6 MiB are best or within a few per cent of it over B = 8 … 128 MiB at N = 192 … 768 (B = 12 MiB: 2 panels,
+//     24 MiB: 3–4, 48 MiB: 8, 128 MiB: 8); every pass walks the row's columns up to its panel, which is why rows of thousands
+//     of entries want half as many (8192 × 65536 × 256 at 5 %, 3277 per row: 4 panels 1.13 ms, 8 panels 1.19);
+//   * a pass carries C once (two rows' worth of gathers) and costs a launch: it needs ≥ 8 entries per row, more when the
+//     product is small (16384² × 256 with 82 per row: 2 panels 0.085 ms, 3 panels 0.096; 230656 × 9472 × 768 with 66 per row:
+//     2 panels 4.70 ms, 4 panels 3.38, 6 panels 3.12; 22272 × 14080 × 384 with 41 per row: one pass 0.158, 3 panels 0.127) —
+//     8 + 200 000 / M;
+//   * panels turn RE-gathers into L2 hits, the first touch of a row of B comes from beyond either way: with fewer than ≈ 24
+//     gathers per row of B nothing is won (1280 × 14592 × 256 with 38 per row, 3.3 gathers per row of B: one pass 0.008 ms,
+//     four panels 0.019; 1536 × 39424 × 768 with 715 per row, 28 per row of B: two panels 0.296 against 0.344);
+//   * up to 192 MiB of B (242176 × 188928 × 192, 138 MiB, 1010 per row: one pass 24.7 ms, 8 panels 19.4), up to 384 MiB for
+//     rows of ≥ 256 entries (57344 × 326656 × 256, 319 MiB, 869 per row: 6.79 → 6.00; with 38 per row at 206 MiB panels lose
+//     7 – 30 %); between that and the Infinity-Cache regime (768 MiB) panels move a product by ± 5 %: one pass;
+//   * B barely beyond the L2s (< 12 MiB) needs ≥ 48 entries per row (95488 × 6144 × 320 with 21 per row, 7.5 MiB: one pass
+//     0.187 ms, two panels 0.215; 309504 × 4864 × 384 with 65 per row, 7.1 MiB: 1.86 → 1.34);
+//   * N ≤ 128 (rows of B of ≤ 512 bytes, several rows per wave): two panels (four for ≥ 500 K rows of ≥ 128 entries and
+//     ≥ 32 MiB), only for launches that are throughput-bound — ≥ 28 K rows at N = 64 (four rows per wave), ≥ 60 K rows beyond
+//     (two); ≥ 48 entries per row, ≥ 48 gathers per row of B, 8 … 128 MiB (129536 × 22784 × 128 1.53 → 1.24 ms, 961024 × 82176
+//     × 128 10.2 → 8.0, 154368 × 278528 × 64 1.13 → 0.99, 55040 × 268800 × 64 0.63 → 0.50, 79872 × 34048 × 64 0.49 → 0.37,
+//     67328 × 90624 × 100 2.01 → 1.45); with fewer rows a pass is latency-bound and splitting it only multiplies that (16384 ×
+//     65536 × 128: one pass 0.31 ms, two panels 0.37; 12032 × 67328 × 64: 0.077 vs 0.153; 24832 × 25856 × 96: 0.094 vs 0.151);
+//     N = 32 never;
+//   * fewer than ≈ 10 Ki rows: only with B far beyond the L2s (≥ 32 MiB) and ≥ 7e8 multiply-adds in the product (4096 × 13056 ×
+//     256 with 393 per row, 12.8 MiB: one pass 0.065 ms, two panels 0.093; 4096 × 49920 × 192 with 478 per row: 0.092 vs
+//     0.141; 2304 × 59904 × 384 with 847 per row, 88 MiB: 0.296 → 0.232), and in at most 3 (< 4 Ki rows) or 4 (< 8 Ki) passes.
+// Returns 2, 3, 4, 6 or 8, or 0.
 int l2_group_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
-  (void)N;
-  const double b_bytes = (double)K * (double)ldb * 4.0;
-  if (b_bytes <= 6.0 * 1048576.0 || b_bytes > 128.0 * 1048576.0 || M <= 0) return 0;
-  const double want = b_bytes / ((nnz >= 2048L * M ? 12.0 : 6.0) * 1048576.0);
+  const double b_bytes = (double)K * (double)ldb * 4.0, mib = 1048576.0;
+  if (b_bytes <= 6.0 * mib || b_bytes > (nnz >= 256L * M ? 384.0 : 192.0) * mib || M <= 0) return 0;
+  if (nnz < 24L * K || (b_bytes < 12.0 * mib && nnz < 48L * M)) return 0;
+  if (M < 10240 && (b_bytes < 32.0 * mib || (double)nnz * (double)N < 7e8)) return 0;
+  const long per_pass = 8 + 200000L / M;
+  if (N <= 128) {
+    if (!(N >= 64 && nnz >= 48L * M && nnz >= 48L * K && b_bytes >= 8.0 * mib && b_bytes <= 128.0 * mib)) return 0;
+    if (M < (N == 64 ? 28000 : 60000)) return 0;
+    // rows long enough for two passes: 48 at N = 64, 96 at N = 128 (48 from 96 Ki rows; config C2 — 65536² × 128, 65 per row —
+    // is level: 0.2516 one pass, 0.2476 in two panels, and stays one pass), 160 between (65536² × 96 with 100 per row: 0.249 vs 0.265)
+    const long len_min = N == 64 ? 48 : (N == 128 ? (M >= 98304 ? 48 : 96) : 160);
+    if (nnz < len_min * M) return 0;
+    return (M >= 500000 && b_bytes >= 32.0 * mib && nnz >= 128L * M) ? 4 : 2;
+  }
+  const double want = b_bytes / ((nnz >= 2048L * M ? 12.0 : 6.0) * mib);
   int p = 2;
   for (int c : {2, 3, 4, 6, 8})
     if ((c < want ? want - c : c - want) < (p < want ? want - p : p - want)) p = c;
   static const int kLower[9] = {0, 0, 0, 2, 3, 0, 4, 0, 6};
-  while (p >= 2 && nnz < 32L * p * M) p = kLower[p];
+  while (p >= 2 && nnz < per_pass * p * M) p = kLower[p];
+  // a few thousand rows are fewer waves than the chip holds: every further pass is one more latency-bound launch (3072 × 20480 ×
+  // 768 with 739 per row: 8 panels 0.365 ms, 3 panels 0.310; 2304 × 59904 × 384 with 847 per row: 0.278 vs 0.231; from 8 Ki rows
+  // eight panels are the best again: 8192 × 131072 × 256 with 1311 per row 0.58 ms, four panels 0.74)
+  const int p_cap = M < 4096 ? 3 : (M < 8192 ? 4 : 8);
+  while (p > p_cap) p = kLower[p];
   return p >= 2 ? p : 0;
 }
 
@@ -1312,15 +1366,19 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
       ((long)batch * M >= 16384 || ((long)batch * M >= 8192 && nnz >= 1500000)) &&
       nnz >= MI_SPMM_LDSB_MIN_ROW * (long)batch * M)
     return MI_SPMM_LDS_B;
+  // N = 20 … 32, up to 16 Ki rows of ≥ 32 entries: 16 lanes per row (half of them idle) instead of 8 — the launch form of the
+  // column tiles with ONE tile: twice the waves for a launch that has too few — was ahead on every such shape of
+  // tools/plan_grid.py (2816 × 6400 × 32 with 506 per row 0.066 → 0.046 ms, 14336 × 90112 × 32 with 65 per row 0.021 → 0.018);
+  // with many rows it loses (969984 × 2304 × 32 with 63 per row: 0.49 vs 0.72)
+  if (batch == 1 && sh.vec4_ok && N > 16 && N <= 32 && nnz >= 32L * M && M <= 16384) return MI_SPMM_COLTILE;
   int lp = (sh.wave_ok && batch == 1) ? l2_panels(M, K, N, ldb, nnz) : 0;
   // L2-level panels on the lane-group panel kernel (round 5): for the widths the one-wave-per-row panel kernel does not take
   // (128 < N ≤ 1024 other than 256 / 512 / 1024) and, at N = 256, for long rows — it beats the wave-per-row panel kernel there
   // (its passes stop at the first chunk behind their panel; 8192 × 131072 × 256 at 1 %: 0.99 → 0.58 ms, 16384² × 256 at 10 %:
-  // 1.04 → 0.96) and loses on short rows (65536 × 16384 at 0.3 %, 49 per row: 0.21 vs 0.24).  N ≤ 128 gains nothing from
-  // panels at this level (16384 × 65536 × 128: one pass 0.31 ms, two panels 0.37).  tools/probes/l2_regime_shapes*.sh,
-  // profiles/r05_l2_regime_plans.log.
+  // 1.04 → 0.96) and loses on short rows (65536 × 16384 at 0.3 %, 49 per row: 0.21 vs 0.24).  N ≤ 128: two panels in a narrow band of B only
+  // (l2_group_panels).  tools/probes/l2_regime_shapes*.sh, tools/plan_grid.py; profiles/r05_l2_regime_plans.log, r05_plan_grid.log.
   int gp = 0;
-  if (sh.vec4_ok && batch == 1 && N > 128 && N <= 1024 && (N == 256 ? nnz >= 128L * M : !sh.wave_ok)) gp = l2_group_panels(M, K, N, ldb, nnz);
+  if (sh.vec4_ok && batch == 1 && N >= 36 && N <= 1024 && (N == 256 ? nnz >= 224L * M : !sh.wave_ok)) gp = l2_group_panels(M, K, N, ldb, nnz);
   if (gp > 0) lp = 0;
   // Moderate density: stage B through LDS (spmm_slab.hip) when its cost model beats the L2-blocked
   // row-split plans.  Fitted on MI355X (tools/bench_density.py, tools/bench_plans.py): a slab

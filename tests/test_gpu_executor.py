@@ -309,7 +309,7 @@ def test_validate_csr_rejects_bad_contents_for_every_plan(cmm, dev, oracle_mod):
     must catch an out-of-range column, a negative column and non-monotone offsets on inputs that would take the
     row-split, the two L2-panel plans and the LDS-slab plan alike (the check does not depend on the plan: asserted per shape)."""
     shapes = [("spmm_wave_row_kernel", 2000, 3000, 256, 0.01), ("spmm_wave_row_panel_kernel", 16384, 16384, 256, 0.005),
-              ("spmm_group_panel_kernel", 8192, 16384, 256, 0.01),
+              ("spmm_group_panel_kernel", 16384, 16384, 256, 0.02),
               ("spmm_slab_kernel", 4096, 4096, 2048, 0.2), ("spmm_group_kernel", 500, 700, 64, 0.05)]
     for plan, M, K, N, density in shapes:
         rowptr, col, val = oracle_mod.make_csr(M, K, density, seed=M)

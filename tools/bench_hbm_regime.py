@@ -25,7 +25,6 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "matrix-multiplication_amd"))
 sys.path.insert(0, str(ROOT))
 import custom_mm  # noqa: E402
-import oracle  # noqa: E402  (checker only)
 
 lib = ctypes.CDLL(str(Path(custom_mm.__file__).parent / "libmi_spmm.so"))
 vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
@@ -73,6 +72,7 @@ def make_csr(M, K, per_row, pattern, seed=0):
 
 def check_rows(rowptr, col, val, B, C, K, n_rows=192, seed=0):
     """Sampled rows of C bit-exact against the oracle."""
+    import oracle  # the checker, here only (tools/plan_grid.py imports this module for its generator and timer, not for this)
     M = rowptr.numel() - 1
     rs = np.unique(np.concatenate([[0, M - 1], np.random.default_rng(seed).integers(0, M, n_rows)]))
     rp = rowptr.cpu().numpy().astype(np.int64)
@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--widths", default="", help="comma-separated N: a sweep over these widths instead (100 / 400 per row)")
     ap.add_argument("--rows", type=int, default=1 << 21, help="M = K of the --widths sweep")
     a = ap.parse_args()
+    import oracle
     oracle.build()
     print(f"# device {torch.cuda.get_device_name(0)}; ms per product through custom_mm.naive_spmm; frac = algorithmic GB/s / 8000",
           flush=True)
