@@ -1298,7 +1298,9 @@ int l2_group_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
     if (nnz < len_min * M) return 0;
     return (M >= 500000 && b_bytes >= 32.0 * mib && nnz >= 128L * M) ? 4 : 2;
   }
-  const double want = b_bytes / ((nnz >= 2048L * M ? 12.0 : 6.0) * mib);
+  // (panels of ≈ 4 MiB from 64 Ki rows: 316160 × 10240 × 384 with 299 per row, 15 MiB: 2 panels 9.35 ms, 4 panels 6.85; 349952 ×
+  // 19456 × 256, 19 MiB: 3 panels 7.45, 4 panels 6.60; 259840 × 18176 × 384, 26.6 MiB: 4 panels 4.21, 6 panels 3.69)
+  const double want = b_bytes / ((nnz >= 2048L * M ? 12.0 : (M >= 65536 ? 4.0 : 6.0)) * mib);
   int p = 2;
   for (int c : {2, 3, 4, 6, 8})
     if ((c < want ? want - c : c - want) < (p < want ? want - p : p - want)) p = c;
@@ -1416,6 +1418,15 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
   }
   if (sh.vec4_ok && batch == 1 && coltile_panels(M, K, N, ldb, nnz) > 0) return MI_SPMM_COLTILE_PANELS;
   if (sh.vec4_ok && batch == 1 && coltile_width(M, K, N, ldb) > 0) return MI_SPMM_COLTILE;
+  // N = 256, one pass, a few thousand rows, B beyond the L2s but small: the lane-group kernel's whole-wave form (its col / val
+  // travel by vector load + ds_bpermute, the one-wave-per-row kernel's through the scalar unit) is ahead on such latency-bound
+  // launches — 4096 × 16384 × 256 with 164 per row 0.052 → 0.035 ms, 4096 × 13056 with 393 per row 0.078 → 0.065, 8960 × 8704
+  // with 213 per row 0.117 → 0.097, 16384² with 20 per row 0.047 → 0.040; with ≤ 3000 rows the other way round (1536 × 9728
+  // with 499 per row: 0.044 vs 0.063); tools/plan_grid.py, tools/probes/l2_regime_shapes3.sh
+  if (sh.wave_ok && N == 256 && batch == 1 && M >= 3500 && M <= 16384) {
+    const double b_bytes = (double)K * (double)ldb * 4.0;
+    if (b_bytes > 6.0 * 1048576.0 && b_bytes <= 64.0 * 1048576.0) return MI_SPMM_GROUP_VEC4;
+  }
   if (sh.wave_ok) return MI_SPMM_WAVE_ROW_U8;
   // rows that do not start on 16 bytes (N % 4 != 0, odd leading dimensions, offset views): four floats per lane all the
   // same, on dword-aligned 16-byte accesses (2 M rows, 100 per row: N = 77 0.38 → of 8 TB/s with one float per lane, 130: 0.35, 250: 0.49)

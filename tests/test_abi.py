@@ -142,18 +142,18 @@ def test_every_variant_id_has_a_kernel_name_and_the_plan_query_needs_no_gpu(lib)
     assert plan(int(0.1 * 16384 * 16384), 16384, 16384, 256) == 20  # B = 16 MiB: three of them beat the slab plan
     assert plan(int(0.05 * 8192 * 65536), 8192, 65536, 256) == 22   # 64 MiB, 3277 per row: six (12 MiB panels for very long rows)
     assert plan(int(0.01 * 32768 * 32768), 32768, 32768, 192) == 21 and plan(int(0.01 * 16384 * 32768), 16384, 32768, 384) == 23
-    assert plan(40 * 16384, 16384, 16384, 256) == 9 and plan(20 * 16384, 16384, 16384, 256) == 2  # < 24 gathers per row of B: one pass
+    assert plan(40 * 16384, 16384, 16384, 256) == 9 and plan(20 * 16384, 16384, 16384, 256) == 4  # < 24 gathers per row of B: one pass (few rows at N = 256: the lane-group kernel)
     assert plan(499 * 1536, 1536, 9728, 256) == 2                  # fewer rows than the chip holds waves: passes only multiply latency
     assert plan(45 * 162560, 162560, 106240, 256) == 2            # 104 MiB with short rows: the panels they can pay for miss the L2s
-    assert plan(66 * 230656, 230656, 9472, 768) == 21             # many rows: 8 + 400 000 / M entries per row and pass are enough
+    assert plan(66 * 230656, 230656, 9472, 768) == 22             # many rows: panels of ≈ 4 MiB, 8 + 200 000 / M entries per row and pass are enough
     assert plan(333 * 129536, 129536, 22784, 128) == 19 and plan(655 * 16384, 16384, 65536, 128) == 4   # N ≤ 128: throughput-bound launches only
     assert plan(341 * 55040, 55040, 268800, 64) == 19 and plan(172 * 24832, 24832, 25856, 96) == 4  # … ≥ 28 K rows at N = 64, ≥ 60 K beyond
     assert plan(506 * 2816, 2816, 6400, 32) == 14 and plan(63 * 969984, 969984, 2304, 32) == 4      # N = 32, few long rows: 16 lanes per row
     assert plan(478 * 4096, 4096, 49920, 192) == 4                # few rows and a small product: one pass
     assert plan(1010 * 242176, 242176, 188928, 192) == 23         # up to 192 MiB of B
     assert plan(168 * 961024, 961024, 82176, 128) == 21 and plan(502 * 19712, 19712, 38400, 1024) == 12
-    assert plan(393 * 4096, 4096, 13056, 256) == 2 and plan(847 * 2304, 2304, 59904, 384) == 20   # few rows: only where B is far beyond the L2s, and in three passes at most
-    assert plan(8 * 16384, 16384, 16384, 256) == 2                 # too short to carry C at all
+    assert plan(393 * 4096, 4096, 13056, 256) == 4 and plan(38 * 1280, 1280, 14592, 256) == 2 and plan(847 * 2304, 2304, 59904, 384) == 20   # few rows: only where B is far beyond the L2s, and in three passes at most
+    assert plan(8 * 16384, 16384, 16384, 256) == 4                 # too short to carry C at all
     # B beyond the Infinity Cache (round 5, fitted on tools/bench_hbm_regime.py): P ≈ |B| / 683 MiB panels when the rows
     # are long enough (≥ 16 P non-zeros per row), the lane-group panel kernel for N ≤ 128; none beyond ≈ 6 GiB
     m2, m4 = 1 << 21, 1 << 22

@@ -66,7 +66,7 @@ def test_spmm_every_variant_is_bit_identical(capi, dev, oracle_mod, M, K, N, den
     (131072, 28416, 128, 0.004, "spmm_group_panel_kernel", 2),
     # too few rows, or too few gathers per row of B, for passes to pay: one pass
     (1536, 9728, 256, 0.05, "spmm_wave_row_kernel", 1), (3000, 16384, 256, 0.004, "spmm_wave_row_kernel", 1),
-    (4096, 13056, 256, 0.03, "spmm_wave_row_kernel", 1)])
+    (4096, 13056, 256, 0.03, "spmm_group_kernel", 1)])
 def test_spmm_auto_takes_l2_panels_for_mid_size_b(cmm, dev, oracle_mod, M, K, N, density, kernel, panels):
     """B beyond the L2s (> 6 MiB) but far from the Infinity-Cache regime: AUTO cuts K into panels of about
     4 – 6 MiB (one launch per panel, C carried) — still the CSR-order chain for every row, rows whose columns do not
