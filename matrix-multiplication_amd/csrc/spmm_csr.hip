@@ -1391,7 +1391,9 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
   if (sh.vec4_ok && batch == 1 && K >= 64 && N >= 128 && nnz > 0) {
     const double wgs = (double)(((long)M + 127) / 128) * (double)(((long)N + 255) / 256);
     const double density = (double)nnz / ((double)M * (double)K);
-    const double rounds = wgs <= 256.0 ? 1.0 : wgs / 256.0;  // beyond one wave of workgroups the tail averages out
+    // whole rounds of workgroups up to four of them (312 workgroups take two rounds, not 1.22: 13312 × 2304 × 768 at 7 % measured
+    // 0.347 ms = 2 × 36 slabs × 4.8 µs; round 5, tools/plan_grid.py); beyond that the tail averages out
+    const double rounds = wgs <= 256.0 ? 1.0 : (wgs < 1024.0 ? (double)(((long)wgs + 255) / 256) : wgs / 256.0);
     const double t_slab = rounds * (double)(((long)K + 63) / 64) * (2.35e-6 + 34e-6 * density);
     // … and as much for narrower N while B (≤ 8 MiB) stays in the L2s: 16384 × 4096 × 256 at 10 %: row-split
     // 0.25 ms (13.7 TFLOP/s) vs slab 0.38; 16384 × 768 × 128 at 30 %: 0.082 vs 0.164; the 5 TFLOP/s figure
@@ -1399,10 +1401,15 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
     const bool b_in_l2 = (double)K * (double)ldb * 4.0 <= 8.0 * 1024 * 1024;
     // with L2 panels the row-split plan gathers at the L2 rate and carries C (2·lp − 1) times
     const int panels = lp > 0 ? lp : gp;
-    const double t_rows = panels > 0 ? 2.0 * (double)nnz * (double)N / 13e12 + (2.0 * panels - 1.0) * (double)M * (double)N * 4.0 / 4e12
-                                 : 2.0 * (double)nnz * (double)N /
-                                       ((double)K * (double)ldb * 4.0 <= 2.0 * 1024 * 1024 ? 15e12  // B in every L2 at once
-                                        : (N >= 512 || b_in_l2) ? 13e12 : 5e12);
+    // (round 5, fitted on the grids' slab-vs-rows misroutes: the panel plans at 15 TFLOP/s with C carried at 5 TB/s — 97792 ×
+    // 3584 × 768 with 140 per row: three panels 1.55 ms, slabs 1.84; "B in every L2 at once" up to 3.5 MiB — 61184 × 3072 × 256:
+    // one pass 0.327 ms = 15.9 TFLOP/s, slabs 0.407; and the lane-group kernel's idle lanes where N is not a whole number of
+    // 256-column tiles — 15104 × 1536 × 320: 0.327 ms = 11 TFLOP/s, slabs 0.270)
+    const double lanes_used = sh.wave_ok || N <= 256 ? 1.0 : (double)N / (256.0 * (double)((N + 255) / 256));
+    const double t_rows = (panels > 0 ? 2.0 * (double)nnz * (double)N / 15e12 + (2.0 * panels - 1.0) * (double)M * (double)N * 4.0 / 5e12
+                                  : 2.0 * (double)nnz * (double)N /
+                                        ((double)K * (double)ldb * 4.0 <= 3.5 * 1024 * 1024 ? 15e12  // B in every L2 at once
+                                         : (N >= 512 || b_in_l2) ? 13e12 : 5e12)) / lanes_used;
     // below ≈100 workgroups too few CUs have work for the model to hold
     if (wgs >= 96.0 && t_slab < t_rows) return MI_SPMM_SLAB;
   }

@@ -136,7 +136,7 @@ def test_inspect_handles_amortise_transpose_and_long_rows(cmm, dev, oracle_mod):
 
 
 @pytest.mark.parametrize("M,K,N,density,native", [(1024, 256, 4096, 0.5, True), (1100, 300, 4100, 0.6, True),
-                                                  (12301, 1030, 516, 0.25, False)])
+                                                  (20011, 1030, 516, 0.25, False)])
 def test_column_major_executor_native_slab_form(cmm, capi, dev, oracle_mod, M, K, N, density, native):
     """Where the LDS-slab plan serves the product, the column-major executor reads the activations
     X = Bᵀ [N, K] and writes Y = Cᵀ [N, M] directly (transposing slab loads, transposed tile store, no
