@@ -1404,12 +1404,18 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
     // (round 5, fitted on the grids' slab-vs-rows misroutes: the panel plans at 15 TFLOP/s with C carried at 5 TB/s — 97792 ×
     // 3584 × 768 with 140 per row: three panels 1.55 ms, slabs 1.84; "B in every L2 at once" up to 3.5 MiB — 61184 × 3072 × 256:
     // one pass 0.327 ms = 15.9 TFLOP/s, slabs 0.407; and the lane-group kernel's idle lanes where N is not a whole number of
-    // 256-column tiles — 15104 × 1536 × 320: 0.327 ms = 11 TFLOP/s, slabs 0.270)
+    // 256-column tiles — 15104 × 1536 × 320: 0.327 ms = 11 TFLOP/s, slabs 0.270; N ≥ 512 gathers at the L2 rate only where
+    // a column-tile plan keeps an XCD's slice of B in its L2 — 25856 × 57344 × 1024 with 1003 per row, 224 MiB, K too tall for
+    // any tile width: one pass 13.95 ms = 3.8 TFLOP/s, slabs 9.39)
     const double lanes_used = sh.wave_ok || N <= 256 ? 1.0 : (double)N / (256.0 * (double)((N + 255) / 256));
-    const double t_rows = (panels > 0 ? 2.0 * (double)nnz * (double)N / 15e12 + (2.0 * panels - 1.0) * (double)M * (double)N * 4.0 / 5e12
+    // (… but N ≥ 512 in eight panels of 8 – 10 MiB, many rows, a few per cent dense: 7 TFLOP/s — 78848 × 19456 × 1024 at 3.7 %:
+    // eight panels 18.1 ms, slabs 10.8; 25856 × 16640 × 1024 at 4.2 %: 4.9 vs 3.8; with 5120 rows the panels stay ahead, 0.94 vs 1.21)
+    const double panel_rate = (lp > 0 && N >= 512 && M >= 16384 && density >= 0.03) ? 7e12 : 15e12;
+    const double t_rows = (panels > 0 ? 2.0 * (double)nnz * (double)N / panel_rate + (2.0 * panels - 1.0) * (double)M * (double)N * 4.0 / 5e12
                                   : 2.0 * (double)nnz * (double)N /
                                         ((double)K * (double)ldb * 4.0 <= 3.5 * 1024 * 1024 ? 15e12  // B in every L2 at once
-                                         : (N >= 512 || b_in_l2) ? 13e12 : 5e12)) / lanes_used;
+                                         : (b_in_l2 || (N >= 512 && (coltile_width(M, K, N, ldb) > 0 || coltile_panels(M, K, N, ldb, nnz) > 0))) ? 13e12
+                                                                                                                                         : 5e12)) / lanes_used;
     // below ≈100 workgroups too few CUs have work for the model to hold
     if (wgs >= 96.0 && t_slab < t_rows) return MI_SPMM_SLAB;
   }
