@@ -58,7 +58,79 @@ struct LongArg {
   int thresh;               // rows with more non-zeros are left to spmm_long_rows_kernel
   int cap_e, cap_s, cap_p;  // list capacities (hold for any rowptr consistent with nnz)
   int* ws;                  // the list; nullptr: skip only (the list was prepared beforehand) or nothing is skipped
+  const int* adapt;         // kAdaptSlots verdicts of spmm_locality_probe_kernel (L2-level panel plans with a workspace), or nullptr
 };
+
+// ---------------------------------------------------------------------------
+// Structure-aware panels without a host round trip (round 5).  The L2-level panel plans are chosen from the SHAPE alone; on a
+// matrix whose rows gather from a narrow band of B (banded / block-diagonal structure) one pass is already served by the
+// caches and P panels only add passes (tools/plan_grid.py --pattern band1k: up to 2 × behind one pass).  When the caller
+// gave a workspace, a probe launch ahead of the passes looks at kAdaptSlots windows of kAdaptWindow consecutive rows
+// (first / last four columns of every row) and writes one verdict per window: "the rows of B this window touches span
+// ≤ a quarter of B and ≤ 32 MiB".  Every workgroup of the panel kernels reads the verdicts (uniform scalar loads): with
+// ≥ 7/8 of the windows local the FIRST pass takes every column (and the bias) and the other passes return at once — the
+// one-pass chain, the same bits, decided on the device: no read-back, graph-capturable, the launches stay as they were.
+// ---------------------------------------------------------------------------
+constexpr int kAdaptSlots = 16;
+constexpr int kAdaptWindow = 2048;
+
+__device__ __forceinline__ bool adapt_says_local(const int* __restrict__ verdicts) {  // wave-uniform
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < kAdaptSlots; ++i) s += __builtin_amdgcn_readfirstlane(verdicts[i]);
+  return 8 * s >= 7 * kAdaptSlots;
+}
+
+__global__ __launch_bounds__(256) void spmm_locality_probe_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                                  int M, long ldb, double b_bytes, int* __restrict__ verdicts) {
+  __shared__ int s_mn[4], s_mx[4];
+  const int w = blockIdx.x;
+  const int win = M < kAdaptWindow ? M : kAdaptWindow;
+  const long first = kAdaptSlots > 1 ? (long)w * (M - win) / (kAdaptSlots - 1) : 0;
+  int mn = 0x7fffffff, mx = -1;
+  // every fourth row of the window, two rows per thread, all of a thread's loads of one kind in flight together: the launch is
+  // two dependent trips to memory (offsets, then columns) long — ≈ 3 µs ahead of a product of ≥ 50 µs
+  constexpr int kRows = 2;
+  int s0[kRows], n0[kRows];
+#pragma unroll
+  for (int i = 0; i < kRows; ++i) {
+    const int r = 4 * ((int)threadIdx.x + 256 * i);
+    s0[i] = 0, n0[i] = 0;
+    if (r < win) {
+      s0[i] = rowptr[first + r];
+      n0[i] = rowptr[first + r + 1] - s0[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kRows; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // rows need not ascend: a few entries from either end
+      if (j < n0[i]) {
+        const int a = col[s0[i] + j], b = col[s0[i] + n0[i] - 1 - j];
+        mn = a < mn ? a : mn;
+        mn = b < mn ? b : mn;
+        mx = a > mx ? a : mx;
+        mx = b > mx ? b : mx;
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const int a = __shfl_xor(mn, d, 64), b = __shfl_xor(mx, d, 64);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if ((threadIdx.x & 63) == 0) s_mn[threadIdx.x >> 6] = mn, s_mx[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; ++i) {
+      mn = s_mn[i] < mn ? s_mn[i] : mn;
+      mx = s_mx[i] > mx ? s_mx[i] : mx;
+    }
+    const double span_bytes = mx >= mn ? ((double)mx - (double)mn + 1.0) * (double)ldb * 4.0 : 0.0;
+    verdicts[w] = (span_bytes <= 0.25 * b_bytes && span_bytes <= 32.0 * 1048576.0) ? 1 : 0;
+  }
+}
 
 // One lane per long row.  The order of the list does not matter: every slot is a fixed function of (row, g).
 __device__ __forceinline__ void long_list_append(const LongArg& la, int row, int len) {
@@ -338,12 +410,18 @@ __global__ __launch_bounds__(256) void spmm_wave_row_vl_kernel(
 // the FIRST pass recomputes such a row from scratch over all its non-zeros in plain CSR order
 // (+ bias) and the later passes leave it untouched.
 // ---------------------------------------------------------------------------
-template <bool FIRST, int T, int U>
+template <bool FIRST, int T, int U, bool ADAPT = false>
 __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
     int M, long ldb, long ldc, int c_lo, int c_hi, const float* __restrict__ bias, int last_pass, int ctiles,
     unsigned row_blocks, LongArg la) {
+  if constexpr (ADAPT) {  // (the Infinity-Cache level — config C3 — runs the ADAPT = false build: nothing added there)
+    if (adapt_says_local(la.adapt)) {
+      if (!FIRST) return;
+      c_lo = 0, c_hi = 0x7fffffff, last_pass = 1;
+    }
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned rb = blockIdx.x;
@@ -476,14 +554,17 @@ int launch_panels_t(int panels, const int* rowptr, const int* col, const float* 
   for (int q = 0; q < panels; ++q) {
     const int lo = (int)(q * kp);
     const int hi = (int)((q + 1) * kp < K ? (q + 1) * kp : K);
-    if (q == 0)
-      hipLaunchKernelGGL((spmm_wave_row_panel_kernel<true, T, U>), dim3((unsigned)blocks), dim3(256), 0,
-                         s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi, bias, q == panels - 1 ? 1 : 0, ctiles,
-                         (unsigned)row_blocks, la);
-    else
-      hipLaunchKernelGGL((spmm_wave_row_panel_kernel<false, T, U>), dim3((unsigned)blocks), dim3(256), 0,
-                         s, rowptr, col, val, B, C, M, ldb, ldc, lo, hi, bias, q == panels - 1 ? 1 : 0, ctiles,
-                         (unsigned)row_blocks, la);
+#define MI_PANEL_PASS(FIRST_, ADAPT_)                                                                                          \
+  hipLaunchKernelGGL((spmm_wave_row_panel_kernel<FIRST_, T, U, ADAPT_>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, \
+                     val, B, C, M, ldb, ldc, lo, hi, bias, q == panels - 1 ? 1 : 0, ctiles, (unsigned)row_blocks, la)
+    if (la.adapt != nullptr && ctiles == 1) {
+      if (q == 0) MI_PANEL_PASS(true, true);
+      else MI_PANEL_PASS(false, true);
+    } else {
+      if (q == 0) MI_PANEL_PASS(true, false);
+      else MI_PANEL_PASS(false, false);
+    }
+#undef MI_PANEL_PASS
   }
   return mi::check_launch();
 }
@@ -752,6 +833,10 @@ __global__ __launch_bounds__(256) void spmm_group_panel_kernel(
   // T > 1 (G = 64 only): T tiles of 256 columns per lane — the widths between and beyond the one-wave-per-row panel kernel's
   // 256 / 512 / 1024 (N = 160 … 1024, any multiple of 4): the same passes for every N the path takes
   static_assert(T == 1 || G == 64, "column tiles only with a whole wave per row");
+  if (la.adapt != nullptr && adapt_says_local(la.adapt)) {  // see spmm_locality_probe_kernel
+    if (!FIRST) return;
+    c_lo = kIntMin, c_hi = 0x7fffffff, last_pass = 1;
+  }
   constexpr int RPW = 64 / G;
   constexpr int UI = T >= 3 ? 2 : 4;  // gathers in flight per group and batch (T float4 each)
   const int lane = threadIdx.x & 63;
@@ -1038,6 +1123,7 @@ __global__ __launch_bounds__(256) void spmm_narrow_kernel(
 struct LongWs {
   long cap_e, cap_s, cap_p;
   size_t owner_off, partial_off, bytes;  // offsets in ints / bytes
+  size_t adapt_off;                      // bytes: kAdaptSlots verdicts of the locality probe, behind everything else
 };
 
 LongWs long_ws_layout(int64_t nnz, int32_t N) {
@@ -1048,7 +1134,8 @@ LongWs long_ws_layout(int64_t nnz, int32_t N) {
   w.owner_off = 4 + (size_t)kLongEnt * (size_t)w.cap_e;
   const size_t ints = w.owner_off + (size_t)w.cap_s;
   w.partial_off = (ints * sizeof(int) + 15) / 16 * 16;
-  w.bytes = w.partial_off + (size_t)w.cap_p * (size_t)N * sizeof(float);
+  w.adapt_off = (w.partial_off + (size_t)w.cap_p * (size_t)N * sizeof(float) + 15) / 16 * 16;
+  w.bytes = w.adapt_off + kAdaptSlots * sizeof(int);
   return w;
 }
 
@@ -1567,8 +1654,19 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
                      long_mode != MI_LONG_ROWS_NONE && (variant != MI_SPMM_SLAB || pinned_split);
   int* ws = static_cast<int*>(workspace);
   const LongWs lw = long_ws_layout(nnz, N);
-  LongArg la = {0x7fffffff, 0, 0, 0, nullptr};
+  LongArg la = {0x7fffffff, 0, 0, 0, nullptr, nullptr};
   const bool prepared = long_mode == MI_LONG_ROWS_PREPARED;
+  // L2-level panel plans with a workspace at hand: the probe's verdicts decide on the device whether the passes stay
+  // passes (spmm_locality_probe_kernel).  The Infinity-Cache level (B ≥ 768 MiB: config C3) is left alone.
+  const bool panel_plan = (variant >= MI_SPMM_PANELS_2 && variant <= MI_SPMM_PANELS_8) ||
+                          (variant >= MI_SPMM_GROUP_PANELS_2 && variant <= MI_SPMM_GROUP_PANELS_8);
+  const double b_bytes_all = (double)K * (double)ldb * 4.0;
+  if (panel_plan && batch == 1 && nnz > 0 && b_bytes_all < 768.0 * 1048576.0 && workspace != nullptr && workspace_bytes >= lw.bytes &&
+      (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0) {
+    int* verdicts = reinterpret_cast<int*>(static_cast<char*>(workspace) + lw.adapt_off);
+    hipLaunchKernelGGL(spmm_locality_probe_kernel, dim3(kAdaptSlots), dim3(256), 0, s, rowptr, col, M, (long)ldb, b_bytes_all, verdicts);
+    la.adapt = verdicts;
+  }
   if (split) {
     if (workspace_bytes < lw.bytes) return MI_ENOMEM;
     if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return MI_EINVAL;
@@ -1681,7 +1779,7 @@ int mi_spmm_long_rows_prepare(const int32_t* rowptr, int32_t M, int64_t nnz, int
   if (workspace_bytes < lw.bytes) return MI_ENOMEM;
   int* ws = static_cast<int*>(workspace);
   MI_HIP_TRY(hipMemsetAsync(ws, 0, 16, s));
-  const LongArg la = {kLongRow, (int)lw.cap_e, (int)lw.cap_s, (int)lw.cap_p, ws};
+  const LongArg la = {kLongRow, (int)lw.cap_e, (int)lw.cap_s, (int)lw.cap_p, ws, nullptr};
   hipLaunchKernelGGL(find_long_rows_kernel, dim3((unsigned)(((long)M + 255) / 256)), dim3(256), 0, s, rowptr, M, la);
   return mi::check_launch();
 }

@@ -956,3 +956,70 @@ def test_hbm_regime_panel_plans_at_full_size(capi, cmm, dev, oracle_mod, N, plan
     want = oracle_mod.spmm_csr(sub_rp, inv.astype(np.int32), vs, len(rs), len(uniq), Bs)
     got = C[torch.from_numpy(rs).to(dev)].cpu().numpy()
     assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+
+
+@pytest.mark.parametrize("N,variants", [(256, (7, 9, 12, 19, 21)), (192, (19, 20, 23)), (512, (8, 11, 22)), (128, (19, 21))])
+def test_panel_passes_adapt_to_banded_structure_on_the_device(capi, cmm, dev, oracle_mod, N, variants):
+    """Round 5: the L2-level panel plans are chosen from the shape alone; with a workspace at hand a probe launch ahead of the
+    passes writes, per window of 2048 rows, whether the rows of B it touches span ≤ a quarter of B (and ≤ 32 MiB), and every
+    workgroup of the panel kernels reads those verdicts: on a banded matrix the FIRST pass takes every column and the bias, the
+    other passes return — one pass's chain, decided on the device (no read-back).  Checked here: the verdicts (all local for
+    a band of ± 600 columns, none for uniform columns, mixed for a half-and-half matrix), and bit-identical results to the
+    oracle in all three cases for every pinned panel plan — rows out of column order, empty rows, a row beyond the long-row
+    threshold, with and without the bias — and through custom_mm.naive_spmm (AUTO + the extension's own workspace).
+    Reference: src/naive_sparse_mm.cu:60-92 (one CSR-order chain per output element, whatever the matrix looks like)."""
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_spmm_csr_ex_variant_f32.argtypes = [ctypes.c_int, vp, vp, vp, i64, i32, i32, i32, vp, i64, vp, vp, i64, ctypes.c_int,
+                                                vp, ctypes.c_size_t, vp]
+    capi.mi_spmm_csr_workspace_bytes.restype = ctypes.c_size_t
+    capi.mi_spmm_csr_workspace_bytes.argtypes = [i64, i32]
+    stream = torch.cuda.current_stream().cuda_stream
+    M, K = 20000, 24000
+    g = np.random.Generator(np.random.PCG64(900 + N))
+
+    def matrix(kind):
+        lens = g.integers(0, 40, size=M)
+        lens[g.integers(0, M, size=30)] = 0
+        lens[4000] = 9001                                   # beyond the long-row threshold
+        cols = []
+        for r, n in enumerate(lens):
+            banded = kind == "banded" or (kind == "mixed" and r < M // 2)
+            if banded:
+                centre = r * K // M
+                lo, hi = max(0, centre - 600), min(K, centre + 600)
+            else:
+                lo, hi = 0, K
+            c = g.integers(lo, hi, size=int(n))
+            cols.append(np.sort(c) if r % 4 else c)          # a quarter of the rows out of column order (duplicates allowed)
+        col = np.concatenate(cols).astype(np.int32)
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        val = g.random(len(col), dtype=np.float32) - 0.5
+        return rowptr, col, val
+
+    B, bias = g.random((K, N), dtype=np.float32) - 0.5, g.random(N, dtype=np.float32)
+    d_B, d_bias = t(B, dev), t(bias, dev)
+    for kind, expect_local in (("banded", 16), ("uniform", 0), ("mixed", None)):
+        rowptr, col, val = matrix(kind)
+        chain = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+        split = oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B)
+        d = [t(x, dev) for x in (rowptr, col, val)]
+        ws_bytes = capi.mi_spmm_csr_workspace_bytes(len(col), N)
+        ws = torch.zeros(ws_bytes + 16, dtype=torch.uint8, device=dev)
+        for variant in variants:
+            for with_bias in (False, True):
+                for rule, want in ((0, chain), (1, split)):     # MI_LONG_ROWS_NONE / _SPLIT
+                    C = torch.full((M, N), float("nan"), device=dev)
+                    st = capi.mi_spmm_csr_ex_variant_f32(variant, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), len(col), M, K, N,
+                                                         d_B.data_ptr(), N, d_bias.data_ptr() if with_bias else None, C.data_ptr(), N,
+                                                         rule, ws.data_ptr(), ws_bytes, stream)
+                    assert st == 0, (kind, variant, with_bias, rule)
+                    expect = want + bias[None, :] if with_bias else want
+                    assert np.array_equal(C.cpu().numpy().view(np.int32), expect.view(np.int32)), (kind, variant, with_bias, rule)
+            verdicts = ws[ws_bytes - 64:ws_bytes].view(torch.int32).cpu().numpy()
+            assert set(verdicts.tolist()) <= {0, 1}
+            if expect_local is not None:
+                assert int(verdicts.sum()) == expect_local, (kind, variant, verdicts)
+            else:
+                assert 0 < int(verdicts.sum()) < 14, (kind, verdicts)   # below 7/8: the passes stay passes
+        got = run_spmm(cmm, dev, rowptr, col, val, M, K, B)              # AUTO through the extension (its own workspace)
+        assert np.array_equal(got.view(np.int32), split.view(np.int32)) or np.array_equal(got.view(np.int32), chain.view(np.int32)), kind

@@ -9,7 +9,7 @@ order — the per-element chain is unchanged — times the gathered rows of B, o
 `--variants` also times the candidate plans pinned through the C-ABI (`mi_spmm_csr_f32_variant`), AUTO's starred.
 
 Patterns: `uniform` (the pinned generator's distribution: unique uniform keys in [0, M·K)), `banded` (columns within
-± 32 K of the diagonal), `powerlaw` (column popularity ∝ rank^-1.5 or so: col = ⌊K·u⁴⌋ scattered by an odd multiplier).
+± 32 K of the diagonal; `band1k`: ± 1 K), `powerlaw` (column popularity ∝ rank^-1.5 or so: col = ⌊K·u⁴⌋ scattered by an odd multiplier).
 Reference: src/naive_sparse_mm.cu:39,116 takes any N through one kernel.
 """
 import argparse
@@ -45,8 +45,9 @@ def make_csr(M, K, per_row, pattern, seed=0):
             keys = torch.randint(0, rows * K, (n,), device=dev, generator=g, dtype=torch.int64)
         else:
             r = torch.randint(0, rows, (n,), device=dev, generator=g, dtype=torch.int64)
-            if pattern == "banded":
-                off = torch.randint(-32768, 32769, (n,), device=dev, generator=g, dtype=torch.int64)
+            if pattern in ("banded", "band1k"):
+                half = 32768 if pattern == "banded" else 1024
+                off = torch.randint(-half, half + 1, (n,), device=dev, generator=g, dtype=torch.int64)
                 c = (r + r0) * K // M + off
                 c = c.clamp_(0, K - 1)
             elif pattern == "powerlaw":

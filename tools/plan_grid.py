@@ -24,6 +24,7 @@ ap.add_argument("--cases", type=int, default=120)
 ap.add_argument("--seed", type=int, default=5)
 ap.add_argument("--log", default="")
 ap.add_argument("--variants", default="2,4,7,8,9,10,11,12,14,15,17,18,19,20,21,22,23,24")
+ap.add_argument("--pattern", default="uniform", help="uniform | banded (± 32 K of the diagonal) | band1k (± 1 K) | powerlaw")
 a = ap.parse_args()
 variants = [int(x) for x in a.variants.split(",")]
 lib, dev = h.lib, h.dev
@@ -31,7 +32,7 @@ lib.mi_spmm_csr_f32_plan.argtypes = [h.i64, h.i32, h.i32, h.i32, h.vp, h.i64, h.
 g = np.random.Generator(np.random.PCG64(a.seed))
 st = torch.cuda.current_stream().cuda_stream
 rows_out = []
-print(f"# device {torch.cuda.get_device_name(0)}; tools/plan_grid.py --cases {a.cases} --seed {a.seed}; ms per product", flush=True)
+print(f"# device {torch.cuda.get_device_name(0)}; tools/plan_grid.py --cases {a.cases} --seed {a.seed} --pattern {a.pattern}; ms per product", flush=True)
 case = 0
 while case < a.cases:
     M = int(2 ** g.uniform(10, 20)) // 256 * 256
@@ -42,7 +43,7 @@ while case < a.cases:
     if K * N * 4 > (4 << 30) or M * N * 4 > (4 << 30) or M * d > 2.5e8 or M * d * N > 6e10:
         continue
     case += 1
-    rowptr, col, val = h.make_csr(M, K, d, "uniform", seed=case)
+    rowptr, col, val = h.make_csr(M, K, d, a.pattern, seed=case)
     nnz = col.numel()
     B = torch.rand(K, N, device=dev)
     C = torch.empty(M, N, device=dev)
