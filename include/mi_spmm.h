@@ -79,7 +79,13 @@ int mi_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
  * depends on the row length only.  Rows up to 8192 non-zeros keep the plain CSR-order chain, so
  * results equal mi_spmm_csr_f32 for them.  When the plan (mi_spmm_csr_f32_plan) is MI_SPMM_SLAB
  * or MI_SPMM_NARROW no row is split: every row keeps that plan's own order.  bias (N entries)
- * may be NULL.  This is what custom_mm.naive_spmm / cusparse_mmul call. */
+ * may be NULL.  This is what custom_mm.naive_spmm / cusparse_mmul call.
+ * The workspace also lets the column-panel plans look at the MATRIX, not only at its shape (round 5): its last 64 bytes take
+ * the verdicts of a probe launch — per window of 2048 rows, do the rows of B it gathers span ≤ 0.4 of B — that runs ahead of
+ * the passes whenever B is below the Infinity-Cache regime (768 MiB); the panel kernels read them on the device, and on a
+ * banded / block-diagonal matrix the first pass takes every column while the others return (one pass's chain: the same
+ * bits; no read-back, capturable).  Without a workspace the passes always stay passes.  Reference: src/naive_sparse_mm.cu:24-136
+ * is one kernel for any matrix; the plans and their adaptation are this library's. */
 size_t mi_spmm_csr_workspace_bytes(int64_t nnz, int32_t N);
 int mi_spmm_csr_ws_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                        int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,

@@ -66,8 +66,8 @@ struct LongArg {
 // matrix whose rows gather from a narrow band of B (banded / block-diagonal structure) one pass is already served by the
 // caches and P panels only add passes (tools/plan_grid.py --pattern band1k: up to 2 × behind one pass).  When the caller
 // gave a workspace, a probe launch ahead of the passes looks at kAdaptSlots windows of kAdaptWindow consecutive rows
-// (first / last four columns of every row) and writes one verdict per window: "the rows of B this window touches span
-// ≤ a quarter of B and ≤ 32 MiB".  Every workgroup of the panel kernels reads the verdicts (uniform scalar loads): with
+// (first / last four columns of every fourth row) and writes one verdict per window: "the rows of B this window touches span
+// ≤ 0.4 of B and ≤ 128 MiB" (uniform columns span all of B; a band of ± 1 K columns a few per cent of it).  Every workgroup of the panel kernels reads the verdicts (uniform scalar loads): with
 // ≥ 7/8 of the windows local the FIRST pass takes every column (and the bias) and the other passes return at once — the
 // one-pass chain, the same bits, decided on the device: no read-back, graph-capturable, the launches stay as they were.
 // ---------------------------------------------------------------------------
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void spmm_locality_probe_kernel(const int* __r
       mx = s_mx[i] > mx ? s_mx[i] : mx;
     }
     const double span_bytes = mx >= mn ? ((double)mx - (double)mn + 1.0) * (double)ldb * 4.0 : 0.0;
-    verdicts[w] = (span_bytes <= 0.25 * b_bytes && span_bytes <= 32.0 * 1048576.0) ? 1 : 0;
+    verdicts[w] = (span_bytes <= 0.4 * b_bytes && span_bytes <= 128.0 * 1048576.0) ? 1 : 0;
   }
 }
 

@@ -961,7 +961,7 @@ def test_hbm_regime_panel_plans_at_full_size(capi, cmm, dev, oracle_mod, N, plan
 @pytest.mark.parametrize("N,variants", [(256, (7, 9, 12, 19, 21)), (192, (19, 20, 23)), (512, (8, 11, 22)), (128, (19, 21))])
 def test_panel_passes_adapt_to_banded_structure_on_the_device(capi, cmm, dev, oracle_mod, N, variants):
     """Round 5: the L2-level panel plans are chosen from the shape alone; with a workspace at hand a probe launch ahead of the
-    passes writes, per window of 2048 rows, whether the rows of B it touches span ≤ a quarter of B (and ≤ 32 MiB), and every
+    passes writes, per window of 2048 rows, whether the rows of B it touches span ≤ 0.4 of B (and ≤ 128 MiB), and every
     workgroup of the panel kernels reads those verdicts: on a banded matrix the FIRST pass takes every column and the bias, the
     other passes return — one pass's chain, decided on the device (no read-back).  Checked here: the verdicts (all local for
     a band of ± 600 columns, none for uniform columns, mixed for a half-and-half matrix), and bit-identical results to the
