@@ -1299,7 +1299,9 @@ int l2_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
   const double b_bytes = (double)K * (double)ldb * 4.0;
   // (from 32 Ki rows already at 4.5 MiB — B then fills the L2s to the brim and the many rows keep evicting it: 170752 × 2816 ×
   // 512 with 129 per row, 5.5 MiB: one pass 1.90 ms, two panels 1.50; 134912 × 5376 × 256, 5.2 MiB: 0.74 → 0.63)
-  if (b_bytes <= (M >= 32768 ? 4.5 : (N == 256 ? 6.0 : 8.0)) * 1024 * 1024 || b_bytes > 192.0 * 1024 * 1024) return 0;
+  // (N = 512 / 1024 from 6 MiB like N = 256 — the column tiles only start beyond 8 MiB: 14592 × 4096 × 512 with 138 per row,
+  // 8.0 MiB: one pass 0.249 ms, two panels 0.162)
+  if (b_bytes <= (M >= 32768 ? 4.5 : 6.0) * 1024 * 1024 || b_bytes > 192.0 * 1024 * 1024) return 0;
   // panels turn re-gathers into L2 hits: below ≈ 32 gathers per row of B nothing is won (round 5, tools/plan_grid.py:
   // 1280 × 14592 × 256 with 38 per row — 3.3 gathers per row of B — one pass 0.008 ms, the four panels taken until then 0.019)
   // … and a launch of fewer waves than the chip holds is latency-bound: cutting it into passes multiplies that (1536 × 9728

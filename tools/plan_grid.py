@@ -25,6 +25,8 @@ ap.add_argument("--seed", type=int, default=5)
 ap.add_argument("--log", default="")
 ap.add_argument("--variants", default="2,4,7,8,9,10,11,12,14,15,17,18,19,20,21,22,23,24")
 ap.add_argument("--pattern", default="uniform", help="uniform | banded (± 32 K of the diagonal) | band1k (± 1 K) | powerlaw")
+ap.add_argument("--extension", action="store_true", help="AUTO = custom_mm.naive_spmm (the extension's workspace: long-row kernels and the "
+                "device-side locality probe are active) instead of the plain C-ABI entry")
 a = ap.parse_args()
 variants = [int(x) for x in a.variants.split(",")]
 lib, dev = h.lib, h.dev
@@ -32,7 +34,7 @@ lib.mi_spmm_csr_f32_plan.argtypes = [h.i64, h.i32, h.i32, h.i32, h.vp, h.i64, h.
 g = np.random.Generator(np.random.PCG64(a.seed))
 st = torch.cuda.current_stream().cuda_stream
 rows_out = []
-print(f"# device {torch.cuda.get_device_name(0)}; tools/plan_grid.py --cases {a.cases} --seed {a.seed} --pattern {a.pattern}; ms per product", flush=True)
+print(f"# device {torch.cuda.get_device_name(0)}; tools/plan_grid.py --cases {a.cases} --seed {a.seed} --pattern {a.pattern}{' --extension' if a.extension else ''}; ms per product", flush=True)
 case = 0
 while case < a.cases:
     M = int(2 ** g.uniform(10, 20)) // 256 * 256
@@ -58,6 +60,12 @@ while case < a.cases:
             ref = C.clone()
         same[v] = torch.equal(C.view(torch.int32), ref.view(torch.int32))
         entries[v] = (lambda ar: (lambda: lib.mi_spmm_csr_f32_variant(*ar)))(args)
+    if a.extension:
+        import custom_mm
+        C.fill_(float("nan"))
+        custom_mm.naive_spmm(val, col, rowptr, nnz, M, K, B, C)
+        same[0] = torch.equal(C.view(torch.int32), ref.view(torch.int32))
+        entries[0] = lambda: custom_mm.naive_spmm(val, col, rowptr, nnz, M, K, B, C)
     del ref
     ms = h.time_interleaved(entries, rounds=3, budget_ms=60.0)
     auto = ms[0]
