@@ -1023,3 +1023,58 @@ def test_panel_passes_adapt_to_banded_structure_on_the_device(capi, cmm, dev, or
                 assert 0 < int(verdicts.sum()) < 14, (kind, verdicts)   # below 7/8: the passes stay passes
         got = run_spmm(cmm, dev, rowptr, col, val, M, K, B)              # AUTO through the extension (its own workspace)
         assert np.array_equal(got.view(np.int32), split.view(np.int32)) or np.array_equal(got.view(np.int32), chain.view(np.int32)), kind
+
+
+def test_adaptive_panel_passes_fuzz_against_oracle(cmm, dev, oracle_mod):
+    """Random structured matrices on shapes where AUTO takes an L2-level panel plan, through custom_mm.naive_spmm (the
+    extension's workspace: the locality probe decides on the device whether the passes stay passes) — bands of random
+    width around a diagonal of random slope, block-diagonal matrices, uniform columns and mixtures by row range; rows
+    partly out of column order; a bias on every other case.  Bit-identical to the oracle whatever the probe decided.
+    MI_FUZZ_CASES (default 10) / MI_FUZZ_SEED set the number of cases and the seed."""
+    import os
+    g = np.random.Generator(np.random.PCG64(int(os.environ.get("MI_FUZZ_SEED", "77"))))
+    cases = int(os.environ.get("MI_FUZZ_CASES", "10"))
+    panel_plans = 0
+    for case in range(cases):
+        N = int(g.choice([128, 192, 256, 320, 512]))
+        M = int(g.integers(10, 40)) * 1024 if N != 128 else int(g.integers(100, 140)) * 1024
+        K = int(g.integers(8, 48)) * 1024
+        d = int(g.integers(24, 90)) if N != 128 else int(g.integers(100, 130))
+        kind = str(g.choice(["band", "blocks", "uniform", "mixed"]))
+        half = int(g.integers(50, 3000))
+        rows = np.repeat(np.arange(M, dtype=np.int64), d)
+        u = g.integers(0, 1 << 30, size=M * d, dtype=np.int64)
+        centre = rows * K // M
+        if kind == "band" or kind == "mixed":
+            c_band = np.clip(centre + (u % (2 * half + 1)) - half, 0, K - 1)
+        if kind == "blocks":
+            nb = int(g.integers(4, 40))
+            blk = rows * nb // M
+            c_band = blk * (K // nb) + u % (K // nb)
+        c_uni = u % K
+        if kind == "uniform":
+            cols = c_uni
+        elif kind == "mixed":
+            cut = int(g.integers(M // 4, 3 * M // 4))
+            cols = np.where(rows < cut, c_band, c_uni)
+        else:
+            cols = c_band
+        # rows sorted by column, except every fifth row (left in generation order: duplicates and descents are legal CSR)
+        order = np.lexsort((np.where(rows % 5 == 0, 0, cols), rows))
+        col = cols[order].astype(np.int32)
+        rowptr = (np.arange(M + 1, dtype=np.int64) * d).astype(np.int32)
+        val = g.random(M * d, dtype=np.float32) - 0.5
+        B = g.random((K, N), dtype=np.float32) - 0.5
+        d_B = t(B, dev)
+        C = torch.full((M, N), float("nan"), device=dev)
+        plan = cmm.spmm_plan(len(val), M, K, d_B, C)
+        panel_plans += plan[1] in ("spmm_wave_row_panel_kernel", "spmm_group_panel_kernel")
+        want = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+        if case % 2:
+            bias = g.random(N, dtype=np.float32)
+            cmm.naive_spmm_bias(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, d_B, t(bias, dev), C)
+            want = want + bias[None, :]
+        else:
+            cmm.naive_spmm(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, d_B, C)
+        assert np.array_equal(C.cpu().numpy().view(np.int32), want.view(np.int32)), (case, kind, M, K, N, d, half, plan)
+    assert panel_plans >= cases // 2, panel_plans   # the fuzz is about the panel plans: most cases must reach them
