@@ -432,10 +432,13 @@ def main():
         # by agreement — so both are part of the default trial.  Independent direct sends (p2p) can fail on some ranks
         # only; they join the trial only on request AND after sharded.probe_p2p (own process group, short timeout,
         # outcome agreed over the main group) succeeded everywhere.  A failed probe costs nothing but the option.
-        # The IPC push exchange is part of the default trial too (round 5: peers' C mapped through CUDA IPC, blocks copied straight into them on
-        # a side stream, one tiny all-reduce as the fence — no RCCL data movement): also probed and agreed at construction,
-        # a refusal folds it into the all_to_all candidate.
-        exch_cands = {"auto": ("allgather", "alltoall", "push"), "try-p2p": ("allgather", "alltoall", "push"),
+        # The IPC push exchange (round 5: peers' C mapped through CUDA IPC, blocks copied straight into them on a side stream,
+        # one tiny all-reduce as the fence — no RCCL data movement) is probed and agreed at construction like the others, but
+        # joins the trial only on request (--exchange try-push / push): a 4-rank rehearsal on one GPU aborted once inside
+        # torch's IPC reference counting when several ranks released one producer's buffer at the same moment (see
+        # sharded.ShardedSpMM.release_peers, which now serialises the releases) — not something to meet for the first
+        # time on the driver's 8-GPU run.
+        exch_cands = {"auto": ("allgather", "alltoall"), "try-p2p": ("allgather", "alltoall"),
                       "try-push": ("allgather", "alltoall", "push")}.get(args.exchange, (args.exchange,))
         if args.exchange == "try-p2p":
             p2p_probe = sharded.probe_p2p(dev, timeout_s=20.0)
@@ -467,6 +470,7 @@ def main():
                     tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                     chunk_trials[(trial.exchange, cand)] = float(tt[0]) / 3 * 1e3
+                    trial.release_peers()  # (collective; a no-op unless the trial pushed through IPC mappings)
                     del trial, Ct
             args.exchange, args.chunks = min(chunk_trials, key=chunk_trials.get)
             torch.cuda.empty_cache()
@@ -663,6 +667,7 @@ def main():
             rec["cpu_baseline"] = cpu_baseline(rowptr, col, val, M, K, B_host, N, C.cpu().numpy())
         print(json.dumps(rec), flush=True)
     if world > 1:
+        op.release_peers()  # (collective; peers' buffers mapped by the push exchange are let go one rank at a time)
         dist.destroy_process_group()
 
 

@@ -256,8 +256,9 @@ class ShardedSpMM:
                 except Exception as err:  # noqa: BLE001
                     ok, why = False, f"{type(err).__name__}: {str(err)[:120]}"
                 ok = self._agreed(ok)
-            self._peer_out.clear()
             del views
+            self.release_peers()  # consumers first, one rank at a time …
+            del probe             # … then the producer's own buffer
             if not ok:
                 self.fallbacks.append(f"push refused on some rank ({why or 'on a peer'}): alltoall from now on")
                 self.exchange = "alltoall"
@@ -291,6 +292,23 @@ class ShardedSpMM:
             nxt = "allgather" if self.exchange == "alltoall" else "allgather_copy"
             self.fallbacks.append(f"{self.exchange} refused on some rank ({why or 'on a peer'}): {nxt} from now on")
             self.exchange = nxt
+
+    def release_peers(self):
+        '''Drops this rank's views of its peers' buffers (exchange="push"), ONE RANK AT A TIME (collective: a barrier per rank).
+        torch's CUDA IPC keeps a reference-counter file per shared allocation and unlinks it when the count reaches zero; when
+        several consumers release one producer's storage at the same moment two of them can see zero, the second unlink fails
+        and the error is raised from a destructor — the process aborts (seen once in a 4-rank rehearsal on one GPU:
+        "could not unlink the shared memory file", at::RefcountedMapAllocator::close).  Call this before an operator that has
+        pushed is dropped and before the buffers it mapped are freed; bench.py does.'''
+        if self.world <= 1 or self.group is None:
+            self._peer_out.clear()
+            return
+        import gc
+        for r in range(self.world):
+            if r == self.rank:
+                self._peer_out.clear()
+                gc.collect()
+            dist.barrier(group=self.group)
 
     def _map_peers(self, out: torch.Tensor):
         '''Every rank's `out` as a tensor in THIS process (own entry: `out` itself), through torch's CUDA IPC; collective

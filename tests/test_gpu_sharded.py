@@ -140,9 +140,9 @@ def test_bench_multi_gpu_path_rehearsal(dev):
     # the default trial times the two COLLECTIVE forms (in-place all-gather, list all_to_all); gloo has no list
     # all_to_all: the construction-time probe sees the refusal, the ranks agree and that candidate folds into the
     # all-gather (recorded in exchange_fallbacks).  Direct sends can half-fail: they are tried on request only.
-    # … and (round 5) the IPC push exchange: CUDA IPC works between the two processes on this GPU, so it joins the trial
-    assert cfg["rccl_ranks"] == 2 and cfg["chunks"] in (2, 4) and cfg["exchange"] in ("allgather", "push")
-    assert set(cfg["chunk_trials_ms_per_step"]) == {"allgather/2", "allgather/4", "push/2", "push/4"}
+    # (the IPC push exchange joins the trial on request only: --exchange try-push, below)
+    assert cfg["rccl_ranks"] == 2 and cfg["chunks"] in (2, 4) and cfg["exchange"] == "allgather"
+    assert set(cfg["chunk_trials_ms_per_step"]) == {"allgather/2", "allgather/4"}
     assert len(cfg["exchange_fallbacks"]) == 1 and "alltoall refused" in cfg["exchange_fallbacks"][0]
     assert [d["rank"] for d in cfg["rank_devices"]] == [0, 1] and all("name" in d and "pid" in d for d in cfg["rank_devices"])
     assert cfg["compute_only_ms_per_step"] > 0 and rec["value"] > 0 and "cpu_baseline" not in rec
@@ -153,8 +153,15 @@ def test_bench_multi_gpu_path_rehearsal(dev):
     assert proc.returncode == 0, proc.stderr[-3000:]
     cfg = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')][0])["config"]
     assert cfg["p2p_probe_ok"] is True  # probed in its own group before the trial
-    assert set(cfg["chunk_trials_ms_per_step"]) == {"allgather/2", "allgather/4", "push/2", "push/4", "p2p/2", "p2p/4"}
-    assert cfg["exchange"] in ("allgather", "p2p", "push")
+    assert set(cfg["chunk_trials_ms_per_step"]) == {"allgather/2", "allgather/4", "p2p/2", "p2p/4"}
+    assert cfg["exchange"] in ("allgather", "p2p")
+    # the IPC push exchange in the trial (round 5): CUDA IPC works between the two processes on this GPU
+    proc = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                           "--workload", "c2", "--exchange", "try-push"], capture_output=True, text=True, timeout=600, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    cfg = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')][0])["config"]
+    assert set(cfg["chunk_trials_ms_per_step"]) == {"allgather/2", "allgather/4", "push/2", "push/4"}
+    assert cfg["exchange"] in ("allgather", "push")
     # and the nnz-balanced split (in-place broadcasts) through the same driver
     proc = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
                            "--workload", "c2", "--split", "nnz", "--chunks", "3", "--exchange", "allgather"],
