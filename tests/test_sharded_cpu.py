@@ -334,3 +334,57 @@ def test_single_process_layout(oracle_mod):
     rp = torch.tensor([0, 2, 2, 5, 9], dtype=torch.int32)
     assert sharded.shard_rowptr(rp, 1, 3, 4).tolist() == [0, 0, 3]
     assert sharded.shard_rowptr(rp, 3, 6, 4).tolist() == [0, 4, 4, 4]  # padded tail rows are empty
+
+
+def test_push_mapping_failure_on_one_rank_only_keeps_every_rank_in_step(tmp_path, oracle_mod):
+    """Round 5: the IPC push exchange maps every peer's buffer (a collective hand-over of handles, then a per-rank open that
+    can fail on one rank alone — IPC limits, a refused mapping).  Here rank 1's mapping fails AFTER the hand-over while ranks
+    0 and 2 succeed: the probe's two agreements must carry that to everybody, every rank ends on the same collective form,
+    nobody is left waiting in a collective its peer never enters, release_peers() (a barrier per rank) returns on all of
+    them, and the product is the single-rank product bit for bit."""
+    M, K, N, world, chunks = 120, 64, 24, 3, 2
+    mp.spawn(_worker_partial_push, args=(world, _free_port(), M, K, N, chunks, str(tmp_path)), nprocs=world, join=True)
+    rowptr, col, val = oracle_mod.make_csr(M, K, 0.05, seed=0)
+    B = np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32)
+    single = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"c_{r}.npy"), single), f"rank {r}"
+        assert (tmp_path / f"form_{r}.txt").read_text() == (tmp_path / "form_0.txt").read_text()
+        assert "push refused" in (tmp_path / f"fallbacks_{r}.txt").read_text()
+
+
+def _worker_partial_push(rank, world, port, M, K, N, chunks, out_dir):
+    for p in (str(REPO), str(REPO / "matrix-multiplication_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        import sharded
+
+        def map_peers(self, out):
+            # the hand-over every rank takes part in, then the per-rank open: fails on rank 1 only
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, ("handle of rank", self.rank), group=self.group)
+            if self.rank == 1:
+                raise RuntimeError("hipIpcOpenMemHandle: simulated refusal on this rank")
+            views = [out for _ in range(self.world)]  # (stand-ins: no IPC on the CPU; the probe's pushes land in the own buffer)
+            self._peer_out[(out.data_ptr(), tuple(out.shape))] = views
+            return views
+
+        sharded.ShardedSpMM._map_peers = map_peers
+        rowptr, col, val = oracle.make_csr(M, K, 0.05, seed=0)
+        B = np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32)
+
+        def cpu_mm(v, ci, rp, nnz, rows, K_, Bt, out):
+            out.copy_(torch.from_numpy(oracle.spmm_csr(rp.numpy(), ci.numpy(), v.numpy(), rows, K_, Bt.numpy())))
+
+        op = sharded.ShardedSpMM(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), M, K,
+                                 torch.device("cpu"), chunks=chunks, exchange="push", mm_op=cpu_mm)
+        C = op.forward(torch.from_numpy(B))
+        op.release_peers()
+        np.save(Path(out_dir) / f"c_{rank}.npy", C[:M].numpy())
+        (Path(out_dir) / f"form_{rank}.txt").write_text(op.exchange)
+        (Path(out_dir) / f"fallbacks_{rank}.txt").write_text(" | ".join(op.fallbacks))
+    finally:
+        dist.destroy_process_group()
