@@ -336,24 +336,27 @@ def test_single_process_layout(oracle_mod):
     assert sharded.shard_rowptr(rp, 3, 6, 4).tolist() == [0, 4, 4, 4]  # padded tail rows are empty
 
 
-def test_push_mapping_failure_on_one_rank_only_keeps_every_rank_in_step(tmp_path, oracle_mod):
+@pytest.mark.parametrize("fail_at", ["probe", "first_product"])
+def test_push_mapping_failure_on_one_rank_only_keeps_every_rank_in_step(tmp_path, oracle_mod, fail_at):
     """Round 5: the IPC push exchange maps every peer's buffer (a collective hand-over of handles, then a per-rank open that
     can fail on one rank alone — IPC limits, a refused mapping).  Here rank 1's mapping fails AFTER the hand-over while ranks
     0 and 2 succeed: the probe's two agreements must carry that to everybody, every rank ends on the same collective form,
     nobody is left waiting in a collective its peer never enters, release_peers() (a barrier per rank) returns on all of
-    them, and the product is the single-rank product bit for bit."""
+    them, and the product is the single-rank product bit for bit.  `first_product`: the probe's tiny buffer maps everywhere
+    (push is agreed) and the mapping of the real output buffer fails on rank 1 — forward() agrees on that too and every
+    rank moves to the collective forms before anything was exchanged."""
     M, K, N, world, chunks = 120, 64, 24, 3, 2
-    mp.spawn(_worker_partial_push, args=(world, _free_port(), M, K, N, chunks, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_partial_push, args=(world, _free_port(), M, K, N, chunks, str(tmp_path), fail_at), nprocs=world, join=True)
     rowptr, col, val = oracle_mod.make_csr(M, K, 0.05, seed=0)
     B = np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32)
     single = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"c_{r}.npy"), single), f"rank {r}"
         assert (tmp_path / f"form_{r}.txt").read_text() == (tmp_path / "form_0.txt").read_text()
-        assert "push refused" in (tmp_path / f"fallbacks_{r}.txt").read_text()
+        assert ("push refused" if fail_at == "probe" else "not mappable") in (tmp_path / f"fallbacks_{r}.txt").read_text()
 
 
-def _worker_partial_push(rank, world, port, M, K, N, chunks, out_dir):
+def _worker_partial_push(rank, world, port, M, K, N, chunks, out_dir, fail_at):
     for p in (str(REPO), str(REPO / "matrix-multiplication_amd")):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -366,9 +369,12 @@ def _worker_partial_push(rank, world, port, M, K, N, chunks, out_dir):
             # the hand-over every rank takes part in, then the per-rank open: fails on rank 1 only
             gathered = [None] * self.world
             dist.all_gather_object(gathered, ("handle of rank", self.rank), group=self.group)
-            if self.rank == 1:
+            if self.rank == 1 and (fail_at == "probe" or out.shape[0] > self.world):
                 raise RuntimeError("hipIpcOpenMemHandle: simulated refusal on this rank")
             views = [out for _ in range(self.world)]  # (stand-ins: no IPC on the CPU; the probe's pushes land in the own buffer)
+            if out.shape[0] == self.world:            # … so what the peers would have pushed into the probe buffer is put there
+                for r in range(self.world):
+                    out[r] = float(r + 1)
             self._peer_out[(out.data_ptr(), tuple(out.shape))] = views
             return views
 
