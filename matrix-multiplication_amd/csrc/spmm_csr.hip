@@ -1367,7 +1367,7 @@ int ic_panels(int64_t nnz, int32_t M, int32_t K, int32_t N, int64_t ldb) {
 //     × 128 10.2 → 8.0, 154368 × 278528 × 64 1.13 → 0.99, 55040 × 268800 × 64 0.63 → 0.50, 79872 × 34048 × 64 0.49 → 0.37,
 //     67328 × 90624 × 100 2.01 → 1.45); with fewer rows a pass is latency-bound and splitting it only multiplies that (16384 ×
 //     65536 × 128: one pass 0.31 ms, two panels 0.37; 12032 × 67328 × 64: 0.077 vs 0.153; 24832 × 25856 × 96: 0.094 vs 0.151);
-//     N = 32 never;
+//     N = 32 … 60 only for ≥ 96 Ki rows of ≥ 128 entries;
 //   * fewer than ≈ 10 Ki rows: only with B far beyond the L2s (≥ 32 MiB) and ≥ 7e8 multiply-adds in the product (4096 × 13056 ×
 //     256 with 393 per row, 12.8 MiB: one pass 0.065 ms, two panels 0.093; 4096 × 49920 × 192 with 478 per row: 0.092 vs
 //     0.141; 2304 × 59904 × 384 with 847 per row, 88 MiB: 0.296 → 0.232), and in at most 3 (< 4 Ki rows) or 4 (< 8 Ki) passes.
@@ -1379,7 +1379,13 @@ int l2_group_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
   if (M < 10240 && (b_bytes < 32.0 * mib || (double)nnz * (double)N < 7e8)) return 0;
   const long per_pass = 8 + 200000L / M;
   if (N <= 128) {
-    if (!(N >= 64 && nnz >= 48L * M && nnz >= 48L * K && b_bytes >= 8.0 * mib && b_bytes <= 128.0 * mib)) return 0;
+    if (N < 64)  // N = 32 … 60 (16-lane groups, half of them idle at 32): many long rows only — 117248 × 295936 × 32 with 210 per row
+                 // 0.50 → 0.41 ms, 290048 × 136192 × 32 with 343 per row 1.76 → 1.43; short rows lose (17 per row: 0.18 vs 0.34)
+      return (N >= 32 && M >= 98304 && nnz >= 128L * M && nnz >= 48L * K && b_bytes >= 16.0 * mib && b_bytes <= 128.0 * mib) ? 2 : 0;
+    if (!(nnz >= 48L * M && nnz >= 48L * K && b_bytes >= 8.0 * mib && b_bytes <= 128.0 * mib)) return 0;
+    // (between 64 and 128 columns from 24 MiB only: below that uniform columns are level — 271104 × 29952 × 96, 11 MiB: 2.21 vs
+    // 2.20 ms — and banded or power-law ones lose, 1.36 vs 1.58 / 1.49 vs 2.05)
+    if (N > 64 && N < 128 && b_bytes < 24.0 * mib) return 0;
     if (M < (N == 64 ? 28000 : 60000)) return 0;
     // rows long enough for two passes: 48 at N = 64, 96 at N = 128 (48 from 96 Ki rows; config C2 — 65536² × 128, 65 per row —
     // is level: 0.2516 one pass, 0.2476 in two panels, and stays one pass), 160 between (65536² × 96 with 100 per row: 0.249 vs 0.265)
@@ -1469,7 +1475,7 @@ int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32
   // 1.04 → 0.96) and loses on short rows (65536 × 16384 at 0.3 %, 49 per row: 0.21 vs 0.24).  N ≤ 128: two panels in a narrow band of B only
   // (l2_group_panels).  tools/probes/l2_regime_shapes*.sh, tools/plan_grid.py; profiles/r05_l2_regime_plans.log, r05_plan_grid.log.
   int gp = 0;
-  if (sh.vec4_ok && batch == 1 && N >= 36 && N <= 1024 && (N == 256 ? nnz >= 224L * M : !sh.wave_ok)) gp = l2_group_panels(M, K, N, ldb, nnz);
+  if (sh.vec4_ok && batch == 1 && N >= 32 && N <= 1024 && (N == 256 ? nnz >= 224L * M : !sh.wave_ok)) gp = l2_group_panels(M, K, N, ldb, nnz);
   if (gp > 0) lp = 0;
   // Moderate density: stage B through LDS (spmm_slab.hip) when its cost model beats the L2-blocked
   // row-split plans.  Fitted on MI355X (tools/bench_density.py, tools/bench_plans.py): a slab

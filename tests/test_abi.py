@@ -150,6 +150,8 @@ def test_every_variant_id_has_a_kernel_name_and_the_plan_query_needs_no_gpu(lib)
     assert plan(341 * 55040, 55040, 268800, 64) == 19 and plan(172 * 24832, 24832, 25856, 96) == 4  # … ≥ 28 K rows at N = 64, ≥ 60 K beyond
     assert plan(506 * 2816, 2816, 6400, 32) == 14 and plan(63 * 969984, 969984, 2304, 32) == 4      # N = 32, few long rows: 16 lanes per row
     assert plan(478 * 4096, 4096, 49920, 192) == 4                # few rows and a small product: one pass
+    assert plan(210 * 117248, 117248, 295936, 32) == 19 and plan(17 * 645120, 645120, 117248, 32) == 4   # N = 32: many LONG rows only
+    assert plan(260 * 271104, 271104, 29952, 96) == 4 and plan(624 * 67328, 67328, 90624, 100) == 19      # 64 < N < 128: from 24 MiB of B
     assert plan(1010 * 242176, 242176, 188928, 192) == 23         # up to 192 MiB of B
     assert plan(168 * 961024, 961024, 82176, 128) == 21 and plan(502 * 19712, 19712, 38400, 1024) == 12
     assert plan(393 * 4096, 4096, 13056, 256) == 4 and plan(38 * 1280, 1280, 14592, 256) == 2 and plan(847 * 2304, 2304, 59904, 384) == 20   # few rows: only where B is far beyond the L2s, and in three passes at most
