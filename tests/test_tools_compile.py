@@ -20,3 +20,14 @@ def test_shell_probes_only_call_scripts_that_exist():
     for sh in sorted((ROOT / "tools").glob("*.sh")) + sorted((ROOT / "tools" / "probes").glob("*.sh")):
         for rel in re.findall(r"python3? +((?:tools|benchmarks)/[\w/]+\.py|bench\.py)", sh.read_text()):
             assert (ROOT / rel).exists(), (sh.name, rel)
+
+
+def test_every_profile_of_this_round_is_indexed():
+    """profiles/README.md names the command behind every committed r05_* summary (brace / star patterns allowed)."""
+    import re
+    text = (ROOT / "profiles" / "README.md").read_text()
+    patterns = [re.escape(p).replace(r"\*", ".*").replace(r"\{fetch,write,dram\}", "(fetch|write|dram)")
+                for p in re.findall(r"`([^`]*r05_[^`]*)`", text)]
+    missing = [f.name for f in sorted((ROOT / "profiles").glob("r05_*"))
+               if not any(re.fullmatch(p, f.name) or re.fullmatch(p, f.stem) for p in patterns)]
+    assert not missing, missing
