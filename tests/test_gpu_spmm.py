@@ -1078,3 +1078,43 @@ def test_adaptive_panel_passes_fuzz_against_oracle(cmm, dev, oracle_mod):
             cmm.naive_spmm(t(val, dev), t(col, dev), t(rowptr, dev), len(val), M, K, d_B, C)
         assert np.array_equal(C.cpu().numpy().view(np.int32), want.view(np.int32)), (case, kind, M, K, N, d, half, plan)
     assert panel_plans >= cases // 2, panel_plans   # the fuzz is about the panel plans: most cases must reach them
+
+
+def test_adaptive_panel_product_is_graph_capturable_and_decides_per_replay(cmm, dev, oracle_mod):
+    """The locality probe and the passes that read its verdicts are plain launches on the caller's stream: a hipGraph
+    captures a panel-plan product once, and every REPLAY decides anew on the device — the same graph is replayed on a banded
+    matrix (the first pass takes everything) and, after the CSR arrays were overwritten in place, on a uniform one (the
+    passes stay passes); both results bit-identical to the oracle.  Reference: one kernel for any matrix,
+    src/naive_sparse_mm.cu:24-136."""
+    M, K, N, d = 12288, 16384, 256, 64
+    g = np.random.Generator(np.random.PCG64(31))
+    rows = np.repeat(np.arange(M, dtype=np.int64), d)
+
+    def matrix(banded):
+        u = g.integers(0, 1 << 30, size=M * d, dtype=np.int64)
+        cols = np.clip(rows * K // M + (u % 801) - 400, 0, K - 1) if banded else u % K
+        order = np.lexsort((cols, rows))
+        return cols[order].astype(np.int32), (g.random(M * d, dtype=np.float32) - 0.5)
+
+    rowptr = (np.arange(M + 1, dtype=np.int64) * d).astype(np.int32)
+    col_b, val_b = matrix(True)
+    col_u, val_u = matrix(False)
+    B = g.random((K, N), dtype=np.float32) - 0.5
+    d_rp, d_col, d_val, d_B = t(rowptr, dev), t(col_b, dev), t(val_b, dev), t(B, dev)
+    C = torch.full((M, N), float("nan"), device=dev)
+    assert cmm.spmm_plan(M * d, M, K, d_B, C)[1] == "spmm_wave_row_panel_kernel"
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # warm-up outside capture (sizes the extension's workspace)
+        cmm.naive_spmm(d_val, d_col, d_rp, M * d, M, K, d_B, C)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        cmm.naive_spmm(d_val, d_col, d_rp, M * d, M, K, d_B, C)
+    for col, val in ((col_b, val_b), (col_u, val_u), (col_b, val_b)):
+        d_col.copy_(torch.from_numpy(col))
+        d_val.copy_(torch.from_numpy(val))
+        C.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(C.cpu().numpy().view(np.int32), oracle_mod.spmm_csr(rowptr, col, val, M, K, B).view(np.int32))
