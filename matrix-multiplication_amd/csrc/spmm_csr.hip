@@ -1400,7 +1400,12 @@ int l2_group_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
   for (int c : {2, 3, 4, 6, 8})
     if ((c < want ? want - c : c - want) < (p < want ? want - p : p - want)) p = c;
   static const int kLower[9] = {0, 0, 0, 2, 3, 0, 4, 0, 6};
+  const int p_by_size = p;
   while (p >= 2 && nnz < per_pass * p * M) p = kLower[p];
+  // panels that short rows leave too large for the L2s only add passes (as in l2_panels): 339200 × 115456 × 192 with 40 per row,
+  // 85 MiB, in the four panels the rows pay for — 21 MiB each — leaves the L2s with 1.01 × its algorithmic bytes, one pass with
+  // 0.96 × (profiles/r05_l2_panel_traffic.log): 1.44 vs 1.40 ms, and 1.21 vs 0.97 with power-law columns
+  if (p >= 2 && p < p_by_size && b_bytes / p > 16.0 * mib) return 0;
   // a few thousand rows are fewer waves than the chip holds: every further pass is one more latency-bound launch (3072 × 20480 ×
   // 768 with 739 per row: 8 panels 0.365 ms, 3 panels 0.310; 2304 × 59904 × 384 with 847 per row: 0.278 vs 0.231; from 8 Ki rows
   // eight panels are the best again: 8192 × 131072 × 256 with 1311 per row 0.58 ms, four panels 0.74)

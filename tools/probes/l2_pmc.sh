@@ -1,14 +1,14 @@
 #!/bin/bash
 # Bytes that leave the L2s (FETCH_SIZE, gfx950: x 2 for 16-byte-per-lane reads; WRITE_SIZE) per product for pinned plans on one L2-regime
-# shape — what the column panels are for:   bash tools/probes/l2_pmc.sh M K N per_row "variant variant …"
+# shape — what the column panels are for:   bash tools/probes/l2_pmc.sh M K N per_row "variant variant …" [pattern]
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for v in $5; do
-  OUT=$R/gpurun_out/l2_pmc/$1_$2_$3_$4_v$v
+  OUT=$R/gpurun_out/l2_pmc/$1_$2_$3_$4_${6:-uniform}_v$v
   mkdir -p $OUT
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $R/tools/probes/l2_pmc_one.py $1 $2 $3 $4 $v > $OUT/$c.log 2>&1 || { echo "$c pass failed"; tail -5 $OUT/$c.log; exit 1; }
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $R/tools/probes/l2_pmc_one.py $1 $2 $3 $4 $v ${6:-uniform} > $OUT/$c.log 2>&1 || { echo "$c pass failed"; tail -5 $OUT/$c.log; exit 1; }
   done
   python3 - "$OUT" "$v" <<'PY'
 import csv, glob, sys, re
