@@ -200,37 +200,64 @@ def cpu_baseline(rowptr, col, val, M, K, B, N, gpu_C=None):
     return rec
 
 
+def shared_dir_for(nbytes):
+    """A directory every rank of this node can memory-map `nbytes` of input files from: /dev/shm when it has the room (a
+    container's default /dev/shm is 64 MB — C3's arrays are 1.9 GB), else $TMPDIR or /tmp, else None (every rank then
+    generates the inputs itself).  Free space is asked of the file system, with a tenth of headroom."""
+    import shutil
+    import tempfile
+    for cand in (Path("/dev/shm"), Path(os.environ.get("TMPDIR", tempfile.gettempdir()))):
+        try:
+            if cand.is_dir() and os.access(cand, os.W_OK) and shutil.disk_usage(cand).free >= 1.1 * nbytes + (16 << 20):
+                return cand
+        except OSError:
+            continue
+    return None
+
+
 def load_inputs(M, K, density, N, rank, world, dist):
     """The pinned synthetic inputs.  One rank: generated in place.  N ranks of one node: rank 0
-    generates ONCE and publishes the arrays under /dev/shm; the others wait at a barrier and memory-map them (each
-    then copies only its own row blocks to its GPU) — instead of N ranks each spending 2 s and 2 GB of host memory on
-    the same matrix on shared cores.  The files are removed by rank 0 when it exits."""
+    generates ONCE and publishes the arrays as files the others memory-map (each then copies only its own row blocks to
+    its GPU) — instead of N ranks each spending 2 s and 2 GB of host memory on the same matrix on shared cores.  Where the
+    files go is decided by rank 0 from the free space it finds (shared_dir_for) and told to the others; with no room
+    anywhere every rank generates its own copy (the generator is deterministic).  Rank 0 removes the files when it exits."""
     import synthetic
     if world == 1:
         rowptr, col, val = synthetic.make_csr(M, K, density, seed=0)
         return rowptr, col, val, synthetic.make_dense(K, N, seed=1)
     import atexit
     import warnings
-    shm = Path("/dev/shm") if Path("/dev/shm").is_dir() else Path(os.environ.get("TMPDIR", "/tmp"))
-    tag = f"mi_bench_{os.environ.get('MASTER_PORT', '0')}_{M}_{K}_{N}"
-    names = {k: shm / f"{tag}_{k}.npy" for k in ("rowptr", "col", "val", "B")}
+    where = [None]
     if rank == 0:
-        def cleanup():
-            for f in names.values():
-                try:
-                    f.unlink()
-                except OSError:
-                    pass
-        atexit.register(cleanup)
         rowptr, col, val = synthetic.make_csr(M, K, density, seed=0)
         B = synthetic.make_dense(K, N, seed=1)
-        for k, arr in (("rowptr", rowptr), ("col", col), ("val", val), ("B", B)):
-            np.save(names[k], arr)
-    dist.barrier()
+        arrays = {"rowptr": rowptr, "col": col, "val": val, "B": B}
+        shm = shared_dir_for(sum(a.nbytes for a in arrays.values()))
+        if shm is not None:
+            tag = f"mi_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getpid()}_{M}_{K}_{N}"
+            names = {k: shm / f"{tag}_{k}.npy" for k in arrays}
+
+            def cleanup():
+                for f in names.values():
+                    try:
+                        f.unlink()
+                    except OSError:
+                        pass
+            atexit.register(cleanup)
+            try:
+                for k, arr in arrays.items():
+                    np.save(names[k], arr)
+                where = [{k: str(v) for k, v in names.items()}]
+            except OSError:  # the room was gone after all: the others generate their own
+                cleanup()
+    dist.broadcast_object_list(where, src=0)  # (also the barrier behind rank 0's writes)
     if rank == 0:
         return rowptr, col, val, B
+    if where[0] is None:
+        rowptr, col, val = synthetic.make_csr(M, K, density, seed=0)
+        return rowptr, col, val, synthetic.make_dense(K, N, seed=1)
     warnings.filterwarnings("ignore", message="The given NumPy array is not writable")
-    return tuple(np.load(names[k], mmap_mode="r") for k in ("rowptr", "col", "val", "B"))
+    return tuple(np.load(where[0][k], mmap_mode="r") for k in ("rowptr", "col", "val", "B"))
 
 
 def self_launch(args):
@@ -432,12 +459,10 @@ def main():
         # by agreement — so both are part of the default trial.  Independent direct sends (p2p) can fail on some ranks
         # only; they join the trial only on request AND after sharded.probe_p2p (own process group, short timeout,
         # outcome agreed over the main group) succeeded everywhere.  A failed probe costs nothing but the option.
-        # The IPC push exchange (round 5: peers' C mapped through CUDA IPC, blocks copied straight into them on a side stream,
-        # one tiny all-reduce as the fence — no RCCL data movement) is probed and agreed at construction like the others, but
-        # joins the trial only on request (--exchange try-push / push): a 4-rank rehearsal on one GPU aborted once inside
-        # torch's IPC reference counting when several ranks released one producer's buffer at the same moment (see
-        # sharded.ShardedSpMM.release_peers, which now serialises the releases) — not something to meet for the first
-        # time on the driver's 8-GPU run.
+        # The IPC push exchange (peers' C mapped through hipIpc handles with explicit lifetimes, blocks copied straight into
+        # them on a side stream between an entry and an exit fence — no RCCL data movement) is probed and agreed at
+        # construction like the others, but joins the trial only on request (--exchange try-push / push): it has run on ONE
+        # GPU only (two and four processes), never across xGMI, and the driver's 8-GPU run is not the place for a first.
         exch_cands = {"auto": ("allgather", "alltoall"), "try-p2p": ("allgather", "alltoall"),
                       "try-push": ("allgather", "alltoall", "push")}.get(args.exchange, (args.exchange,))
         if args.exchange == "try-p2p":
@@ -600,8 +625,8 @@ def main():
                                                       "alltoall": "C exchanged by one list-form RCCL all_to_all per step (every block "
                                                                   "straight to every peer, in place)",
                                                       "p2p": "C exchanged by direct RCCL sends to every peer",
-                                                      "push": "C blocks copied straight into every peer's C through CUDA-IPC mappings "
-                                                              "(side-stream device copies, one tiny all-reduce as the fence)"}[op.exchange if world > 1 else "allgather"],
+                                                      "push": "C blocks copied straight into every peer's C through hipIpc mappings "
+                                                              "(side-stream device copies between an entry and an exit fence: two tiny all-reduces)"}[op.exchange if world > 1 else "allgather"],
                 "rccl_ranks": world if world > 1 else None,
                 "chunks": None if world == 1 else args.chunks,
                 "exchange": None if world == 1 else op.exchange,

@@ -489,6 +489,28 @@ int mi_coo_to_csr_host(int32_t M, int64_t nnz, const int32_t* coo_row,
                        const int32_t* coo_col, const float* coo_val,
                        int32_t* rowptr, int32_t* col_out, float* val_out);
 
+/* ------------------------------------------------------------------------ *
+ * Peer mappings (multi-GPU exchange) — NEW relative to the reference, which is
+ * single-device (`cudaSetDevice(0)`, src/sparse_mm.cu:295; no collective, no peer access).
+ * One process per GPU; rank A exports the allocation its C buffer lives in, the 64 handle bytes + the
+ * buffer's offset travel to the peers by whatever channel the host side has (torch.distributed's
+ * all_gather_object), every peer opens the handle and copies its row blocks straight into A's C
+ * (device-to-device over xGMI).  Lifetimes are EXPLICIT: a mapping lives from mi_ipc_open to the matching
+ * mi_ipc_close; opens of one handle in one process are counted (one hipIpcOpenMemHandle, closed with the
+ * last mi_ipc_close).  The exporter keeps the allocation alive until every peer has closed (the host side
+ * puts a barrier between the peers' closes and the free).  No stream argument: these are host calls.
+ *   mi_ipc_export : handle_out[MI_IPC_HANDLE_BYTES], *offset_out = dev_ptr − base of its allocation,
+ *                   *alloc_bytes_out (may be NULL) = size of that allocation
+ *   mi_ipc_open   : *base_out = the peer allocation's base in this process (add the offset)
+ *   mi_ipc_close  : drops one open of that handle; MI_EINVAL if it is not open here
+ *   mi_ipc_open_count : opens not yet closed in this process (tests: nothing is left mapped)
+ * ------------------------------------------------------------------------ */
+#define MI_IPC_HANDLE_BYTES 64
+int mi_ipc_export(const void* dev_ptr, void* handle_out, int64_t* offset_out, int64_t* alloc_bytes_out);
+int mi_ipc_open(const void* handle, void** base_out);
+int mi_ipc_close(const void* handle);
+int mi_ipc_open_count(void);
+
 /* Replaces dummy_kernel_launch (src/baseline_mm.cu:24-35): launches a 64×64
  * grid on the stream; each thread writes its global id into out[4096]
  * (the reference printf()s it). */

@@ -132,5 +132,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("naive_spmm_bias_ex", &naive_spmm_bias_ex, "naive_spmm_bias with the long-row rule pinned (-1 auto, 0 none, 1 split)");
   m.def("spmm_plan", &spmm_plan, "(variant, kernel name, launches, splits_long_rows) of the AUTO plan");
   m.def("validate_csr", &validate_csr, "opt-in check of CSR contents (offsets monotone, columns in range); raises");
+  m.def("ipc_export", &ipc_export, "(handle bytes, offset, allocation bytes) of a device buffer, for a peer process to map");
+  m.def("ipc_open", &ipc_open, "a peer's exported buffer as a tensor (valid until ipc_close of the handle)");
+  m.def("ipc_close", &ipc_close, "drop one open of a peer handle");
+  m.def("ipc_open_count", []() { return mi_ipc_open_count(); }, "peer mappings not yet closed in this process");
   m.def("long_row_threshold", &long_row_threshold, "rows with more non-zeros are 'long' (split rule)");
 }

@@ -45,13 +45,21 @@ Ways to exchange a step's blocks:
     send / recv pairs, i.e. the one-shard-per-link pattern below without leaving collective semantics (every rank
     calls it alike; nothing can half-fail the way independent sends can).  Probed and agreed like the in-place form;
     a build that refuses it (gloo has no list all_to_all) falls back to "allgather";
-  * exchange="push" (round 5): no RCCL data movement at all — every rank maps every peer's C buffer into its own address
-    space once (torch's CUDA IPC: `torch.multiprocessing.reductions.reduce_tensor`, handles exchanged with
-    `all_gather_object`) and, when a block is computed, COPIES it into its final position in every peer's C on a side
-    stream (device-to-device copies over xGMI, one shard per peer link, no collective kernel taking CUs from the
-    product); one tiny all-reduce behind the last copy is the completion fence (a rank's fence starts after its copies
-    and ends when every rank's has started: every push has landed everywhere).  Probed at construction on a tiny
-    buffer and agreed like the other forms; refused (CPU tensors, a build without CUDA IPC) → "alltoall";
+  * exchange="push": no RCCL data movement at all — every rank maps every peer's C buffer into its own address
+    space once (hipIpcGetMemHandle / hipIpcOpenMemHandle behind `custom_mm.ipc_export / ipc_open / ipc_close`, explicit
+    lifetimes; the 64 handle bytes travel by `all_gather_object`) and, when a block is computed, COPIES it into its final
+    position in every peer's C on a side stream (device-to-device copies over xGMI, one shard per peer link, no
+    collective kernel taking CUs from the product).  Two tiny all-reduces on that side stream order it against the
+    peers: an ENTRY fence before the first copy (it starts behind this rank's current stream and ends only once every
+    rank's has started — so every rank's readers of the PREVIOUS product, and whatever else it had enqueued on C, are
+    done before anybody overwrites a peer's rows: no cross-rank write-after-read) and an EXIT fence behind the last
+    copy (it ends once every rank's copies are done: all blocks have landed everywhere).
+    Only REGISTERED buffers are pushed into: `alloc_output()` / `register_output()` are COLLECTIVE under this exchange
+    (every rank calls them at the same point, like a constructor) and keep the buffer alive until `release_peers()`;
+    `forward()` without `out` uses one persistent registered buffer per width (the next product overwrites it), and an
+    unregistered `out` raises before any collective — there is no per-call, per-rank cache lookup that could send
+    some ranks into a mapping collective and others not.  Probed at construction on a tiny buffer and agreed like the
+    other forms; refused (CPU tensors, a build without IPC, a mapping some rank cannot open) → "alltoall";
   * exchange="p2p": every rank sends its block straight to every peer and receives each peer's block
     straight into its final position (one grouped batch of isend / irecv per step).  On a fully connected
     xGMI node that uses each of the 7 peer links for exactly one shard at a time — the pattern SURVEY.md
@@ -210,10 +218,15 @@ class ShardedSpMM:
         self._two_streams = {}  # N -> alternate the blocks over two streams?
         self._side = None
         self._scratch = {}     # (step, shape) -> out-of-place gather target (exchange="allgather_copy")
-        self._peer_out = {}    # (data_ptr, shape) of an output buffer -> every rank's view of it (exchange="push")
+        self._registered = {}  # (data_ptr, shape) of a REGISTERED output buffer -> its registration (exchange="push"); the
+                               # registration holds the buffer, so its address cannot be handed to another tensor meanwhile
+        self._own_out = {}     # N -> this operator's persistent registered output (forward() without `out` under "push")
+        self._serial = 0       # registrations so far (the same on every rank: registering is collective)
         self._push_stream = None
         self._fence = None
+        self._tag_check = None  # (pinned [max serial, max -serial] of the last entry fence, event): checked one call later
         self.fallbacks = []    # what was refused and replaced: reported by bench.py
+        self._last_refusal = ''
         if self.world > 1 and not self.modelled and dist.is_initialized():
             self._probe_exchange()
 
@@ -230,37 +243,40 @@ class ShardedSpMM:
         DistBackendError (communicator, transport) is not a refusal: it is re-raised.'''
         refusals = (RuntimeError, ValueError, TypeError, NotImplementedError)
         if self.exchange == "push":
-            # Every rank issues the SAME collectives whatever goes wrong on it (the handle exchange inside _map_peers, then
-            # two agreements): a rank that failed early must not leave its peers in a collective it never enters.
-            ok, why = True, ""
-            probe = views = None
-            try:
-                probe = torch.zeros((self.world, 4), device=self.device, dtype=torch.float32)
-                views = self._map_peers(probe)
-                for r in range(self.world):
-                    if r != self.rank:
-                        views[r][self.rank].copy_(torch.full((4,), float(self.rank + 1), device=self.device))
-                probe[self.rank] = float(self.rank + 1)
-                if self.device.type == "cuda":
-                    torch.cuda.synchronize(self.device)
-            except Exception as err:  # noqa: BLE001 — IPC is optional: whatever went wrong, the collectives remain
-                if isinstance(err, getattr(dist, "DistBackendError", ())):
-                    raise
-                ok, why = False, f"{type(err).__name__}: {str(err)[:120]}"
-            ok = self._agreed(ok)  # also the barrier behind every rank's pushes
+            # Every rank issues the SAME collectives whatever goes wrong on it (the registration's hand-over and agreement,
+            # two more agreements, the release's barrier): a rank that failed early never leaves its peers in a
+            # collective it does not enter.
+            probe = self._new_buffer(self.world, 4).zero_()
+            ok, why = self.register_output(probe, _quiet=True), ""
             if ok:
                 try:
-                    expect = torch.arange(1, self.world + 1, device=self.device, dtype=torch.float32)
-                    if not torch.equal(probe, expect.unsqueeze(1).expand(self.world, 4)):
-                        ok, why = False, "pushed rows did not arrive"
-                except Exception as err:  # noqa: BLE001
-                    ok, why = False, f"{type(err).__name__}: {str(err)[:120]}"
-                ok = self._agreed(ok)
-            del views
-            self.release_peers()  # consumers first, one rank at a time …
-            del probe             # … then the producer's own buffer
+                    reg = self._registered[self._key(probe)]
+                    for r in range(self.world):
+                        if r != self.rank:
+                            self._push_block(reg["views"][r][self.rank], torch.full((4,), float(self.rank + 1), device=self.device))
+                    probe[self.rank] = float(self.rank + 1)
+                    if self.device.type == "cuda":
+                        torch.cuda.synchronize(self.device)
+                except Exception as err:  # noqa: BLE001 — IPC is optional: whatever went wrong, the collectives remain
+                    if isinstance(err, getattr(dist, "DistBackendError", ())):
+                        raise
+                    ok, why = False, self._describe(err, "pushing the probe rows")
+                ok = self._agreed(ok)  # also the barrier behind every rank's pushes
+                if ok:
+                    try:
+                        expect = torch.arange(1, self.world + 1, device=self.device, dtype=torch.float32)
+                        if not torch.equal(probe, expect.unsqueeze(1).expand(self.world, 4)):
+                            ok, why = False, f"rank {self.rank}: pushed probe rows did not arrive"
+                    except Exception as err:  # noqa: BLE001
+                        ok, why = False, self._describe(err, "reading the probe rows")
+                    ok = self._agreed(ok)
+                self.release_peers()  # peers' mappings closed, a barrier, then the probe buffer may go
+                if not ok:
+                    self.fallbacks.append(f"push refused ({why or 'on a peer'}): alltoall from now on")
+            else:
+                self.fallbacks.append(f"push refused ({self._last_refusal}): alltoall from now on")
+            del probe
             if not ok:
-                self.fallbacks.append(f"push refused on some rank ({why or 'on a peer'}): alltoall from now on")
                 self.exchange = "alltoall"
         while self.exchange == "alltoall" or (self.exchange == "allgather" and self.split == "rows"):
             ok, why = True, ""
@@ -286,60 +302,157 @@ class ShardedSpMM:
             except refusals as err:
                 if isinstance(err, getattr(dist, "DistBackendError", ())):
                     raise
-                ok, why = False, f"{type(err).__name__}: {str(err)[:120]}"
+                ok, why = False, self._describe(err, f"probing {self.exchange}")
             if self._agreed(ok):
                 return
             nxt = "allgather" if self.exchange == "alltoall" else "allgather_copy"
             self.fallbacks.append(f"{self.exchange} refused on some rank ({why or 'on a peer'}): {nxt} from now on")
             self.exchange = nxt
 
-    def release_peers(self):
-        '''Drops this rank's views of its peers' buffers (exchange="push"), ONE RANK AT A TIME (collective: a barrier per rank).
-        torch's CUDA IPC keeps a reference-counter file per shared allocation and unlinks it when the count reaches zero; when
-        several consumers release one producer's storage at the same moment two of them can see zero, the second unlink fails
-        and the error is raised from a destructor — the process aborts (seen once in a 4-rank rehearsal on one GPU:
-        "could not unlink the shared memory file", at::RefcountedMapAllocator::close).  Call this before an operator that has
-        pushed is dropped and before the buffers it mapped are freed; bench.py does.'''
-        if self.world <= 1 or self.group is None:
-            self._peer_out.clear()
-            return
-        import gc
-        for r in range(self.world):
-            if r == self.rank:
-                self._peer_out.clear()
-                gc.collect()
-            dist.barrier(group=self.group)
+    def _describe(self, err, doing: str) -> str:
+        '''A failure as it goes into `fallbacks`: which rank, doing what, the WHOLE message (a HIP error text was once
+        cut at 120 characters and could no longer be told apart from its neighbours).'''
+        return f"rank {self.rank} {doing}: {type(err).__name__}: {err}"
 
-    def _map_peers(self, out: torch.Tensor):
-        '''Every rank's `out` as a tensor in THIS process (own entry: `out` itself), through torch's CUDA IPC; collective
-        (handles travel by all_gather_object), cached per output buffer.  CPU tensors have no such mapping: raises.'''
-        key = (out.data_ptr(), tuple(out.shape))
-        hit = self._peer_out.get(key)
-        if hit is not None:
-            return hit
-        payload, failure = None, None
+    @staticmethod
+    def _key(out: torch.Tensor):
+        return (out.data_ptr(), tuple(out.shape))
+
+    # -- the three calls the push exchange makes to map a peer's buffer (tests replace them on the CPU) ---------------
+    def _export_buffer(self, out: torch.Tensor):
+        '''What a peer needs to map `out`: (handle bytes, offset in the allocation); picklable.'''
+        if not out.is_cuda:
+            raise RuntimeError("push exchange needs device buffers (hipIpc mappings)")
+        import custom_mm
+        handle, offset, _ = custom_mm.ipc_export(out)
+        return (handle, int(offset))
+
+    def _open_peer(self, payload, shape):
+        import custom_mm
+        return custom_mm.ipc_open(payload[0], payload[1], list(shape), self.device.index or 0)
+
+    def _close_peer(self, payload):
+        import custom_mm
+        custom_mm.ipc_close(payload[0])
+
+    def _new_buffer(self, rows: int, cols: int) -> torch.Tensor:
+        '''Uninitialised [rows, cols] float32 storage for an output (tests hand out shared host memory here).'''
+        return torch.empty((rows, cols), device=self.device, dtype=torch.float32)
+
+    def _push_block(self, dst: torch.Tensor, src: torch.Tensor):
+        '''One block into its place in one peer's C (a device-to-device copy on the current stream).'''
+        dst.copy_(src, non_blocking=True)
+
+    def register_output(self, out: torch.Tensor, _quiet: bool = False) -> bool:
+        '''COLLECTIVE (exchange="push"): every rank hands in ITS buffer of the same shape at the same point; each exports its
+        buffer, the handles travel by all_gather_object, each maps every peer's buffer, and the outcome is agreed (every
+        rank learns every rank's failure text).  True: `out` is registered — forward(out=out) pushes into the peers'
+        buffers of THIS registration — and is kept alive by the operator until release_peers().  False (some rank could
+        not export or map): every rank has closed what it opened, nothing is registered, the reasons are in
+        `fallbacks`.  A communicator failure (DistBackendError) is not a refusal: it propagates.'''
+        key = self._key(out)
+        if key in self._registered:
+            return True
+        backend_error = getattr(dist, "DistBackendError", ())
+        payload, why = None, ""
         try:
-            if not out.is_cuda:
-                raise RuntimeError("push exchange needs device buffers (CUDA IPC)")
-            from torch.multiprocessing.reductions import reduce_tensor
-            payload = reduce_tensor(out)
-        except Exception as err:  # noqa: BLE001 — raised again below, AFTER the collective every peer is waiting in
-            failure = err
+            payload = self._export_buffer(out)
+        except Exception as err:  # noqa: BLE001 — told to everybody below, AFTER the collective every peer is waiting in
+            if isinstance(err, backend_error):
+                raise
+            why = self._describe(err, "exporting its buffer")
         gathered = [None] * self.world
-        dist.all_gather_object(gathered, payload, group=self.group)
-        if failure is not None:
-            raise failure
-        if any(g is None for g in gathered):
-            raise RuntimeError("push exchange: a peer could not export its buffer")
-        views = [out if r == self.rank else gathered[r][0](*gathered[r][1]) for r in range(self.world)]
-        for r, v in enumerate(views):
-            if tuple(v.shape) != tuple(out.shape):
-                raise RuntimeError(f"push exchange: rank {r}'s buffer has shape {tuple(v.shape)}, expected {tuple(out.shape)}")
-        self._peer_out[key] = views
-        return views
+        dist.all_gather_object(gathered, (payload, tuple(out.shape)), group=self.group)
+        views, opened = [None] * self.world, []
+        if not why:
+            for r in range(self.world):
+                if r == self.rank:
+                    views[r] = out
+                    continue
+                try:
+                    if gathered[r][0] is None:
+                        raise RuntimeError(f"rank {r} exported nothing")
+                    if tuple(gathered[r][1]) != tuple(out.shape):
+                        raise RuntimeError(f"rank {r} registers shape {tuple(gathered[r][1])}, this rank {tuple(out.shape)}")
+                    views[r] = self._open_peer(gathered[r][0], out.shape)
+                    opened.append(gathered[r][0])
+                except Exception as err:  # noqa: BLE001
+                    if isinstance(err, backend_error):
+                        raise
+                    why = self._describe(err, f"mapping rank {r}'s buffer")
+                    break
+        whys = [None] * self.world
+        dist.all_gather_object(whys, why, group=self.group)  # the agreement: everybody sees every failure, in full
+        if any(whys):
+            del views
+            for p in opened:
+                try:
+                    self._close_peer(p)
+                except Exception:  # noqa: BLE001 — already refusing; the first failure is the one reported
+                    pass
+            dist.barrier(group=self.group)  # every peer has closed before any owner frees its buffer
+            self._last_refusal = " | ".join(w for w in whys if w)
+            if not _quiet:
+                self.fallbacks.append(f"push: output buffer not mappable ({self._last_refusal})")
+            return False
+        self._serial += 1
+        tag = torch.tensor([self._serial, -self._serial], device=self.device, dtype=torch.int32)
+        self._registered[key] = {"out": out, "views": views, "opened": opened, "serial": self._serial, "tag": tag}
+        return True
+
+    def release_peers(self):
+        '''COLLECTIVE whenever the operator runs in a process group of more than one rank (the default group included):
+        every rank drops its views of its peers' registered buffers and closes the mappings (mi_ipc_close — each process
+        closes its own mapping; there is no shared reference counter to race on), then ONE barrier: every mapping of a
+        buffer is closed before its owner may free it.  The registrations (and the operator's own persistent outputs) are
+        forgotten.  Call it before an operator that has pushed is dropped; bench.py does.  Without a process group, or in a
+        one-rank group, nothing was mapped and nothing is issued.'''
+        self._check_tags(final=True)
+        regs, self._registered, self._own_out = self._registered, {}, {}
+        if self.world <= 1 or self.modelled or not dist.is_initialized():
+            return
+        errors = []
+        for reg in regs.values():
+            reg["views"] = None
+            for p in reg["opened"]:
+                try:
+                    self._close_peer(p)
+                except Exception as err:  # noqa: BLE001 — close the rest, keep the peers in step, report afterwards
+                    errors.append(self._describe(err, "closing a peer mapping"))
+        dist.barrier(group=self.group)
+        del regs
+        if errors:
+            raise RuntimeError("; ".join(errors))
+
+    def _check_tags(self, final: bool = False):
+        '''The entry fence carries (serial, −serial) of the registration this rank pushes into, reduced with MAX: the two
+        differ in magnitude iff two ranks handed in buffers of different registrations (a caller bug that would put rows
+        into a buffer its owner is not looking at).  Read one call later from pinned memory — never a synchronisation on
+        the product path.'''
+        if self._tag_check is None:
+            return
+        host, ev = self._tag_check
+        if ev is not None:
+            if not final and not ev.query():
+                return
+            ev.synchronize()
+        self._tag_check = None
+        if int(host[0]) != -int(host[1]):
+            raise RuntimeError(f"push exchange: the ranks pushed into buffers of different registrations (serials "
+                               f"{-int(host[1])} … {int(host[0])}): every rank must pass the buffer of the same alloc_output / "
+                               f"register_output call")
 
     def alloc_output(self, N: int) -> torch.Tensor:
-        return torch.empty((self.padded_rows, N), device=self.device, dtype=torch.float32)
+        '''A [padded_rows, N] output buffer.  Under exchange="push" (more than one rank) this is COLLECTIVE: the buffer is
+        registered with the peers; should that fail on any rank, every rank moves to the collective forms (settled by the
+        same probe as at construction) and the buffer is an ordinary one.'''
+        out = self._new_buffer(self.padded_rows, N)
+        if self.exchange == "push" and self.world > 1 and not self.modelled and dist.is_initialized():
+            if not self.register_output(out):
+                self.fallbacks.append("alltoall from now on")
+                self.exchange = "alltoall"
+                self._probe_exchange()  # (collective, on every rank alike) all_to_all itself may be refused
+        return out
 
     def _global_rule(self, B, out):
         '''Whether the single-GPU product of the WHOLE matrix with this B would sum rows beyond the
@@ -382,6 +495,17 @@ class ShardedSpMM:
     def _src(self, r):
         return dist.get_global_rank(self.group, r) if self.group is not None else r
 
+    def _on_push_stream(self, wait_for_current: bool = False, wait_for_event=None):
+        '''The side stream the pushes and their fences run on (CPU tensors, tests: no streams — program order).'''
+        import contextlib
+        if self.device.type != "cuda":
+            return contextlib.nullcontext()
+        if wait_for_current:
+            self._push_stream.wait_stream(torch.cuda.current_stream(self.device))
+        if wait_for_event is not None:
+            self._push_stream.wait_event(wait_for_event)
+        return torch.cuda.stream(self._push_stream)
+
     def forward(self, B: torch.Tensor, out: torch.Tensor = None, gather: bool = True,
                 force_collective: bool = False, compute: bool = True) -> torch.Tensor:
         '''Returns C [M, N] (a view of the padded buffer), complete on every rank
@@ -390,36 +514,50 @@ class ShardedSpMM:
         compute=False issues only the exchanges of a step (what is in `out` travels): the gather-only
         leg bench.py times beside compute-only and end-to-end.'''
         N = B.shape[1]
-        if out is None:
-            out = self.alloc_output(N)
-        assert out.shape == (self.padded_rows, N) and out.is_contiguous()
-        works, copies = [], []
         collective = gather and (self.world > 1 or force_collective)
         if collective and self.modelled:
             raise RuntimeError("a modelled layout has no process group: call forward(..., gather=False)")
-        peers = None
-        if collective and self.exchange == "push":
-            peers = self._peer_out.get((out.data_ptr(), tuple(out.shape)))
-            if peers is None:
-                # first use of this buffer: collective (handles exchanged), and agreed like the probe — a rank that cannot
-                # map a peer's buffer (IPC limits, a multi-GiB mapping refused) sends every rank to the all_to_all form
-                why = ""
-                try:
-                    peers = self._map_peers(out)
-                except Exception as err:  # noqa: BLE001
-                    if isinstance(err, getattr(dist, "DistBackendError", ())):
-                        raise
-                    peers, why = None, f"{type(err).__name__}: {str(err)[:120]}"
-                if not self._agreed(peers is not None):
-                    self._peer_out.pop((out.data_ptr(), tuple(out.shape)), None)
-                    self.fallbacks.append(f"push: output buffer not mappable on some rank ({why or 'on a peer'}): alltoall from now on")
-                    self.exchange = "alltoall"
-                    self._probe_exchange()  # (collective, on every rank alike) all_to_all itself may be refused: settles the form
-                    return self.forward(B, out=out, gather=gather, compute=compute, force_collective=force_collective)
-            if self._push_stream is None:
+        pushing = collective and self.exchange == "push" and self.world > 1
+        if out is None:
+            if pushing:
+                # the operator's persistent registered buffer for this width (first use: collective, on every rank alike);
+                # a failed registration has moved every rank to a collective form and the buffer is an ordinary one
+                if N not in self._own_out:
+                    self._own_out[N] = self.alloc_output(N)
+                out = self._own_out[N]
+                pushing = self.exchange == "push"
+            else:
+                out = self._new_buffer(self.padded_rows, N)
+        assert out.shape == (self.padded_rows, N) and out.is_contiguous()
+        works, copies = [], []
+        reg = peers = None
+        on_gpu = self.device.type == "cuda"
+        if pushing:
+            reg = self._registered.get(self._key(out))
+            if reg is None:
+                raise ValueError("exchange='push' moves blocks into REGISTERED buffers only: take `out` from alloc_output() or "
+                                 "pass it to register_output() first (both collective), or call forward() without `out`")
+            peers = reg["views"]
+            self._check_tags()  # the previous call's entry fence, if it has landed
+            if on_gpu and self._push_stream is None:
                 self._push_stream = torch.cuda.Stream(self.device)
+            if self._fence is None:
                 self._fence = torch.zeros(1, device=self.device, dtype=torch.int32)
-            self._push_stream.wait_stream(torch.cuda.current_stream(self.device))  # `out` as the caller left it
+                self._fence_in = torch.zeros(2, device=self.device, dtype=torch.int32)
+                self._fence_host = torch.zeros(2, dtype=torch.int32).pin_memory() if on_gpu else torch.zeros(2, dtype=torch.int32)
+            # ENTRY fence — behind everything this rank has enqueued on `out` so far (its readers of the previous product
+            # included), ahead of the first copy: it ends only once EVERY rank's has started, so nobody's rows are
+            # overwritten while their owner still reads them.  It delays the copies, not the kernels: the first block is
+            # still being computed while it runs.
+            with self._on_push_stream(wait_for_current=True):
+                self._fence_in.copy_(reg["tag"])
+                dist.all_reduce(self._fence_in, op=dist.ReduceOp.MAX, group=self.group)
+                self._fence_host.copy_(self._fence_in, non_blocking=True)
+                ev = None
+                if on_gpu:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                self._tag_check = (self._fence_host, ev)
         streams = None
         if compute and self._alternate(B, out):
             main = torch.cuda.current_stream(self.device)
@@ -436,15 +574,16 @@ class ShardedSpMM:
             if not collective:
                 return
             first = j * self.world
-            if self.exchange == "push":
+            if peers is not None:
                 if r1 > r0:
-                    done = torch.cuda.Event()
-                    done.record()  # the block is computed (current stream)
-                    with torch.cuda.stream(self._push_stream):
-                        self._push_stream.wait_event(done)
+                    done = None
+                    if on_gpu:
+                        done = torch.cuda.Event()
+                        done.record()  # the block is computed (current stream)
+                    with self._on_push_stream(wait_for_event=done):
                         for k in range(1, self.world):  # every rank starts with a different peer: one shard per link at a time
                             r = (self.rank + k) % self.world
-                            peers[r][r0:r1].copy_(mine, non_blocking=True)
+                            self._push_block(peers[r][r0:r1], mine)
                 return
             if self.exchange == "p2p":
                 ops = []
@@ -496,11 +635,12 @@ class ShardedSpMM:
         if streams is not None:
             streams[0].wait_stream(streams[1])
         if peers is not None:
-            # completion fence: a tiny all-reduce BEHIND this rank's copies on the push stream — it ends only once every
+            # EXIT fence: a tiny all-reduce BEHIND this rank's copies on the push stream — it ends only once every
             # rank's has started, i.e. once every rank's pushes are done: all blocks have landed in this rank's C
-            with torch.cuda.stream(self._push_stream):
+            with self._on_push_stream():
                 dist.all_reduce(self._fence, op=dist.ReduceOp.MAX, group=self.group)  # (zeros stay zeros)
-            torch.cuda.current_stream(self.device).wait_stream(self._push_stream)
+            if on_gpu:
+                torch.cuda.current_stream(self.device).wait_stream(self._push_stream)
         for w in works:
             w.wait()
         for span, scratch in copies:

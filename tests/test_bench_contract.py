@@ -155,3 +155,62 @@ def test_plain_multi_gpu_invocation_spawns_ranks_without_touching_hip():
     assert proc.stderr.count("bench.py needs an MI355X") >= 1, proc.stderr[-2000:]
     assert "parent: torch imported = False" in proc.stderr
     assert not [ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')]
+
+
+# --- N ranks share rank 0's generated inputs through files: where they go depends on the free space found -------------
+
+def test_shared_dir_needs_room_for_the_inputs(monkeypatch, tmp_path):
+    """A container's default /dev/shm is 64 MB and C3's arrays are 1.9 GB: the directory is chosen by free space (with
+    headroom), $TMPDIR is the second choice, and None — every rank generates its own inputs — the last."""
+    import collections
+    import shutil
+    bench = _load_bench()
+    usage = collections.namedtuple("usage", "total used free")
+    free = {"/dev/shm": 64 << 20, str(tmp_path): 10 << 30}
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    monkeypatch.setattr(shutil, "disk_usage", lambda p: usage(0, 0, free[str(p)]))
+    assert bench.shared_dir_for(8 << 20) == Path("/dev/shm")       # small inputs fit a 64 MB /dev/shm
+    assert bench.shared_dir_for(1900 << 20) == tmp_path            # C3's do not: $TMPDIR
+    free[str(tmp_path)] = 1 << 30
+    assert bench.shared_dir_for(1900 << 20) is None                # no room anywhere
+
+
+def _load_inputs_worker(rank, world, port, out_dir, no_room):
+    import os
+    import sys
+    import numpy as np
+    import torch.distributed as dist
+    repo = PROFILES.parent
+    for p in (str(repo), str(repo / "matrix-multiplication_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bench = _load_bench()
+        if no_room:
+            bench.shared_dir_for = lambda nbytes: None
+        rowptr, col, val, B = bench.load_inputs(300, 200, 0.05, 8, rank, world, dist)
+        kind = "generated" if isinstance(B, np.ndarray) and not isinstance(B, np.memmap) else "mapped"
+        np.savez(os.path.join(out_dir, f"in_{rank}.npz"), rowptr=rowptr, col=col, val=val, B=B, kind=kind)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("no_room", [False, True])
+def test_ranks_get_rank0s_inputs_with_or_without_room_for_the_files(tmp_path, no_room):
+    import socket
+    import sys
+    import numpy as np
+    import torch.multiprocessing as mp
+    sys.path.insert(0, str(PROFILES.parent / "matrix-multiplication_amd"))
+    import synthetic
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_load_inputs_worker, args=(2, port, str(tmp_path), no_room), nprocs=2, join=True)
+    rowptr, col, val = synthetic.make_csr(300, 200, 0.05, seed=0)
+    B = synthetic.make_dense(200, 8, seed=1)
+    for r in range(2):
+        got = np.load(tmp_path / f"in_{r}.npz")
+        assert all(np.array_equal(got[k], w) for k, w in (("rowptr", rowptr), ("col", col), ("val", val), ("B", B)))
+        assert str(got["kind"]) == ("generated" if (r == 0 or no_room) else "mapped")

@@ -187,3 +187,39 @@ def test_bench_multi_gpu_path_rehearsal(dev):
     rec = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{"metric"')][0])
     assert rec["config"]["exchange"] == "push" and rec["config"]["exchange_fallbacks"] == [], rec["config"]
     assert rec["config"]["gathered_C_equals_single_gpu_product"] is True and rec["config"]["speedup_vs_single_gpu_on_rank0"] > 0
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_push_exchange_between_processes_on_one_gpu_with_a_reader_between_products(dev, tmp_path, world):
+    """Round 6 (review: the push exchange's cross-rank write-after-read hazard, its torch-IPC abort, its per-call cache):
+    `world` processes on this one GPU map each other's C through mi_ipc_* (hipIpc handles, explicit lifetimes) and push
+    their blocks.  tests/push_rehearsal.py checks on every rank: the gathered product equals the single-GPU product bit
+    for bit; a reader of C that is still pending when the next product is issued sees the OLD product everywhere (the
+    entry fence orders the peers' pushes behind it); a second product opens no new mapping; a caller's registered buffer
+    works and an unregistered one is refused before any collective; after release_peers() nothing is left mapped."""
+    import json
+    import os
+    import socket
+    import subprocess
+    from pathlib import Path
+    repo = Path(__file__).resolve().parent.parent
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = tmp_path / "push.json"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port),
+                           str(repo / "tests" / "push_rehearsal.py"), str(out)],
+                          capture_output=True, text=True, timeout=600, env=env)
+    assert proc.returncode == 0, proc.stderr[-4000:]
+    recs = json.loads(out.read_text())
+    assert len(recs) == world
+    for rec in recs:
+        assert rec["exchange"] == "push" and rec["fallbacks"] == [] and rec["fallbacks_end"] == [], rec
+        assert rec["first_product_bit_exact"] and rec["second_product_bit_exact"] and rec["callers_buffer_bit_exact"], rec
+        assert rec["reader_saw_the_next_product"] == [False, False, False], rec
+        assert rec["unregistered_refused"] is True
+        # the probe's mappings were closed; one buffer = world-1 mappings, more products add none; release closes all
+        assert rec["open_after_probe"] == 0 and rec["open_after_first_product"] == world - 1
+        assert rec["open_after_more_products"] == world - 1 and rec["open_after_release"] == 0, rec

@@ -336,15 +336,138 @@ def test_single_process_layout(oracle_mod):
     assert sharded.shard_rowptr(rp, 3, 6, 4).tolist() == [0, 4, 4, 4]  # padded tail rows are empty
 
 
+def _shared_buffer_stand_ins(sharded, out_dir, rank, log=None):
+    """CPU stand-ins for the three mapping calls of the push exchange (hipIpc on the GPU): output buffers are float32
+    tensors over shared files, `export` hands out the file's path, `open` maps the same file in the peer.  Everything else
+    — registration, agreements, fences, the copies' index arithmetic, release — is the product code."""
+    paths, counter = {}, [0]
+
+    def new_buffer(self, rows, cols):
+        counter[0] += 1
+        path = os.path.join(out_dir, f"buf_r{rank}_{counter[0]}.bin")
+        t = torch.from_file(path, shared=True, size=max(rows * cols, 1), dtype=torch.float32)[:rows * cols].view(rows, cols)
+        paths[t.data_ptr()] = path
+        return t
+
+    def export(self, out):
+        return ("file", paths[out.data_ptr()])
+
+    def open_peer(self, payload, shape):
+        n = int(np.prod(shape))
+        if log is not None:
+            log.append(("open", payload[1]))
+        return torch.from_file(payload[1], shared=True, size=max(n, 1), dtype=torch.float32)[:n].view(*shape)
+
+    def close_peer(self, payload):
+        if log is not None:
+            log.append(("close", payload[1]))
+
+    sharded.ShardedSpMM._new_buffer = new_buffer
+    sharded.ShardedSpMM._export_buffer = export
+    sharded.ShardedSpMM._open_peer = open_peer
+    sharded.ShardedSpMM._close_peer = close_peer
+
+
+def _worker_push(rank, world, port, M, K, N, chunks, out_dir, split):
+    for p in (str(REPO), str(REPO / "matrix-multiplication_amd")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        import sharded
+        log = []
+        _shared_buffer_stand_ins(sharded, out_dir, rank, log)
+        real_all_reduce, real_barrier, real_push = dist.all_reduce, dist.barrier, sharded.ShardedSpMM._push_block
+
+        def all_reduce(t, *a, **k):
+            log.append(("all_reduce", tuple(t.shape)))
+            return real_all_reduce(t, *a, **k)
+
+        def barrier(*a, **k):
+            log.append(("barrier", k.get("group")))
+            return real_barrier(*a, **k)
+
+        def push(self, dst, src):
+            log.append(("push", tuple(src.shape)))
+            return real_push(self, dst, src)
+        dist.all_reduce, dist.barrier, sharded.ShardedSpMM._push_block = all_reduce, barrier, push
+
+        rowptr, col, val = _skewed_csr(M, K) if split == "nnz" else oracle.make_csr(M, K, 0.05, seed=0)
+        B1 = torch.from_numpy(np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32))
+        B2 = torch.from_numpy(np.random.Generator(np.random.PCG64(2)).random((K, N), dtype=np.float32))
+        op = sharded.ShardedSpMM(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), M, K, "cpu",
+                                 chunks=chunks, mm_op=_oracle_mm_op, split=split, exchange="push")   # group=None: the default group
+        assert op.exchange == "push" and op.fallbacks == [], op.fallbacks
+        # the probe registered a tiny buffer, pushed, released: its mappings are closed, one barrier behind the closes
+        assert [e[0] for e in log].count("open") == world - 1 and [e[0] for e in log].count("close") == world - 1
+        assert ("barrier", None) in log and op._registered == {}
+        del log[:]
+        C = op.forward(B1)                       # the operator's own persistent registered buffer
+        kinds = [e[0] for e in log]
+        # entry fence (2 ints) BEFORE the first copy, exit fence (1 int) behind the last one
+        assert ("all_reduce", (2,)) in log and ("all_reduce", (1,)) in log
+        pushes = [i for i, k in enumerate(kinds) if k == "push"]
+        if pushes:
+            assert log.index(("all_reduce", (2,))) < pushes[0] and pushes[-1] < log.index(("all_reduce", (1,)))
+        np.save(os.path.join(out_dir, f"c_{rank}.npy"), C.numpy().copy())
+        opens_after_first = kinds.count("open")
+        assert opens_after_first == world - 1    # the buffer was mapped once …
+        del log[:]
+        C2 = op.forward(B2)                      # … and a second product maps nothing, pushes into the same registration
+        assert C2.data_ptr() == C.data_ptr() and "open" not in [e[0] for e in log] and "barrier" not in [e[0] for e in log]
+        np.save(os.path.join(out_dir, f"c2_{rank}.npy"), C2.numpy().copy())
+        # a caller's own buffer: an unregistered one is refused before any collective, a registered one is pushed into
+        mine = op._new_buffer(op.padded_rows, N)
+        del log[:]
+        with pytest.raises(ValueError, match="REGISTERED"):
+            op.forward(B1, out=mine)
+        assert log == []
+        assert op.register_output(mine) and op.register_output(mine)   # (the second call: already registered, no collective)
+        C3 = op.forward(B1, out=mine)
+        np.save(os.path.join(out_dir, f"c3_{rank}.npy"), C3.numpy().copy())
+        # ranks that hand in buffers of DIFFERENT registrations are told so (one call later, or at release)
+        other = op._new_buffer(op.padded_rows, N)
+        assert op.register_output(other)
+        op.forward(B1, out=mine if rank == 0 else other)
+        with pytest.raises(RuntimeError, match="different registrations"):
+            op.release_peers()
+        del log[:]
+        op.release_peers()      # (the registrations are still there: the check raised before anything was dropped)
+        kinds = [e[0] for e in log]
+        # release on the DEFAULT group: every mapping closed (3 buffers x the peers), then exactly one barrier
+        assert kinds.count("close") == 3 * (world - 1) and kinds.count("barrier") == 1 and kinds[-1] == "barrier", log
+        assert op._registered == {} and op._own_out == {}
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("M,chunks,split,world", [(96, 2, "rows", 2), (101, 3, "nnz", 2), (90, 2, "rows", 3), (7, 4, "rows", 2)])
+def test_push_exchange_end_to_end_on_shared_memory_stand_ins(tmp_path, oracle_mod, M, chunks, split, world):
+    """Round 6: the whole push exchange over gloo with the hipIpc calls replaced by shared files — construction probe,
+    collective registration (the default group: group=None), entry fence before the first copy, exit fence behind the
+    last, a second product into the same registration without a new mapping, an unregistered `out` refused before any
+    collective, buffers of different registrations detected, and release_peers() closing every mapping behind ONE
+    barrier on the default group (round 5's release returned early there and issued none)."""
+    K, N = 64, 24
+    mp.spawn(_worker_push, args=(world, _free_port(), M, K, N, chunks, str(tmp_path), split), nprocs=world, join=True)
+    rowptr, col, val = _skewed_csr(M, K) if split == "nnz" else oracle_mod.make_csr(M, K, 0.05, seed=0)
+    for name, seed in (("c", 1), ("c2", 2), ("c3", 1)):
+        B = np.random.Generator(np.random.PCG64(seed)).random((K, N), dtype=np.float32)
+        single = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+        for r in range(world):
+            assert np.array_equal(np.load(tmp_path / f"{name}_{r}.npy"), single), f"{name}, rank {r}"
+
+
 @pytest.mark.parametrize("fail_at", ["probe", "first_product"])
 def test_push_mapping_failure_on_one_rank_only_keeps_every_rank_in_step(tmp_path, oracle_mod, fail_at):
-    """Round 5: the IPC push exchange maps every peer's buffer (a collective hand-over of handles, then a per-rank open that
-    can fail on one rank alone — IPC limits, a refused mapping).  Here rank 1's mapping fails AFTER the hand-over while ranks
-    0 and 2 succeed: the probe's two agreements must carry that to everybody, every rank ends on the same collective form,
-    nobody is left waiting in a collective its peer never enters, release_peers() (a barrier per rank) returns on all of
-    them, and the product is the single-rank product bit for bit.  `first_product`: the probe's tiny buffer maps everywhere
-    (push is agreed) and the mapping of the real output buffer fails on rank 1 — forward() agrees on that too and every
-    rank moves to the collective forms before anything was exchanged."""
+    """The IPC push exchange maps every peer's buffer (a collective hand-over of handles, then a per-rank open that can
+    fail on one rank alone — IPC limits, a refused mapping).  Here rank 1's open fails AFTER the hand-over while ranks 0
+    and 2 succeed: the registration's agreement must carry that to everybody WITH rank 1's full message, every rank
+    closes what it had opened and ends on the same collective form, nobody is left waiting in a collective its peer never
+    enters, and the product is the single-rank product bit for bit.  `first_product`: the probe's tiny buffer maps
+    everywhere (push is agreed) and the mapping of the real output buffer fails on rank 1 — alloc_output agrees on that
+    too and every rank moves to the collective forms before anything was exchanged."""
     M, K, N, world, chunks = 120, 64, 24, 3, 2
     mp.spawn(_worker_partial_push, args=(world, _free_port(), M, K, N, chunks, str(tmp_path), fail_at), nprocs=world, join=True)
     rowptr, col, val = oracle_mod.make_csr(M, K, 0.05, seed=0)
@@ -352,8 +475,12 @@ def test_push_mapping_failure_on_one_rank_only_keeps_every_rank_in_step(tmp_path
     single = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"c_{r}.npy"), single), f"rank {r}"
-        assert (tmp_path / f"form_{r}.txt").read_text() == (tmp_path / "form_0.txt").read_text()
-        assert ("push refused" if fail_at == "probe" else "not mappable") in (tmp_path / f"fallbacks_{r}.txt").read_text()
+        assert (tmp_path / f"form_{r}.txt").read_text() == (tmp_path / "form_0.txt").read_text() == "allgather"
+        text = (tmp_path / f"fallbacks_{r}.txt").read_text()
+        assert ("push refused" if fail_at == "probe" else "not mappable") in text
+        # every rank knows WHO failed doing WHAT, and the message is whole (round 5 cut it at 120 characters)
+        assert "rank 1 mapping rank 0's buffer: RuntimeError: hipIpcOpenMemHandle: simulated refusal" in text
+        assert "x" * 200 in text
 
 
 def _worker_partial_push(rank, world, port, M, K, N, chunks, out_dir, fail_at):
@@ -364,30 +491,24 @@ def _worker_partial_push(rank, world, port, M, K, N, chunks, out_dir, fail_at):
     try:
         import oracle
         import sharded
+        log = []
+        _shared_buffer_stand_ins(sharded, out_dir, rank, log)
+        real_open = sharded.ShardedSpMM._open_peer
 
-        def map_peers(self, out):
-            # the hand-over every rank takes part in, then the per-rank open: fails on rank 1 only
-            gathered = [None] * self.world
-            dist.all_gather_object(gathered, ("handle of rank", self.rank), group=self.group)
-            if self.rank == 1 and (fail_at == "probe" or out.shape[0] > self.world):
-                raise RuntimeError("hipIpcOpenMemHandle: simulated refusal on this rank")
-            views = [out for _ in range(self.world)]  # (stand-ins: no IPC on the CPU; the probe's pushes land in the own buffer)
-            if out.shape[0] == self.world:            # … so what the peers would have pushed into the probe buffer is put there
-                for r in range(self.world):
-                    out[r] = float(r + 1)
-            self._peer_out[(out.data_ptr(), tuple(out.shape))] = views
-            return views
-
-        sharded.ShardedSpMM._map_peers = map_peers
+        def open_peer(self, payload, shape):
+            # the per-rank open: fails on rank 1 only (the probe's buffer has `world` rows)
+            if self.rank == 1 and (fail_at == "probe" or shape[0] > self.world):
+                raise RuntimeError("hipIpcOpenMemHandle: simulated refusal on this rank " + "x" * 200)
+            return real_open(self, payload, shape)
+        sharded.ShardedSpMM._open_peer = open_peer
         rowptr, col, val = oracle.make_csr(M, K, 0.05, seed=0)
         B = np.random.Generator(np.random.PCG64(1)).random((K, N), dtype=np.float32)
-
-        def cpu_mm(v, ci, rp, nnz, rows, K_, Bt, out):
-            out.copy_(torch.from_numpy(oracle.spmm_csr(rp.numpy(), ci.numpy(), v.numpy(), rows, K_, Bt.numpy())))
-
         op = sharded.ShardedSpMM(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), M, K,
-                                 torch.device("cpu"), chunks=chunks, exchange="push", mm_op=cpu_mm)
+                                 torch.device("cpu"), chunks=chunks, exchange="push", mm_op=_oracle_mm_op)
+        assert op.exchange == ("allgather" if fail_at == "probe" else "push")
         C = op.forward(torch.from_numpy(B))
+        # whatever a rank had opened before the refusal was agreed is closed again
+        assert [e[0] for e in log].count("open") == [e[0] for e in log].count("close")
         op.release_peers()
         np.save(Path(out_dir) / f"c_{rank}.npy", C[:M].numpy())
         (Path(out_dir) / f"form_{rank}.txt").write_text(op.exchange)
