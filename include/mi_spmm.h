@@ -188,6 +188,40 @@ int mi_spmm_variant_launches(int variant);
 const char* mi_spmm_variant_name(int variant);
 
 /* ------------------------------------------------------------------------ *
+ * Row schedules — the inspector's format for degree-skewed matrices (power-law row lengths: adjacency matrices).
+ * Counterpart of what the reference's inspector builds once per matrix (TiledSpMM_inspect: footprint tiles + warp-sliced
+ * ELL, src/sparse_mm.cu:137-368) and of the merge-spmm lineage of its kernel (src/naive_sparse_mm.cu:20-21); here the CSR
+ * arrays stay as they are and the inspector builds the ORDER in which rows are handed to waves:
+ *     order[slot] = row, rows by descending length class (exact below 32 entries, eight classes per octave above).
+ * Longest rows first (no serial chain left for the end of the grid), rows sharing a wave / workgroup alike in length, and
+ * the rows beyond a heavy length — chosen from nnz, see mi_spmm_schedule_info — in a launch of their own with more gathers in
+ * flight per row on the schedule's side stream, beside the launch(es) of the rest.  Every row's fmaf chain is that of the
+ * unscheduled product: mi_spmm_csr_scheduled_f32 returns the SAME BITS as mi_spmm_csr_ex_f32 for every plan and long-row
+ * mode (plans that cannot take a row order — column tiles, MI_SPMM_SLAB, MI_SPMM_LDS_B, MI_SPMM_NARROW — run unscheduled).
+ *   mi_spmm_schedule_create: `order` (device, M ints) is caller-owned and must outlive the schedule; workspace ≥
+ *     mi_spmm_schedule_workspace_bytes(M) is only used during the call.  Builds on `stream` and SYNCHRONISES it (reads the
+ *     1 KiB class table back): inspection time, not capturable.  N: the dense width the schedule will mostly be used with.
+ *   Products on one schedule must be ordered on one stream (they share its side stream and fork / join events).
+ *   mi_spmm_schedule_info: info[8] = {rows, heavy slots, heavy length, non-empty classes, lower bound of the longest row,
+ *     flags (1: has a side stream; 2: ACTIVE — an order costs the locality of consecutive rows, so a matrix of short, alike
+ *     rows keeps its products unscheduled: active with heavy rows, or mean ≥ 16 entries and longest ≥ 1.5 × mean), nnz, N}.
+ *   mi_spmm_schedule_set_heavy: another heavy length (0: every row; ≥ the longest: none) / every launch in line on the caller's
+ *     stream instead of the rest beside the heavy launch — tests and A/B measurements; makes the schedule active.
+ *   mi_spmm_csr_scheduled_f32: mi_spmm_csr_ex_variant_f32 (variant MI_SPMM_AUTO = by plan) on the schedule.
+ * ------------------------------------------------------------------------ */
+typedef struct mi_spmm_schedule mi_spmm_schedule_t;
+size_t mi_spmm_schedule_workspace_bytes(int32_t M);
+int mi_spmm_schedule_create(const int32_t* rowptr, int32_t M, int64_t nnz, int32_t N, int32_t* order, void* workspace,
+                            size_t workspace_bytes, mi_stream_t stream, mi_spmm_schedule_t** out);
+int mi_spmm_schedule_destroy(mi_spmm_schedule_t* schedule);
+int mi_spmm_schedule_info(const mi_spmm_schedule_t* schedule, int64_t* info);
+int mi_spmm_schedule_set_heavy(mi_spmm_schedule_t* schedule, int32_t heavy_len, int use_side_stream);
+int mi_spmm_csr_scheduled_f32(const mi_spmm_schedule_t* schedule, int variant, const int32_t* rowptr, const int32_t* col,
+                              const float* val, int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,
+                              const float* bias, float* C, int64_t ldc, int long_rows, void* workspace,
+                              size_t workspace_bytes, mi_stream_t stream);
+
+/* ------------------------------------------------------------------------ *
  * Batched form — `batch` independent products in ONE launch:
  *   C[b] (M×N) = A[b] (M×K, CSR) · B[b] (K×N).
  * rowptr is [batch, M+1]; entry rowptr[b*(M+1)+r] indexes into col/val with

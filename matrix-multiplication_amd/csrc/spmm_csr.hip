@@ -23,181 +23,13 @@
 //  * narrower N: G = N/4 lanes per row and 64/G rows per wave (col/val are
 //    broadcast inside the G-lane group with ds_bpermute); arbitrary N or
 //    unaligned operands: the same kernel with one float per lane.
-#include "mi_common.h"
-#include "mi_lanes.h"
+#include "spmm_device.h"
+#include "spmm_internal.h"
 
 namespace {
 
-using mi::f32x4;
-
-__device__ __forceinline__ f32x4 fma4(float a, f32x4 x, f32x4 acc) {
-  acc.x = __builtin_fmaf(a, x.x, acc.x);
-  acc.y = __builtin_fmaf(a, x.y, acc.y);
-  acc.z = __builtin_fmaf(a, x.z, acc.z);
-  acc.w = __builtin_fmaf(a, x.w, acc.w);
-  return acc;
-}
-
-// ---------------------------------------------------------------------------
-// Rows beyond the long-row threshold (see "Skewed matrices" below) are skipped by the kernels of this file and
-// LISTED by them on the way: the wave (or lane group) that meets such a row appends it to the list in the
-// caller's workspace, so a product costs no separate scan of rowptr — main kernel + one follow-up launch that
-// sums the listed rows (or finds the list empty and exits).
-// Workspace (ints): [0] rows listed, [1] workgroup slots handed out, [2] partial-row slots handed out,
-// [3] follow-up workgroups done; then cap_e entries of 8 ints {row, slot base, S, partial base, arrivals, –, –, –};
-// then cap_s slot → entry indices; then (16-B aligned) cap_p × N floats of partial rows.
-// ---------------------------------------------------------------------------
-constexpr int kLongRow = 8192;
-constexpr int kLongChunk = 1024;
-constexpr int kLongWaves = 16;
-constexpr int kLongSplitShift = 15;  // one workgroup per 32768 non-zeros of a row …
-constexpr int kLongSplitMax = 128;   // … up to 128 workgroups
-constexpr int kLongEnt = 8;          // ints per list entry
-
-struct LongArg {
-  int thresh;               // rows with more non-zeros are left to spmm_long_rows_kernel
-  int cap_e, cap_s, cap_p;  // list capacities (hold for any rowptr consistent with nnz)
-  int* ws;                  // the list; nullptr: skip only (the list was prepared beforehand) or nothing is skipped
-  const int* adapt;         // kAdaptSlots verdicts of spmm_locality_probe_kernel (L2-level panel plans with a workspace), or nullptr
-};
-
-// ---------------------------------------------------------------------------
-// Structure-aware panels without a host round trip (round 5).  The L2-level panel plans are chosen from the SHAPE alone; on a
-// matrix whose rows gather from a narrow band of B (banded / block-diagonal structure) one pass is already served by the
-// caches and P panels only add passes (tools/plan_grid.py --pattern band1k: up to 2 × behind one pass).  When the caller
-// gave a workspace, a probe launch ahead of the passes looks at kAdaptSlots windows of kAdaptWindow consecutive rows
-// (first / last four columns of every fourth row) and writes one verdict per window: "the rows of B this window touches span
-// ≤ 0.4 of B and ≤ 128 MiB" (uniform columns span all of B; a band of ± 1 K columns a few per cent of it).  Every workgroup of the panel kernels reads the verdicts (uniform scalar loads): with
-// ≥ 7/8 of the windows local the FIRST pass takes every column (and the bias) and the other passes return at once — the
-// one-pass chain, the same bits, decided on the device: no read-back, graph-capturable, the launches stay as they were.
-// ---------------------------------------------------------------------------
-constexpr int kAdaptSlots = 16;
-constexpr int kAdaptWindow = 2048;
-
-__device__ __forceinline__ bool adapt_says_local(const int* __restrict__ verdicts) {  // wave-uniform
-  int s = 0;
-#pragma unroll
-  for (int i = 0; i < kAdaptSlots; ++i) s += __builtin_amdgcn_readfirstlane(verdicts[i]);
-  return 8 * s >= 7 * kAdaptSlots;
-}
-
-__global__ __launch_bounds__(256) void spmm_locality_probe_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
-                                                                  int M, long ldb, double b_bytes, int* __restrict__ verdicts) {
-  __shared__ int s_mn[4], s_mx[4];
-  const int w = blockIdx.x;
-  const int win = M < kAdaptWindow ? M : kAdaptWindow;
-  const long first = kAdaptSlots > 1 ? (long)w * (M - win) / (kAdaptSlots - 1) : 0;
-  int mn = 0x7fffffff, mx = -1;
-  // every fourth row of the window, two rows per thread, all of a thread's loads of one kind in flight together: the launch is
-  // two dependent trips to memory (offsets, then columns) long — ≈ 3 µs ahead of a product of ≥ 50 µs
-  constexpr int kRows = 2;
-  int s0[kRows], n0[kRows];
-#pragma unroll
-  for (int i = 0; i < kRows; ++i) {
-    const int r = 4 * ((int)threadIdx.x + 256 * i);
-    s0[i] = 0, n0[i] = 0;
-    if (r < win) {
-      s0[i] = rowptr[first + r];
-      n0[i] = rowptr[first + r + 1] - s0[i];
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < kRows; ++i) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {  // rows need not ascend: a few entries from either end
-      if (j < n0[i]) {
-        const int a = col[s0[i] + j], b = col[s0[i] + n0[i] - 1 - j];
-        mn = a < mn ? a : mn;
-        mn = b < mn ? b : mn;
-        mx = a > mx ? a : mx;
-        mx = b > mx ? b : mx;
-      }
-    }
-  }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    const int a = __shfl_xor(mn, d, 64), b = __shfl_xor(mx, d, 64);
-    mn = a < mn ? a : mn;
-    mx = b > mx ? b : mx;
-  }
-  if ((threadIdx.x & 63) == 0) s_mn[threadIdx.x >> 6] = mn, s_mx[threadIdx.x >> 6] = mx;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < 4; ++i) {
-      mn = s_mn[i] < mn ? s_mn[i] : mn;
-      mx = s_mx[i] > mx ? s_mx[i] : mx;
-    }
-    const double span_bytes = mx >= mn ? ((double)mx - (double)mn + 1.0) * (double)ldb * 4.0 : 0.0;
-    verdicts[w] = (span_bytes <= 0.4 * b_bytes && span_bytes <= 128.0 * 1048576.0) ? 1 : 0;
-  }
-}
-
-// One lane per long row.  The order of the list does not matter: every slot is a fixed function of (row, g).
-__device__ __forceinline__ void long_list_append(const LongArg& la, int row, int len) {
-  int* ws = la.ws;
-  if (ws == nullptr) return;
-  int S = len >> kLongSplitShift;
-  S = S < 1 ? 1 : (S > kLongSplitMax ? kLongSplitMax : S);
-  const int e = atomicAdd(&ws[0], 1);
-  const int sb = atomicAdd(&ws[1], S);
-  const int pb = S > 1 ? atomicAdd(&ws[2], S) : 0;
-  // the caps hold for any rowptr consistent with nnz; a lying rowptr must not write out of bounds, and an
-  // entry below the count must never hold garbage (its S = 0 makes every slot that points at it a no-op)
-  if (e >= la.cap_e) return;
-  const bool fits = sb + S <= la.cap_s && (S <= 1 || pb + S <= la.cap_p);
-  int* ent = ws + 4 + kLongEnt * (long)e;
-  ent[0] = row;
-  ent[1] = sb;
-  ent[2] = fits ? S : 0;
-  ent[3] = pb;
-  ent[4] = 0;  // workgroups of this row that have delivered their partial sums
-  if (!fits) return;
-  int* owner = ws + 4 + kLongEnt * (long)la.cap_e;
-  for (int g = 0; g < S; ++g) owner[sb + g] = e;
-}
-
-// The last end − p < U entries of a row (wave-uniform p, end; col / val through the scalar unit): their gathers are
-// issued TOGETHER — blocks of U/2, U/4, … 1 entries, every block's loads before the first block's FMAs — instead of
-// one entry at a time with its latency exposed (a row of 20 entries at U = 8 used to end in four dependent trips to
-// memory, as long as its two full batches took).  The FMAs run in entry order: the chain is unchanged.
-template <int T, int U>
-__device__ __forceinline__ void row_tail(const int* __restrict__ col, const float* __restrict__ val, const float* Bl,
-                                         long ldb, int p, int end, f32x4 (&acc)[T]) {
-  const int rem = end - p;  // 0 … U-1
-  if (rem <= 0) return;
-  f32x4 x[U > 1 ? U - 1 : 1][T];
-  float v[U > 1 ? U - 1 : 1];
-  int q = p;  // (compile-time slot of each block: U/2 entries at slots [0, U/2), U/4 at [U/2, 3U/4), …)
-  mi::static_for<7>([&](auto k_) {  // blocks of U >> 1, U >> 2, …
-    constexpr int blk = U >> (decltype(k_)::value + 1);
-    if constexpr (blk >= 1) {
-      constexpr int slot = U - 2 * blk;  // Σ of the larger blocks = U − 2·blk
-      if (rem & blk) {
-#pragma unroll
-        for (int u = 0; u < blk; ++u) {
-          const int c = col[q + u];
-          v[slot + u] = val[q + u];
-          const float* src = Bl + (long)c * ldb;
-#pragma unroll
-          for (int t = 0; t < T; ++t) x[slot + u][t] = *reinterpret_cast<const f32x4*>(src + t * 256);
-        }
-        q += blk;
-      }
-    }
-  });
-  mi::static_for<7>([&](auto k_) {
-    constexpr int blk = U >> (decltype(k_)::value + 1);
-    if constexpr (blk >= 1) {
-      constexpr int slot = U - 2 * blk;
-      if (rem & blk) {
-#pragma unroll
-        for (int u = 0; u < blk; ++u)
-#pragma unroll
-          for (int t = 0; t < T; ++t) acc[t] = fma4(v[slot + u], x[slot + u][t], acc[t]);
-      }
-    }
-  });
-}
+using mi::LongArg;
+using mi::Shape;
 
 // ---------------------------------------------------------------------------
 // One wave per row, N == 256·T exactly.  col/val through the scalar unit.
@@ -211,8 +43,9 @@ __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
     LongArg la) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const long row = (long)blockIdx.x * 4 + wave;
-  if (row >= M) return;
+  const long slot = (long)blockIdx.x * 4 + wave;
+  if (slot >= (la.order ? la.nslots : M)) return;
+  const long row = la.order ? la.order[slot] : slot;  // (wave-uniform: a scalar load) a schedule's slot → row map
   const long item = blockIdx.y;
   const int* rp = rowptr + item * ((long)M + 1);
   const float* Bl = B + item * strideB + lane * 4;
@@ -392,254 +225,11 @@ __global__ __launch_bounds__(256) void spmm_wave_row_vl_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Column-panel pass (Infinity-Cache blocking), N == 256.  When B is larger than
-// the 256 MiB Infinity Cache a uniformly random gather misses it ~(1 - 256MiB/|B|)
-// of the time.  Cutting K into P panels whose B slice fits the cache and running
-// one launch per panel (all CUs work on the same panel at the same time) turns
-// the gathers into cache hits; the price is that C is carried through memory
-// between passes ((2P-1) row passes instead of 1) and col is scanned P times.
-// A pass handles the nonzeros with c_lo <= col < c_hi in CSR order on top of the
-// previous pass's C, so for rows whose columns do not descend (torch CSR, the pinned
-// generator) the per-element fmaf chain is exactly the CSR-order chain of the one-pass
-// kernel: bit-identical results.
-// Rows whose columns DO descend somewhere (legal CSR: the reference's COO→CSR keeps the
-// input order inside a row, src/sparse_mm.cu:110-134) would be summed panel by panel, i.e.
-// in another order.  Every pass therefore checks, on the col entries it scans anyway
-// (one ds_bpermute + compare + ballot per 64 entries), whether the row's columns ascend; the
-// verdict is a function of the row alone, so all passes agree without any flag in memory:
-// the FIRST pass recomputes such a row from scratch over all its non-zeros in plain CSR order
-// (+ bias) and the later passes leave it untouched.
-// ---------------------------------------------------------------------------
-template <bool FIRST, int T, int U, bool ADAPT = false>
-__global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
-    const int* __restrict__ rowptr, const int* __restrict__ col,
-    const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
-    int M, long ldb, long ldc, int c_lo, int c_hi, const float* __restrict__ bias, int last_pass, int ctiles,
-    unsigned row_blocks, LongArg la) {
-  if constexpr (ADAPT) {  // (the Infinity-Cache level — config C3 — runs the ADAPT = false build: nothing added there)
-    if (adapt_says_local(la.adapt)) {
-      if (!FIRST) return;
-      c_lo = 0, c_hi = 0x7fffffff, last_pass = 1;
-    }
-  }
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  unsigned rb = blockIdx.x;
-  bool lists = FIRST;  // the first pass over the first column tile lists the long rows it skips
-  if (ctiles > 1) {
-    // wide N: column tiles of 256·T columns dealt XCD-aware exactly as in spmm_group_kernel, so the
-    // (row panel × column tile) slice of B this pass gathers from stays in the XCD's L2
-    const unsigned xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
-    const int tile = (int)(xcd + 8 * (idx / row_blocks));
-    if (tile >= ctiles) return;
-    lists = FIRST && tile == 0;
-    rb = idx % row_blocks;
-    B += (long)tile * (256 * T);
-    C += (long)tile * (256 * T);
-    if (bias) bias += (long)tile * (256 * T);
-  }
-  const long row = (long)rb * 4 + wave;
-  if (row >= M) return;
-  const float* Bl = B + lane * 4;
-  float* Cl = C + row * ldc + lane * 4;
-  const int start = rowptr[row];
-  const int end = rowptr[row + 1];
-  if (end - start > la.thresh) {  // left to spmm_long_rows_kernel (in every pass)
-    if (lists && lane == 0) long_list_append(la, (int)row, end - start);
-    return;
-  }
-  f32x4 acc[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-    acc[t] = FIRST ? f32x4{0.f, 0.f, 0.f, 0.f}
-                   : __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Cl + t * 256));
-  const unsigned width = (unsigned)(c_hi - c_lo);
-  bool descends = false;   // wave-uniform: some column of the row is smaller than its predecessor
-  int prev_last = -1;      // last column of the previous chunk
-
-  for (int p = start; p < end; p += 64) {
-    const int idx = p + lane;
-    const int myc = idx < end ? col[idx] : 0x7fffffff;
-    int before = __shfl_up(myc, 1, 64);
-    if (lane == 0) before = prev_last;
-    descends |= __ballot(myc < before) != 0ull;
-    if (descends) break;  // no point in gathering on: the first pass redoes the row, the others drop it
-    prev_last = __builtin_amdgcn_readlane(myc, 63);  // 0x7fffffff past the end: only the last chunk has such lanes
-    const bool in = (unsigned)(myc - c_lo) < width && idx < end;
-    const float myv = in ? val[idx] : 0.f;
-    unsigned long long mask = __ballot(in);  // this chunk's nonzeros that fall in the panel
-    // batches of up to U entries of this panel: every gather of a batch is issued before its first FMA — the last,
-    // partial batch of a chunk too (it used to go one entry at a time, each with its latency exposed)
-    while (mask) {
-      const int n = __builtin_popcountll(mask);  // wave-uniform
-      f32x4 x[U][T];
-      float v[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (u < n) {
-          const int i = __builtin_ctzll(mask);
-          mask &= mask - 1;
-          const int c = __builtin_amdgcn_readlane(myc, i);
-          v[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), i));
-          const float* src = Bl + (long)c * ldb;
-#pragma unroll
-          for (int t = 0; t < T; ++t) x[u][t] = *reinterpret_cast<const f32x4*>(src + t * 256);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (u < n) {
-#pragma unroll
-          for (int t = 0; t < T; ++t) acc[t] = fma4(v[u], x[u][t], acc[t]);
-        }
-      }
-    }
-  }
-  bool add_bias = bias != nullptr && last_pass != 0;
-  if (descends) {
-    if (!FIRST) return;  // the first pass wrote the whole row
-    // plain CSR-order chain over every non-zero of the row, whatever its panel
-#pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int p = start; p < end; p += 64) {
-      const int idx = p + lane;
-      const int myc = idx < end ? col[idx] : 0;
-      const float myv = idx < end ? val[idx] : 0.f;
-      const int cnt = (end - p) < 64 ? (end - p) : 64;
-      int i = 0;
-      for (; i + 4 <= cnt; i += 4) {
-        f32x4 x[4][T];
-        float v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int c = __builtin_amdgcn_readlane(myc, i + u);
-          v[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), i + u));
-          const float* src = Bl + (long)c * ldb;
-#pragma unroll
-          for (int t = 0; t < T; ++t) x[u][t] = *reinterpret_cast<const f32x4*>(src + t * 256);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int t = 0; t < T; ++t) acc[t] = fma4(v[u], x[u][t], acc[t]);
-      }
-      for (; i < cnt; ++i) {
-        const int c = __builtin_amdgcn_readlane(myc, i);
-        const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), i));
-        const float* src = Bl + (long)c * ldb;
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-          acc[t] = fma4(v, *reinterpret_cast<const f32x4*>(src + t * 256), acc[t]);
-      }
-    }
-    add_bias = bias != nullptr;
-  }
-  if (add_bias) {
-#pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] += *reinterpret_cast<const f32x4*>(bias + lane * 4 + t * 256);
-  }
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-    __builtin_nontemporal_store(acc[t], reinterpret_cast<f32x4*>(Cl + t * 256));
-}
-
-template <int T, int U>
-int launch_panels_t(int panels, const int* rowptr, const int* col, const float* val, const float* B,
-                    float* C, int M, int K, long ldb, long ldc, const float* bias, LongArg la,
-                    hipStream_t s, int ctiles = 1) {
-  const long row_blocks = ((long)M + 3) / 4;
-  const long blocks = ctiles > 1 ? 8L * ((ctiles + 7) / 8) * row_blocks : row_blocks;
-  if (blocks > 0x7fffffffL) return MI_ERANGE;
-  const long kp = ((long)K + panels - 1) / panels;
-  for (int q = 0; q < panels; ++q) {
-    const int lo = (int)(q * kp);
-    const int hi = (int)((q + 1) * kp < K ? (q + 1) * kp : K);
-#define MI_PANEL_PASS(FIRST_, ADAPT_)                                                                                          \
-  hipLaunchKernelGGL((spmm_wave_row_panel_kernel<FIRST_, T, U, ADAPT_>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, \
-                     val, B, C, M, ldb, ldc, lo, hi, bias, q == panels - 1 ? 1 : 0, ctiles, (unsigned)row_blocks, la)
-    if (la.adapt != nullptr && ctiles == 1) {
-      if (q == 0) MI_PANEL_PASS(true, true);
-      else MI_PANEL_PASS(false, true);
-    } else {
-      if (q == 0) MI_PANEL_PASS(true, false);
-      else MI_PANEL_PASS(false, false);
-    }
-#undef MI_PANEL_PASS
-  }
-  return mi::check_launch();
-}
-
-int launch_panels(int panels, const int* rowptr, const int* col, const float* val, const float* B,
-                  float* C, int M, int K, int N, long ldb, long ldc, const float* bias, LongArg la,
-                  hipStream_t s) {
-  if (N == 256) return launch_panels_t<1, 8>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, la, s);
-  if (N == 512) return launch_panels_t<2, 4>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, la, s);
-  return launch_panels_t<4, 2>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, la, s);
-}
-
-// ---------------------------------------------------------------------------
 // G lanes per row (G a power of two ≤ 64), 64/G rows per wave, VEC floats per
 // lane per tile, T tiles per pass; columns beyond G·VEC·T are covered by an
 // outer pass loop (col/val re-read once per pass).  Handles every N.
 // grid = (⌈M / (4·64/G)⌉, batch), block = 256.
 // ---------------------------------------------------------------------------
-template <int VEC>
-struct Vec;
-template <>
-struct Vec<4> {
-  static constexpr int width = 4;
-  typedef f32x4 type;
-  static __device__ __forceinline__ type zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-  static __device__ __forceinline__ type load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-  static __device__ __forceinline__ void store(float* p, type v) {
-    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
-  }
-  static __device__ __forceinline__ type fma(float a, type x, type acc) { return fma4(a, x, acc); }
-};
-// 44: four floats per lane at ANY 4-byte alignment (rows of B / C that do not start on 16 bytes: N % 4 != 0, odd leading
-// dimensions, offset views) — dword-aligned global_load / store_dwordx4, which gfx950 serves (split where a request
-// crosses a line).  The kernel shifts a row's last, partial quad back to end at column N − 1: it overlaps its neighbour,
-// the shared columns are computed twice from the same chain and stored twice with the same bits.
-template <>
-struct Vec<44> {
-  static constexpr int width = 4;
-  typedef float type __attribute__((ext_vector_type(4), aligned(4)));
-  static __device__ __forceinline__ type zero() { return type{0.f, 0.f, 0.f, 0.f}; }
-  static __device__ __forceinline__ type load(const float* p) { return *reinterpret_cast<const type*>(p); }
-  static __device__ __forceinline__ void store(float* p, type v) { __builtin_nontemporal_store(v, reinterpret_cast<type*>(p)); }
-  static __device__ __forceinline__ type fma(float a, type x, type acc) {
-    acc.x = __builtin_fmaf(a, x.x, acc.x);
-    acc.y = __builtin_fmaf(a, x.y, acc.y);
-    acc.z = __builtin_fmaf(a, x.z, acc.z);
-    acc.w = __builtin_fmaf(a, x.w, acc.w);
-    return acc;
-  }
-};
-template <>
-struct Vec<2> {
-  static constexpr int width = 2;
-  typedef float type __attribute__((ext_vector_type(2)));
-  static __device__ __forceinline__ type zero() { return type{0.f, 0.f}; }
-  static __device__ __forceinline__ type load(const float* p) { return *reinterpret_cast<const type*>(p); }
-  static __device__ __forceinline__ void store(float* p, type v) {
-    __builtin_nontemporal_store(v, reinterpret_cast<type*>(p));
-  }
-  static __device__ __forceinline__ type fma(float a, type x, type acc) {
-    acc.x = __builtin_fmaf(a, x.x, acc.x);
-    acc.y = __builtin_fmaf(a, x.y, acc.y);
-    return acc;
-  }
-};
-template <>
-struct Vec<1> {
-  static constexpr int width = 1;
-  typedef float type;
-  static __device__ __forceinline__ type zero() { return 0.f; }
-  static __device__ __forceinline__ type load(const float* p) { return *p; }
-  static __device__ __forceinline__ void store(float* p, type v) { __builtin_nontemporal_store(v, p); }
-  static __device__ __forceinline__ type fma(float a, type x, type acc) { return __builtin_fmaf(a, x, acc); }
-};
-
 template <int G, int VEC, int T>
 __global__ __launch_bounds__(256) void spmm_group_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ col,
@@ -675,10 +265,12 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
     if (bias) bias += c0;
     N = N - c0 < tile_cols ? N - c0 : tile_cols;
   }
-  const long row = ((long)rb * 4 + (threadIdx.x >> 6)) * RPW + (lane / G);
+  const long slot = ((long)rb * 4 + (threadIdx.x >> 6)) * RPW + (lane / G);
+  const bool live = slot < (la.order ? la.nslots : M);
+  const long row = (la.order && live) ? la.order[slot] : slot;  // a schedule's slot → row map
 
   int start = 0, end = 0;
-  if (row < M) {
+  if (live) {
     start = rp[row];
     end = rp[row + 1];
   }
@@ -777,7 +369,7 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
       });
     }
     }
-    if (row < M && !skipped) {
+    if (live && !skipped) {
       float* dst = Ci + row * ldc;
 #pragma unroll
       for (int t = 0; t < T; ++t)
@@ -786,182 +378,21 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
   }
 }
 
+// rows a launch covers: all M, or the slots of a schedule
+inline long slots_of(const LongArg& la, int M) { return la.order ? la.nslots : M; }
+
 template <int G, int VEC, int T>
 int launch_group(const int* rowptr, const int* col, const float* val, const float* B,
                  float* C, int M, int N, long ldb, long ldc, long strideB, long strideC,
                  int batch, const float* bias, LongArg la, hipStream_t s) {
   constexpr int rows_per_block = 4 * (64 / G);
-  const long blocks = ((long)M + rows_per_block - 1) / rows_per_block;
+  const long blocks = (slots_of(la, M) + rows_per_block - 1) / rows_per_block;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
+  if (blocks == 0) return MI_OK;
   hipLaunchKernelGGL((spmm_group_kernel<G, VEC, T>), dim3((unsigned)blocks, (unsigned)batch),
                      dim3(256), 0, s, rowptr, col, val, B, C, M, N, ldb, ldc, strideB, strideC, bias, 1, N,
                      (unsigned)blocks, la);
   return mi::check_launch();
-}
-
-// ---------------------------------------------------------------------------
-// Column-panel passes for the lane-group kernel (round 5): N ≤ 128 with B beyond the Infinity Cache (N = 64 at
-// K ≥ 3 M, N = 128 at K ≥ 1.5 M: a 256- or 512-byte row gathered at random from 1 GiB and more).  Same idea as
-// spmm_wave_row_panel_kernel — K cut into P panels whose slice of B the cache can hold, one launch per panel, all
-// CUs on the same panel at the same time, C carried through memory — with another way of staying exact: a pass
-// takes the entries whose RUNNING MAXIMUM of the columns so far (m_i = max_{j ≤ i} col_j, a prefix maximum over the
-// row) falls in its panel.  m is non-decreasing, so the passes cut every row into P contiguous index ranges in CSR
-// order, whatever the order of its columns: the per-element fmaf chain is the one-pass chain for every legal CSR
-// input, with no descent check and no recomputation (for a sorted row m_i = col_i and a pass gathers exactly its own
-// panel's rows of B; in an unsorted row an entry may be gathered in a later panel's pass — slower, same bits).
-// A pass scans the row's columns from its start (4 bytes per non-zero and pass against 4N + 8 of gathers) and stops
-// at the first chunk that ends beyond its panel.
-// G = 16 (N ≤ 64) or 32 (N ≤ 128) lanes per row, float4 per lane; grid = ⌈M / (4·64/G)⌉, block = 256.
-// ---------------------------------------------------------------------------
-constexpr int kIntMin = -0x7fffffff - 1;
-
-template <int G>
-__device__ __forceinline__ int group_prefix_max(int x, int gl) {
-#pragma unroll
-  for (int d = 1; d < G; d <<= 1) {
-    const int y = __shfl_up(x, d, G);
-    if (gl >= d) x = x > y ? x : y;
-  }
-  return x;
-}
-
-template <bool FIRST, int G, int T>
-__global__ __launch_bounds__(256) void spmm_group_panel_kernel(
-    const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
-    const float* __restrict__ B, float* __restrict__ C, int M, int N, long ldb, long ldc, int c_lo, int c_hi,
-    const float* __restrict__ bias, int last_pass, LongArg la) {
-  // T > 1 (G = 64 only): T tiles of 256 columns per lane — the widths between and beyond the one-wave-per-row panel kernel's
-  // 256 / 512 / 1024 (N = 160 … 1024, any multiple of 4): the same passes for every N the path takes
-  static_assert(T == 1 || G == 64, "column tiles only with a whole wave per row");
-  if (la.adapt != nullptr && adapt_says_local(la.adapt)) {  // see spmm_locality_probe_kernel
-    if (!FIRST) return;
-    c_lo = kIntMin, c_hi = 0x7fffffff, last_pass = 1;
-  }
-  constexpr int RPW = 64 / G;
-  constexpr int UI = T >= 3 ? 2 : 4;  // gathers in flight per group and batch (T float4 each)
-  const int lane = threadIdx.x & 63;
-  const int gl = lane & (G - 1);
-  const int gshift = lane & ~(G - 1);  // first lane of this group inside the wave
-  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + (lane / G);
-  int coff[T];
-  bool on[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    coff[t] = (t * G + gl) * 4;
-    on[t] = coff[t] < N;
-  }
-  int start = 0, end = 0;
-  if (row < M) {
-    start = rowptr[row];
-    end = rowptr[row + 1];
-  }
-  const bool skipped = end - start > la.thresh;  // left to spmm_long_rows_kernel (in every pass)
-  if (skipped) {
-    if (FIRST && gl == 0) long_list_append(la, (int)row, end - start);
-    end = start;
-  }
-  float* dst = C + row * ldc;
-  f32x4 acc[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) {
-    acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!FIRST && row < M && !skipped && on[t]) acc[t] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dst + coff[t]));
-  }
-  int prev_max = kIntMin;  // running maximum of the columns of the chunks behind
-  constexpr unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
-  for (int p = start; p < end; p += G) {  // trip count differs between groups
-    const int idx = p + gl;
-    const bool there = idx < end;
-    const int myc = there ? col[idx] : kIntMin;
-    int m = group_prefix_max<G>(myc, gl);
-    m = m > prev_max ? m : prev_max;
-    prev_max = __shfl(m, G - 1, G);
-    const bool below = there && m < c_lo;
-    const bool inq = there && m >= c_lo && m < c_hi;
-    const int i0 = __builtin_popcountll((__ballot(below) >> gshift) & gmask);       // group-uniform: first entry of this pass
-    const int i1 = i0 + __builtin_popcountll((__ballot(inq) >> gshift) & gmask);    // … one past its last
-    if (i1 > i0) {
-      const float myv = inq ? val[idx] : 0.f;
-      mi::static_for<G / UI>([&](auto b_) {
-        constexpr int b = UI * decltype(b_)::value;
-        if (b >= i0 && b + UI <= i1) {
-          f32x4 x[UI][T];
-          float v[UI];
-          mi::static_for<UI>([&](auto u_) {
-            constexpr int u = decltype(u_)::value;
-            const int c = mi::group_lane<G, b + u, false>(myc);
-            v[u] = mi::group_lane<G, b + u, false>(myv);
-            const float* src = B + (long)c * ldb;
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-              if (on[t]) x[u][t] = *reinterpret_cast<const f32x4*>(src + coff[t]);
-          });
-#pragma unroll
-          for (int u = 0; u < UI; ++u)
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-              if (on[t]) acc[t] = fma4(v[u], x[u][t], acc[t]);
-        } else if (b + UI > i0 && b < i1) {
-          mi::static_for<UI>([&](auto u_) {
-            constexpr int u = decltype(u_)::value;
-            const int c = mi::group_lane<G, b + u, false>(myc);
-            const float v = mi::group_lane<G, b + u, false>(myv);
-            if (b + u >= i0 && b + u < i1) {
-              const float* src = B + (long)c * ldb;
-#pragma unroll
-              for (int t = 0; t < T; ++t)
-                if (on[t]) acc[t] = fma4(v, *reinterpret_cast<const f32x4*>(src + coff[t]), acc[t]);
-            }
-          });
-        }
-      });
-    }
-    if (prev_max >= c_hi) break;  // every later entry belongs to a later pass
-  }
-  if (row < M && !skipped) {
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-      if (on[t]) {
-        if (bias && last_pass) acc[t] += *reinterpret_cast<const f32x4*>(bias + coff[t]);
-        __builtin_nontemporal_store(acc[t], reinterpret_cast<f32x4*>(dst + coff[t]));
-      }
-  }
-}
-
-template <int G, int T>
-int launch_group_panels_t(int panels, const int* rowptr, const int* col, const float* val, const float* B, float* C,
-                          int M, int K, int N, long ldb, long ldc, const float* bias, LongArg la, hipStream_t s) {
-  constexpr int rows_per_block = 4 * (64 / G);
-  const long blocks = ((long)M + rows_per_block - 1) / rows_per_block;
-  if (blocks > 0x7fffffffL) return MI_ERANGE;
-  const long kp = ((long)K + panels - 1) / panels;
-  for (int q = 0; q < panels; ++q) {
-    const int lo = (int)(q * kp);
-    // the last pass takes whatever is left (columns ≥ K of a lying matrix included: every entry is summed exactly once)
-    const int hi = q == panels - 1 ? 0x7fffffff : (int)((q + 1) * kp);
-    if (q == 0)
-      hipLaunchKernelGGL((spmm_group_panel_kernel<true, G, T>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, val, B, C,
-                         M, N, ldb, ldc, kIntMin, hi, bias, q == panels - 1 ? 1 : 0, la);  // (first pass: from the smallest int, as lo is unused)
-    else
-      hipLaunchKernelGGL((spmm_group_panel_kernel<false, G, T>), dim3((unsigned)blocks), dim3(256), 0, s, rowptr, col, val, B, C,
-                         M, N, ldb, ldc, lo, hi, bias, q == panels - 1 ? 1 : 0, la);
-  }
-  return mi::check_launch();
-}
-
-int group_panel_count(int variant) {
-  static const int kCount[] = {2, 3, 4, 6, 8};
-  return kCount[variant - MI_SPMM_GROUP_PANELS_2];
-}
-
-int launch_group_panels(int panels, const int* rowptr, const int* col, const float* val, const float* B, float* C, int M,
-                        int K, int N, long ldb, long ldc, const float* bias, LongArg la, hipStream_t s) {
-  if (N <= 64) return launch_group_panels_t<16, 1>(panels, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
-  if (N <= 128) return launch_group_panels_t<32, 1>(panels, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
-  if (N <= 256) return launch_group_panels_t<64, 1>(panels, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
-  if (N <= 512) return launch_group_panels_t<64, 2>(panels, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
-  if (N <= 768) return launch_group_panels_t<64, 3>(panels, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
-  return launch_group_panels_t<64, 4>(panels, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
 }
 
 // Column-tiled launch of the float4 group kernel: tile_cols = 4·G columns per tile.
@@ -977,22 +408,6 @@ int launch_coltile(const int* rowptr, const int* col, const float* val, const fl
   hipLaunchKernelGGL((spmm_group_kernel<G, 4, 1>), dim3((unsigned)blocks, 1u), dim3(256), 0, s, rowptr, col, val,
                      B, C, M, N, ldb, ldc, 0L, 0L, bias, ctiles, tile_cols, (unsigned)row_blocks, la);
   return mi::check_launch();
-}
-
-// Tile width (columns) for the XCD-aware column-tiled launch, or 0 when it does not apply.
-// The K-row slice of B an XCD gathers from should fit its 4 MiB L2; the tiles must spread evenly
-// over the 8 XCDs and each tile needs enough row blocks to occupy an XCD's 32 CUs.  Measured on
-// MI355X (tools/bench_wide.py): 4096² 1 % 0.344 → 0.129 ms (21 TB/s of gathers served by L2),
-// 65536×8192 × 1024 0.5 % 1.33 → 0.51 ms, 8192² 1 % 2.96 → 2.13 ms, 16384² 1 % 24.2 → 20.7 ms.
-int coltile_width(int32_t M, int32_t K, int32_t N, int64_t ldb) {
-  const long slice_budget = 4L << 20;
-  if (N < 512 || M < 512 || (long)K * ldb * 4 <= (8L << 20)) return 0;  // narrow, short, or B small as it is
-  for (int w : {256, 128, 64}) {
-    if ((long)K * w * 4 > slice_budget || N < 8 * w) continue;
-    const int tiles = (N + w - 1) / w, rounds = (tiles + 7) / 8;
-    if (tiles * 5 >= rounds * 8 * 4) return w;  // at least 80 % of the XCD × round slots used
-  }
-  return 0;
 }
 
 template <int VEC>
@@ -1047,8 +462,9 @@ template <int T, int U>
 int launch_wave_row(const int* rowptr, const int* col, const float* val, const float* B,
                     float* C, int M, long ldb, long ldc, long strideB, long strideC,
                     int batch, const float* bias, LongArg la, hipStream_t s) {
-  const long blocks = ((long)M + 3) / 4;
+  const long blocks = (slots_of(la, M) + 3) / 4;
   if (blocks > 0x7fffffffL) return MI_ERANGE;
+  if (blocks == 0) return MI_OK;
   hipLaunchKernelGGL((spmm_wave_row_kernel<T, U>), dim3((unsigned)blocks, (unsigned)batch),
                      dim3(256), 0, s, rowptr, col, val, B, C, M, ldb, ldc, strideB, strideC, bias, la);
   return mi::check_launch();
@@ -1104,450 +520,6 @@ __global__ __launch_bounds__(256) void spmm_narrow_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------
-// Skewed matrices.  A row is owned by one wave, which sustains only a few GB/s of gathers, so
-// a row with 10⁵–10⁶ non-zeros would be a serial tail of tens of milliseconds.  When the caller
-// supplies a workspace (custom_mm always does), rows with more than kLongRow non-zeros are
-// skipped AND listed by the kernels above (`la`: long_list_append; find_long_rows_kernel builds the same
-// list for plans whose kernel lives elsewhere, and for prepared lists), and summed
-// here by S = clamp(len / 32768, 1, 128) 16-wave workgroups: the row's 1024-non-zero chunks are
-// dealt round-robin to 16·S chains (chain q runs the fmaf chain over chunks q, q+16S, q+32S, …
-// in increasing position), workgroup g owns chains 16g … 16g+15 and adds them in that order,
-// and the S workgroup sums are added in order g = 0 … S-1 — by the same workgroup when S = 1,
-// else through the workspace by whichever of the S workgroups delivers its partial row LAST
-// (an arrival counter per row; agent-scope release by every deliverer, acquire by the last: the sum
-// itself is always taken in the order g = 0 … S-1, so it does not depend on who arrives when).
-// That is a different — fixed, launch-independent, a function of the row length only — summation
-// order for those rows; oracle_spmm_csr_long_f32 restates it, so results stay bit-identical to the oracle.
-// ---------------------------------------------------------------------------
-struct LongWs {
-  long cap_e, cap_s, cap_p;
-  size_t owner_off, partial_off, bytes;  // offsets in ints / bytes
-  size_t adapt_off;                      // bytes: kAdaptSlots verdicts of the locality probe, behind everything else
-};
-
-LongWs long_ws_layout(int64_t nnz, int32_t N) {
-  LongWs w;
-  w.cap_e = nnz / kLongRow + 1;
-  w.cap_p = nnz >> kLongSplitShift;
-  w.cap_s = w.cap_e + w.cap_p;
-  w.owner_off = 4 + (size_t)kLongEnt * (size_t)w.cap_e;
-  const size_t ints = w.owner_off + (size_t)w.cap_s;
-  w.partial_off = (ints * sizeof(int) + 15) / 16 * 16;
-  w.adapt_off = (w.partial_off + (size_t)w.cap_p * (size_t)N * sizeof(float) + 15) / 16 * 16;
-  w.bytes = w.adapt_off + kAdaptSlots * sizeof(int);
-  return w;
-}
-
-__global__ void find_long_rows_kernel(const int* __restrict__ rowptr, int M, LongArg la) {
-  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= M) return;
-  const int len = rowptr[r + 1] - rowptr[r];
-  if (len > kLongRow) long_list_append(la, (int)r, len);
-}
-
-// reset != 0: the list was built for this product only — the workgroup that finishes last zeroes the four
-// counters, so a workspace that entered with a zero header leaves with one (MI_LONG_ROWS_AUTO_ZEROED: no memset
-// per product).  reset == 0: a prepared list, used again by the next product (only the arrival counters are reset).
-template <int VEC>
-__global__ __launch_bounds__(kLongWaves * 64) void spmm_long_rows_kernel(
-    int* __restrict__ ws, int cap_e, int cap_s, float* __restrict__ partial, const int* __restrict__ rowptr,
-    const int* __restrict__ col, const float* __restrict__ val, const float* __restrict__ B, float* __restrict__ C,
-    int N, long ldb, long ldc, const float* __restrict__ bias, int reset) {
-  typedef Vec<VEC> V;
-  typedef typename V::type vec_t;
-  __shared__ vec_t part[kLongWaves][64];
-  __shared__ int last_flag;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int listed = ws[0], handed = ws[1], handed_p = ws[2];
-  if (listed == 0 && handed == 0 && handed_p == 0) return;  // no long row: nothing to sum, nothing to reset
-  const int count = listed < cap_e ? listed : cap_e;
-  const int slots = handed < cap_s ? handed : cap_s;
-  const int* owner = ws + 4 + kLongEnt * (long)cap_e;
-  for (int t = blockIdx.x; t < slots; t += gridDim.x) {
-    const int e = owner[t];
-    if ((unsigned)e >= (unsigned)count) continue;  // slot of a dropped entry
-    int* ent = ws + 4 + kLongEnt * (long)e;
-    const int row = ent[0], S = ent[2], pb = ent[3];
-    const int g = t - ent[1];
-    if ((unsigned)g >= (unsigned)S) continue;  // not a slot of that entry
-    const long start = rowptr[row], end = rowptr[row + 1];
-    const long stride = (long)kLongWaves * S * kLongChunk;
-    for (int n0 = 0; n0 < N; n0 += 64 * VEC) {  // 64·VEC output columns per pass
-      const int c0 = n0 + lane * VEC;
-      const bool on = c0 < N;
-      vec_t acc = V::zero();
-      for (long cb = start + ((long)g * kLongWaves + wave) * kLongChunk; cb < end; cb += stride) {
-        const long ce = cb + kLongChunk < end ? cb + kLongChunk : end;
-        for (long p = cb; p < ce; p += 64) {
-          const long idx = p + lane;
-          const int myc = idx < ce ? col[idx] : 0;
-          const float myv = idx < ce ? val[idx] : 0.f;
-          const int cnt = ce - p < 64 ? (int)(ce - p) : 64;
-          int i = 0;
-          for (; i + 8 <= cnt; i += 8) {
-            vec_t x[8];
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const int c = __builtin_amdgcn_readlane(myc, i + u);
-              v[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), i + u));
-              if (on) x[u] = V::load(B + (long)c * ldb + c0);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-              if (on) acc = V::fma(v[u], x[u], acc);
-          }
-          for (; i < cnt; ++i) {
-            const int c = __builtin_amdgcn_readlane(myc, i);
-            const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), i));
-            if (on) acc = V::fma(v, V::load(B + (long)c * ldb + c0), acc);
-          }
-        }
-      }
-      part[wave][lane] = acc;
-      __syncthreads();
-      if (wave == 0 && on) {
-        vec_t tot = part[0][lane];
-#pragma unroll
-        for (int w = 1; w < kLongWaves; ++w) tot += part[w][lane];
-        if (S == 1) {
-          if (bias) tot += V::load(bias + c0);
-          V::store(C + (long)row * ldc + c0, tot);
-        } else {
-          V::store(partial + (long)(pb + g) * N + c0, tot);  // N % VEC == 0 and 16-B base when VEC = 4
-        }
-      }
-      __syncthreads();
-    }
-    if (S > 1) {
-      // Deliver: wave 0 is the only wave that stored partial sums.  Its stores are drained, written back at
-      // agent scope, and only then does one lane take an arrival ticket (cdna_hip_programming.md Guideline 16:
-      // fence before the ticket, with the explicit wait hipcc may drop).  The workgroup that draws the last
-      // ticket acquires and adds the S partial rows in order g = 0 … S-1, then the bias.
-      if (wave == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) {
-          const int ticket = __hip_atomic_fetch_add(&ent[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          last_flag = ticket == S - 1;
-          if (ticket == S - 1) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
-        }
-      }
-      __syncthreads();
-      if (last_flag) {
-        for (int c = threadIdx.x; c < N; c += blockDim.x) {
-          // sc1 loads: served by L2 / memory, never by a line this CU cached before the other workgroups wrote
-          float tot = __hip_atomic_load(partial + (long)pb * N + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          for (int gg = 1; gg < S; ++gg)
-            tot += __hip_atomic_load(partial + (long)(pb + gg) * N + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (bias) tot += bias[c];
-          C[(long)row * ldc + c] = tot;
-        }
-        if (threadIdx.x == 0) ent[4] = 0;  // a prepared list serves the next product too
-      }
-      __syncthreads();  // last_flag is rewritten by the next slot
-    }
-  }
-  if (reset) {
-    // every read of the counters by this workgroup is done (they were read into registers at the top)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int done = __hip_atomic_fetch_add(&ws[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (done == (int)gridDim.x - 1) {
-        __hip_atomic_store(&ws[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ws[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ws[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ws[3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  }
-}
-
-// Wide N with K too tall for a K × 256 slice to fit an L2: block BOTH ways — 256-column tiles
-// dealt XCD-aware and K cut into row panels of B (one launch per panel, C carried through memory
-// like the two-panel path), so each XCD gathers from a (K/P) × 256 slice of ≈3 MiB.
-// Returns the number of panels, or 0 when the plan does not apply.
-int coltile_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
-  if (N % 256 != 0 || N < 2048 || M < 512 || ldb != N) return 0;
-  if ((long)K * 1024 <= (4L << 20)) return 0;              // plain column tiling already fits
-  const int panels = (int)(((long)K * 1024 + (3L << 20) - 1) / (3L << 20));
-  if (panels > 16 || nnz < 8L * panels * M) return 0;       // too many C round trips for the work per pass
-  const int tiles = N / 256, rounds = (tiles + 7) / 8;
-  return tiles * 5 >= rounds * 8 * 4 ? panels : 0;
-}
-
-// L2-level panel blocking for N = 256 (one wave per row): when B is too large for the L2s (> 6 MiB) every
-// gathered row comes from the Infinity Cache or HBM and the one-pass kernels drop from ≈13 to ≈5 TFLOP/s.
-// Cutting K into P panels of ≈4 MiB (one launch per panel, all CUs on the same panel, C carried through
-// memory) keeps the gathers in L2 — the same mechanism as the two Infinity-Cache panels of config C3, one
-// level down.  Measured (tools/bench_plans.py, profiles/r02_plan_choice.log): 16384² × 256 at 10 %: 1.02 ms
-// with 4 panels vs 1.77 one-pass (slab 1.46); 8192 × 32768 × 256 at 10 %: 1.14 vs 1.83; 8192 × 65536 × 256
-// at 5 %: 1.50 (8 panels) vs 2.43; 8192 × 131072 × 256 at 1 %: 1.04 vs 1.27; at 0.5 % (82 non-zeros per row):
-// 0.091 vs 0.141; B = 4 MiB: one pass stays ahead.  N = 512 is left to the XCD-aware column tiles, which need
-// no second pass over C (16384² × 512 at 0.5 %: 0.150 ms vs 0.206 with panels) and to the slab plan.
-// Returns the number of panels (2, 3, 4, 5, 6 or 8), or 0 when the plan does not apply.
-int l2_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
-  // N = 512 / 1024 only where no column-tile width keeps an XCD's slice of B in its L2 (K too tall): 32768² × 512 at
-  // 0.3 %: 0.64 ms with 8 panels vs 0.86 one-pass
-  if (N != 256 && !((N == 512 || N == 1024) && coltile_width(M, K, N, ldb) == 0)) return 0;
-  const double b_bytes = (double)K * (double)ldb * 4.0;
-  // (from 32 Ki rows already at 4.5 MiB — B then fills the L2s to the brim and the many rows keep evicting it: 170752 × 2816 ×
-  // 512 with 129 per row, 5.5 MiB: one pass 1.90 ms, two panels 1.50; 134912 × 5376 × 256, 5.2 MiB: 0.74 → 0.63)
-  // (N = 512 / 1024 from 6 MiB like N = 256 — the column tiles only start beyond 8 MiB: 14592 × 4096 × 512 with 138 per row,
-  // 8.0 MiB: one pass 0.249 ms, two panels 0.162)
-  if (b_bytes <= (M >= 32768 ? 4.5 : 6.0) * 1024 * 1024 || b_bytes > 192.0 * 1024 * 1024) return 0;
-  // panels turn re-gathers into L2 hits: below ≈ 32 gathers per row of B nothing is won (round 5, tools/plan_grid.py:
-  // 1280 × 14592 × 256 with 38 per row — 3.3 gathers per row of B — one pass 0.008 ms, the four panels taken until then 0.019)
-  // … and a launch of fewer waves than the chip holds is latency-bound: cutting it into passes multiplies that (1536 × 9728
-  // × 256 with 499 per row: one pass 0.044 ms, three panels 0.080) — unless B is far beyond the L2s (3328 × 27904 × 512 with 240 per
-  // row, 54 MiB: 0.170 → 0.129)
-  // (with a B that half fits the L2s as it is, up to ≈ 10 Ki rows: 4096 × 13056 × 256 with 393 per row one pass 0.065 ms, two
-  // panels 0.080 – 0.096; 8192 × 131072 × 256 with 1311 per row, 128 MiB: 1.27 → 0.58)
-  if (nnz < 24L * K || (M < 10240 && b_bytes < 32.0 * 1024 * 1024)) return 0;
-  int p = (int)((b_bytes + (4 << 20) - 1) / (4 << 20));
-  p = p > 6 ? 8 : p;
-  const int p_by_size = p;
-  while (p >= 2 && nnz < 8L * p * M) p = p > 6 ? 6 : p - 1;  // each pass carries C once: it needs work to pay for that
-  // … and panels that short rows leave too large for the L2s only add passes (162560 × 106240 × 256 with 45 per row, 104 MiB:
-  // five panels of 21 MiB 1.11 ms, one pass 1.03; eight panels of 19 – 21 MiB for long rows pay: 19712 × 38400 × 1024 with 502
-  // per row 5.18 → 4.36 ms)
-  if (p >= 2 && p < p_by_size && b_bytes / p > 16.0 * 1024 * 1024) return 0;
-  return p >= 2 ? p : 0;
-}
-
-// Infinity-Cache panels for B beyond the cache (≥ 768 MiB): how many column panels K is cut into, or 0 for one pass.
-// Measured on MI355X over N 64 … 512, K = M 1 … 4 M, 20 / 100 / 400 non-zeros per row, every plan on the same operands and
-// the same output buffer (tools/bench_hbm_regime.py --variants, profiles/r05_hbm_regime.log): panels pay when a panel's
-// slice of B is ≈ 0.5–0.7 GiB — about twice the cache, so that about half of a pass's gathers hit it — i.e. P ≈ |B| / 683 MiB
-// (1 GiB: 2 panels −6 %; 2 GiB: 3–4 panels −5 … −11 %; 4 GiB: 6 panels −9 … −11 %; fewer, larger panels than that bring
-// nothing: 4 GiB in 2–3 panels +1 … +2 %), and when the rows are long enough to carry C through memory once more per
-// panel (2 (P − 1) row passes against nnz/M gathered rows per row: 20 per row never pays, 100 per row pays up to 6
-// panels).  Beyond ≈ 6 GiB no panel count helps (8 GiB in 8 panels: ± 1 %): one pass at the HBM random-row rate.
-// The launch must also re-touch a panel often enough to keep it resident (gathered bytes ≥ 8 × |B|), which excludes the
-// short row blocks of a sharded run.
-int ic_panels(int64_t nnz, int32_t M, int32_t K, int32_t N, int64_t ldb) {
-  const double b_bytes = (double)K * (double)ldb * 4.0;
-  if (b_bytes < 768.0 * 1048576.0 || M <= 0) return 0;
-  if ((double)nnz * (double)N < 8.0 * (double)K * (double)ldb) return 0;
-  const double want = b_bytes / (683.0 * 1048576.0);
-  if (want > 9.0) return 0;
-  int best = 2;
-  for (int p : {2, 3, 4, 6, 8})
-    if ((p - want < 0 ? want - p : p - want) <= (best - want < 0 ? want - best : best - want)) best = p;  // nearest, ties up
-  return nnz >= 16L * best * M ? best : 0;
-}
-
-// L2-level panels for the lane-group panel kernel: B beyond the L2s but inside the Infinity Cache (6 MiB < |B| ≤ 128 MiB).
-// Fitted on tools/probes/l2_regime_shapes*.sh (17 shapes) and tools/plan_grid.py (120 random shapes, every plan pinned;
-// profiles/r05_l2_regime_plans.log, r05_plan_grid.log):
-//   * panels of ≈ 6 MiB are best or within a few per cent of it over B = 8 … 128 MiB at N = 192 … 768 (B = 12 MiB: 2 panels,
-//     24 MiB: 3–4, 48 MiB: 8, 128 MiB: 8); every pass walks the row's columns up to its panel, which is why rows of thousands
-//     of entries want half as many (8192 × 65536 × 256 at 5 %, 3277 per row: 4 panels 1.13 ms, 8 panels 1.19);
-//   * a pass carries C once (two rows' worth of gathers) and costs a launch: it needs ≥ 8 entries per row, more when the
-//     product is small (16384² × 256 with 82 per row: 2 panels 0.085 ms, 3 panels 0.096; 230656 × 9472 × 768 with 66 per row:
-//     2 panels 4.70 ms, 4 panels 3.38, 6 panels 3.12; 22272 × 14080 × 384 with 41 per row: one pass 0.158, 3 panels 0.127) —
-//     8 + 200 000 / M;
-//   * panels turn RE-gathers into L2 hits, the first touch of a row of B comes from beyond either way: with fewer than ≈ 24
-//     gathers per row of B nothing is won (1280 × 14592 × 256 with 38 per row, 3.3 gathers per row of B: one pass 0.008 ms,
-//     four panels 0.019; 1536 × 39424 × 768 with 715 per row, 28 per row of B: two panels 0.296 against 0.344);
-//   * up to 192 MiB of B (242176 × 188928 × 192, 138 MiB, 1010 per row: one pass 24.7 ms, 8 panels 19.4), up to 384 MiB for
-//     rows of ≥ 256 entries (57344 × 326656 × 256, 319 MiB, 869 per row: 6.79 → 6.00; with 38 per row at 206 MiB panels lose
-//     7 – 30 %); between that and the Infinity-Cache regime (768 MiB) panels move a product by ± 5 %: one pass;
-//   * B barely beyond the L2s (< 12 MiB) needs ≥ 48 entries per row (95488 × 6144 × 320 with 21 per row, 7.5 MiB: one pass
-//     0.187 ms, two panels 0.215; 309504 × 4864 × 384 with 65 per row, 7.1 MiB: 1.86 → 1.34);
-//   * N ≤ 128 (rows of B of ≤ 512 bytes, several rows per wave): two panels (four for ≥ 500 K rows of ≥ 128 entries and
-//     ≥ 32 MiB), only for launches that are throughput-bound — ≥ 28 K rows at N = 64 (four rows per wave), ≥ 60 K rows beyond
-//     (two); ≥ 48 entries per row, ≥ 48 gathers per row of B, 8 … 128 MiB (129536 × 22784 × 128 1.53 → 1.24 ms, 961024 × 82176
-//     × 128 10.2 → 8.0, 154368 × 278528 × 64 1.13 → 0.99, 55040 × 268800 × 64 0.63 → 0.50, 79872 × 34048 × 64 0.49 → 0.37,
-//     67328 × 90624 × 100 2.01 → 1.45); with fewer rows a pass is latency-bound and splitting it only multiplies that (16384 ×
-//     65536 × 128: one pass 0.31 ms, two panels 0.37; 12032 × 67328 × 64: 0.077 vs 0.153; 24832 × 25856 × 96: 0.094 vs 0.151);
-//     N = 32 … 60 only for ≥ 96 Ki rows of ≥ 128 entries;
-//   * fewer than ≈ 10 Ki rows: only with B far beyond the L2s (≥ 32 MiB) and ≥ 7e8 multiply-adds in the product (4096 × 13056 ×
-//     256 with 393 per row, 12.8 MiB: one pass 0.065 ms, two panels 0.093; 4096 × 49920 × 192 with 478 per row: 0.092 vs
-//     0.141; 2304 × 59904 × 384 with 847 per row, 88 MiB: 0.296 → 0.232), and in at most 3 (< 4 Ki rows) or 4 (< 8 Ki) passes.
-// Returns 2, 3, 4, 6 or 8, or 0.
-int l2_group_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
-  const double b_bytes = (double)K * (double)ldb * 4.0, mib = 1048576.0;
-  if (b_bytes <= 6.0 * mib || b_bytes > (nnz >= 256L * M ? 384.0 : 192.0) * mib || M <= 0) return 0;
-  if (nnz < 24L * K || (b_bytes < 12.0 * mib && nnz < 48L * M)) return 0;
-  if (M < 10240 && (b_bytes < 32.0 * mib || (double)nnz * (double)N < 7e8)) return 0;
-  const long per_pass = 8 + 200000L / M;
-  if (N <= 128) {
-    if (N < 64)  // N = 32 … 60 (16-lane groups, half of them idle at 32): many long rows only — 117248 × 295936 × 32 with 210 per row
-                 // 0.50 → 0.41 ms, 290048 × 136192 × 32 with 343 per row 1.76 → 1.43; short rows lose (17 per row: 0.18 vs 0.34)
-      return (N >= 32 && M >= 98304 && nnz >= 128L * M && nnz >= 48L * K && b_bytes >= 16.0 * mib && b_bytes <= 128.0 * mib) ? 2 : 0;
-    if (!(nnz >= 48L * M && nnz >= 48L * K && b_bytes >= 8.0 * mib && b_bytes <= 128.0 * mib)) return 0;
-    // (between 64 and 128 columns from 24 MiB only: below that uniform columns are level — 271104 × 29952 × 96, 11 MiB: 2.21 vs
-    // 2.20 ms — and banded or power-law ones lose, 1.36 vs 1.58 / 1.49 vs 2.05)
-    if (N > 64 && N < 128 && b_bytes < 24.0 * mib) return 0;
-    if (M < (N == 64 ? 28000 : 60000)) return 0;
-    // rows long enough for two passes: 48 at N = 64, 96 at N = 128 (48 from 96 Ki rows; config C2 — 65536² × 128, 65 per row —
-    // is level: 0.2516 one pass, 0.2476 in two panels, and stays one pass), 160 between (65536² × 96 with 100 per row: 0.249 vs 0.265)
-    const long len_min = N == 64 ? 48 : (N == 128 ? (M >= 98304 ? 48 : 96) : 160);
-    if (nnz < len_min * M) return 0;
-    return (M >= 500000 && b_bytes >= 32.0 * mib && nnz >= 128L * M) ? 4 : 2;
-  }
-  // (panels of ≈ 4 MiB from 64 Ki rows: 316160 × 10240 × 384 with 299 per row, 15 MiB: 2 panels 9.35 ms, 4 panels 6.85; 349952 ×
-  // 19456 × 256, 19 MiB: 3 panels 7.45, 4 panels 6.60; 259840 × 18176 × 384, 26.6 MiB: 4 panels 4.21, 6 panels 3.69)
-  const double want = b_bytes / ((nnz >= 2048L * M ? 12.0 : (M >= 65536 ? 4.0 : 6.0)) * mib);
-  int p = 2;
-  for (int c : {2, 3, 4, 6, 8})
-    if ((c < want ? want - c : c - want) < (p < want ? want - p : p - want)) p = c;
-  static const int kLower[9] = {0, 0, 0, 2, 3, 0, 4, 0, 6};
-  const int p_by_size = p;
-  while (p >= 2 && nnz < per_pass * p * M) p = kLower[p];
-  // panels that short rows leave too large for the L2s only add passes (as in l2_panels): 339200 × 115456 × 192 with 40 per row,
-  // 85 MiB, in the four panels the rows pay for — 21 MiB each — leaves the L2s with 1.01 × its algorithmic bytes, one pass with
-  // 0.96 × (profiles/r05_l2_panel_traffic.log): 1.44 vs 1.40 ms, and 1.21 vs 0.97 with power-law columns
-  if (p >= 2 && p < p_by_size && b_bytes / p > 16.0 * mib) return 0;
-  // a few thousand rows are fewer waves than the chip holds: every further pass is one more latency-bound launch (3072 × 20480 ×
-  // 768 with 739 per row: 8 panels 0.365 ms, 3 panels 0.310; 2304 × 59904 × 384 with 847 per row: 0.278 vs 0.231; from 8 Ki rows
-  // eight panels are the best again: 8192 × 131072 × 256 with 1311 per row 0.58 ms, four panels 0.74)
-  const int p_cap = M < 4096 ? 3 : (M < 8192 ? 4 : 8);
-  while (p > p_cap) p = kLower[p];
-  return p >= 2 ? p : 0;
-}
-
-struct Shape {
-  bool vec4_ok, vec2_ok, wave_ok;
-};
-
-Shape classify(int32_t N, int64_t ldb, int64_t ldc, int64_t strideB, int64_t strideC, const float* B,
-               const float* C) {
-  Shape sh;
-  sh.vec4_ok = (N % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && (strideB % 4 == 0) &&
-               (strideC % 4 == 0) && mi::aligned16(B) && mi::aligned16(C);
-  sh.vec2_ok = (N % 2 == 0) && (ldb % 2 == 0) && (ldc % 2 == 0) && (strideB % 2 == 0) &&
-               (strideC % 2 == 0) &&
-               ((reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 7u) == 0;
-  sh.wave_ok = sh.vec4_ok && (N == 256 || N == 512 || N == 1024);
-  return sh;
-}
-
-#ifndef MI_SPMM_LDSB_MIN_ROW
-#define MI_SPMM_LDSB_MIN_ROW 4L  // mean non-zeros per row from which MI_SPMM_LDS_B is AUTO's choice (tools/bench_attn_csr.py)
-#endif
-// The kernel AUTO resolves to.
-int choose_variant(const Shape& sh, int64_t nnz, int32_t batch, int32_t M, int32_t K, int32_t N,
-                   int64_t ldb) {
-  // B beyond the 256 MiB Infinity Cache: K in column panels, one launch per panel (ic_panels: how many, fitted on
-  // tools/bench_hbm_regime.py, profiles/r05_hbm_regime.log) — the one-wave-per-row panel kernel for N = 256 / 512 / 1024,
-  // the lane-group panel kernel for N ≤ 128
-  if (batch == 1 && sh.vec4_ok) {
-    const int p = ic_panels(nnz, M, K, N, ldb);
-    if (p > 0 && sh.wave_ok) {
-      static const int kWave[9] = {0, 0, MI_SPMM_PANELS_2, MI_SPMM_PANELS_3, MI_SPMM_PANELS_4, 0, MI_SPMM_PANELS_6, 0, MI_SPMM_PANELS_8};
-      return kWave[p];
-    }
-    if (p > 0 && N >= 36 && N <= 1024) {  // every other width, N % 4 == 0 (narrower rows: 16-lane groups would idle half their lanes)
-      static const int kGroup[9] = {0, 0, MI_SPMM_GROUP_PANELS_2, MI_SPMM_GROUP_PANELS_3, MI_SPMM_GROUP_PANELS_4, 0,
-                                    MI_SPMM_GROUP_PANELS_6, 0, MI_SPMM_GROUP_PANELS_8};
-      return kGroup[p];
-    }
-  }
-  if (N < 4) return MI_SPMM_NARROW;
-  // Many small products (or one tall one) whose B fits a CU's LDS: gather from LDS instead of from the L2s
-  // (spmm_ldsb.hip).  It pays once rows are long enough to amortise copying B per workgroup.
-  // (tools/bench_attn_csr.py, profiles/r04_attention_csr.log: 384 × 512² × 64 at 10 % kept 0.121 → 0.050 ms, at
-  // 1 % 0.038 → 0.026; N = 256 has the one-wave-per-row kernels, whose col / val travel through scalar registers:
-  // 65536 × 128 × 256 at 5 % 0.020 ms there vs 0.026 here, at 25 % 0.069 (0.055 as the slab plan) vs 0.035)
-  // With the quad form the plan pays from ≈4 non-zeros per row whatever the number of column tiles (tools/bench_plans.py,
-  // one tall matrix: 65536 × 256 × 128 at 3 % — 7.7 per row, two tiles — 0.014 ms against 0.025 for the group kernel;
-  // 65536 × 128 × 256 at 5 % — 6.4 per row, four tiles — 0.021 against 0.025 for the one-wave-per-row kernel and at 10 %
-  // 0.025 against 0.040 for the slab plan; 32768 × 512 × 128 at 1 %: 0.010 against 0.014; 131072 × 512 × 64 at 0.5 % — 2.6
-  // per row — level with the group kernel)
-  // (rows: enough 256-row units for the persistent grid — or, from 8192 rows, enough non-zeros that the gathers decide:
-  // 12 heads of 1024 tokens at 25 % kept 0.041 → 0.020 ms, 24 × 512² 0.024 → 0.017, tools/probes/small_batch_probe.py)
-  if (sh.vec4_ok && mi::spmm_ldsb_fits(K, N) &&
-      ((long)batch * M >= 16384 || ((long)batch * M >= 8192 && nnz >= 1500000)) &&
-      nnz >= MI_SPMM_LDSB_MIN_ROW * (long)batch * M)
-    return MI_SPMM_LDS_B;
-  // N = 20 … 32, up to 16 Ki rows of ≥ 32 entries: 16 lanes per row (half of them idle) instead of 8 — the launch form of the
-  // column tiles with ONE tile: twice the waves for a launch that has too few — was ahead on every such shape of
-  // tools/plan_grid.py (2816 × 6400 × 32 with 506 per row 0.066 → 0.046 ms, 14336 × 90112 × 32 with 65 per row 0.021 → 0.018);
-  // with many rows it loses (969984 × 2304 × 32 with 63 per row: 0.49 vs 0.72)
-  if (batch == 1 && sh.vec4_ok && N > 16 && N <= 32 && nnz >= 32L * M && M <= 16384) return MI_SPMM_COLTILE;
-  int lp = (sh.wave_ok && batch == 1) ? l2_panels(M, K, N, ldb, nnz) : 0;
-  // L2-level panels on the lane-group panel kernel (round 5): for the widths the one-wave-per-row panel kernel does not take
-  // (128 < N ≤ 1024 other than 256 / 512 / 1024) and, at N = 256, for long rows — it beats the wave-per-row panel kernel there
-  // (its passes stop at the first chunk behind their panel; 8192 × 131072 × 256 at 1 %: 0.99 → 0.58 ms, 16384² × 256 at 10 %:
-  // 1.04 → 0.96) and loses on short rows (65536 × 16384 at 0.3 %, 49 per row: 0.21 vs 0.24).  N ≤ 128: two panels in a narrow band of B only
-  // (l2_group_panels).  tools/probes/l2_regime_shapes*.sh, tools/plan_grid.py; profiles/r05_l2_regime_plans.log, r05_plan_grid.log.
-  int gp = 0;
-  if (sh.vec4_ok && batch == 1 && N >= 32 && N <= 1024 && (N == 256 ? nnz >= 224L * M : !sh.wave_ok)) gp = l2_group_panels(M, K, N, ldb, nnz);
-  if (gp > 0) lp = 0;
-  // Moderate density: stage B through LDS (spmm_slab.hip) when its cost model beats the L2-blocked
-  // row-split plans.  Fitted on MI355X (tools/bench_density.py, tools/bench_plans.py): a slab
-  // workgroup (128 rows × 256 columns) spends ≈2.35 µs + 34 µs × density per 64-row slab of B, one
-  // workgroup per CU at a time; the row-split plans sustain ≈13 TFLOP/s with L2 blocking (N ≥ 512)
-  // and ≈5 without.  E.g. 8192² × 8192 at 10 %: 5.9 ms slab vs 9.4 ms; 4096² × 2048 at 20 %: 0.60 vs
-  // 0.96 ms; 8192² × 8192 at 3 %: 3.3 vs 3.0 ms (row-split kept).
-  if (sh.vec4_ok && batch == 1 && K >= 64 && N >= 128 && nnz > 0) {
-    const double wgs = (double)(((long)M + 127) / 128) * (double)(((long)N + 255) / 256);
-    const double density = (double)nnz / ((double)M * (double)K);
-    // whole rounds of workgroups up to four of them (312 workgroups take two rounds, not 1.22: 13312 × 2304 × 768 at 7 % measured
-    // 0.347 ms = 2 × 36 slabs × 4.8 µs; round 5, tools/plan_grid.py); beyond that the tail averages out
-    const double rounds = wgs <= 256.0 ? 1.0 : (wgs < 1024.0 ? (double)(((long)wgs + 255) / 256) : wgs / 256.0);
-    const double t_slab = rounds * (double)(((long)K + 63) / 64) * (2.35e-6 + 34e-6 * density);
-    // … and as much for narrower N while B (≤ 8 MiB) stays in the L2s: 16384 × 4096 × 256 at 10 %: row-split
-    // 0.25 ms (13.7 TFLOP/s) vs slab 0.38; 16384 × 768 × 128 at 30 %: 0.082 vs 0.164; the 5 TFLOP/s figure
-    // holds once B streams from the Infinity Cache or HBM (profiles/r02_plan_choice.log)
-    const bool b_in_l2 = (double)K * (double)ldb * 4.0 <= 8.0 * 1024 * 1024;
-    // with L2 panels the row-split plan gathers at the L2 rate and carries C (2·lp − 1) times
-    const int panels = lp > 0 ? lp : gp;
-    // (round 5, fitted on the grids' slab-vs-rows misroutes: the panel plans at 15 TFLOP/s with C carried at 5 TB/s — 97792 ×
-    // 3584 × 768 with 140 per row: three panels 1.55 ms, slabs 1.84; "B in every L2 at once" up to 3.5 MiB — 61184 × 3072 × 256:
-    // one pass 0.327 ms = 15.9 TFLOP/s, slabs 0.407; and the lane-group kernel's idle lanes where N is not a whole number of
-    // 256-column tiles — 15104 × 1536 × 320: 0.327 ms = 11 TFLOP/s, slabs 0.270; N ≥ 512 gathers at the L2 rate only where
-    // a column-tile plan keeps an XCD's slice of B in its L2 — 25856 × 57344 × 1024 with 1003 per row, 224 MiB, K too tall for
-    // any tile width: one pass 13.95 ms = 3.8 TFLOP/s, slabs 9.39)
-    const double lanes_used = sh.wave_ok || N <= 256 ? 1.0 : (double)N / (256.0 * (double)((N + 255) / 256));
-    // (… but N ≥ 512 in eight panels of 8 – 10 MiB, many rows, a few per cent dense: 7 TFLOP/s — 78848 × 19456 × 1024 at 3.7 %:
-    // eight panels 18.1 ms, slabs 10.8; 25856 × 16640 × 1024 at 4.2 %: 4.9 vs 3.8; with 5120 rows the panels stay ahead, 0.94 vs 1.21)
-    const double panel_rate = (lp > 0 && N >= 512 && M >= 16384 && density >= 0.03) ? 7e12 : 15e12;
-    const double t_rows = (panels > 0 ? 2.0 * (double)nnz * (double)N / panel_rate + (2.0 * panels - 1.0) * (double)M * (double)N * 4.0 / 5e12
-                                  : 2.0 * (double)nnz * (double)N /
-                                        ((double)K * (double)ldb * 4.0 <= 3.5 * 1024 * 1024 ? 15e12  // B in every L2 at once
-                                         : (b_in_l2 || (N >= 512 && (coltile_width(M, K, N, ldb) > 0 || coltile_panels(M, K, N, ldb, nnz) > 0))) ? 13e12
-                                                                                                                                         : 5e12)) / lanes_used;
-    // below ≈100 workgroups too few CUs have work for the model to hold
-    if (wgs >= 96.0 && t_slab < t_rows) return MI_SPMM_SLAB;
-  }
-  if (gp > 0) {
-    static const int kGroupOf[9] = {0, 0, MI_SPMM_GROUP_PANELS_2, MI_SPMM_GROUP_PANELS_3, MI_SPMM_GROUP_PANELS_4, 0,
-                                    MI_SPMM_GROUP_PANELS_6, 0, MI_SPMM_GROUP_PANELS_8};
-    return kGroupOf[gp];
-  }
-  if (lp > 0) {
-    static const int kVariantOf[9] = {0, 0, MI_SPMM_PANELS_2, MI_SPMM_PANELS_3, MI_SPMM_PANELS_4, MI_SPMM_PANELS_5,
-                                      MI_SPMM_PANELS_6, 0, MI_SPMM_PANELS_8};
-    return kVariantOf[lp];
-  }
-  if (sh.vec4_ok && batch == 1 && coltile_panels(M, K, N, ldb, nnz) > 0) return MI_SPMM_COLTILE_PANELS;
-  if (sh.vec4_ok && batch == 1 && coltile_width(M, K, N, ldb) > 0) return MI_SPMM_COLTILE;
-  // N = 256, one pass, a few thousand rows, B beyond the L2s but small: the lane-group kernel's whole-wave form (its col / val
-  // travel by vector load + ds_bpermute, the one-wave-per-row kernel's through the scalar unit) is ahead on such latency-bound
-  // launches — 4096 × 16384 × 256 with 164 per row 0.052 → 0.035 ms, 4096 × 13056 with 393 per row 0.078 → 0.065, 8960 × 8704
-  // with 213 per row 0.117 → 0.097, 16384² with 20 per row 0.047 → 0.040; with ≤ 3000 rows the other way round (1536 × 9728
-  // with 499 per row: 0.044 vs 0.063); tools/plan_grid.py, tools/probes/l2_regime_shapes3.sh
-  if (sh.wave_ok && N == 256 && batch == 1 && M >= 3500 && M <= 16384) {
-    const double b_bytes = (double)K * (double)ldb * 4.0;
-    if (b_bytes > 6.0 * 1048576.0 && b_bytes <= 64.0 * 1048576.0) return MI_SPMM_GROUP_VEC4;
-  }
-  if (sh.wave_ok) return MI_SPMM_WAVE_ROW_U8;
-  // rows that do not start on 16 bytes (N % 4 != 0, odd leading dimensions, offset views): four floats per lane all the
-  // same, on dword-aligned 16-byte accesses (2 M rows, 100 per row: N = 77 0.38 → of 8 TB/s with one float per lane, 130: 0.35, 250: 0.49)
-  return sh.vec4_ok ? MI_SPMM_GROUP_VEC4 : (N >= 4 ? MI_SPMM_GROUP_VEC4U : MI_SPMM_GROUP_SCALAR);
-}
-
-size_t long_rows_workspace_bytes(int64_t nnz, int32_t N) { return long_ws_layout(nnz, N).bytes; }
-
 int launch_variant(int variant, const Shape& sh, const int32_t* rowptr, const int32_t* col, const float* val,
                    int64_t nnz, int32_t batch, int32_t M, int32_t K, int32_t N, const float* B,
                    int64_t ldb, int64_t strideB, float* C, int64_t ldc, int64_t strideC,
@@ -1579,21 +551,21 @@ int launch_variant(int variant, const Shape& sh, const int32_t* rowptr, const in
     case MI_SPMM_PANELS_6: case MI_SPMM_PANELS_8: {
       if (!(wave_ok && batch == 1)) return MI_EINVAL;
       static const int kPanels[] = {2, 3, 4, 5, 6, 8};
-      return launch_panels(kPanels[variant - MI_SPMM_PANELS_2], rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
+      return mi::launch_panels(kPanels[variant - MI_SPMM_PANELS_2], rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
     }
     case MI_SPMM_GROUP_PANELS_2: case MI_SPMM_GROUP_PANELS_3: case MI_SPMM_GROUP_PANELS_4: case MI_SPMM_GROUP_PANELS_6:
     case MI_SPMM_GROUP_PANELS_8:
       if (!(vec4_ok && batch == 1 && N <= 1024)) return MI_EINVAL;
-      return launch_group_panels(group_panel_count(variant), rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
+      return mi::launch_group_panels(mi::group_panel_count(variant), rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
     case MI_SPMM_COLTILE_PANELS: {
       if (!(vec4_ok && batch == 1 && N % 256 == 0 && N >= 256)) return MI_EINVAL;
-      int panels = coltile_panels(M, K, N, ldb, nnz);
+      int panels = mi::coltile_panels(M, K, N, ldb, nnz);
       if (panels == 0) panels = 3;  // forced by the caller
-      return launch_panels_t<1, 8>(panels, rowptr, col, val, B, C, M, K, ldb, ldc, bias, la, s, N / 256);
+      return mi::launch_coltile_panels(panels, rowptr, col, val, B, C, M, K, N, ldb, ldc, bias, la, s);
     }
     case MI_SPMM_COLTILE: {
       if (!(vec4_ok && batch == 1)) return MI_EINVAL;
-      int w = coltile_width(M, K, N, ldb);
+      int w = mi::coltile_width(M, K, N, ldb);
       if (w == 0) w = N >= 256 ? 256 : (N >= 128 ? 128 : 64);  // forced by the caller: any width works
       if (w == 256) return launch_coltile<64>(rowptr, col, val, B, C, M, N, ldb, ldc, bias, la, s);
       if (w == 128) return launch_coltile<32>(rowptr, col, val, B, C, M, N, ldb, ldc, bias, la, s);
@@ -1635,11 +607,32 @@ int launch_variant(int variant, const Shape& sh, const int32_t* rowptr, const in
 #undef MI_WAVE
 }
 
+// Can this plan take its rows through a schedule's slot → row map?  (The kernels of this file and of spmm_panels.hip that
+// walk rows one wave or one lane group at a time; the column-tiled launches, the slab / LDS-resident plans and N < 4 keep
+// their own row order.)
+bool variant_takes_order(int variant) {
+  switch (variant) {
+    case MI_SPMM_WAVE_ROW_U4: case MI_SPMM_WAVE_ROW_U8: case MI_SPMM_WAVE_ROW_U16:
+    case MI_SPMM_GROUP_VEC4: case MI_SPMM_GROUP_VEC2: case MI_SPMM_GROUP_SCALAR: case MI_SPMM_GROUP_VEC4U:
+    case MI_SPMM_PANELS_2: case MI_SPMM_PANELS_3: case MI_SPMM_PANELS_4: case MI_SPMM_PANELS_5: case MI_SPMM_PANELS_6:
+    case MI_SPMM_PANELS_8:
+    case MI_SPMM_GROUP_PANELS_2: case MI_SPMM_GROUP_PANELS_3: case MI_SPMM_GROUP_PANELS_4: case MI_SPMM_GROUP_PANELS_6:
+    case MI_SPMM_GROUP_PANELS_8:
+      return true;
+    default:
+      return false;
+  }
+}
+
+}  // namespace
+
+namespace mi {
+
 int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const float* val,
                   int64_t nnz, int32_t batch, int32_t M, int32_t K, int32_t N, const float* B,
                   int64_t ldb, int64_t strideB, float* C, int64_t ldc, int64_t strideC,
                   const float* bias, void* workspace, size_t workspace_bytes, hipStream_t s,
-                  int long_mode = MI_LONG_ROWS_AUTO) {
+                  int long_mode, const RowSchedule* sched) {
   if (M < 0 || K < 0 || N < 0 || nnz < 0 || batch < 0) return MI_EINVAL;
   if (variant < 0 || variant >= MI_SPMM_VARIANT_COUNT) return MI_EINVAL;
   if (long_mode < MI_LONG_ROWS_AUTO || long_mode > MI_LONG_ROWS_AUTO_ZEROED) return MI_EINVAL;
@@ -1649,11 +642,13 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
   if (!rowptr || !C) return MI_EINVAL;
   if (nnz > 0 && (!col || !val || !B)) return MI_EINVAL;
   if (ldb < N || ldc < N) return MI_EINVAL;
+  if (sched != nullptr && (sched->rows != M || sched->order == nullptr || batch != 1)) return MI_EINVAL;
 
   Shape sh = classify(N, ldb, ldc, strideB, strideC, B, C);
   if (bias && !mi::aligned16(bias)) sh.vec4_ok = sh.wave_ok = false;
   if (bias && (reinterpret_cast<uintptr_t>(bias) & 7u)) sh.vec2_ok = false;
   if (variant == MI_SPMM_AUTO) variant = choose_variant(sh, nnz, batch, M, K, N, ldb);
+  if (sched != nullptr && (!sched->active || !variant_takes_order(variant))) sched = nullptr;  // (this plan keeps its own row order: same bits)
 
   // long rows get their own kernel when a workspace is there to list them (no row can be long
   // unless the matrix has more than kLongRow non-zeros)
@@ -1667,7 +662,7 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
                      long_mode != MI_LONG_ROWS_NONE && (variant != MI_SPMM_SLAB || pinned_split);
   int* ws = static_cast<int*>(workspace);
   const LongWs lw = long_ws_layout(nnz, N);
-  LongArg la = {0x7fffffff, 0, 0, 0, nullptr, nullptr};
+  LongArg la = {0x7fffffff, 0, 0, 0, nullptr, nullptr, nullptr, 0};
   const bool prepared = long_mode == MI_LONG_ROWS_PREPARED;
   // L2-level panel plans with a workspace at hand: the probe's verdicts decide on the device whether the passes stay
   // passes (spmm_locality_probe_kernel).  The Infinity-Cache level (B ≥ 768 MiB: config C3) is left alone.
@@ -1677,7 +672,8 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
   if (panel_plan && batch == 1 && nnz > 0 && b_bytes_all < 768.0 * 1048576.0 && workspace != nullptr && workspace_bytes >= lw.bytes &&
       (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0) {
     int* verdicts = reinterpret_cast<int*>(static_cast<char*>(workspace) + lw.adapt_off);
-    hipLaunchKernelGGL(spmm_locality_probe_kernel, dim3(kAdaptSlots), dim3(256), 0, s, rowptr, col, M, (long)ldb, b_bytes_all, verdicts);
+    const int st = launch_locality_probe(rowptr, col, M, ldb, b_bytes_all, verdicts, s);
+    if (st != MI_OK) return st;
     la.adapt = verdicts;
   }
   if (split) {
@@ -1692,28 +688,68 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
       if (variant == MI_SPMM_SLAB || variant == MI_SPMM_LDS_B) {  // those kernels live in files of their own and only skip: list here
         LongArg fl = la;
         fl.ws = ws;
-        hipLaunchKernelGGL(find_long_rows_kernel, dim3((unsigned)(((long)M + 255) / 256)), dim3(256), 0, s, rowptr, M, fl);
+        const int st = launch_find_long_rows(rowptr, M, fl, s);
+        if (st != MI_OK) return st;
       } else {
         la.ws = ws;  // the main kernel lists the rows it skips
       }
     }
   }
-  int st = launch_variant(variant, sh, rowptr, col, val, nnz, batch, M, K, N, B, ldb, strideB, C, ldc, strideC,
-                          bias, la, s);
-  if (st != MI_OK || !split) return st;
+  int st = MI_OK;
+  bool long_rows_done = false;
+  if (sched == nullptr) {
+    st = launch_variant(variant, sh, rowptr, col, val, nnz, batch, M, K, N, B, ldb, strideB, C, ldc, strideC, bias, la, s);
+  } else {
+    // A schedule: slots are rows by DESCENDING length class (longest first: no long row is left for the end of the grid;
+    // rows that share a wave or a workgroup have about the same length).  Slots [0, heavy) — rows beyond the schedule's
+    // heavy length, those the long-row kernel takes among them (skipped and listed as ever) — go in a launch of their own
+    // with more gathers in flight per row, on the schedule's side stream BESIDE the launch(es) of the rest.  Per-row
+    // arithmetic is that of the unscheduled plan: the same bits.
+    int heavy = sched->heavy < 0 ? 0 : (sched->heavy > M ? M : sched->heavy);
+    if (!sh.vec4_ok || N > 512) heavy = 0;  // the heavy-row kernel moves float4s and gives every column a chain lane: other shapes keep every row in the ordinary launch (longest first all the same)
+    LongArg lh = la, lr = la;
+    lh.order = sched->order, lh.nslots = heavy;
+    lh.adapt = nullptr;  // one pass, every column
+    const bool fork = sched->side != nullptr && sched->fork != nullptr && sched->join != nullptr &&
+                      (heavy > 0 || (split && prepared));
+    // The few big launches — the prepared long rows' kernel (16-wave workgroups), the heavy rows' kernel (8 waves + 129 KB of
+    // LDS per workgroup) — go FIRST and on the caller's stream: a workgroup of that size only finds room on a CU before the
+    // ordinary launch has filled every wave slot with its small ones.  The ordinary launch(es) follow on the schedule's side
+    // stream and fill what is left; the caller's stream then waits for them.
+    hipStream_t rest = s;
+    if (fork) {
+      MI_HIP_TRY(hipEventRecord(sched->fork, s));
+      MI_HIP_TRY(hipStreamWaitEvent(sched->side, sched->fork, 0));
+      rest = sched->side;
+    }
+    // a PREPARED list of the rows beyond the long-row threshold: their kernel needs nothing from this product's other
+    // launches (unprepared: the launches below build the list, the follow-up comes last)
+    if (split && prepared) {
+      st = launch_long_rows(sh.vec4_ok, ws, lw, rowptr, col, val, B, C, N, ldb, ldc, bias, false, s);
+      if (st != MI_OK) return st;
+      long_rows_done = true;
+    }
+    if (heavy > 0) {
+      st = launch_heavy_rows(rowptr, col, val, M, N, B, ldb, C, ldc, bias, lh, s);
+      if (st != MI_OK) return st;
+    }
+    lr.order = sched->order + heavy, lr.nslots = M - heavy;  // (rows beyond the threshold may sit on either side of `heavy`: both launches list)
+    st = launch_variant(variant, sh, rowptr, col, val, nnz, batch, M, K, N, B, ldb, strideB, C, ldc, strideC, bias, lr, rest);
+    if (fork) {
+      MI_HIP_TRY(hipEventRecord(sched->join, sched->side));
+      MI_HIP_TRY(hipStreamWaitEvent(s, sched->join, 0));
+    }
+  }
+  if (st != MI_OK || !split || long_rows_done) return st;
   // One follow-up launch: the listed rows, their combination (by the last workgroup of each row) and, for a list
   // built by this product, the reset of the counters.  With no long row every workgroup reads three zeros and exits.
-  float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + lw.partial_off);
-  const unsigned grid = lw.cap_s < 256 ? (unsigned)lw.cap_s : 256u;  // one 16-wave workgroup per CU (grid-stride over the slots)
-  if (sh.vec4_ok)
-    hipLaunchKernelGGL(spmm_long_rows_kernel<4>, dim3(grid), dim3(kLongWaves * 64), 0, s, ws, (int)lw.cap_e,
-                       (int)lw.cap_s, partial, rowptr, col, val, B, C, N, ldb, ldc, bias, prepared ? 0 : 1);
-  else
-    hipLaunchKernelGGL(spmm_long_rows_kernel<1>, dim3(grid), dim3(kLongWaves * 64), 0, s, ws, (int)lw.cap_e,
-                       (int)lw.cap_s, partial, rowptr, col, val, B, C, N, ldb, ldc, bias, prepared ? 0 : 1);
-  return mi::check_launch();
+  return launch_long_rows(sh.vec4_ok, ws, lw, rowptr, col, val, B, C, N, ldb, ldc, bias, !prepared, s);
 }
 
+}  // namespace mi
+
+namespace {
+using mi::spmm_dispatch;
 }  // namespace
 
 namespace mi {
@@ -1760,10 +796,6 @@ int mi_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                        static_cast<hipStream_t>(stream));
 }
 
-size_t mi_spmm_csr_workspace_bytes(int64_t nnz, int32_t N) {
-  return nnz > 0 && N > 0 ? long_rows_workspace_bytes(nnz, N) : 0;
-}
-
 int mi_spmm_csr_ws_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
                        int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb, const float* bias,
                        float* C, int64_t ldc, void* workspace, size_t workspace_bytes,
@@ -1780,31 +812,6 @@ int mi_spmm_csr_ex_f32(const int32_t* rowptr, const int32_t* col, const float* v
   return spmm_dispatch(MI_SPMM_AUTO, rowptr, col, val, nnz, 1, M, K, N, B, ldb, 0, C, ldc, 0, bias, workspace,
                        workspace_bytes, static_cast<hipStream_t>(stream), long_rows);
 }
-
-int mi_spmm_long_rows_prepare(const int32_t* rowptr, int32_t M, int64_t nnz, int32_t N, void* workspace,
-                              size_t workspace_bytes, mi_stream_t stream) {
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (M < 0 || nnz < 0 || N < 0) return MI_EINVAL;
-  if (nnz > 0x7fffffffLL) return MI_ERANGE;
-  if (nnz <= kLongRow || M == 0 || N == 0) return MI_OK;  // no row can be long: the list is never read
-  if (!rowptr || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return MI_EINVAL;
-  const LongWs lw = long_ws_layout(nnz, N);
-  if (workspace_bytes < lw.bytes) return MI_ENOMEM;
-  int* ws = static_cast<int*>(workspace);
-  MI_HIP_TRY(hipMemsetAsync(ws, 0, 16, s));
-  const LongArg la = {kLongRow, (int)lw.cap_e, (int)lw.cap_s, (int)lw.cap_p, ws, nullptr};
-  hipLaunchKernelGGL(find_long_rows_kernel, dim3((unsigned)(((long)M + 255) / 256)), dim3(256), 0, s, rowptr, M, la);
-  return mi::check_launch();
-}
-
-int mi_spmm_auto_splits_long_rows(int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,
-                                  const float* C, int64_t ldc) {
-  const int v = mi_spmm_csr_f32_plan(nnz, M, K, N, B, ldb, C, ldc);
-  if (v < 0) return v;
-  return (nnz > kLongRow && v != MI_SPMM_NARROW && v != MI_SPMM_SLAB) ? 1 : 0;
-}
-
-int mi_spmm_long_row_threshold(void) { return kLongRow; }
 
 int mi_spmm_csr_bias_f32(const int32_t* rowptr, const int32_t* col, const float* val, int64_t nnz,
                          int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,
@@ -1848,10 +855,10 @@ int mi_spmm_csr_batched_perm_f32(const int32_t* rowptr, const int32_t* col, cons
   if (!rowptr || !C || !perm) return MI_EINVAL;
   if (nnz_total > 0 && (!col || !val || !B)) return MI_EINVAL;
   if (ldb < N || ldc < N) return MI_EINVAL;
-  const Shape sh = classify(N, ldb, ldc, strideB, strideC, B, C);
+  const Shape sh = mi::classify(N, ldb, ldc, strideB, strideC, B, C);
   // only the LDS-resident-B kernel reads its values through a permutation; every row keeps the plain CSR-order chain
   // (what mi_spmm_csr_batched_f32 gives a batch: no long-row rule without a workspace)
-  if (choose_variant(sh, nnz_total, batch, M, K, N, ldb) != MI_SPMM_LDS_B || !sh.vec4_ok || !mi::spmm_ldsb_fits(K, N))
+  if (mi::choose_variant(sh, nnz_total, batch, M, K, N, ldb) != MI_SPMM_LDS_B || !sh.vec4_ok || !mi::spmm_ldsb_fits(K, N))
     return 1;
   // a B that goes in as column tiles reads a row's entries once per tile — and would gather every value through the
   // permutation once per tile (2048 tokens × 64 at 5 % kept: 0.214 ms against 0.068 for a gathered copy + the plain
@@ -1868,45 +875,6 @@ int mi_spmm_csr_batched_variant_f32(int variant, const int32_t* rowptr, const in
   if (strideB < 0 || strideC < 0) return MI_EINVAL;
   return spmm_dispatch(variant, rowptr, col, val, nnz_total, batch, M, K, N, B, ldb, strideB, C, ldc, strideC, nullptr,
                        nullptr, 0, static_cast<hipStream_t>(stream));
-}
-
-int mi_spmm_csr_batched_f32_plan(int64_t nnz_total, int32_t batch, int32_t M, int32_t K, int32_t N, const float* B,
-                                 int64_t ldb, int64_t strideB, const float* C, int64_t ldc, int64_t strideC) {
-  if (M < 0 || K < 0 || N < 0 || nnz_total < 0 || batch < 0 || strideB < 0 || strideC < 0) return MI_EINVAL;
-  return choose_variant(classify(N, ldb, ldc, strideB, strideC, B, C), nnz_total, batch, M, K, N, ldb);
-}
-
-int mi_spmm_csr_f32_plan(int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,
-                         const float* C, int64_t ldc) {
-  if (M < 0 || K < 0 || N < 0 || nnz < 0) return MI_EINVAL;
-  return choose_variant(classify(N, ldb, ldc, 0, 0, B, C), nnz, 1, M, K, N, ldb);
-}
-
-int mi_spmm_variant_launches(int variant) {
-  static const int kPanels[] = {2, 3, 4, 5, 6, 8};
-  if (variant >= MI_SPMM_PANELS_2 && variant <= MI_SPMM_PANELS_8) return kPanels[variant - MI_SPMM_PANELS_2];
-  if (variant >= MI_SPMM_GROUP_PANELS_2 && variant <= MI_SPMM_GROUP_PANELS_8) return group_panel_count(variant);
-  if (variant == MI_SPMM_COLTILE_PANELS) return 0;  // one per row panel of B: depends on K
-  return (variant > MI_SPMM_AUTO && variant < MI_SPMM_VARIANT_COUNT) ? 1 : MI_EINVAL;
-}
-
-const char* mi_spmm_variant_name(int variant) {
-  switch (variant) {
-    case MI_SPMM_AUTO: return "auto";
-    case MI_SPMM_WAVE_ROW_U4: case MI_SPMM_WAVE_ROW_U8: case MI_SPMM_WAVE_ROW_U16: return "spmm_wave_row_kernel";
-    case MI_SPMM_WAVE_ROW_VL: return "spmm_wave_row_vl_kernel";
-    case MI_SPMM_GROUP_VEC4: case MI_SPMM_GROUP_VEC2: case MI_SPMM_GROUP_SCALAR: case MI_SPMM_COLTILE: case MI_SPMM_GROUP_VEC4U:
-      return "spmm_group_kernel";
-    case MI_SPMM_NARROW: return "spmm_narrow_kernel";
-    case MI_SPMM_SLAB: return "spmm_slab_kernel";
-    case MI_SPMM_LDS_B: return "spmm_ldsq_kernel";  // (its quad form; spmm_ldsb_kernel where only the 16-lane form covers the shape)
-    case MI_SPMM_PANELS_2: case MI_SPMM_PANELS_3: case MI_SPMM_PANELS_4: case MI_SPMM_PANELS_5:
-    case MI_SPMM_PANELS_6: case MI_SPMM_PANELS_8: case MI_SPMM_COLTILE_PANELS:
-      return "spmm_wave_row_panel_kernel";
-    case MI_SPMM_GROUP_PANELS_2: case MI_SPMM_GROUP_PANELS_3: case MI_SPMM_GROUP_PANELS_4: case MI_SPMM_GROUP_PANELS_6:
-    case MI_SPMM_GROUP_PANELS_8: return "spmm_group_panel_kernel";
-    default: return "unknown";
-  }
 }
 
 }  // extern "C"

@@ -1,0 +1,168 @@
+"""Row schedules (include/mi_spmm.h "Row schedules"; csrc/spmm_sched.hip): the inspector's format for degree-skewed matrices
+— rows handed to waves longest first, like lengths together, the heavy rows in a launch of their own (SURVEY.md §8f-3;
+reference: the inspector that builds a format once, src/sparse_mm.cu:137-368, and the merge-spmm lineage of the kernel,
+src/naive_sparse_mm.cu:20-21).  A schedule changes WHO computes a row, never how: every check here is bit for bit —
+against the unscheduled product, and against the CPU oracle on the same seeded inputs.  Needs the MI355X (`-m gpu`).
+"""
+import numpy as np
+import pytest
+import torch
+
+from gpu_helpers import *  # noqa: F401,F403
+
+pytestmark = pytest.mark.gpu
+
+
+def _length_class(n):
+    n = np.asarray(n, dtype=np.int64)
+    e = np.floor(np.log2(np.maximum(n, 1))).astype(np.int64)
+    return np.where(n < 32, n, 32 + (e - 5) * 8 + ((n >> np.maximum(e - 3, 0)) & 7))
+
+
+def _pareto_lens(M, mean, top, seed, empty=0.0):
+    g = np.random.Generator(np.random.PCG64(seed))
+    w = g.random(M) ** (-1.0 / 1.6)
+    lens = np.clip(np.round(w * mean / w.mean() * 0.6), 1, top).astype(np.int64)
+    if empty:
+        lens[g.random(M) < empty] = 0
+    return lens
+
+
+def _product(cmm, dev, sched, rowptr, col, val, M, K, B, **kw):
+    C = torch.full((M, B.shape[1]), float("nan"), device=dev)
+    if sched is None:
+        long_rows = kw.pop("long_rows", -1)
+        bias = kw.pop("bias", None)
+        assert not kw
+        if bias is None:
+            cmm.naive_spmm_ex(val, col, rowptr, col.numel(), M, K, B, C, long_rows)
+        else:
+            cmm.naive_spmm_bias_ex(val, col, rowptr, col.numel(), M, K, B, bias, C, long_rows)
+    else:
+        out = cmm.naive_spmm_scheduled(sched, val, col, rowptr, col.numel(), M, K, B, C, **kw)
+        assert out.data_ptr() == C.data_ptr()
+    return C
+
+
+def test_schedule_is_a_permutation_by_descending_length_class(cmm, dev):
+    """order[] holds every row once; length classes (exact below 32 entries, eight per octave above) never increase along
+    it; the heavy slots are exactly the rows of the classes above the heavy length's class; info() agrees."""
+    M = 50_000
+    lens = _pareto_lens(M, 20, 20_000, seed=1, empty=0.05)
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    nnz = int(rowptr[-1])
+    sched = cmm.spmm_schedule(t(rowptr, dev), nnz, M, 128)
+    order = sched.order.cpu().numpy()
+    assert order.dtype == np.int32 and np.array_equal(np.sort(order), np.arange(M))
+    cls = _length_class(lens[order])
+    assert np.all(np.diff(cls) <= 0)
+    info = sched.info()
+    assert info["rows"] == M and info["nnz"] == nnz and info["width"] == 128 and info["side_stream"] is True
+    assert info["classes"] == len(np.unique(cls))
+    assert info["heavy_length"] == min(max(nnz // 4096, 128), cmm.long_row_threshold())
+    assert info["heavy_rows"] == int((_length_class(lens) > _length_class(info["heavy_length"])).sum())
+    assert np.all(lens[order[:info["heavy_rows"]]] > info["heavy_length"])
+    assert info["longest_at_least"] <= lens.max() < info["longest_at_least"] * 1.13 + 1
+    sched.set_heavy(1000, True)
+    assert sched.info()["heavy_rows"] == int((_length_class(lens) > _length_class(1000)).sum())
+    # a schedule of an empty matrix, and of one row
+    for m in (0, 1):
+        rp = np.zeros(m + 1, np.int32)
+        s0 = cmm.spmm_schedule(t(rp, dev), 0, m, 64)
+        assert s0.order.numel() == m and s0.info()["heavy_rows"] == 0
+    with pytest.raises(RuntimeError):
+        cmm.spmm_schedule(t(rowptr, dev)[:-1], nnz, M, 128)
+
+
+@pytest.mark.parametrize("N", [256, 128, 100, 64, 602, 512, 40, 33, 2])
+def test_scheduled_product_equals_the_plain_product_and_the_oracle(cmm, dev, oracle_mod, N):
+    """Pareto row lengths with empty rows and rows beyond the long-row threshold: the scheduled product has the bits of the
+    unscheduled one under every long-row rule and with a bias, with the heavy launch on the side stream, in line, for every
+    row (heavy length 0) and for none; and both equal the oracle (split order for the rows beyond the threshold)."""
+    M, K = 6000, 40_000
+    lens = _pareto_lens(M, 30, 12_000, seed=N, empty=0.03)
+    lens[7], lens[4321] = 9000, 20_000      # beyond the threshold whatever the draw
+    rowptr, col, val = _random_rows_csr(M, K, lens, seed=N + 1)
+    g = np.random.Generator(np.random.PCG64(N + 2))
+    B = g.random((K, N), dtype=np.float32) - 0.5
+    bias = g.random(N, dtype=np.float32)
+    d = [t(x, dev) for x in (rowptr, col, val, B, bias)]
+    d_rp, d_col, d_val, d_B, d_bias = d
+    sched = cmm.spmm_schedule(d_rp, len(val), M, N)
+    assert sched.info()["heavy_rows"] > 0
+    want_split = oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B) if N >= 4 else oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    want_plain = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    for long_rows, want in ((-1, want_split), (1, want_split), (0, want_plain)):
+        plain = _product(cmm, dev, None, d_rp, d_col, d_val, M, K, d_B, long_rows=long_rows)
+        assert np.array_equal(plain.cpu().numpy().view(np.uint32), want.view(np.uint32)), (N, long_rows)
+        for heavy, side in ((None, True), (None, False), (0, True), (1 << 30, True), (64, False)):
+            s2 = cmm.spmm_schedule(d_rp, len(val), M, N) if heavy is not None or not side else sched
+            if heavy is not None or not side:
+                s2.set_heavy(sched.info()["heavy_length"] if heavy is None else heavy, side)
+            got = _product(cmm, dev, s2, d_rp, d_col, d_val, M, K, d_B, long_rows=long_rows)
+            assert torch.equal(got.view(torch.int32), plain.view(torch.int32)), (N, long_rows, heavy, side)
+    with_bias = _product(cmm, dev, None, d_rp, d_col, d_val, M, K, d_B, bias=d_bias)
+    got = _product(cmm, dev, sched, d_rp, d_col, d_val, M, K, d_B, bias=d_bias)
+    assert torch.equal(got.view(torch.int32), with_bias.view(torch.int32))
+    # a schedule built for another matrix is refused; unknown long-row rules too
+    other = cmm.spmm_schedule(d_rp[:101].contiguous(), int(rowptr[100]), 100, N)
+    with pytest.raises(RuntimeError):
+        _product(cmm, dev, other, d_rp, d_col, d_val, M, K, d_B)
+    with pytest.raises(ValueError):
+        _product(cmm, dev, sched, d_rp, d_col, d_val, M, K, d_B, long_rows=2)
+
+
+@pytest.mark.parametrize("N,variants", [(256, (1, 2, 3, 4, 5, 7, 9, 13, 19, 21, 24, 6, 14, 17)), (128, (4, 5, 13, 19, 20, 24, 14, 18)),
+                                        (512, (2, 4, 7, 8, 19, 14))])
+def test_every_plan_gives_the_same_bits_on_a_schedule(cmm, dev, oracle_mod, N, variants):
+    """The schedule under every pinned plan: the plans that walk rows wave by wave or group by group take the order (one-pass
+    and column-panel kernels alike, rows out of column order included), the others (column tiles 14, slabs 17, LDS-resident
+    18, the vector-load form 6) run unscheduled — all the same bits as the plain CSR-order oracle."""
+    M, K = 5000, 9000
+    lens = _pareto_lens(M, 40, 3000, seed=N + 5, empty=0.02)
+    rowptr, col, val = _random_rows_csr(M, K, lens, seed=N + 6, shuffle=0.2)
+    B = np.random.Generator(np.random.PCG64(N + 7)).random((K, N), dtype=np.float32) - 0.5
+    d_rp, d_col, d_val, d_B = (t(x, dev) for x in (rowptr, col, val, B))
+    want = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    sched = cmm.spmm_schedule(d_rp, len(val), M, N)
+    sched.set_heavy(200, True)
+    assert 0 < sched.info()["heavy_rows"] < M
+    ran = 0
+    for v in variants:
+        try:
+            got = _product(cmm, dev, sched, d_rp, d_col, d_val, M, K, d_B, long_rows=0, variant=v)
+        except ValueError:
+            continue  # the variant does not cover this shape (invalid argument)
+        ran += 1
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32)), (N, v)
+    assert ran >= len(variants) - 3
+
+
+def test_scheduled_product_is_graph_capturable(cmm, dev, oracle_mod):
+    """The heavy launch forks onto the schedule's side stream and joins again: under capture that is a fork / join inside
+    the graph; replays on new contents of the same buffers give the right bits."""
+    M, K, N = 4000, 6000, 128
+    lens = _pareto_lens(M, 25, 4000, seed=3)
+    rowptr, col, val = _random_rows_csr(M, K, lens, seed=4)
+    g = np.random.Generator(np.random.PCG64(5))
+    B1, B2 = g.random((K, N), dtype=np.float32), g.random((K, N), dtype=np.float32)
+    d_rp, d_col, d_val = (t(x, dev) for x in (rowptr, col, val))
+    d_B = t(B1, dev)
+    C = torch.empty(M, N, device=dev)
+    sched = cmm.spmm_schedule(d_rp, len(val), M, N)
+    sched.set_heavy(150, True)
+    assert sched.info()["heavy_rows"] > 0
+    cmm.naive_spmm_scheduled(sched, d_val, d_col, d_rp, len(val), M, K, d_B, C, None, 0)  # warm-up outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            cmm.naive_spmm_scheduled(sched, d_val, d_col, d_rp, len(val), M, K, d_B, C, None, 0)
+    for Bh in (B1, B2):
+        d_B.copy_(t(Bh, dev))
+        C.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(C.cpu().numpy().view(np.uint32), oracle_mod.spmm_csr(rowptr, col, val, M, K, Bh).view(np.uint32))
