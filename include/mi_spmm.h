@@ -220,6 +220,14 @@ int mi_spmm_csr_scheduled_f32(const mi_spmm_schedule_t* schedule, int variant, c
                               const float* val, int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B, int64_t ldb,
                               const float* bias, float* C, int64_t ldc, int long_rows, void* workspace,
                               size_t workspace_bytes, mi_stream_t stream);
+/* The column-major executor (mi_spmm_csr_colmajor_ex_f32, below: B3 / K2) on a schedule — what an inspector handle runs for a
+ * degree-skewed matrix (custom_mm.cusparse_mmul_opt / tiledspmm_mm).  schedule may be NULL or inactive: then exactly
+ * mi_spmm_csr_colmajor_ex_f32.  Same bits either way. */
+int mi_spmm_csr_colmajor_sched_f32(const mi_spmm_schedule_t* schedule, const int32_t* rowptr, const int32_t* col,
+                                   const float* val, int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
+                                   int64_t ldb, float* C, int64_t ldc, int long_rows, void* long_rows_workspace,
+                                   size_t long_rows_workspace_bytes, void* workspace, size_t workspace_bytes,
+                                   mi_stream_t stream);
 
 /* ------------------------------------------------------------------------ *
  * Batched form — `batch` independent products in ONE launch:

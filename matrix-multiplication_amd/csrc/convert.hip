@@ -600,12 +600,20 @@ int mi_spmm_colmajor_form(int64_t nnz, int32_t M, int32_t K, int32_t N, const fl
   return 0;
 }
 
-int mi_spmm_csr_colmajor_ex_f32(const int32_t* rowptr, const int32_t* col, const float* val,
-                                int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
-                                int64_t ldb, float* C, int64_t ldc, int long_rows, void* long_rows_workspace,
-                                size_t long_rows_workspace_bytes, void* workspace, size_t workspace_bytes,
-                                mi_stream_t stream) {
+int mi_spmm_csr_colmajor_sched_f32(const mi_spmm_schedule_t* schedule, const int32_t* rowptr, const int32_t* col,
+                                   const float* val, int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
+                                   int64_t ldb, float* C, int64_t ldc, int long_rows, void* long_rows_workspace,
+                                   size_t long_rows_workspace_bytes, void* workspace, size_t workspace_bytes,
+                                   mi_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // an ACTIVE row schedule (a degree-skewed matrix: include/mi_spmm.h "Row schedules") runs the row-major product between the
+  // two operand transposes — the form that can hand rows to waves in the schedule's order; the LDS-slab form on column-major
+  // operands stays (a long row is ordinary work there), the fused-output kernel (16 consecutive rows per workgroup) does not
+  bool scheduled = false;
+  if (schedule != nullptr) {
+    int64_t info[8];
+    if (mi_spmm_schedule_info(schedule, info) == MI_OK) scheduled = (info[5] & 2) != 0 && info[0] == M;
+  }
   if (M < 0 || K < 0 || N < 0 || nnz < 0) return MI_EINVAL;
   if (M == 0 || N == 0) return MI_OK;
   if (!rowptr || !C || ldc < M) return MI_EINVAL;
@@ -619,16 +627,27 @@ int mi_spmm_csr_colmajor_ex_f32(const int32_t* rowptr, const int32_t* col, const
   // column-major K×N with ldb  ==  row-major [N, ldb]; its transpose is [K, N].
   int st = launch_transpose(B, N, K, ldb, Bt, N, s);
   if (st != MI_OK) return st;
-  if (long_rows == MI_LONG_ROWS_NONE && nnz > 0 && K > 0) {
+  if (long_rows == MI_LONG_ROWS_NONE && nnz > 0 && K > 0 && !scheduled) {
     // one wave per row with the output transpose fused into its epilogue, where that is the plan
     st = mi::launch_spmm_wave_row_colmajor_out(rowptr, col, val, nnz, M, K, N, Bt, N, C, ldc, true, s);
     if (st <= MI_OK) return st;
   }
-  st = mi_spmm_csr_ex_f32(rowptr, col, val, nnz, M, K, N, Bt, N, nullptr, Ct, N, long_rows, long_rows_workspace,
-                          long_rows_workspace_bytes, stream);
+  st = scheduled ? mi_spmm_csr_scheduled_f32(schedule, MI_SPMM_AUTO, rowptr, col, val, nnz, M, K, N, Bt, N, nullptr, Ct, N, long_rows,
+                                             long_rows_workspace, long_rows_workspace_bytes, stream)
+                 : mi_spmm_csr_ex_f32(rowptr, col, val, nnz, M, K, N, Bt, N, nullptr, Ct, N, long_rows, long_rows_workspace,
+                                      long_rows_workspace_bytes, stream);
   if (st != MI_OK) return st;
   // row-major [M, N] → row-major [N, ldc]  ==  column-major M×N with ldc.
   return launch_transpose(Ct, M, N, N, C, ldc, s);
+}
+
+int mi_spmm_csr_colmajor_ex_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                                int64_t nnz, int32_t M, int32_t K, int32_t N, const float* B,
+                                int64_t ldb, float* C, int64_t ldc, int long_rows, void* long_rows_workspace,
+                                size_t long_rows_workspace_bytes, void* workspace, size_t workspace_bytes,
+                                mi_stream_t stream) {
+  return mi_spmm_csr_colmajor_sched_f32(nullptr, rowptr, col, val, nnz, M, K, N, B, ldb, C, ldc, long_rows, long_rows_workspace,
+                                        long_rows_workspace_bytes, workspace, workspace_bytes, stream);
 }
 
 int mi_spmm_csr_colmajor_f32(const int32_t* rowptr, const int32_t* col, const float* val,

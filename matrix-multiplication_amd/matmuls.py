@@ -279,6 +279,36 @@ def _csr_props_cached(a: torch.Tensor):
     return props
 
 
+def _row_schedule(holder: torch.Tensor, slot: str, key, offsets: torch.Tensor, nnz: int, rows: int, width: int):
+    '''The inspector's row schedule (custom_mm.spmm_schedule: rows handed to waves longest first, like lengths together,
+    heavy rows in a launch of their own — the same bits as the plain product) for a CSR pattern that is being used AGAIN:
+    kept on the tensor object `holder` under `slot`, per dense width, keyed like the other per-tensor caches (index
+    tensors' storage and version counters).  The first product of a pattern runs plain and only leaves a mark — building
+    a schedule reads 1 KiB back (it synchronises), which a one-shot operand should not pay for; from the second product
+    on the schedule is there.  Never built under stream capture.  Returns None when there is none (yet), or when the
+    inspector found no skew worth an indirection (short, alike rows).  Counterpart of the reference's inspect-once /
+    multiply-many pair (src/sparse_mm.cu:137-385), without asking the caller to name a layer.'''
+    if not hasattr(custom_mm, 'spmm_schedule') or not offsets.is_cuda or rows < 2 or nnz < 4096:
+        return None
+    book = getattr(holder, slot, None)
+    if book is None or book[0] != key:
+        book = (key, {})
+        try:
+            setattr(holder, slot, book)
+        except (AttributeError, RuntimeError):
+            return None  # a tensor type that takes no attributes: no schedule
+    ent = book[1].get(width)
+    if ent is None:
+        book[1][width] = 'seen'
+        return None
+    if ent == 'seen':
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        ent = custom_mm.spmm_schedule(offsets, nnz, rows, width)
+        book[1][width] = ent
+    return ent if ent.info()['active'] else None
+
+
 def _dense_to_csr(a: torch.Tensor, est_density=None):
     '''(values, columns, offsets, nnz) of a dense tensor's last two dims (batched: the "rowptr of rowptrs" layout).
     With neither capture nor an estimate: the exact arrays (one read-back of the count sizes them; the kernels' plan
@@ -326,6 +356,11 @@ def _csr_product(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, mm_op, defau
     if one_launch and not a.is_sparse_csr and a.is_cuda and a.numel() > 0 and not torch.cuda.is_current_stream_capturing():
         est = sampled_density(a, (tuple(a.shape), tuple(b.shape), a.device.index), a.shape[-1], owner)
     props = _csr_of(a, est)
+    if a.is_sparse_csr and mm_op is default_op and b.dim() == 2:
+        # a CSR tensor that has been multiplied before (a static sparse operand: weights, an adjacency matrix): its row schedule
+        sched = _row_schedule(a, '_mi_csr_sched', _csr_key(a)[1:3] + _csr_key(a)[4:], props[2], props[3], props[4], b.shape[-1])
+        if sched is not None:
+            return custom_mm.naive_spmm_scheduled(sched, *props, b, c, None, 0 if one_launch else -1)
     if one_launch:
         return custom_mm.naive_spmm_ex(*props, b, c, 0)
     return mm_op(*props, b, c)
@@ -858,7 +893,13 @@ def _sparse_backward(ctx, grad_output):
                                               gvals.to(m1.device), size=m1.shape)
         if ctx.needs_input_grad[1]:
             gb = torch.empty((cols, g.shape[-1]), device=g.device, dtype=torch.float32)
-            gb = custom_mm.naive_spmm(t_val, t_col, t_off, nnz, cols, rows, g, gb)
+            # m1ᵀ's pattern is cached on m1: so is its row schedule (the transpose of a skewed matrix is as skewed)
+            sched = _row_schedule(m1, '_mi_csr_sched_t', _csr_key(m1)[1:3] + _csr_key(m1)[4:], t_off, nnz, cols, g.shape[-1]) \
+                if g.is_contiguous() else None
+            if sched is not None:
+                gb = custom_mm.naive_spmm_scheduled(sched, t_val, t_col, t_off, nnz, cols, rows, g, gb)
+            else:
+                gb = custom_mm.naive_spmm(t_val, t_col, t_off, nnz, cols, rows, g, gb)
             if m2.dim() > 2:
                 gb = gb.view(cols, -1, m2.shape[-1]).permute(1, 0, 2)
             grad_m2 = gb.reshape(m2.shape)

@@ -166,3 +166,74 @@ def test_scheduled_product_is_graph_capturable(cmm, dev, oracle_mod):
         graph.replay()
         torch.cuda.synchronize()
         assert np.array_equal(C.cpu().numpy().view(np.uint32), oracle_mod.spmm_csr(rowptr, col, val, M, K, Bh).view(np.uint32))
+
+
+def test_inspector_handles_run_skewed_matrices_on_their_schedule(cmm, dev, oracle_mod):
+    """cusparse_inspect / tiledspmm_inspect_csr build the row schedule of A and of Aᵀ (what an inspector is for: reference
+    src/sparse_mm.cu:137-368 restructures A once); cusparse_mmul_opt / _t and tiledspmm_mm then run the column-major
+    executor on it — the same bits as the oracle's column-major product (split order for the rows beyond the threshold),
+    for a skewed matrix (schedule active, long rows prepared) and for a uniform one (schedule inactive)."""
+    K, N = 30_000, 128
+    for tag, lens in (("skewed", _pareto_lens(5000, 30, 12_000, seed=11, empty=0.02)), ("uniform", np.full(5000, 24))):
+        M = len(lens)
+        if tag == "skewed":
+            lens[17] = 9500
+        rowptr, col, val = _random_rows_csr(M, K, lens, seed=12)
+        nnz = len(val)
+        g = np.random.Generator(np.random.PCG64(13))
+        Bt = g.random((N, K), dtype=np.float32) - 0.5      # column-major K x N  ==  row-major [N, K]
+        d_rp, d_col, d_val = (t(x, dev) for x in (rowptr, col, val))
+        cmm.cusparse_inspect(d_rp, d_col, d_val, nnz, M, N, K, "sk")
+        info = cmm.inspect_info("sk", False)
+        assert info["schedule_active"] is (tag == "skewed"), info
+        Ct = torch.full((N, M), float("nan"), device=dev)
+        cmm.cusparse_mmul_opt(t(Bt, dev), Ct, "sk")
+        B = np.ascontiguousarray(Bt.T)
+        want = (oracle_mod.spmm_csr_long if tag == "skewed" else oracle_mod.spmm_csr)(rowptr, col, val, M, K, B)
+        assert np.array_equal(Ct.cpu().numpy().view(np.uint32), np.ascontiguousarray(want.T).view(np.uint32)), tag
+        # the transposed product with the cached Aᵀ (its own schedule)
+        Gt = g.random((N, M), dtype=np.float32) - 0.5
+        Dt = torch.full((N, K), float("nan"), device=dev)
+        cmm.cusparse_mmul_opt_t(t(Gt, dev), Dt, "sk")
+        t_rp, t_col, t_val = oracle_mod.csr_transpose(rowptr, col, val, M, K)
+        want_t = oracle_mod.spmm_csr_long(t_rp, t_col, t_val, K, M, np.ascontiguousarray(Gt.T))
+        assert np.array_equal(Dt.cpu().numpy().view(np.uint32), np.ascontiguousarray(want_t.T).view(np.uint32)), tag
+        cmm.cusparse_clean()
+        # the tiled inspector (host CSR, int64 indices) ends on the same handle
+        cmm.tiledspmm_inspect_csr(M, K, N, torch.from_numpy(rowptr.astype(np.int64)), torch.from_numpy(col.astype(np.int64)),
+                                  torch.from_numpy(val), "tl")
+        Ct.fill_(float("nan"))
+        cmm.tiledspmm_mm(t(Bt, dev), Ct, "tl")
+        assert np.array_equal(Ct.cpu().numpy().view(np.uint32), np.ascontiguousarray(want.T).view(np.uint32)), tag
+        cmm.tiledspmm_clean()
+
+
+def test_matmuls_keeps_a_schedule_on_a_csr_tensor_that_is_used_again(mm, cmm, dev, oracle_mod):
+    """cusparseMM.apply(A_csr, b): the first product of a pattern runs plain and leaves a mark, the second builds the row
+    schedule and keeps it on the tensor (per dense width), later ones reuse it; the backward's Aᵀ·dC does the same on the
+    cached transposed pattern.  Forward values equal the oracle bit for bit every time, gradients equal torch autograd's."""
+    M, K, N = 6000, 8000, 64
+    lens = _pareto_lens(M, 20, 4000, seed=21, empty=0.02)
+    rowptr, col, val = _random_rows_csr(M, K, lens, seed=22)
+    g = np.random.Generator(np.random.PCG64(23))
+    B = g.random((K, N), dtype=np.float32) - 0.5
+    a = torch.sparse_csr_tensor(torch.from_numpy(rowptr.astype(np.int64)), torch.from_numpy(col.astype(np.int64)),
+                                torch.from_numpy(val), (M, K)).to(dev).requires_grad_(True)
+    b = t(B, dev).requires_grad_(True)
+    want = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    dC = g.random((M, N), dtype=np.float32)
+    for i in range(3):
+        b.grad = None
+        out = mm.cusparseMM.apply(a, b)
+        assert np.array_equal(out.detach().cpu().numpy().view(np.uint32), want.view(np.uint32)), i
+        out.backward(t(dC, dev))
+        book = a._mi_csr_sched[1]
+        assert (book[N] == 'seen') if i == 0 else (book[N].info()["active"] and book[N].info()["heavy_rows"] > 0), (i, book)
+        book_t = a._mi_csr_sched_t[1]
+        assert (book_t[N] == 'seen') if i == 0 else (book_t[N].info()["rows"] == K)
+        t_rp, t_col, t_val = oracle_mod.csr_transpose(rowptr, col, val, M, K)
+        assert np.array_equal(b.grad.cpu().numpy().view(np.uint32), oracle_mod.spmm_csr(t_rp, t_col, t_val, K, M, dC).view(np.uint32)), i
+    # another width: its own entry
+    b2 = t(g.random((K, 32), dtype=np.float32), dev)
+    mm.cusparseMM.apply(a, b2)
+    assert a._mi_csr_sched[1][32] == 'seen' and a._mi_csr_sched[1][N] != 'seen'
