@@ -1607,7 +1607,7 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void tr_item_lds_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                                  const float* __restrict__ val, int M, int K,
                                                                  int* __restrict__ t_rowptr, int* __restrict__ t_col,
-                                                                 float* __restrict__ t_val, int cap, int nseg) {
+                                                                 float* __restrict__ t_val, int cap, int nseg, int nnz_total) {
   extern __shared__ __attribute__((aligned(16))) int tr_lds[];
   // [cap] staged rows, [cap] staged values (both 16-byte aligned: cap % 4 == 0), [WAVES][K] counters → cursors,
   // [K + 1] column starts of the item (relative), WAVES + 1 ints of scan scratch
@@ -1635,8 +1635,10 @@ __global__ __launch_bounds__(WAVES * 64) void tr_item_lds_kernel(const int* __re
   // The kernel is a chain of dependent trips to memory (row bounds → entries → … ) with the CU to itself, so the chain is
   // kept short: the wave's row bounds arrive as ONE vector load, the counting pass's entries and the first placement
   // group's entries are requested together right behind it.
-  const int last_e = rp[M] > base ? rp[M] - 1 : base;  // (an item without entries never dereferences it: every `has` is false … but the
-                                                       // load is issued: the caller's arrays hold ≥ 1 entry whenever nnz > 0)
+  // (an item without entries never USES what it loads — every `has` is false — but the loads are issued: the index must lie
+  // inside the caller's arrays.  For an empty item at the END of the batch `base` is nnz_total, one past them: clamp to the
+  // last entry of the whole batch — nnz_total > 0 here, the launcher returns early on an empty batch)
+  const int last_e = rp[M] > base ? rp[M] - 1 : (base < nnz_total ? base : nnz_total - 1);
   const bool rp_in_reg = r1 - r0 <= 63;
   const int rpv = rp_in_reg ? rp[r0 + lane <= r1 ? r0 + lane : r1] : 0;
   auto bound = [&](int row) {  // rp[min(row, r1)], wave-uniform
@@ -1938,7 +1940,7 @@ int launch_tr_item_lds(int waves, int64_t nnz, const int32_t* rowptr, const int3
     auto k = tr_item_lds_kernel<W_>;                                                                                         \
     if (lds > 64 * 1024) MI_HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL(k, dim3((unsigned)(batch * nseg)), dim3(W_ * 64), lds, s, rowptr, col, val, M, K, t_rowptr, t_col, t_val, \
-                       (int)cap, nseg);                                                                                      \
+                       (int)cap, nseg, (int)nnz);                                                                            \
   } while (0)
   if (waves == 16) MI_TR_ITEM(16);
   else if (waves == 8) MI_TR_ITEM(8);

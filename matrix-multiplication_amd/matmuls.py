@@ -56,6 +56,17 @@ def _sum_to_shape(grad, shape):
     return grad
 
 
+# the HIP-backed extension (tests/fake_custom_mm.py — the oracle-backed stand-in the host-logic tests import instead — is a
+# plain Python module: with it every call goes through the dispatch code, which is what those tests are for)
+_REAL_EXTENSION = str(getattr(custom_mm, '__file__', '')).endswith('.so')
+
+
+def _host_operands(a: torch.Tensor, b: torch.Tensor) -> bool:
+    '''Two dense float tensors in host memory, with the real extension loaded.'''
+    return (_REAL_EXTENSION and not a.is_cuda and not b.is_cuda and a.layout == torch.strided and b.layout == torch.strided
+            and a.dim() >= 1 and b.dim() >= 1)
+
+
 def custom_matmul(a: torch.Tensor,
                   b: torch.Tensor,
                   mm_op=custom_mm.cublas_mmul,
@@ -77,6 +88,12 @@ def custom_matmul(a: torch.Tensor,
     :param transb: transpose B
     :returns: Matrix multiplication output
     '''
+    if _host_operands(a, b):
+        # BASELINE.json configs[0] as written ("torch.mm dense 8×64 @ 64×8 on CPU via the matmuls.py wrapper"): both operands are
+        # dense HOST tensors, nothing asks for the GPU — the reference's own expression for the ranks its kernels do not take,
+        # `return a @ b` (reference matmuls.py:39-41).  torch, not a kernel of this package and not the oracle; a device operand
+        # (or a mixed pair, or a CSR operand) never comes here: custom_mm raises on host tensors.
+        return (a.transpose(-1, -2) if transa and a.dim() > 1 else a) @ (b.transpose(-1, -2) if transb and b.dim() > 1 else b)
     # matrix-vector forms: promote the vector to a matrix, as torch.matmul does.
     if a.dim() == 1 or b.dim() == 1:
         if a.dim() == 0 or b.dim() == 0:
@@ -330,7 +347,10 @@ def _dense_to_csr(a: torch.Tensor, est_density=None):
     return values, columns, offsets, values.numel()
 
 
-_NO_READBACK_MAX_ELEMS = 1 << 28  # capacity-sized CSR arrays (8 B per element of A) stay under 2 GiB
+# capacity-sized CSR arrays are 8 B per ELEMENT of A, whatever its density (a 1 % dense operand: 100 × what the exact arrays
+# need) — transient, but real: the no-read-back route is for operands up to 128 Mi elements (≤ 1 GiB of arrays on a 288 GB
+# part; BERT's 384 × 512² probabilities are 100 Mi), larger ones pay the one read-back of the count (round-5 advisor: was 256 Mi)
+_NO_READBACK_MAX_ELEMS = 1 << 27
 
 
 def _csr_of(a: torch.Tensor, est_density=None):
@@ -356,6 +376,8 @@ def _csr_product(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, mm_op, defau
     if one_launch and not a.is_sparse_csr and a.is_cuda and a.numel() > 0 and not torch.cuda.is_current_stream_capturing():
         est = sampled_density(a, (tuple(a.shape), tuple(b.shape), a.device.index), a.shape[-1], owner)
     props = _csr_of(a, est)
+    # an ESTIMATED count may only meet rule 0 (no long-row workspace is sized from it: include/mi_spmm.h, K1 section)
+    assert est is None or one_launch
     if a.is_sparse_csr and mm_op is default_op and b.dim() == 2:
         # a CSR tensor that has been multiplied before (a static sparse operand: weights, an adjacency matrix): its row schedule
         sched = _row_schedule(a, '_mi_csr_sched', _csr_key(a)[1:3] + _csr_key(a)[4:], props[2], props[3], props[4], b.shape[-1])
@@ -628,6 +650,8 @@ def _spmm_dispatch(a: torch.Tensor, b: torch.Tensor, mm_op, default_op, dense_ro
     '''Shared body of sparse_matmul / naive_matmul: op = ``a @ b`` with ``a``
     taken as sparse (a CSR tensor, or a dense tensor whose exact zeros are
     dropped), semantics of torch.matmul for every rank combination.'''
+    if _host_operands(a, b):
+        return a @ b  # config C1: dense host operands — the reference's own expression (matmuls.py:279,302); see custom_matmul
     if a.dim() == 1 or b.dim() == 1:
         if a.dim() == 0 or b.dim() == 0:
             raise ValueError('sparse matmul: both arguments need to be at least 1-d')

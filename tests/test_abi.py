@@ -244,13 +244,51 @@ def test_custom_mm_error_convention(custom_mm):
                                         torch.zeros(0), "x")
 
 
+def test_config_c1_dense_host_operands_through_the_wrappers(built):
+    """BASELINE.json configs[0], literally: "torch.mm dense 8×64 @ 64×8 on CPU via the matmuls.py wrapper".  With the REAL
+    extension imported, two dense host tensors take the reference's own CPU expression `a @ b` (reference matmuls.py:39-41,
+    279, 302) — torch, never the oracle — forward and backward, through every class; the README shapes (reference
+    README.md:24-30)."""
+    for k in ("custom_mm", "matmuls"):
+        sys.modules.pop(k, None)
+    import matmuls
+    assert "fake" not in matmuls.custom_mm.__name__ and matmuls._REAL_EXTENSION
+    torch.manual_seed(0)
+    a0, b0 = torch.rand(8, 64), torch.rand(64, 8)
+    dc = torch.rand(8, 8)
+    for cls, fa, fb in ((matmuls.cublasMM, lambda x: x, lambda x: x), (matmuls.naiveSpMM, lambda x: x, lambda x: x),
+                        (matmuls.cusparseMM, lambda x: x, lambda x: x), (matmuls.cublasTransbMM, lambda x: x, lambda x: x.t().contiguous()),
+                        (matmuls.cublasTransaMM, lambda x: x.t().contiguous(), lambda x: x),
+                        (matmuls.cublasTransabMM, lambda x: x.t().contiguous(), lambda x: x.t().contiguous())):
+        a1, b1 = fa(a0).clone().requires_grad_(True), fb(b0).clone().requires_grad_(True)
+        a2, b2 = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        out = cls.apply(a1, b1)
+        ref = torch.mm(a2, b2)
+        assert not out.is_cuda and torch.equal(out, ref), cls.__name__
+        out.backward(dc)
+        ref.backward(dc)
+        assert torch.allclose(fa(a2.grad), a1.grad, rtol=1e-5, atol=1e-8) and torch.allclose(fb(b2.grad), b1.grad, rtol=1e-5, atol=1e-8), cls.__name__
+    # batched and matrix-vector forms follow torch.matmul
+    x, w = torch.rand(3, 5, 16), torch.rand(16, 4)
+    assert torch.equal(matmuls.cublasMM.apply(x, w), x @ w) and torch.equal(matmuls.naiveSpMM.apply(x, w), x @ w)
+    assert torch.equal(matmuls.cublasMM.apply(x[0], w[:, 0]), x[0] @ w[:, 0])
+
+
 def test_matmuls_product_path_fails_loudly_on_cpu(built):
-    """The real matmuls + real custom_mm on CPU tensors raise; nothing falls back to torch."""
+    """Everything else on the host raises: a CSR operand in host memory has no kernel to go to (custom_mm takes device tensors
+    only), and the entry points themselves refuse host tensors — nothing falls back to the oracle or to a CPU kernel of this
+    package.  (A device operand paired with a host one raises too: tests/test_gpu_matmuls.py.)"""
     for k in ("custom_mm", "matmuls"):
         sys.modules.pop(k, None)
     import matmuls
     assert "fake" not in matmuls.custom_mm.__name__
     a, b = torch.rand(8, 64), torch.rand(64, 8)
-    for cls in (matmuls.cublasMM, matmuls.naiveSpMM, matmuls.cusparseMM):
-        with pytest.raises(RuntimeError, match="device"):
-            cls.apply(a, b)
+    if not torch.cuda.is_available():
+        for cls in (matmuls.naiveSpMM, matmuls.cusparseMM):
+            with pytest.raises((RuntimeError, AssertionError)):
+                cls.apply(a.to_sparse_csr(), b)
+    c = torch.empty(8, 8)
+    with pytest.raises(RuntimeError, match="device"):
+        matmuls.custom_mm.cublas_mmul(a, b, c, False, False)
+    with pytest.raises(RuntimeError, match="device"):
+        matmuls.custom_mm.cublas_bmm(a[None], b[None], c[None], 3, False, False)

@@ -611,3 +611,16 @@ def test_cusparse_linear_lds_fit_layer_with_a_stale_low_density_estimate(mm, cmm
     assert torch.equal(outs["exact"], outs["stale_low"]) and torch.equal(outs["exact"], outs["high"])
     ref = torch.nn.functional.linear(x, layer.weight.detach().cpu(), layer.bias.detach().cpu())
     assert torch.allclose(ref, outs["exact"], rtol=RTOL, atol=1e-6)
+
+
+def test_mixed_host_and_device_operands_raise(mm, dev):
+    """Two dense HOST operands take the reference's own CPU expression (config C1: tests/test_abi.py); anything that involves
+    the device goes to the kernels — and a device operand paired with a host one raises instead of silently moving data or
+    falling back."""
+    a, b = torch.rand(8, 64), torch.rand(64, 8)
+    for cls in (mm.cublasMM, mm.naiveSpMM, mm.cusparseMM):
+        for x, y in ((a.to(dev), b), (a, b.to(dev))):
+            with pytest.raises(RuntimeError):
+                cls.apply(x, y)
+        assert torch.equal(cls.apply(a, b), a @ b) and not cls.apply(a, b).is_cuda
+        assert cls.apply(a.to(dev), b.to(dev)).is_cuda

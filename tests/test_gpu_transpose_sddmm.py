@@ -319,6 +319,8 @@ def test_csr_transpose_small_items_lds_plan_skewed_batch_bit_exact(cmm, dev, ora
     lens[0] = g.integers(8, 18, size=M)                            # item 0: ≈ 37 K entries
     lens[0, 5] = 200                                               # a row of several chunks
     lens[7] = 0                                                    # an empty item
+    lens[batch - 2:] = 0                                           # … and the LAST items empty: their base offset is nnz itself, one
+                                                                   # past the arrays (round-5 advisor: the clamped loads must stay inside)
     cols = []
     for i in range(batch):
         for r in range(M):
