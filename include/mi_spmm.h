@@ -198,21 +198,31 @@ const char* mi_spmm_variant_name(int variant);
  * flight per row on the schedule's side stream, beside the launch(es) of the rest.  Every row's fmaf chain is that of the
  * unscheduled product: mi_spmm_csr_scheduled_f32 returns the SAME BITS as mi_spmm_csr_ex_f32 for every plan and long-row
  * mode (plans that cannot take a row order — column tiles, MI_SPMM_SLAB, MI_SPMM_LDS_B, MI_SPMM_NARROW — run unscheduled).
+ * LOCALITY the row order hides (the reference compacts each block's footprint of B through `mapindex`, src/sparse_mm.cu:62-68,
+ * 259): given the columns, the inspector also tries the rows in the order of their median column inside a length class, MEASURES
+ * what a window of 2048 consecutive slots then touches of B against the natural order (its FOOTPRINT: the 256ths of B that hold
+ * three quarters of its gathers), and keeps that order only when the natural order is not local already (footprint > 40 % of
+ * B) and the new one more than halves it — a banded or
+ * community-structured matrix whose rows arrive shuffled then gathers like the unshuffled one.  Same bits, again.
  *   mi_spmm_schedule_create: `order` (device, M ints) is caller-owned and must outlive the schedule; workspace ≥
- *     mi_spmm_schedule_workspace_bytes(M) is only used during the call.  Builds on `stream` and SYNCHRONISES it (reads the
- *     1 KiB class table back): inspection time, not capturable.  N: the dense width the schedule will mostly be used with.
+ *     mi_spmm_schedule_workspace_bytes(M) is only used during the call.  col may be NULL (no locality pass).  Builds on
+ *     `stream` and SYNCHRONISES it (reads ≈ 1.5 KiB back: the class table, the window statistics): inspection time, not
+ *     capturable.  N: the dense width the schedule will mostly be used with.
  *   Products on one schedule must be ordered on one stream (they share its side stream and fork / join events).
- *   mi_spmm_schedule_info: info[8] = {rows, heavy slots, heavy length, non-empty classes, lower bound of the longest row,
+ *   mi_spmm_schedule_info: info[12] = {rows, heavy slots, heavy length, non-empty classes, lower bound of the longest row,
  *     flags (1: has a side stream; 2: ACTIVE — an order costs the locality of consecutive rows, so a matrix of short, alike
- *     rows keeps its products unscheduled: active with heavy rows, or mean ≥ 16 entries and longest ≥ 1.5 × mean), nnz, N}.
+ *     rows keeps its products unscheduled: active with heavy rows, with a locality order, or mean ≥ 16 entries and longest ≥
+ *     1.5 × mean; 4: locality order), nnz, N, a window's footprint in natural order / in this order (‰ of B), mean row span (‰ of
+ *     K) (-1: not measured), 0}.
  *   mi_spmm_schedule_set_heavy: another heavy length (0: every row; ≥ the longest: none) / every launch in line on the caller's
  *     stream instead of the rest beside the heavy launch — tests and A/B measurements; makes the schedule active.
  *   mi_spmm_csr_scheduled_f32: mi_spmm_csr_ex_variant_f32 (variant MI_SPMM_AUTO = by plan) on the schedule.
  * ------------------------------------------------------------------------ */
 typedef struct mi_spmm_schedule mi_spmm_schedule_t;
 size_t mi_spmm_schedule_workspace_bytes(int32_t M);
-int mi_spmm_schedule_create(const int32_t* rowptr, int32_t M, int64_t nnz, int32_t N, int32_t* order, void* workspace,
-                            size_t workspace_bytes, mi_stream_t stream, mi_spmm_schedule_t** out);
+int mi_spmm_schedule_create(const int32_t* rowptr, const int32_t* col, int32_t M, int32_t K, int64_t nnz, int32_t N,
+                            int32_t* order, void* workspace, size_t workspace_bytes, mi_stream_t stream,
+                            mi_spmm_schedule_t** out);
 int mi_spmm_schedule_destroy(mi_spmm_schedule_t* schedule);
 int mi_spmm_schedule_info(const mi_spmm_schedule_t* schedule, int64_t* info);
 int mi_spmm_schedule_set_heavy(mi_spmm_schedule_t* schedule, int32_t heavy_len, int use_side_stream);

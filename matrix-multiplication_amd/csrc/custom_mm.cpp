@@ -134,11 +134,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("spmm_plan", &spmm_plan, "(variant, kernel name, launches, splits_long_rows) of the AUTO plan");
   m.def("validate_csr", &validate_csr, "opt-in check of CSR contents (offsets monotone, columns in range); raises");
   py::class_<PySchedule, std::shared_ptr<PySchedule>>(m, "SpmmSchedule")
-      .def("info", &PySchedule::info, "rows, heavy_rows, heavy_length, classes, longest_at_least, side_stream, nnz, width")
+      .def("info", &PySchedule::info, "rows, heavy_rows, heavy_length, classes, longest_at_least, side_stream, active, locality_order, window spans, nnz, width")
       .def("set_heavy", &PySchedule::set_heavy, py::arg("heavy_length"), py::arg("side_stream") = true,
            "another heavy length / the heavy launch in line (tests, A/B)")
       .def_readonly("order", &PySchedule::order, "int32 [rows] on the device: slot -> row, rows by descending length class");
-  m.def("spmm_schedule", &spmm_schedule, "Inspector: the row schedule of a CSR matrix (offsets, nnz, rows, dense width)");
+  m.def("spmm_schedule", &spmm_schedule, py::arg("A_offsets"), py::arg("nnzA"), py::arg("A_rows"), py::arg("N"),
+        py::arg("A_columns") = py::none(), py::arg("A_cols") = 0,
+        "Inspector: the row schedule of a CSR matrix (offsets, nnz, rows, dense width; with the columns: also tries the locality order)");
   m.def("naive_spmm_scheduled", &naive_spmm_scheduled, py::arg("schedule"), py::arg("A_values"), py::arg("A_columns"),
         py::arg("A_offsets"), py::arg("nnzA"), py::arg("A_rows"), py::arg("A_cols"), py::arg("B"), py::arg("C"),
         py::arg("bias") = py::none(), py::arg("long_rows") = -1, py::arg("variant") = 0,

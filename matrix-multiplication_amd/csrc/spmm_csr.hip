@@ -672,7 +672,7 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
   if (panel_plan && batch == 1 && nnz > 0 && b_bytes_all < 768.0 * 1048576.0 && workspace != nullptr && workspace_bytes >= lw.bytes &&
       (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0) {
     int* verdicts = reinterpret_cast<int*>(static_cast<char*>(workspace) + lw.adapt_off);
-    const int st = launch_locality_probe(rowptr, col, M, ldb, b_bytes_all, verdicts, s);
+    const int st = launch_locality_probe(rowptr, col, M, ldb, b_bytes_all, verdicts, sched != nullptr ? sched->order : nullptr, s);
     if (st != MI_OK) return st;
     la.adapt = verdicts;
   }

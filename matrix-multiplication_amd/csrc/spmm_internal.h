@@ -38,7 +38,7 @@ int launch_long_rows(bool vec4, int* ws, const LongWs& lw, const int32_t* rowptr
 
 // ---- column-panel passes (spmm_panels.hip) -------------------------------------------------------------------------
 int launch_locality_probe(const int32_t* rowptr, const int32_t* col, int32_t M, int64_t ldb, double b_bytes, int* verdicts,
-                          hipStream_t s);
+                          const int32_t* order, hipStream_t s);  // order (may be null): a schedule's slot → row map
 int launch_panels(int panels, const int* rowptr, const int* col, const float* val, const float* B, float* C, int M, int K,
                   int N, long ldb, long ldc, const float* bias, LongArg la, hipStream_t s);
 // 256-column tiles dealt XCD-aware × row panels of B (MI_SPMM_COLTILE_PANELS)

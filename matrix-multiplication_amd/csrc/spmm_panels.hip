@@ -11,7 +11,8 @@ namespace {
 using mi::LongArg;
 
 __global__ __launch_bounds__(256) void spmm_locality_probe_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
-                                                                  int M, long ldb, double b_bytes, int* __restrict__ verdicts) {
+                                                                  int M, long ldb, double b_bytes, int* __restrict__ verdicts,
+                                                                  const int* __restrict__ order) {
   __shared__ int s_mn[4], s_mx[4];
   const int w = blockIdx.x;
   const int win = M < kAdaptWindow ? M : kAdaptWindow;
@@ -26,8 +27,9 @@ __global__ __launch_bounds__(256) void spmm_locality_probe_kernel(const int* __r
     const int r = 4 * ((int)threadIdx.x + 256 * i);
     s0[i] = 0, n0[i] = 0;
     if (r < win) {
-      s0[i] = rowptr[first + r];
-      n0[i] = rowptr[first + r + 1] - s0[i];
+      const long row = order ? order[first + r] : first + r;  // a schedule: windows of consecutive SLOTS — what runs together
+      s0[i] = rowptr[row];
+      n0[i] = rowptr[row + 1] - s0[i];
     }
   }
 #pragma unroll
@@ -388,8 +390,9 @@ int launch_group_panels_t(int panels, const int* rowptr, const int* col, const f
 namespace mi {
 
 int launch_locality_probe(const int32_t* rowptr, const int32_t* col, int32_t M, int64_t ldb, double b_bytes, int* verdicts,
-                          hipStream_t s) {
-  hipLaunchKernelGGL(spmm_locality_probe_kernel, dim3(kAdaptSlots), dim3(256), 0, s, rowptr, col, M, (long)ldb, b_bytes, verdicts);
+                          const int32_t* order, hipStream_t s) {
+  hipLaunchKernelGGL(spmm_locality_probe_kernel, dim3(kAdaptSlots), dim3(256), 0, s, rowptr, col, M, (long)ldb, b_bytes, verdicts,
+                     order);
   return check_launch();
 }
 

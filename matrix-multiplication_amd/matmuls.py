@@ -296,7 +296,7 @@ def _csr_props_cached(a: torch.Tensor):
     return props
 
 
-def _row_schedule(holder: torch.Tensor, slot: str, key, offsets: torch.Tensor, nnz: int, rows: int, width: int):
+def _row_schedule(holder: torch.Tensor, slot: str, key, offsets: torch.Tensor, nnz: int, rows: int, width: int, columns=None, cols: int = 0):
     '''The inspector's row schedule (custom_mm.spmm_schedule: rows handed to waves longest first, like lengths together,
     heavy rows in a launch of their own — the same bits as the plain product) for a CSR pattern that is being used AGAIN:
     kept on the tensor object `holder` under `slot`, per dense width, keyed like the other per-tensor caches (index
@@ -321,7 +321,7 @@ def _row_schedule(holder: torch.Tensor, slot: str, key, offsets: torch.Tensor, n
     if ent == 'seen':
         if torch.cuda.is_current_stream_capturing():
             return None
-        ent = custom_mm.spmm_schedule(offsets, nnz, rows, width)
+        ent = custom_mm.spmm_schedule(offsets, nnz, rows, width, columns, cols)
         book[1][width] = ent
     return ent if ent.info()['active'] else None
 
@@ -380,7 +380,7 @@ def _csr_product(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, mm_op, defau
     assert est is None or one_launch
     if a.is_sparse_csr and mm_op is default_op and b.dim() == 2:
         # a CSR tensor that has been multiplied before (a static sparse operand: weights, an adjacency matrix): its row schedule
-        sched = _row_schedule(a, '_mi_csr_sched', _csr_key(a)[1:3] + _csr_key(a)[4:], props[2], props[3], props[4], b.shape[-1])
+        sched = _row_schedule(a, '_mi_csr_sched', _csr_key(a)[1:3] + _csr_key(a)[4:], props[2], props[3], props[4], b.shape[-1], props[1], props[5])
         if sched is not None:
             return custom_mm.naive_spmm_scheduled(sched, *props, b, c, None, 0 if one_launch else -1)
     if one_launch:
@@ -918,7 +918,7 @@ def _sparse_backward(ctx, grad_output):
         if ctx.needs_input_grad[1]:
             gb = torch.empty((cols, g.shape[-1]), device=g.device, dtype=torch.float32)
             # m1ᵀ's pattern is cached on m1: so is its row schedule (the transpose of a skewed matrix is as skewed)
-            sched = _row_schedule(m1, '_mi_csr_sched_t', _csr_key(m1)[1:3] + _csr_key(m1)[4:], t_off, nnz, cols, g.shape[-1]) \
+            sched = _row_schedule(m1, '_mi_csr_sched_t', _csr_key(m1)[1:3] + _csr_key(m1)[4:], t_off, nnz, cols, g.shape[-1], t_col, rows) \
                 if g.is_contiguous() else None
             if sched is not None:
                 gb = custom_mm.naive_spmm_scheduled(sched, t_val, t_col, t_off, nnz, cols, rows, g, gb)

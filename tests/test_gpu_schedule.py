@@ -237,3 +237,49 @@ def test_matmuls_keeps_a_schedule_on_a_csr_tensor_that_is_used_again(mm, cmm, de
     b2 = t(g.random((K, 32), dtype=np.float32), dev)
     mm.cusparseMM.apply(a, b2)
     assert a._mi_csr_sched[1][32] == 'seen' and a._mi_csr_sched[1][N] != 'seen'
+
+
+def test_locality_order_is_taken_where_it_measurably_helps_and_changes_no_bit(cmm, dev, oracle_mod):
+    """Given the columns, the inspector also tries the rows in the order of their median column inside a length class and
+    MEASURES a window's footprint in B against the natural order (reference: the inspector that compacts each block's
+    footprint of B, src/sparse_mm.cu:62-68,259).  A banded matrix whose rows arrive shuffled: taken (footprint more than
+    halved), rows that run together centre on neighbouring columns; the same matrix unshuffled: the natural order is local
+    already — declined; uniform columns: nothing to recover — declined.  The product has the oracle's bits either way."""
+    M = K = 40_000
+    N = 64
+    g = np.random.Generator(np.random.PCG64(31))
+    per = 24
+    rows = np.repeat(np.arange(M), per)
+    band_cols = np.clip(rows + g.integers(-300, 301, size=len(rows)), 0, K - 1)
+    perm = g.permutation(M)
+
+    def csr_of(r, c):
+        keys = np.unique(r.astype(np.int64) * K + c)
+        rr, cc = keys // K, (keys % K).astype(np.int32)
+        rowptr = np.concatenate([[0], np.cumsum(np.bincount(rr, minlength=M))]).astype(np.int32)
+        return rowptr, cc, g.random(len(cc), dtype=np.float32) - 0.5
+
+    B = g.random((K, N), dtype=np.float32) - 0.5
+    d_B = t(B, dev)
+    for tag, (rowptr, col, val), expect in (("shuffled band", csr_of(perm[rows], band_cols), True),
+                                            ("band", csr_of(rows, band_cols), False),
+                                            ("uniform", csr_of(rows, g.integers(0, K, size=len(rows))), False)):
+        d_rp, d_col, d_val = (t(x, dev) for x in (rowptr, col, val))
+        sched = cmm.spmm_schedule(d_rp, len(val), M, N, d_col, K)
+        info = sched.info()
+        assert info["locality_order"] is expect, (tag, info)
+        assert info["window_span_natural"] >= 0 and info["window_span_scheduled"] >= 0
+        if expect:
+            assert info["active"] and 2 * info["window_span_scheduled"] < info["window_span_natural"], info
+            order = sched.order.cpu().numpy()
+            med = col[(rowptr[:-1] + (rowptr[1:] - rowptr[:-1]) // 2).clip(max=len(col) - 1)][order].astype(np.int64)
+            lens = np.diff(rowptr)[order]
+            same = lens[1:] == lens[:-1]   # inside a length class the median columns ascend (up to the 2048-slot tiles' inner order)
+            assert np.mean(np.abs(np.diff(med))[same]) < 0.02 * K
+        elif tag == "band":
+            assert info["window_span_natural"] <= 0.4
+        sched.set_heavy(info["heavy_length"], True)   # run scheduled whatever the activity rule says
+        got = _product(cmm, dev, sched, d_rp, d_col, d_val, M, K, d_B)
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), oracle_mod.spmm_csr(rowptr, col, val, M, K, B).view(np.uint32)), tag
+    # without the columns the pass is not tried
+    assert cmm.spmm_schedule(d_rp, len(val), M, N).info()["window_span_natural"] == -1.0

@@ -113,7 +113,7 @@ def product_entries(rowptr, col, val, M, K, B, C, handle, layer):
     entries = {"naive_spmm": lambda: custom_mm.naive_spmm(val, col, rowptr, nnz, M, K, B, C)}
     # the inspector's row schedule (built once per matrix, outside the timed region): the same product, rows handed to
     # waves longest first / like lengths together / heavy rows apart — the same bits
-    sched = custom_mm.spmm_schedule(rowptr, nnz, M, B.shape[1])
+    sched = custom_mm.spmm_schedule(rowptr, nnz, M, B.shape[1], col, K)  # (with the columns: the locality pass is tried, and must decline on uniform columns)
     Cs = torch.empty_like(C)
     custom_mm.naive_spmm(val, col, rowptr, nnz, M, K, B, C)
     custom_mm.naive_spmm_scheduled(sched, val, col, rowptr, nnz, M, K, B, Cs)
@@ -180,7 +180,7 @@ def run(tag, M, K, N, mean, clip, out, handle, lo=None, hi=None):
         line = (f"{tag:<22} {name:<10} M={M:>8} N={N:>4} nnz={nnz:>10} mean {nnz / M:6.1f} longest {longest:>8} top1% {top1:5.1%}  "
                 f"plan {plan[0]:>2} {plan[1]:<30} x{plan[2]}  {t:8.3f} ms {alg / t / 1e6:6.0f} GB/s frac {alg / t / 8e9:.3f}  |  "
                 f"uniform twin plan {plan_u[0]:>2} {tu:8.3f} ms frac {alg_u / tu / 8e9:.3f}  skewed/uniform {t / tu * nnz_u / nnz:5.2f}  "
-                f"rows {'bit-exact' if ok else 'MISMATCH'} ({nr})" + (f"  heavy {info['heavy_rows']} rows > {info['heavy_length']}" if name == "scheduled" else "") + f"   [{time.time() - t0:.0f} s]")
+                f"rows {'bit-exact' if ok else 'MISMATCH'} ({nr})" + (f"  heavy {info['heavy_rows']} rows > {info['heavy_length']} locality_order {info['locality_order']}" if name == "scheduled" else "") + f"   [{time.time() - t0:.0f} s]")
         print(line, flush=True)
         out.append(line)
     assert ok, "sampled rows differ from the oracle"
