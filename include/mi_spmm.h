@@ -357,6 +357,21 @@ int mi_gemm_f32(int transa, int transb, int32_t m, int32_t n, int32_t k,
 int mi_gemm_pair_a_at_f32(const float* A, const float* B1, const float* B2, float* C1, float* C2,
                           int32_t batch, int32_t m, int32_t k, int32_t n, mi_stream_t stream);
 
+/* Deterministic split-k (what custom_mm.cublas_mmul / cublas_bmm call): products with few output tiles and a long k — weight
+ * gradients over thousands of tokens — leave most of the chip idle as one chain per element.  mi_gemm_split_count(m, n, k, batch)
+ * is a function of the SHAPE alone: 1 (the plain chain) unless batch == 1, k ≥ 4096 and fewer than 128 output tiles of 128 × 128;
+ * else S = the largest power of two ≤ min(320 / tiles, k / 1024) with k % (32·S) == 0.  With S > 1, k is cut into S equal ranges,
+ * each the usual k-ordered fmaf chain from zero, and an element's S partial sums are added in index order ((p0 + p1) + p2) + …,
+ * then the bias — a fixed order the oracle restates (oracle_gemm_f32).  The reference's criterion is torch.allclose at 1e-5 with
+ * cuBLAS's unspecified order (tests/cublas_kernel_test.py:27-28, src/baseline_mm.cu:96-101).  workspace ≥
+ * mi_gemm_workspace_bytes (S·m·n floats; 0 when S == 1), 16-byte aligned; too small a workspace is MI_ENOMEM, never a silent
+ * plain chain.  mi_gemm_f32 / mi_gemm_bias_f32 (no workspace) always run the plain chain. */
+int mi_gemm_split_count(int32_t m, int32_t n, int32_t k, int32_t batch);
+size_t mi_gemm_workspace_bytes(int32_t m, int32_t n, int32_t k, int32_t batch);
+int mi_gemm_ws_f32(int transa, int transb, int32_t m, int32_t n, int32_t k, const float* A, int64_t lda, int64_t strideA,
+                   const float* B, int64_t ldb, int64_t strideB, const float* bias, float* C, int64_t ldc, int64_t strideC,
+                   int32_t batch, void* workspace, size_t workspace_bytes, mi_stream_t stream);
+
 /* Which kernel family mi_gemm_f32 / mi_gemm_bias_f32 take (process-wide; every
  * plan produces the same bits — tests pin one to compare it with another):
  * AUTO picks; TILES = one output tile (or a short chain) per 4-wave workgroup;

@@ -11,7 +11,7 @@ from pathlib import Path
 
 import numpy as np
 
-__all__ = ["build", "lib", "spmm_csr", "spmm_csr_omp", "spmm_csr_long", "spmm_csr_chain", "spmm_csr_batched", "spmm_csr_colmajor", "gemm",
+__all__ = ["build", "lib", "gemm_split_count", "spmm_csr", "spmm_csr_omp", "spmm_csr_long", "spmm_csr_chain", "spmm_csr_batched", "spmm_csr_colmajor", "gemm",
            "coo_to_csr", "dense_to_csr", "csr_transpose", "sddmm", "make_csr"]
 
 _DIR = Path(__file__).resolve().parent
@@ -46,6 +46,10 @@ def lib():
         L.oracle_gemm_f32.argtypes = [ctypes.c_int, ctypes.c_int, _c32, _c32, _c32, _f32, _c64, _c64, _f32, _c64,
                                       _c64, _f32, _c64, _c64, _c32]
         L.oracle_gemm_f32.restype = None
+        L.oracle_gemm_ex_f32.argtypes = list(L.oracle_gemm_f32.argtypes) + [ctypes.c_int]
+        L.oracle_gemm_ex_f32.restype = None
+        L.oracle_gemm_split_count.argtypes = [_c32, _c32, _c32, _c32]
+        L.oracle_gemm_split_count.restype = _c32
         L.oracle_coo_to_csr.argtypes = [_c32, _c64, _i32, _i32, _f32, _i32, _i32, _f32]
         L.oracle_coo_to_csr.restype = ctypes.c_int
         L.oracle_dense_to_csr.argtypes = [_f32, _c32, _c32, _c32, _c64, _c64, _i32, ctypes.c_void_p, ctypes.c_void_p]
@@ -132,8 +136,15 @@ def spmm_csr_colmajor(rowptr, col, val, M, K, N, B_colmajor):
     return C
 
 
-def gemm(A, B, transa=False, transb=False):
-    """C = op(A)·op(B) over the last two dims; leading dims (equal on both) are the batch."""
+def gemm_split_count(m, n, k, batch=1):
+    """The product path's split rule (include/mi_spmm.h, "Deterministic split-k"), restated: 1 = one chain per element."""
+    return int(lib().oracle_gemm_split_count(int(m), int(n), int(k), int(batch)))
+
+
+def gemm(A, B, transa=False, transb=False, split=True):
+    """C = op(A)·op(B) over the last two dims; leading dims (equal on both) are the batch.  split=True: the order of
+    custom_mm.cublas_mmul / cublas_bmm (few output tiles and k ≥ 4096: S equal k-ranges added in index order); split=False: one
+    k-ordered fmaf chain per element whatever the shape (the raw C-ABI entries mi_gemm_f32 / mi_gemm_bias_f32)."""
     A, B = _f(A), _f(B)
     batch_shape = A.shape[:-2]
     assert batch_shape == B.shape[:-2]
@@ -144,9 +155,9 @@ def gemm(A, B, transa=False, transb=False):
     k2, n = (bc, br) if transb else (br, bc)
     assert k == k2, (A.shape, B.shape, transa, transb)
     C = np.empty(batch_shape + (m, n), dtype=np.float32)
-    lib().oracle_gemm_f32(int(transa), int(transb), m, n, k, _pad1(A, np.float32), max(ac, 1), ar * ac,
-                          _pad1(B, np.float32), max(bc, 1), br * bc, C if C.size else np.zeros(1, np.float32),
-                          max(n, 1), m * n, batch)
+    lib().oracle_gemm_ex_f32(int(transa), int(transb), m, n, k, _pad1(A, np.float32), max(ac, 1), ar * ac,
+                             _pad1(B, np.float32), max(bc, 1), br * bc, C if C.size else np.zeros(1, np.float32),
+                             max(n, 1), m * n, batch, 1 if split else 0)
     return C
 
 

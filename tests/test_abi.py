@@ -292,3 +292,25 @@ def test_matmuls_product_path_fails_loudly_on_cpu(built):
         matmuls.custom_mm.cublas_mmul(a, b, c, False, False)
     with pytest.raises(RuntimeError, match="device"):
         matmuls.custom_mm.cublas_bmm(a[None], b[None], c[None], 3, False, False)
+
+
+def test_gemm_split_rule_is_a_function_of_the_shape_and_matches_the_oracles_restatement(lib, oracle_mod):
+    """mi_gemm_split_count (include/mi_spmm.h "Deterministic split-k") against the oracle's own restatement of the rule, on a
+    grid of shapes: both sides must cut k alike or no parity check of a split product could be bit for bit."""
+    import ctypes
+    lib.mi_gemm_split_count.argtypes = [ctypes.c_int32] * 4
+    lib.mi_gemm_workspace_bytes.argtypes = [ctypes.c_int32] * 4
+    lib.mi_gemm_workspace_bytes.restype = ctypes.c_size_t
+    seen = set()
+    for m in (1, 64, 128, 129, 768, 1152, 2048, 4096):
+        for n in (1, 64, 256, 768, 1024, 4097):
+            for k in (0, 32, 4095, 4096, 4160, 5000, 8192, 16384, 65536, 100_000):
+                for batch in (1, 2):
+                    S = lib.mi_gemm_split_count(m, n, k, batch)
+                    assert S == oracle_mod.gemm_split_count(m, n, k, batch), (m, n, k, batch)
+                    assert S >= 1 and (S == 1 or (batch == 1 and k >= 4096 and k % (32 * S) == 0 and S & (S - 1) == 0))
+                    assert lib.mi_gemm_workspace_bytes(m, n, k, batch) == (4 * S * m * n if S > 1 else 0)
+                    seen.add(S)
+    assert {1, 2, 4, 8, 64} <= seen
+    assert lib.mi_gemm_split_count(768, 768, 16384, 1) == 8 and lib.mi_gemm_split_count(256, 256, 65536, 1) == 64
+    assert lib.mi_gemm_split_count(4096, 1024, 16384, 1) == 1   # 256 tiles: the chip is busy as it is

@@ -405,3 +405,58 @@ def test_gemm_rows_off_16_byte_boundaries_take_unconditional_loads_bit_exact(cap
             assert np.array_equal(view(got, i, sc, m, n, ldc), want[i]), (pad_a, pad_b, pad_c, lead, i)
             written[(lead + i * sc + np.arange(m)[:, None] * ldc + np.arange(n)[None, :]).ravel()] = True
         assert np.isnan(got[~written]).all(), (pad_a, pad_b, pad_c, lead)
+
+
+@pytest.mark.parametrize("m,n,k,ta,tb,bias", [(256, 256, 8192, True, False, False), (384, 130, 4096, False, False, True),
+                                              (100, 520, 6144, False, True, False), (768, 64, 16384, True, True, True),
+                                              (128, 128, 4160, True, False, False)])
+def test_gemm_deterministic_split_k_bit_exact_vs_oracle(cmm, capi, dev, oracle_mod, m, n, k, ta, tb, bias):
+    """Round 6: few output tiles and a long k (weight gradients over thousands of tokens) — custom_mm.cublas_mmul cuts k into S
+    equal ranges, S a function of the shape alone, each range the k-ordered chain from zero, the partial sums added in index
+    order (include/mi_spmm.h "Deterministic split-k"); the oracle restates the rule, so parity stays bit for bit, and the
+    result stays within the reference tests' criterion of torch (tests/cublas_kernel_test.py:27-28: allclose at 1e-5).  The
+    raw C-ABI entry without a workspace keeps the plain chain; a workspace that is too small is refused, never ignored."""
+    g = np.random.Generator(np.random.PCG64(m + n + k))
+    a = g.random((k, m) if ta else (m, k), dtype=np.float32) - 0.5
+    b = g.random((n, k) if tb else (k, n), dtype=np.float32) - 0.5
+    bv = (g.random(n, dtype=np.float32) - 0.5) if bias else None
+    S = oracle_mod.gemm_split_count(m, n, k)
+    capi.mi_gemm_split_count.argtypes = [ctypes.c_int32] * 4
+    assert capi.mi_gemm_split_count(m, n, k, 1) == S and (S > 1) == (k % 64 == 0)
+    want = oracle_mod.gemm(a, b, ta, tb)
+    chain = oracle_mod.gemm(a, b, ta, tb, split=False)
+    if bias:
+        want, chain = want + bv[None, :], chain + bv[None, :]
+    d_a, d_b = t(a, dev), t(b, dev)
+    C = torch.full((m, n), float("nan"), device=dev)
+    if bias:
+        cmm.cublas_mmul_bias(d_a, d_b, t(bv, dev), C, ta, tb)
+    else:
+        cmm.cublas_mmul(d_a, d_b, C, ta, tb)
+    got = C.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (m, n, k, S)
+    if S > 1:
+        assert not np.array_equal(want, chain)      # the split order is a different (fixed) order …
+    ref = (torch.from_numpy(a).t() if ta else torch.from_numpy(a)).double() @ (torch.from_numpy(b).t() if tb else torch.from_numpy(b)).double()
+    if bias:
+        ref = ref + torch.from_numpy(bv).double()[None, :]
+    scale = (torch.from_numpy(np.abs(a)).t() if ta else torch.from_numpy(np.abs(a))).double() @ \
+        (torch.from_numpy(np.abs(b)).t() if tb else torch.from_numpy(np.abs(b))).double()
+    assert float(((torch.from_numpy(got).double() - ref).abs() / scale).max()) < 1e-5     # … as close to the exact product
+    # the raw entry: plain chain; the workspace form with too little room: refused
+    vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32
+    capi.mi_gemm_bias_f32.argtypes = [ctypes.c_int, ctypes.c_int, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, i32, vp]
+    capi.mi_gemm_ws_f32.argtypes = [ctypes.c_int, ctypes.c_int, i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, vp, i64, i64, i32, vp,
+                                    ctypes.c_size_t, vp]
+    stream = torch.cuda.current_stream().cuda_stream
+    d_bias = t(bv, dev) if bias else None
+    args = (int(ta), int(tb), m, n, k, d_a.data_ptr(), m if ta else k, 0, d_b.data_ptr(), k if tb else n, 0,
+            d_bias.data_ptr() if bias else None, C.data_ptr(), n, 0, 1)
+    assert capi.mi_gemm_bias_f32(*args, stream) == 0
+    assert np.array_equal(C.cpu().numpy().view(np.uint32), chain.view(np.uint32))
+    if S > 1:
+        small = torch.empty(1024, dtype=torch.uint8, device=dev)
+        assert capi.mi_gemm_ws_f32(*args, small.data_ptr(), 1024, stream) == -4
+        assert capi.mi_gemm_ws_f32(*args, None, 0, stream) == -1
+    # a batch is never split
+    assert oracle_mod.gemm_split_count(m, n, k, 2) == 1
