@@ -58,9 +58,9 @@ def algorithmic_bytes(nnz, M, N):
 
 
 def source_fingerprint():
-    """sha256 (16 hex digits) of bench.py and of the SpMM kernel sources: what a committed PMC figure is tied to."""
+    """sha256 (16 hex digits) of bench.py and of the SpMM kernel sources (csrc/spmm_*.hip and spmm_*.h): what a committed PMC figure is tied to."""
     h = hashlib.sha256()
-    for f in [REPO / "bench.py"] + sorted((REPO / "matrix-multiplication_amd" / "csrc").glob("spmm_*.hip")):
+    for f in [REPO / "bench.py"] + sorted((REPO / "matrix-multiplication_amd" / "csrc").glob("spmm_*.h*")):  # the units and their shared headers
         h.update(f.name.encode())
         h.update(f.read_bytes())
     return h.hexdigest()[:16]
@@ -684,7 +684,7 @@ def main():
                         f"{launches_per_step} back-to-back launch(es) (HIP events on the launch stream); "
                         "traffic = fabric-side PMC bytes per product (Infinity-Cache hits included), traffic_dram = the "
                         "DRAM-side share, both from profiles/pmc_traffic.json and null unless that record was taken "
-                        "with these very sources (fingerprint of bench.py + csrc/spmm_*.hip) and this kernel; "
+                        "with these very sources (fingerprint of bench.py + csrc/spmm_* sources) and this kernel; "
                         "frac_dram_only = traffic_dram / time / peak",
             },
         }

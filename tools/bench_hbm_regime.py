@@ -9,7 +9,8 @@ order — the per-element chain is unchanged — times the gathered rows of B, o
 `--variants` also times the candidate plans pinned through the C-ABI (`mi_spmm_csr_f32_variant`), AUTO's starred.
 
 Patterns: `uniform` (the pinned generator's distribution: unique uniform keys in [0, M·K)), `banded` (columns within
-± 32 K of the diagonal; `band1k`: ± 1 K), `powerlaw` (column popularity ∝ rank^-1.5 or so: col = ⌊K·u⁴⌋ scattered by an odd multiplier).
+± 32 K of the diagonal; `band1k`: ± 1 K), `powerlaw` (column popularity ∝ rank^-1.5 or so: col = ⌊K·u⁴⌋ scattered by an odd multiplier),
+`degskew` (power-law ROW lengths: Pareto around the mean, clipped at 8000 — tools/bench_degree_skew.py's generator).
 Reference: src/naive_sparse_mm.cu:39,116 takes any N through one kernel.
 """
 import argparse
@@ -35,6 +36,9 @@ dev = torch.device("cuda")
 
 def make_csr(M, K, per_row, pattern, seed=0):
     """(rowptr int32[M+1], col int32[nnz], val f32[nnz]) on the device; rows sorted, columns unique within a row."""
+    if pattern == "degskew":  # power-law ROW LENGTHS (Pareto, mean per_row, clipped at 8000), uniform columns: tools/bench_degree_skew.py
+        import bench_degree_skew as ds
+        return ds.csr_from_lengths(ds.pareto_lengths(M, per_row, min(8000, K), K, seed=seed + 1000), K, seed=seed)
     g = torch.Generator(device=dev).manual_seed(seed)
     cols, counts = [], []
     step = max(1, min(M, (1 << 28) // max(per_row, 1)))  # ≤ 2²⁸ keys per block of rows

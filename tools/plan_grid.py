@@ -24,7 +24,7 @@ ap.add_argument("--cases", type=int, default=120)
 ap.add_argument("--seed", type=int, default=5)
 ap.add_argument("--log", default="")
 ap.add_argument("--variants", default="2,4,7,8,9,10,11,12,14,15,17,18,19,20,21,22,23,24")
-ap.add_argument("--pattern", default="uniform", help="uniform | banded (± 32 K of the diagonal) | band1k (± 1 K) | powerlaw")
+ap.add_argument("--pattern", default="uniform", help="uniform | banded (± 32 K of the diagonal) | band1k (± 1 K) | powerlaw (column popularity) | degskew (power-law row lengths)")
 ap.add_argument("--extension", action="store_true", help="AUTO = custom_mm.naive_spmm (the extension's workspace: long-row kernels and the "
                 "device-side locality probe are active) instead of the plain C-ABI entry")
 a = ap.parse_args()
