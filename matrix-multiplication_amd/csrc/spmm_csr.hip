@@ -706,7 +706,7 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
     // with more gathers in flight per row, on the schedule's side stream BESIDE the launch(es) of the rest.  Per-row
     // arithmetic is that of the unscheduled plan: the same bits.
     int heavy = sched->heavy < 0 ? 0 : (sched->heavy > M ? M : sched->heavy);
-    if (!sh.vec4_ok || N > 512) heavy = 0;  // the heavy-row kernel moves float4s and gives every column a chain lane: other shapes keep every row in the ordinary launch (longest first all the same)
+    if (!sh.vec4_ok || N > 256) heavy = 0;  // the heavy-row kernel moves float4s and gives every column a chain lane: other shapes keep every row in the ordinary launch (longest first all the same)
     LongArg lh = la, lr = la;
     lh.order = sched->order, lh.nslots = heavy;
     lh.adapt = nullptr;  // one pass, every column

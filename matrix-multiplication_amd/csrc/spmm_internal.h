@@ -49,8 +49,8 @@ int launch_group_panels(int panels, const int* rowptr, const int* col, const flo
                         int K, int N, long ldb, long ldc, const float* bias, LongArg la, hipStream_t s);
 
 // ---- heavy rows of a schedule (spmm_heavy.hip) ----------------------------------------------------------------------
-// One 8-wave workgroup per slot of la.order: the row's B rows gathered cooperatively into LDS, 128 entries at a time, and
-// summed from there by ONE chain per output element in CSR order (the same bits as every other kernel).  N % 4 == 0, N ≤ 512,
+// One 8-wave workgroup per slot of la.order: the row's B rows gathered by the loader waves into LDS, up to 128 entries at a
+// time, and summed from there by the chain waves — ONE chain per output element in CSR order (the same bits as every other kernel).  N % 4 == 0, N ≤ 256,
 // 16-byte aligned operands (the caller checks); rows beyond la.thresh are skipped and listed as everywhere else.
 int launch_heavy_rows(const int32_t* rowptr, const int32_t* col, const float* val, int32_t M, int32_t N, const float* B,
                       int64_t ldb, float* C, int64_t ldc, const float* bias, LongArg la, hipStream_t s);
