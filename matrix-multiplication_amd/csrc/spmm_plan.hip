@@ -120,7 +120,7 @@ int ic_panels(int64_t nnz, int32_t M, int32_t K, int32_t N, int64_t ldb) {
 //     67328 × 90624 × 100 2.01 → 1.45); with fewer rows a pass is latency-bound and splitting it only multiplies that (16384 ×
 //     65536 × 128: one pass 0.31 ms, two panels 0.37; 12032 × 67328 × 64: 0.077 vs 0.153; 24832 × 25856 × 96: 0.094 vs 0.151);
 //     N = 32 … 60 only for ≥ 96 Ki rows of ≥ 128 entries;
-//   * fewer than ≈ 10 Ki rows: only with B far beyond the L2s (≥ 32 MiB) and ≥ 7e8 multiply-adds in the product (4096 × 13056 ×
+//   * fewer than ≈ 10 Ki rows: only with B far beyond the L2s (≥ 32 MiB) and ≥ 6e8 multiply-adds in the product (4096 × 13056 ×
 //     256 with 393 per row, 12.8 MiB: one pass 0.065 ms, two panels 0.093; 4096 × 49920 × 192 with 478 per row: 0.092 vs
 //     0.141; 2304 × 59904 × 384 with 847 per row, 88 MiB: 0.296 → 0.232), and in at most 3 (< 4 Ki rows) or 4 (< 8 Ki) passes.
 // Returns 2, 3, 4, 6 or 8, or 0.
@@ -128,7 +128,8 @@ int l2_group_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
   const double b_bytes = (double)K * (double)ldb * 4.0, mib = 1048576.0;
   if (b_bytes <= 6.0 * mib || b_bytes > (nnz >= 256L * M ? 384.0 : 192.0) * mib || M <= 0) return 0;
   if (nnz < 24L * K || (b_bytes < 12.0 * mib && nnz < 48L * M)) return 0;
-  if (M < 10240 && (b_bytes < 32.0 * mib || (double)nnz * (double)N < 7e8)) return 0;
+  // (round 6, unseen grid: 3584 × 34048 × 384 with 456 per row — 6.3e8 multiply-adds, 50 MiB — one pass 0.234 ms, four panels 0.169)
+  if (M < 10240 && (b_bytes < 32.0 * mib || (double)nnz * (double)N < 6e8)) return 0;
   const long per_pass = 8 + 200000L / M;
   if (N <= 128) {
     if (N < 64)  // N = 32 … 60 (16-lane groups, half of them idle at 32): many long rows only — 117248 × 295936 × 32 with 210 per row
@@ -137,7 +138,9 @@ int l2_group_panels(int32_t M, int32_t K, int32_t N, int64_t ldb, int64_t nnz) {
     if (!(nnz >= 48L * M && nnz >= 48L * K && b_bytes >= 8.0 * mib && b_bytes <= 128.0 * mib)) return 0;
     // (between 64 and 128 columns from 24 MiB only: below that uniform columns are level — 271104 × 29952 × 96, 11 MiB: 2.21 vs
     // 2.20 ms — and banded or power-law ones lose, 1.36 vs 1.58 / 1.49 vs 2.05)
-    if (N > 64 && N < 128 && b_bytes < 24.0 * mib) return 0;
+    // (round 6, unseen grid: with ≥ 400 K long rows already from 12 MiB — 658688 × 37632 × 100 with 169 per row, 14.4 MiB: one pass
+    // 5.25 ms, two panels 3.86)
+    if (N > 64 && N < 128 && b_bytes < ((M >= 400000 && nnz >= 128L * M) ? 12.0 : 24.0) * mib) return 0;
     if (M < (N == 64 ? 28000 : 60000)) return 0;
     // rows long enough for two passes: 48 at N = 64, 96 at N = 128 (48 from 96 Ki rows; config C2 — 65536² × 128, 65 per row —
     // is level: 0.2516 one pass, 0.2476 in two panels, and stays one pass), 160 between (65536² × 96 with 100 per row: 0.249 vs 0.265)
