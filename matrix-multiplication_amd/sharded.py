@@ -247,6 +247,12 @@ class ShardedSpMM:
             # two more agreements, the release's barrier): a rank that failed early never leaves its peers in a
             # collective it does not enter.
             probe = self._new_buffer(self.world, 4).zero_()
+            if self.device.type == "cuda":
+                # the zeros must be IN PLACE before any peer may push into this buffer: zero_() is only enqueued, and a peer's
+                # copy that lands first would be wiped by it (met once in a 4-rank rehearsal: "pushed probe rows did not
+                # arrive").  The registration's hand-over below is the barrier behind every rank's synchronise; forward() has
+                # its entry fence for the same purpose.
+                torch.cuda.synchronize(self.device)
             ok, why = self.register_output(probe, _quiet=True), ""
             if ok:
                 try:
