@@ -460,3 +460,21 @@ def test_gemm_deterministic_split_k_bit_exact_vs_oracle(cmm, capi, dev, oracle_m
         assert capi.mi_gemm_ws_f32(*args, None, 0, stream) == -1
     # a batch is never split
     assert oracle_mod.gemm_split_count(m, n, k, 2) == 1
+
+
+def test_gemm_split_k_golden_v2(cmm, dev, oracle_mod):
+    """The v2 golden fixtures (tests/golden/make_golden_v2.py: torch-CPU products of shapes the split-k rule cuts) through
+    custom_mm.cublas_mmul: bit-identical to the oracle's restatement of the rule, within the reference tests' criterion of
+    torch's fp32 product (tests/cublas_kernel_test.py:27-28)."""
+    from pathlib import Path
+    data = np.load(Path(__file__).resolve().parent / "golden" / "golden_v2.npz")
+    for name in (str(n) for n in data["__names__"]):
+        a, b = data[name + "/a_u8"].astype(np.float32) / 256.0, data[name + "/b_u8"].astype(np.float32) / 256.0
+        ta, tb = bool(data[name + "/transa"]), bool(data[name + "/transb"])
+        m = a.shape[1] if ta else a.shape[0]
+        n = b.shape[0] if tb else b.shape[1]
+        C = torch.full((m, n), float("nan"), device=dev)
+        cmm.cublas_mmul(t(a, dev), t(b, dev), C, ta, tb)
+        got = C.cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), oracle_mod.gemm(a, b, ta, tb).view(np.uint32)), name
+        assert np.allclose(got, data[name + "/c"], rtol=1e-5, atol=1e-8), name

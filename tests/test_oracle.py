@@ -222,3 +222,27 @@ def test_long_row_rule_split_rows(oracle_mod):
             grp = np.float32(grp + chains[16 * gi + w])
         tot = grp if tot is None else np.float32(tot + grp)
     assert tot == long_[0, 1]
+
+
+def test_gemm_split_k_order_matches_the_v2_golden(oracle_mod):
+    """Round 6: the dense product's split-k order (few output tiles, k >= 4096: S equal k-ranges added in index order — what
+    custom_mm.cublas_mmul computes) against fixtures generated from torch-CPU by tests/golden/make_golden_v2.py: within the
+    reference tests' criterion (torch.allclose defaults, tests/cublas_kernel_test.py:27-28) of torch's fp32 product, and of the
+    fp64 product; the plain chain too; and the rule really splits these shapes."""
+    from pathlib import Path
+    data = np.load(Path(__file__).resolve().parent / "golden" / "golden_v2.npz")
+    names = [str(n) for n in data["__names__"]]
+    assert len(names) == 4
+    for name in names:
+        a, b = data[name + "/a_u8"].astype(np.float32) / 256.0, data[name + "/b_u8"].astype(np.float32) / 256.0
+        ta, tb = bool(data[name + "/transa"]), bool(data[name + "/transb"])
+        m, k = (a.shape[1], a.shape[0]) if ta else a.shape
+        n = b.shape[0] if tb else b.shape[1]
+        S = oracle_mod.gemm_split_count(m, n, k)
+        assert S > 1 and k % (32 * S) == 0, (name, S)
+        split = oracle_mod.gemm(a, b, ta, tb)
+        chain = oracle_mod.gemm(a, b, ta, tb, split=False)
+        assert not np.array_equal(split, chain)
+        for got in (split, chain):
+            assert np.allclose(got, data[name + "/c"], rtol=1e-5, atol=1e-8), name
+            assert np.allclose(got, data[name + "/c_fp64"], rtol=1e-5, atol=1e-8), name
