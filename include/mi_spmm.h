@@ -204,15 +204,15 @@ const char* mi_spmm_variant_name(int variant);
  * three quarters of its gathers), and keeps that order only when the natural order is not local already (footprint > 40 % of
  * B) and the new one more than halves it — a banded or
  * community-structured matrix whose rows arrive shuffled then gathers like the unshuffled one.  Same bits, again.
- *   mi_spmm_schedule_create: `order` (device, M ints) is caller-owned and must outlive the schedule; workspace ≥
+ *   mi_spmm_schedule_create: `order` (device; M ints, 2·M when col is given) is caller-owned and must outlive the schedule; workspace ≥
  *     mi_spmm_schedule_workspace_bytes(M) is only used during the call.  col may be NULL (no locality pass).  Builds on
  *     `stream` and SYNCHRONISES it (reads ≈ 1.5 KiB back: the class table, the window statistics): inspection time, not
  *     capturable.  N: the dense width the schedule will mostly be used with.
  *   Products on one schedule must be ordered on one stream (they share its side stream and fork / join events).
  *   mi_spmm_schedule_info: info[12] = {rows, heavy slots, heavy length, non-empty classes, lower bound of the longest row,
  *     flags (1: has a side stream; 2: ACTIVE — an order costs the locality of consecutive rows, so a matrix of short, alike
- *     rows keeps its products unscheduled: active with heavy rows, with a locality order, or mean ≥ 16 entries and longest ≥
- *     1.5 × mean; 4: locality order), nnz, N, a window's footprint in natural order / in this order (‰ of B), mean row span (‰ of
+ *     rows keeps its products unscheduled: active with heavy rows, with a locality order, or mean ≥ 16 entries with ≥ 2 % of the
+ *     entries in rows of ≥ 1.5 × the mean; 4: locality order), nnz, N, a window's footprint in natural order / in this order (‰ of B), mean row span (‰ of
  *     K) (-1: not measured), 0}.
  *   mi_spmm_schedule_set_heavy: another heavy length (0: every row; ≥ the longest: none) / every launch in line on the caller's
  *     stream instead of the rest beside the heavy launch — tests and A/B measurements; makes the schedule active.
@@ -220,6 +220,17 @@ const char* mi_spmm_variant_name(int variant);
  * ------------------------------------------------------------------------ */
 typedef struct mi_spmm_schedule mi_spmm_schedule_t;
 size_t mi_spmm_schedule_workspace_bytes(int32_t M);
+/* The build in two halves for callers that must not synchronise: _begin enqueues the build of both candidate orders (`order`:
+ * by length class; `order_locality`, M ints, may be NULL: + by median column) and the copies of the class table and the window
+ * statistics to host_out (MI_SCHEDULE_HOST_INTS ints; pinned memory keeps the copies asynchronous); once those have landed
+ * (an event behind them), _finish reads them on the host, picks the order and creates the object.  mi_spmm_schedule_create =
+ * _begin + a stream synchronise + _finish, with the locality order in the SECOND half of `order` (2·M ints when col != NULL). */
+#define MI_SCHEDULE_HOST_INTS 512
+int mi_spmm_schedule_begin(const int32_t* rowptr, const int32_t* col, int32_t M, int32_t K, int64_t nnz, int32_t N,
+                           int32_t* order, int32_t* order_locality, void* workspace, size_t workspace_bytes,
+                           int32_t* host_out, mi_stream_t stream);
+int mi_spmm_schedule_finish(const int32_t* host_out, int32_t* order, int32_t* order_locality, int32_t M, int32_t K, int64_t nnz,
+                            int32_t N, mi_spmm_schedule_t** out);
 int mi_spmm_schedule_create(const int32_t* rowptr, const int32_t* col, int32_t M, int32_t K, int64_t nnz, int32_t N,
                             int32_t* order, void* workspace, size_t workspace_bytes, mi_stream_t stream,
                             mi_spmm_schedule_t** out);

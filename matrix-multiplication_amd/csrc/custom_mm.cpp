@@ -27,6 +27,7 @@
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -145,6 +146,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         py::arg("A_offsets"), py::arg("nnzA"), py::arg("A_rows"), py::arg("A_cols"), py::arg("B"), py::arg("C"),
         py::arg("bias") = py::none(), py::arg("long_rows") = -1, py::arg("variant") = 0,
         "naive_spmm on a row schedule: the same bits, rows handed to waves longest first");
+  m.def("auto_schedule_stats", &auto_schedule_stats, "the automatic row schedules of the plain entry points: enabled, entries, pending, active, inactive, built");
+  m.def("auto_schedule_clear", &auto_schedule_clear, "forget every automatic row schedule");
   m.def("ipc_export", &ipc_export, "(handle bytes, offset, allocation bytes) of a device buffer, for a peer process to map");
   m.def("ipc_open", &ipc_open, "a peer's exported buffer as a tensor (valid until ipc_close of the handle)");
   m.def("ipc_close", &ipc_close, "drop one open of a peer handle");

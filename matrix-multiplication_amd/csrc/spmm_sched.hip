@@ -33,6 +33,7 @@ namespace {
 constexpr int kClasses = 256;
 constexpr int kTileRows = 2048;  // slots per workgroup of a counting pass
 constexpr int kWindows = 16;     // windows of kTileRows consecutive slots the locality statistic looks at
+static_assert(kClasses + 1 + 2 * 3 * kWindows < MI_SCHEDULE_HOST_INTS, "the class table and both window statistics fit host_out");
 
 // Length class, larger = longer: exact below 32, then eight classes per octave (2^e … 2^(e+1)) up to 2^31.
 __host__ __device__ __forceinline__ int length_class(int len) {
@@ -238,6 +239,14 @@ int32_t heavy_length_for(int64_t nnz) {
   return (int32_t)(h < 128 ? 128 : (h > mi::kLongRowThreshold ? mi::kLongRowThreshold : h));
 }
 
+int ensure_side_stream(mi_spmm_schedule* sc) {
+  if (sc->rs.side != nullptr) return MI_OK;
+  hipError_t e = hipStreamCreateWithFlags(&sc->rs.side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->rs.fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->rs.join, hipEventDisableTiming);
+  return e == hipSuccess ? MI_OK : mi::record_hip_error(e);
+}
+
 void set_heavy(mi_spmm_schedule* sc, int32_t heavy_len) {
   // slots before the first class that holds a row of ≤ heavy_len entries: every row there is longer than heavy_len
   const int c = length_class(heavy_len);  // rows of this class may be ≤ heavy_len: not heavy
@@ -246,10 +255,17 @@ void set_heavy(mi_spmm_schedule* sc, int32_t heavy_len) {
   // Is the order worth its indirection?  It costs the locality of consecutive rows (rowptr reads, C rows written side by side):
   // 4 M rows of 1 … 8 entries ran 11 – 16 % SLOWER scheduled, 2.4 M rows of ≤ 100 entries around a mean of 50 ran 5 % faster
   // (profiles/r06_degree_skew.log).  Active with heavy rows, or with rows that are long enough to be gather-bound (mean ≥ 16)
-  // and differ in length (longest ≥ 1.5 × mean).
+  // and differ in length.
   // … or when the order recovers locality the row order hides (mi_spmm_schedule_create measured it).
+  // "Differ in length" is asked of the ENTRIES, not of one outlier row: at least 2 % of them in rows of ≥ 1.5 × the mean (config
+  // C3's Binomial lengths — mean 105, a longest row near 155 among a million — must stay inactive whatever its luckiest row).
   const double mean = sc->rs.rows > 0 ? (double)sc->nnz / (double)sc->rs.rows : 0.0;
-  sc->rs.active = sc->rs.heavy > 0 || sc->locality || (mean >= 16.0 && (double)sc->longest >= 1.5 * mean);
+  double long_entries = 0.0;
+  for (int b = 0; b < kClasses; ++b) {
+    const int floor_b = class_floor(kClasses - 1 - b);
+    if ((double)floor_b >= 1.5 * mean) long_entries += (double)(sc->start[b + 1] - sc->start[b]) * (double)floor_b;
+  }
+  sc->rs.active = sc->rs.heavy > 0 || sc->locality || (mean >= 16.0 && long_entries >= 0.02 * (double)sc->nnz);
 }
 
 }  // namespace
@@ -262,16 +278,58 @@ size_t mi_spmm_schedule_workspace_bytes(int32_t M) {
   return (kClasses * ntiles + (kClasses + 1) + (size_t)(M > 0 ? M : 0) + 2 * 3 * kWindows + 16) * sizeof(int);
 }
 
-int mi_spmm_schedule_create(const int32_t* rowptr, const int32_t* col, int32_t M, int32_t K, int64_t nnz, int32_t N,
-                            int32_t* order, void* workspace, size_t workspace_bytes, mi_stream_t stream,
-                            mi_spmm_schedule_t** out) {
+// The build in two halves, so that a caller that must not synchronise (custom_mm's automatic schedules for the plain entry
+// points) can let the tables travel behind an event: _begin enqueues everything on the stream — both candidate orders, the class
+// table and the window statistics copied to `host_out` (MI_SCHEDULE_HOST_INTS ints; pinned memory for the copy to be
+// asynchronous) — and _finish, once that copy has landed, reads the tables on the host, picks the order and creates the object.
+int mi_spmm_schedule_begin(const int32_t* rowptr, const int32_t* col, int32_t M, int32_t K, int64_t nnz, int32_t N,
+                           int32_t* order, int32_t* order_locality, void* workspace, size_t workspace_bytes,
+                           int32_t* host_out, mi_stream_t stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (!out) return MI_EINVAL;
-  *out = nullptr;
-  if (M < 0 || K < 0 || nnz < 0 || N < 0) return MI_EINVAL;
+  if (M < 0 || K < 0 || nnz < 0 || N < 0 || !host_out) return MI_EINVAL;
   if (nnz > 0x7fffffffLL) return MI_ERANGE;
   if (M > 0 && (!rowptr || !order || !workspace)) return MI_EINVAL;
   if (workspace_bytes < mi_spmm_schedule_workspace_bytes(M)) return MI_ENOMEM;
+  for (int i = 0; i < MI_SCHEDULE_HOST_INTS; ++i) host_out[i] = 0;
+  host_out[MI_SCHEDULE_HOST_INTS - 1] = 0;  // 1: the locality order was built and measured
+  if (M == 0) return MI_OK;
+  const size_t ntiles = ((size_t)M + kTileRows - 1) / kTileRows;
+  int* table = static_cast<int*>(workspace);
+  int* start = table + kClasses * ntiles;
+  int* order1 = start + kClasses + 1;
+  int* stats = order1 + M;  // [2][kWindows][3]
+  // a column pass is worth trying on a matrix with columns to look at and enough rows for windows to mean something
+  const bool try_locality = order_locality != nullptr && col != nullptr && K > 0 && nnz > 0 && M >= 4 * kTileRows;
+  hipError_t e = hipSuccess;
+  if (try_locality) {
+    hipLaunchKernelGGL(sched_window_stats_kernel, dim3(kWindows), dim3(256), 0, s, rowptr, col, M, K, (const int*)nullptr, stats);
+    // least significant key first: the column key's low byte, its high byte, then the length class — every pass keeps the
+    // order of the one before inside its buckets (tiles keep their order; a tile of the previous pass's output holds one or a
+    // few neighbouring key values, so the arbitrary order inside a tile costs nothing)
+    e = counting_pass<kKeyColumnLow>(rowptr, col, M, K, nullptr, order_locality, table, nullptr, s);
+    if (e == hipSuccess) e = counting_pass<kKeyColumn>(rowptr, col, M, K, order_locality, order1, table, nullptr, s);
+    if (e == hipSuccess) e = counting_pass<kKeyClass>(rowptr, col, M, K, order1, order_locality, table, start, s);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(sched_window_stats_kernel, dim3(kWindows), dim3(256), 0, s, rowptr, col, M, K, (const int*)order_locality,
+                         stats + 3 * kWindows);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(host_out + kClasses + 1, stats, 2 * 3 * kWindows * sizeof(int), hipMemcpyDeviceToHost, s);
+  }
+  // by length class alone: neighbours in the row order stay neighbours inside a class
+  if (e == hipSuccess) e = counting_pass<kKeyClass>(rowptr, col, M, K, nullptr, order, table, start, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(host_out, start, (kClasses + 1) * sizeof(int), hipMemcpyDeviceToHost, s);
+  if (e != hipSuccess) return mi::record_hip_error(e);
+  host_out[MI_SCHEDULE_HOST_INTS - 1] = try_locality ? 1 : 0;  // (a host-side mark: not part of what the copies write)
+  return MI_OK;
+}
+
+int mi_spmm_schedule_finish(const int32_t* host_out, int32_t* order, int32_t* order_locality, int32_t M, int32_t K, int64_t nnz,
+                            int32_t N, mi_spmm_schedule_t** out) {
+  if (!out) return MI_EINVAL;
+  *out = nullptr;
+  if (!host_out || M < 0 || K < 0 || nnz < 0 || N < 0 || (M > 0 && !order)) return MI_EINVAL;
   mi_spmm_schedule* sc = new (std::nothrow) mi_spmm_schedule();
   if (!sc) return MI_ENOMEM;
   sc->rs = mi::RowSchedule{order, M, 0, 0, true, nullptr, nullptr, nullptr};
@@ -279,57 +337,24 @@ int mi_spmm_schedule_create(const int32_t* rowptr, const int32_t* col, int32_t M
   sc->n_width = N;
   sc->locality = false;
   sc->span_natural = sc->span_scheduled = sc->span_row = -1;
-  for (int b = 0; b <= kClasses; ++b) sc->start[b] = 0;
-  if (M > 0) {
-    const size_t ntiles = ((size_t)M + kTileRows - 1) / kTileRows;
-    int* table = static_cast<int*>(workspace);
-    int* start = table + kClasses * ntiles;
-    int* order1 = start + kClasses + 1;
-    int* stats = order1 + M;  // [2][kWindows][3]
-    int h_stats[2 * 3 * kWindows];
-    // a column pass is worth trying on a matrix with columns to look at and enough rows for windows to mean something
-    const bool try_locality = col != nullptr && K > 0 && nnz > 0 && M >= 4 * kTileRows;
-    hipError_t e = hipSuccess;
-    if (try_locality) {
-      hipLaunchKernelGGL(sched_window_stats_kernel, dim3(kWindows), dim3(256), 0, s, rowptr, col, M, K, (const int*)nullptr, stats);
-      // least significant key first: the column key's low byte, its high byte, then the length class — every pass keeps the
-      // order of the one before inside its buckets (tiles keep their order; a tile of the previous pass's output holds one or a
-      // few neighbouring key values, so the arbitrary order inside a tile costs nothing)
-      e = counting_pass<kKeyColumnLow>(rowptr, col, M, K, nullptr, order, table, nullptr, s);
-      if (e == hipSuccess) e = counting_pass<kKeyColumn>(rowptr, col, M, K, order, order1, table, nullptr, s);
-      if (e == hipSuccess) e = counting_pass<kKeyClass>(rowptr, col, M, K, order1, order, table, start, s);
-      if (e == hipSuccess) {
-        hipLaunchKernelGGL(sched_window_stats_kernel, dim3(kWindows), dim3(256), 0, s, rowptr, col, M, K, (const int*)order,
-                           stats + 3 * kWindows);
-        e = hipGetLastError();
-      }
-      if (e == hipSuccess) e = hipMemcpyAsync(h_stats, stats, sizeof(h_stats), hipMemcpyDeviceToHost, s);
-      if (e == hipSuccess) e = hipStreamSynchronize(s);
-      if (e == hipSuccess) {
-        double nat = 0, neu = 0, row = 0;
-        int wn = 0;
-        for (int w = 0; w < kWindows; ++w) {
-          if (h_stats[3 * w + 2] == 0 && h_stats[3 * (kWindows + w) + 2] == 0) continue;
-          nat += h_stats[3 * w], neu += h_stats[3 * (kWindows + w)], row += h_stats[3 * w + 1];
-          ++wn;
-        }
-        if (wn > 0) {
-          sc->span_natural = (int32_t)(1000.0 * nat / wn / kClasses);   // footprints, ‰ of B
-          sc->span_scheduled = (int32_t)(1000.0 * neu / wn / kClasses);
-          sc->span_row = (int32_t)(1000.0 * row / wn / K);
-          // the natural order is not local already (three quarters of a window's gathers need > 40 % of B) and this order
-          // more than halves the footprint
-          sc->locality = sc->span_natural > 400 && 2 * sc->span_scheduled < sc->span_natural;
-        }
-      }
+  for (int b = 0; b <= kClasses; ++b) sc->start[b] = M > 0 ? host_out[b] : 0;
+  if (M > 0 && host_out[MI_SCHEDULE_HOST_INTS - 1] == 1 && order_locality != nullptr && K > 0) {
+    const int32_t* h_stats = host_out + kClasses + 1;
+    double nat = 0, neu = 0, row = 0;
+    int wn = 0;
+    for (int w = 0; w < kWindows; ++w) {
+      if (h_stats[3 * w + 2] == 0 && h_stats[3 * (kWindows + w) + 2] == 0) continue;
+      nat += h_stats[3 * w], neu += h_stats[3 * (kWindows + w)], row += h_stats[3 * w + 1];
+      ++wn;
     }
-    if (e == hipSuccess && !sc->locality)  // by length class alone: neighbours in the row order stay neighbours inside a class
-      e = counting_pass<kKeyClass>(rowptr, col, M, K, nullptr, order, table, start, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(sc->start, start, (kClasses + 1) * sizeof(int), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) {
-      delete sc;
-      return mi::record_hip_error(e);
+    if (wn > 0) {
+      sc->span_natural = (int32_t)(1000.0 * nat / wn / kClasses);   // footprints, ‰ of B
+      sc->span_scheduled = (int32_t)(1000.0 * neu / wn / kClasses);
+      sc->span_row = (int32_t)(1000.0 * row / wn / K);
+      // the natural order is not local already (three quarters of a window's gathers need > 40 % of B) and the locality order
+      // more than halves the footprint
+      sc->locality = sc->span_natural > 400 && 2 * sc->span_scheduled < sc->span_natural;
+      if (sc->locality) sc->rs.order = order_locality;
     }
   }
   sc->longest = 0, sc->classes = 0;
@@ -340,16 +365,34 @@ int mi_spmm_schedule_create(const int32_t* rowptr, const int32_t* col, int32_t M
     }
   }
   set_heavy(sc, heavy_length_for(nnz));
-  // the side stream of the heavy launch and its fork / join events
-  hipError_t e = hipStreamCreateWithFlags(&sc->rs.side, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->rs.fork, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->rs.join, hipEventDisableTiming);
-  if (e != hipSuccess) {
-    mi_spmm_schedule_destroy(sc);
-    return mi::record_hip_error(e);
+  // the side stream of the ordinary launch beside the heavy one, and its fork / join events — for a schedule that has heavy or
+  // long rows to run beside the rest; an inactive schedule creates nothing (an extra stream is not free: config C3 read 1.7 %
+  // slower with one merely EXISTING in the process, A/B on one box)
+  if (sc->rs.active && (sc->rs.heavy > 0 || sc->longest + sc->longest / 8 + 1 > mi::kLongRowThreshold)) {
+    const int st = ensure_side_stream(sc);
+    if (st != MI_OK) {
+      mi_spmm_schedule_destroy(sc);
+      return st;
+    }
   }
   *out = sc;
   return MI_OK;
+}
+
+// begin + synchronise + finish.  `order` must hold 2·M ints when col is given (the second half takes the locality order; the
+// schedule points at whichever half it picked).
+int mi_spmm_schedule_create(const int32_t* rowptr, const int32_t* col, int32_t M, int32_t K, int64_t nnz, int32_t N,
+                            int32_t* order, void* workspace, size_t workspace_bytes, mi_stream_t stream,
+                            mi_spmm_schedule_t** out) {
+  if (!out) return MI_EINVAL;
+  *out = nullptr;
+  int32_t host[MI_SCHEDULE_HOST_INTS];
+  int32_t* order_locality = (col != nullptr && order != nullptr) ? order + (M > 0 ? M : 0) : nullptr;
+  int st = mi_spmm_schedule_begin(rowptr, col, M, K, nnz, N, order, order_locality, workspace, workspace_bytes, host, stream);
+  if (st != MI_OK) return st;
+  const hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return mi::record_hip_error(e);
+  return mi_spmm_schedule_finish(host, order, order_locality, M, K, nnz, N, out);
 }
 
 int mi_spmm_schedule_destroy(mi_spmm_schedule_t* sc) {
@@ -386,6 +429,7 @@ int mi_spmm_schedule_set_heavy(mi_spmm_schedule_t* sc, int32_t heavy_len, int us
     (void)hipStreamDestroy(sc->rs.side);
     sc->rs.side = nullptr;
   }
+  if (use_side_stream) return ensure_side_stream(sc);
   return MI_OK;
 }
 

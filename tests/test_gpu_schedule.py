@@ -283,3 +283,64 @@ def test_locality_order_is_taken_where_it_measurably_helps_and_changes_no_bit(cm
         assert np.array_equal(got.cpu().numpy().view(np.uint32), oracle_mod.spmm_csr(rowptr, col, val, M, K, B).view(np.uint32)), tag
     # without the columns the pass is not tried
     assert cmm.spmm_schedule(d_rp, len(val), M, N).info()["window_span_natural"] == -1.0
+
+
+def test_plain_entry_points_build_their_own_schedule_without_synchronising(cmm, dev, oracle_mod):
+    """custom_mm.naive_spmm has no inspector in the reference's API, and the reference's tests and benchmarks call it in loops on
+    one matrix: the extension remembers the CSR arrays it has seen, enqueues the schedule's build behind the SECOND product of
+    the same arrays (device kernels + copies to pinned memory + an event), and a later product that finds the event done runs on
+    the schedule — with torch's synchronisation debug mode on "error" throughout.  Every product has the bits of the first;
+    a stale key can cost time, never bits (a schedule is a permutation of the rows): shown by rewriting the arrays in place."""
+    M, K, N = 20_000, 30_000, 64
+    lens = _pareto_lens(M, 120, 6000, seed=41, empty=0.02)
+    rowptr, col, val = _random_rows_csr(M, K, lens, seed=42)
+    assert len(val) >= (1 << 20)
+    g = np.random.Generator(np.random.PCG64(43))
+    B = g.random((K, N), dtype=np.float32) - 0.5
+    d_rp, d_col, d_val, d_B = (t(x, dev) for x in (rowptr, col, val, B))
+    want = oracle_mod.spmm_csr(rowptr, col, val, M, K, B)
+    cmm.auto_schedule_clear()
+    assert cmm.auto_schedule_stats() == {"enabled": True, "entries": 0, "pending": 0, "active": 0, "inactive": 0, "built": cmm.auto_schedule_stats()["built"]}
+    built0 = cmm.auto_schedule_stats()["built"]
+    C = torch.empty(M, N, device=dev)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        states = []
+        for i in range(5):
+            C.fill_(float("nan"))
+            cmm.naive_spmm(d_val, d_col, d_rp, len(val), M, K, d_B, C)
+            states.append(dict(cmm.auto_schedule_stats()))
+            torch.cuda.set_sync_debug_mode("default")
+            torch.cuda.synchronize()     # (the test's own: lets the build's event complete between products)
+            assert np.array_equal(C.cpu().numpy().view(np.uint32), want.view(np.uint32)), i
+            torch.cuda.set_sync_debug_mode("error")
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert states[0]["entries"] == 1 and states[0]["pending"] == 0            # first product: seen, nothing built
+    assert states[1]["pending"] == 1                                          # second: the build is enqueued behind it
+    assert states[2]["pending"] == 0 and states[2]["active"] == 1 and states[2]["built"] == built0 + 1   # third: finished and in use
+    assert states[4] == states[2]
+    # the arrays rewritten IN PLACE (same pointers, same sizes, another matrix): the stale schedule is still a permutation
+    lens2 = _pareto_lens(M, 120, 6000, seed=51, empty=0.02)
+    rp2, col2, val2 = _random_rows_csr(M, K, lens2, seed=52)
+    n2 = min(len(val2), len(val))
+    keep = np.searchsorted(rp2, n2, side="right") - 1          # whole rows that fit the old arrays
+    rp2 = np.minimum(rp2, rp2[keep]).astype(np.int32)
+    col2, val2 = col2[:rp2[-1]], val2[:rp2[-1]]
+    d_rp.copy_(t(rp2, dev))
+    d_col[:len(col2)].copy_(t(col2, dev))
+    d_val[:len(val2)].copy_(t(val2, dev))
+    C.fill_(float("nan"))
+    cmm.naive_spmm(d_val, d_col, d_rp, len(val), M, K, d_B, C)     # (the count is now a capacity: a valid count)
+    assert np.array_equal(C.cpu().numpy().view(np.uint32), oracle_mod.spmm_csr(rp2, col2, val2, M, K, B).view(np.uint32))
+    # a uniform matrix: its schedule is built once and found inactive
+    rpu, colu, valu = _random_rows_csr(M, K, np.full(M, 60), seed=61)
+    du = [t(x, dev) for x in (rpu, colu, valu)]
+    for i in range(4):
+        cmm.naive_spmm(du[2], du[1], du[0], len(valu), M, K, d_B, C)
+        torch.cuda.synchronize()
+    st = cmm.auto_schedule_stats()
+    assert st["inactive"] == 1 and st["active"] == 1 and st["pending"] == 0
+    assert np.array_equal(C.cpu().numpy().view(np.uint32), oracle_mod.spmm_csr(rpu, colu, valu, M, K, B).view(np.uint32))
+    cmm.auto_schedule_clear()
