@@ -705,35 +705,59 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
     // heavy length, those the long-row kernel takes among them (skipped and listed as ever) — go in a launch of their own
     // with more gathers in flight per row, on the schedule's side stream BESIDE the launch(es) of the rest.  Per-row
     // arithmetic is that of the unscheduled plan: the same bits.
-    int heavy = sched->heavy < 0 ? 0 : (sched->heavy > M ? M : sched->heavy);
-    if (!sh.vec4_ok || N > 256) heavy = 0;  // the heavy-row kernel moves float4s and gives every column a chain lane: other shapes keep every row in the ordinary launch (longest first all the same)
+    const int heavy_slots = sched->heavy < 0 ? 0 : (sched->heavy > M ? M : sched->heavy);
+    const int heavy = sh.vec4_ok ? heavy_slots : 0;  // the heavy-row kernel moves float4s: other shapes keep every row in the ordinary launch (longest first all the same)
     LongArg lh = la, lr = la;
     lh.order = sched->order, lh.nslots = heavy;
     lh.adapt = nullptr;  // one pass, every column
+    // No prepared list, but every row beyond the threshold is among the heavy slots (the schedule says so): a scan of those few
+    // slots lists them, and the listed rows are summed in the heavy rows' launch — beside the ordinary launch, not behind it
+    // (the plain entry points on their automatic schedules: 185 long rows beside config C3's shape cost 0.6 ms behind it).
+    const bool early_list = split && !prepared && heavy_slots > 0 && sched->heavy_holds_long && la.ws != nullptr;
     const bool fork = sched->side != nullptr && sched->fork != nullptr && sched->join != nullptr &&
-                      (heavy > 0 || (split && prepared));
-    // The few big launches — the prepared long rows' kernel (16-wave workgroups), the heavy rows' kernel (8 waves + 129 KB of
-    // LDS per workgroup) — go FIRST and on the caller's stream: a workgroup of that size only finds room on a CU before the
+                      (heavy > 0 || (split && prepared) || early_list);
+    // The few big launches — the listed long rows' and the heavy rows' kernel (8 waves + 130 KB of LDS per workgroup; 16-wave
+    // workgroups for shapes that cannot move float4s) — go FIRST and on the caller's stream: a workgroup of that size only finds room on a CU before the
     // ordinary launch has filled every wave slot with its small ones.  The ordinary launch(es) follow on the schedule's side
     // stream and fill what is left; the caller's stream then waits for them.
+    // (the scan goes BEFORE the fork: the ordinary launch must not get to the CUs ahead of the big workgroups)
+    if (early_list) {
+      LongArg scan = lh;
+      scan.nslots = heavy_slots;
+      st = launch_find_long_rows(rowptr, M, scan, s);
+      if (st != MI_OK) return st;
+    }
     hipStream_t rest = s;
     if (fork) {
       MI_HIP_TRY(hipEventRecord(sched->fork, s));
       MI_HIP_TRY(hipStreamWaitEvent(sched->side, sched->fork, 0));
       rest = sched->side;
     }
-    // a PREPARED list of the rows beyond the long-row threshold: their kernel needs nothing from this product's other
-    // launches (unprepared: the launches below build the list, the follow-up comes last)
-    if (split && prepared) {
+    if (early_list) {
+      lh.ws = nullptr;  // (listed just now: the heavy slots only skip them)
+      // the counters are zeroed by a memset behind the launch, not by its last workgroup: counting 700 workgroups that have
+      // nothing to sum through one atomic held the heavy slots' workgroups back until the ordinary launch had taken the CUs
+      // (measured: 245 µs for this launch against 131 with a prepared list)
+      st = heavy > 0 ? launch_staged_rows(ws, lw, false, lh, rowptr, col, val, B, C, N, ldb, ldc, bias, s)
+                     : launch_long_rows(sh.vec4_ok, ws, lw, rowptr, col, val, B, C, N, ldb, ldc, bias, false, s);
+      if (st != MI_OK) return st;
+      MI_HIP_TRY(hipMemsetAsync(ws, 0, 16, s));
+      long_rows_done = true;
+      lr.ws = nullptr;  // none of its rows is beyond the threshold
+    // a PREPARED list of the rows beyond the long-row threshold: their kernel needs nothing from this product's other launches
+    } else if (split && prepared && heavy > 0) {  // (heavy > 0: a float4 shape) both in one launch — neither waits for the other
+      st = launch_staged_rows(ws, lw, false, lh, rowptr, col, val, B, C, N, ldb, ldc, bias, s);
+      if (st != MI_OK) return st;
+      long_rows_done = true;
+    } else if (split && prepared) {
       st = launch_long_rows(sh.vec4_ok, ws, lw, rowptr, col, val, B, C, N, ldb, ldc, bias, false, s);
       if (st != MI_OK) return st;
       long_rows_done = true;
-    }
-    if (heavy > 0) {
+    } else if (heavy > 0) {
       st = launch_heavy_rows(rowptr, col, val, M, N, B, ldb, C, ldc, bias, lh, s);
       if (st != MI_OK) return st;
     }
-    lr.order = sched->order + heavy, lr.nslots = M - heavy;  // (rows beyond the threshold may sit on either side of `heavy`: both launches list)
+    lr.order = sched->order + heavy, lr.nslots = M - heavy;  // (with a pinned heavy length rows beyond the threshold may sit on either side of `heavy`: both launches list)
     st = launch_variant(variant, sh, rowptr, col, val, nnz, batch, M, K, N, B, ldb, strideB, C, ldc, strideC, bias, lr, rest);
     if (fork) {
       MI_HIP_TRY(hipEventRecord(sched->join, sched->side));

@@ -29,12 +29,19 @@ struct LongWs {
   size_t adapt_off;                      // bytes: the locality probe's verdicts, behind everything else
 };
 LongWs long_ws_layout(int64_t nnz, int32_t N);
-// lists the rows beyond la.thresh in la.ws (plans whose kernel lives in a file of its own and only skips; prepared lists)
+// lists the rows beyond la.thresh in la.ws (plans whose kernel lives in a file of its own and only skips; prepared lists);
+// with la.order: among the rows of its la.nslots slots only
 int launch_find_long_rows(const int32_t* rowptr, int32_t M, const LongArg& la, hipStream_t s);
 // the follow-up launch of a product that splits its long rows: sums the listed rows, combines, resets the counters
 int launch_long_rows(bool vec4, int* ws, const LongWs& lw, const int32_t* rowptr, const int32_t* col, const float* val,
                      const float* B, float* C, int32_t N, int64_t ldb, int64_t ldc, const float* bias, bool reset,
                      hipStream_t s);
+
+// the same sums for float4 shapes (N % 4 == 0, 16-byte aligned operands): one 8-wave workgroup per group of 16 chains and 64
+// columns, the chains staged through LDS at the CU's gather rate (spmm_heavy.hip); launch_long_rows sends vec4 shapes here
+int launch_long_rows_staged(int* ws, const LongWs& lw, const int32_t* rowptr, const int32_t* col, const float* val,
+                            const float* B, float* C, int32_t N, int64_t ldb, int64_t ldc, const float* bias, bool reset,
+                            hipStream_t s);
 
 // ---- column-panel passes (spmm_panels.hip) -------------------------------------------------------------------------
 int launch_locality_probe(const int32_t* rowptr, const int32_t* col, int32_t M, int64_t ldb, double b_bytes, int* verdicts,
@@ -49,11 +56,17 @@ int launch_group_panels(int panels, const int* rowptr, const int* col, const flo
                         int K, int N, long ldb, long ldc, const float* bias, LongArg la, hipStream_t s);
 
 // ---- heavy rows of a schedule (spmm_heavy.hip) ----------------------------------------------------------------------
-// One 8-wave workgroup per slot of la.order: the row's B rows gathered by the loader waves into LDS, up to 128 entries at a
-// time, and summed from there by the chain waves — ONE chain per output element in CSR order (the same bits as every other kernel).  N % 4 == 0, N ≤ 256,
-// 16-byte aligned operands (the caller checks); rows beyond la.thresh are skipped and listed as everywhere else.
+// One 8-wave workgroup per slot of la.order and 64 columns: the row's B rows gathered by the loader waves into LDS, up to 224
+// entries at a time, and summed from there by the chain wave — ONE chain per output element in CSR order (the same bits as every
+// other kernel).  N % 4 == 0, 16-byte aligned operands (the caller checks); rows beyond la.thresh are skipped and listed as
+// everywhere else.
 int launch_heavy_rows(const int32_t* rowptr, const int32_t* col, const float* val, int32_t M, int32_t N, const float* B,
                       int64_t ldb, float* C, int64_t ldc, const float* bias, LongArg la, hipStream_t s);
+// both in ONE launch (a prepared list beside a schedule's heavy slots would otherwise wait for each other on the stream):
+// ws == nullptr: no list; heavy.nslots == 0: no heavy slots
+int launch_staged_rows(int* ws, const LongWs& lw, bool reset, const LongArg& heavy, const int32_t* rowptr, const int32_t* col,
+                       const float* val, const float* B, float* C, int32_t N, int64_t ldb, int64_t ldc, const float* bias,
+                       hipStream_t s);
 
 // ---- plan rules (spmm_plan.hip; host only) --------------------------------------------------------------------------
 struct Shape {
@@ -71,6 +84,7 @@ struct RowSchedule {
   int32_t rows;           // M
   int32_t heavy;          // slots [0, heavy): the rows longer than heavy_len — a launch of their own, more gathers in flight per row
   int32_t heavy_len;
+  bool heavy_holds_long;  // every row beyond the long-row threshold is among the heavy slots
   bool active;            // false: the matrix has no skew worth an indirection (short, alike rows) — products run unscheduled
   hipStream_t side;       // the launch(es) of the rest run on this stream beside the heavy launch (nullptr: in line, behind it)
   hipEvent_t fork, join;  // fork / join of `side` against the caller's stream

@@ -27,10 +27,11 @@ using mi::LongArg;
 // ---------------------------------------------------------------------------
 
 __global__ void find_long_rows_kernel(const int* __restrict__ rowptr, int M, LongArg la) {
-  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= M) return;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const int r = la.order != nullptr ? la.order[i] : (int)i;  // (M = the number of slots then)
   const int len = rowptr[r + 1] - rowptr[r];
-  if (len > kLongRow) long_list_append(la, (int)r, len);
+  if (len > kLongRow) long_list_append(la, r, len);
 }
 
 // reset != 0: the list was built for this product only — the workgroup that finishes last zeroes the four
@@ -174,6 +175,8 @@ LongWs long_ws_layout(int64_t nnz, int32_t N) {
 }
 
 int launch_find_long_rows(const int32_t* rowptr, int32_t M, const LongArg& la, hipStream_t s) {
+  if (la.order != nullptr) M = la.nslots;
+  if (M <= 0) return MI_OK;
   hipLaunchKernelGGL(find_long_rows_kernel, dim3((unsigned)(((long)M + 255) / 256)), dim3(256), 0, s, rowptr, M, la);
   return check_launch();
 }
@@ -181,14 +184,12 @@ int launch_find_long_rows(const int32_t* rowptr, int32_t M, const LongArg& la, h
 int launch_long_rows(bool vec4, int* ws, const LongWs& lw, const int32_t* rowptr, const int32_t* col, const float* val,
                      const float* B, float* C, int32_t N, int64_t ldb, int64_t ldc, const float* bias, bool reset,
                      hipStream_t s) {
+  // float4 shapes: a workgroup per group of chains and 64 columns, the chains staged through LDS (spmm_heavy.hip) — the same sums
+  if (vec4) return launch_long_rows_staged(ws, lw, rowptr, col, val, B, C, N, ldb, ldc, bias, reset, s);
   float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + lw.partial_off);
   const unsigned grid = lw.cap_s < 256 ? (unsigned)lw.cap_s : 256u;  // one 16-wave workgroup per CU (grid-stride over the slots)
-  if (vec4)
-    hipLaunchKernelGGL(spmm_long_rows_kernel<4>, dim3(grid), dim3(kLongWaves * 64), 0, s, ws, (int)lw.cap_e,
-                       (int)lw.cap_s, partial, rowptr, col, val, B, C, N, (long)ldb, (long)ldc, bias, reset ? 1 : 0);
-  else
-    hipLaunchKernelGGL(spmm_long_rows_kernel<1>, dim3(grid), dim3(kLongWaves * 64), 0, s, ws, (int)lw.cap_e,
-                       (int)lw.cap_s, partial, rowptr, col, val, B, C, N, (long)ldb, (long)ldc, bias, reset ? 1 : 0);
+  hipLaunchKernelGGL(spmm_long_rows_kernel<1>, dim3(grid), dim3(kLongWaves * 64), 0, s, ws, (int)lw.cap_e,
+                     (int)lw.cap_s, partial, rowptr, col, val, B, C, N, (long)ldb, (long)ldc, bias, reset ? 1 : 0);
   return check_launch();
 }
 

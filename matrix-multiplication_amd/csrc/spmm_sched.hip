@@ -249,9 +249,13 @@ int ensure_side_stream(mi_spmm_schedule* sc) {
 
 void set_heavy(mi_spmm_schedule* sc, int32_t heavy_len) {
   // slots before the first class that holds a row of ≤ heavy_len entries: every row there is longer than heavy_len
-  const int c = length_class(heavy_len);  // rows of this class may be ≤ heavy_len: not heavy
+  // At the long-row threshold itself (where heavy_length_for stops) the slots begin with the threshold's OWN class — rows of
+  // 8192 … 9215 entries: every row the long-row kernel takes then sits among the heavy slots, and a product without a
+  // prepared list can sum the listed rows beside its ordinary launch instead of behind it (spmm_dispatch).
+  const int c = length_class(heavy_len) - (heavy_len == mi::kLongRowThreshold ? 1 : 0);  // rows of class c may be ≤ heavy_len: not heavy
   sc->rs.heavy_len = heavy_len;
   sc->rs.heavy = sc->start[kClasses - 1 - c];  // buckets 0 … (kClasses − 2 − c) = classes above c
+  sc->rs.heavy_holds_long = c < length_class(mi::kLongRowThreshold);  // every row beyond the threshold is of a class above c
   // Is the order worth its indirection?  It costs the locality of consecutive rows (rowptr reads, C rows written side by side):
   // 4 M rows of 1 … 8 entries ran 11 – 16 % SLOWER scheduled, 2.4 M rows of ≤ 100 entries around a mean of 50 ran 5 % faster
   // (profiles/r06_degree_skew.log).  Active with heavy rows, or with rows that are long enough to be gather-bound (mean ≥ 16)
@@ -332,7 +336,7 @@ int mi_spmm_schedule_finish(const int32_t* host_out, int32_t* order, int32_t* or
   if (!host_out || M < 0 || K < 0 || nnz < 0 || N < 0 || (M > 0 && !order)) return MI_EINVAL;
   mi_spmm_schedule* sc = new (std::nothrow) mi_spmm_schedule();
   if (!sc) return MI_ENOMEM;
-  sc->rs = mi::RowSchedule{order, M, 0, 0, true, nullptr, nullptr, nullptr};
+  sc->rs = mi::RowSchedule{order, M, 0, 0, false, true, nullptr, nullptr, nullptr};
   sc->nnz = nnz;
   sc->n_width = N;
   sc->locality = false;

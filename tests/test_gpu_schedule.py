@@ -65,6 +65,10 @@ def test_schedule_is_a_permutation_by_descending_length_class(cmm, dev):
     assert info["longest_at_least"] <= lens.max() < info["longest_at_least"] * 1.13 + 1
     sched.set_heavy(1000, True)
     assert sched.info()["heavy_rows"] == int((_length_class(lens) > _length_class(1000)).sum())
+    # at the long-row threshold itself the slots begin with the threshold's own class: every row the long-row kernel takes is a heavy slot
+    sched.set_heavy(cmm.long_row_threshold(), True)
+    assert sched.info()["heavy_rows"] == int((_length_class(lens) >= _length_class(cmm.long_row_threshold())).sum())
+    assert np.all(lens[order[sched.info()["heavy_rows"]:]] <= cmm.long_row_threshold())
     # a schedule of an empty matrix, and of one row
     for m in (0, 1):
         rp = np.zeros(m + 1, np.int32)

@@ -477,6 +477,40 @@ def test_skewed_rows_long_row_kernel(cmm, dev, oracle_mod, N):
     assert np.array_equal(C.cpu().numpy(), oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B) + bias[None, :])
 
 
+@pytest.mark.parametrize("N", [64, 260, 512, 100])
+def test_many_long_rows_take_the_bulk_form_and_few_the_staged_one(cmm, dev, oracle_mod, N):
+    """How the listed rows are summed is decided on the device from their number (csrc/spmm_heavy.hip): a few — one 8-wave
+    workgroup per group of chains and 64 columns, the chains staged through LDS; ≥ 128 units — one wave per chain over whole rows
+    of B.  The arithmetic is the oracle's statement of the long-row order either way: 150 rows beyond the threshold (two of them
+    split over S = 2 and S = 3 groups) beside short rows, then the same rows thinned to 3 long ones; with and without the bias;
+    the scheduled product (a prepared list, summed in the heavy rows' launch) gives the same bits."""
+    M, K = 400, 100_000
+    g = np.random.Generator(np.random.PCG64(N + 7))
+    lens = g.integers(0, 120, size=M)
+    hubs = g.choice(M, size=150, replace=False)
+    lens[hubs] = g.integers(8193, 8600, size=150)
+    lens[hubs[0]], lens[hubs[1]], lens[hubs[2]] = 65536, 100_000, 8193
+    for keep in (150, 3):
+        l2 = lens.copy()
+        l2[hubs[keep:]] = 50
+        rowptr, col, val = _random_rows_csr(M, K, l2, seed=N + keep)
+        B = g.random((K, N), dtype=np.float32) - 0.5
+        bias = g.random(N, dtype=np.float32)
+        want = oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B)
+        got = run_spmm(cmm, dev, rowptr, col, val, M, K, B, "naive_spmm")
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (N, keep)
+        d_rp, d_col, d_val, d_B = t(rowptr, dev), t(col, dev), t(val, dev), t(B, dev)
+        C = torch.full((M, N), float("nan"), device=dev)
+        cmm.naive_spmm_bias(d_val, d_col, d_rp, len(val), M, K, d_B, t(bias, dev), C)
+        assert np.array_equal(C.cpu().numpy().view(np.uint32), (want + bias[None, :]).view(np.uint32)), (N, keep)
+        sched = cmm.spmm_schedule(d_rp, len(val), M, N)
+        assert sched.info()["long_rows"] == keep
+        sched.set_heavy(64, True)   # the short rows' longer half becomes heavy slots: list and slots share a launch
+        C2 = torch.full((M, N), float("nan"), device=dev)
+        cmm.naive_spmm_scheduled(sched, d_val, d_col, d_rp, len(val), M, K, d_B, C2)
+        assert np.array_equal(C2.cpu().numpy().view(np.uint32), want.view(np.uint32)), (N, keep)
+
+
 @pytest.mark.parametrize("N", [64, 256, 30])
 def test_hub_rows_split_over_workgroups(cmm, dev, oracle_mod, N):
     """Rows of ≥ 65536 non-zeros are summed by S = len/32768 workgroups through partial rows in the
