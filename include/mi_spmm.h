@@ -214,8 +214,7 @@ const char* mi_spmm_variant_name(int variant);
  *     rows keeps its products unscheduled: active with heavy rows, with a locality order, or mean ≥ 16 entries with ≥ 2 % of the
  *     entries in rows of ≥ 1.5 × the mean; 4: locality order), nnz, N, a window's footprint in natural order / in this order (‰ of B), mean row span (‰ of
  *     K) (-1: not measured), 0}.
- *   (Heavy slots: the rows of the length classes above the heavy length's own; at the long-row threshold, where the default stops, the
- *     threshold's own class too — every row the long-row rule takes is then a heavy slot and is summed beside the ordinary launch.)
+ *   (Heavy slots: the rows of the length classes above the heavy length's own — by the rule at most 128 rows, the longest classes.)
  *   mi_spmm_schedule_set_heavy: another heavy length (0: every row; ≥ the longest: none) / every launch in line on the caller's
  *     stream instead of the rest beside the heavy launch — tests and A/B measurements; makes the schedule active.
  *   mi_spmm_csr_scheduled_f32: mi_spmm_csr_ex_variant_f32 (variant MI_SPMM_AUTO = by plan) on the schedule.

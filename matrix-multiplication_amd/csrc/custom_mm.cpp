@@ -153,4 +153,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("ipc_close", &ipc_close, "drop one open of a peer handle");
   m.def("ipc_open_count", []() { return mi_ipc_open_count(); }, "peer mappings not yet closed in this process");
   m.def("long_row_threshold", &long_row_threshold, "rows with more non-zeros are 'long' (split rule)");
+  // Handles and automatic schedules own HIP streams and events: they are released while the interpreter — and with it the HIP
+  // runtime — is still up (left to the destructors of the statics they segfaulted at process exit after the runtime had gone:
+  // a program that never called cusparse_clean / auto_schedule_clear ended with exit code 139 AFTER its last line of output).
+  py::module_::import("atexit").attr("register")(py::cpp_function([]() {
+    auto_schedule_clear();
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    g_cusparse_layers.clear();
+    g_tiled_layers.clear();
+  }));
 }

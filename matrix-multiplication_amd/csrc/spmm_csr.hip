@@ -710,10 +710,12 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
     LongArg lh = la, lr = la;
     lh.order = sched->order, lh.nslots = heavy;
     lh.adapt = nullptr;  // one pass, every column
-    // No prepared list, but every row beyond the threshold is among the heavy slots (the schedule says so): a scan of those few
-    // slots lists them, and the listed rows are summed in the heavy rows' launch — beside the ordinary launch, not behind it
-    // (the plain entry points on their automatic schedules: 185 long rows beside config C3's shape cost 0.6 ms behind it).
-    const bool early_list = split && !prepared && heavy_slots > 0 && sched->heavy_holds_long && la.ws != nullptr;
+    // No prepared list: a scan of rowptr lists the rows beyond the threshold FIRST (4 bytes per row: 3 – 5 µs), and the listed
+    // rows are summed in the heavy rows' launch — beside the ordinary launch, not behind it (the plain entry points on their
+    // automatic schedules: 185 long rows beside config C3's shape cost 0.6 ms behind it).  The scan reads EVERY row, not the
+    // heavy slots alone: the schedule may be stale (the extension's automatic ones are keyed loosely — a permutation of the
+    // rows that no longer knows where the long ones are), and a row that is skipped must be on the list.
+    const bool early_list = split && !prepared && heavy_slots > 0 && la.ws != nullptr;
     const bool fork = sched->side != nullptr && sched->fork != nullptr && sched->join != nullptr &&
                       (heavy > 0 || (split && prepared) || early_list);
     // The few big launches — the listed long rows' and the heavy rows' kernel (8 waves + 130 KB of LDS per workgroup; 16-wave
@@ -722,9 +724,7 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
     // stream and fill what is left; the caller's stream then waits for them.
     // (the scan goes BEFORE the fork: the ordinary launch must not get to the CUs ahead of the big workgroups)
     if (early_list) {
-      LongArg scan = lh;
-      scan.nslots = heavy_slots;
-      st = launch_find_long_rows(rowptr, M, scan, s);
+      st = launch_find_long_rows(rowptr, M, la, s);
       if (st != MI_OK) return st;
     }
     hipStream_t rest = s;
@@ -743,7 +743,7 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
       if (st != MI_OK) return st;
       MI_HIP_TRY(hipMemsetAsync(ws, 0, 16, s));
       long_rows_done = true;
-      lr.ws = nullptr;  // none of its rows is beyond the threshold
+      lr.ws = nullptr;  // its rows beyond the threshold (a stale schedule may leave some there) are on the list already: skipped only
     // a PREPARED list of the rows beyond the long-row threshold: their kernel needs nothing from this product's other launches
     } else if (split && prepared && heavy > 0) {  // (heavy > 0: a float4 shape) both in one launch — neither waits for the other
       st = launch_staged_rows(ws, lw, false, lh, rowptr, col, val, B, C, N, ldb, ldc, bias, s);

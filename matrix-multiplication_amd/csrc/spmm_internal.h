@@ -29,8 +29,8 @@ struct LongWs {
   size_t adapt_off;                      // bytes: the locality probe's verdicts, behind everything else
 };
 LongWs long_ws_layout(int64_t nnz, int32_t N);
-// lists the rows beyond la.thresh in la.ws (plans whose kernel lives in a file of its own and only skips; prepared lists);
-// with la.order: among the rows of its la.nslots slots only
+// lists the rows beyond la.thresh in la.ws (plans whose kernel lives in a file of its own and only skips; prepared lists; scheduled
+// products without a prepared list)
 int launch_find_long_rows(const int32_t* rowptr, int32_t M, const LongArg& la, hipStream_t s);
 // the follow-up launch of a product that splits its long rows: sums the listed rows, combines, resets the counters
 int launch_long_rows(bool vec4, int* ws, const LongWs& lw, const int32_t* rowptr, const int32_t* col, const float* val,
@@ -84,7 +84,6 @@ struct RowSchedule {
   int32_t rows;           // M
   int32_t heavy;          // slots [0, heavy): the rows longer than heavy_len — a launch of their own, more gathers in flight per row
   int32_t heavy_len;
-  bool heavy_holds_long;  // every row beyond the long-row threshold is among the heavy slots
   bool active;            // false: the matrix has no skew worth an indirection (short, alike rows) — products run unscheduled
   hipStream_t side;       // the launch(es) of the rest run on this stream beside the heavy launch (nullptr: in line, behind it)
   hipEvent_t fork, join;  // fork / join of `side` against the caller's stream

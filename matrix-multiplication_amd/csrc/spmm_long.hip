@@ -1,6 +1,7 @@
 // Rows beyond the long-row threshold ("skewed matrices"): listed by the main kernels on the way (spmm_device.h:
-// long_list_append) or by find_long_rows_kernel, summed here by several 16-wave workgroups per row in a fixed order that the
-// oracle restates (oracle_spmm_csr_long_f32).  Contract: include/mi_spmm.h (mi_spmm_csr_ws_f32, MI_LONG_ROWS_*).
+// long_list_append) or by find_long_rows_kernel, summed in a fixed order that the oracle restates (oracle_spmm_csr_long_f32) —
+// here, by several 16-wave workgroups per row, for the shapes that cannot move float4s; float4 shapes go to the staged kernel of
+// spmm_heavy.hip (the same order, other workgroup shapes).  Contract: include/mi_spmm.h (mi_spmm_csr_ws_f32, MI_LONG_ROWS_*).
 // New relative to the reference, whose kernel walks every row with one warp (src/naive_sparse_mm.cu:60-92).
 #include "spmm_device.h"
 #include "spmm_internal.h"
@@ -27,11 +28,10 @@ using mi::LongArg;
 // ---------------------------------------------------------------------------
 
 __global__ void find_long_rows_kernel(const int* __restrict__ rowptr, int M, LongArg la) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M) return;
-  const int r = la.order != nullptr ? la.order[i] : (int)i;  // (M = the number of slots then)
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= M) return;
   const int len = rowptr[r + 1] - rowptr[r];
-  if (len > kLongRow) long_list_append(la, r, len);
+  if (len > kLongRow) long_list_append(la, (int)r, len);
 }
 
 // reset != 0: the list was built for this product only — the workgroup that finishes last zeroes the four
@@ -175,7 +175,6 @@ LongWs long_ws_layout(int64_t nnz, int32_t N) {
 }
 
 int launch_find_long_rows(const int32_t* rowptr, int32_t M, const LongArg& la, hipStream_t s) {
-  if (la.order != nullptr) M = la.nslots;
   if (M <= 0) return MI_OK;
   hipLaunchKernelGGL(find_long_rows_kernel, dim3((unsigned)(((long)M + 255) / 256)), dim3(256), 0, s, rowptr, M, la);
   return check_launch();

@@ -33,6 +33,7 @@ namespace {
 constexpr int kClasses = 256;
 constexpr int kTileRows = 2048;  // slots per workgroup of a counting pass
 constexpr int kWindows = 16;     // windows of kTileRows consecutive slots the locality statistic looks at
+constexpr int kHeavyRowsMost = 128;  // the rule's heavy launch takes at most this many rows (set_heavy)
 static_assert(kClasses + 1 + 2 * 3 * kWindows < MI_SCHEDULE_HOST_INTS, "the class table and both window statistics fit host_out");
 
 // Length class, larger = longer: exact below 32, then eight classes per octave (2^e … 2^(e+1)) up to 2^31.
@@ -233,9 +234,13 @@ namespace {
 // Rows longer than this get the launch of their own.  A wave walks a row at (gathers in flight) / (memory latency): ≈ 6 GB/s of
 // B rows, i.e. a row of L entries takes L · 4N / 6e9 s while the whole product takes ≈ nnz · 4N / 6e12 s on the chip — a row
 // beyond nnz / 1000 entries alone outlasts the product.  A quarter of that, not below 128 entries (shorter rows gain nothing
-// from more gathers in flight) and not above the long-row threshold (those rows have a kernel of their own).
-int32_t heavy_length_for(int64_t nnz) {
-  const int64_t h = nnz / 4096;
+// from more gathers in flight), not below four times the mean length (a heavy row is an OUTLIER: where every row has hundreds of
+// entries the waves that run together are alike and nothing waits for one of them) and not above the long-row threshold (those
+// rows have a kernel of their own).
+int32_t heavy_length_for(int64_t nnz, int32_t rows) {
+  int64_t h = nnz / 4096;
+  const int64_t mean4 = rows > 0 ? 4 * nnz / rows : 0;
+  h = h < mean4 ? mean4 : h;
   return (int32_t)(h < 128 ? 128 : (h > mi::kLongRowThreshold ? mi::kLongRowThreshold : h));
 }
 
@@ -247,15 +252,20 @@ int ensure_side_stream(mi_spmm_schedule* sc) {
   return e == hipSuccess ? MI_OK : mi::record_hip_error(e);
 }
 
-void set_heavy(mi_spmm_schedule* sc, int32_t heavy_len) {
+void set_heavy(mi_spmm_schedule* sc, int32_t heavy_len, bool by_rule) {
   // slots before the first class that holds a row of ≤ heavy_len entries: every row there is longer than heavy_len
-  // At the long-row threshold itself (where heavy_length_for stops) the slots begin with the threshold's OWN class — rows of
-  // 8192 … 9215 entries: every row the long-row kernel takes then sits among the heavy slots, and a product without a
-  // prepared list can sum the listed rows beside its ordinary launch instead of behind it (spmm_dispatch).
-  const int c = length_class(heavy_len) - (heavy_len == mi::kLongRowThreshold ? 1 : 0);  // rows of class c may be ≤ heavy_len: not heavy
+  int c = length_class(heavy_len);  // rows of class c may be ≤ heavy_len: not heavy
+  // The heavy launch is for the FEW outliers (one workgroup per row and 64 columns, one resident per CU): where the rule's
+  // length leaves more than kHeavyRowsMost rows above it, the boundary moves up, class by class, to the longest ones
+  // (not beyond the long-row threshold's class).  7 680 rows of mean 482 with a
+  // tenth of them beyond nnz / 4096 ran 1.37 × slower with 700 heavy rows than unscheduled (tools/plan_grid.py --pattern degskew).
+  if (by_rule) {
+    const int c_most = length_class(mi::kLongRowThreshold);
+    while (c < c_most && sc->start[kClasses - 1 - c] > kHeavyRowsMost) ++c;
+    if (c > length_class(heavy_len)) heavy_len = class_floor(c + 1) - 1;  // the longest length that is not heavy
+  }
   sc->rs.heavy_len = heavy_len;
   sc->rs.heavy = sc->start[kClasses - 1 - c];  // buckets 0 … (kClasses − 2 − c) = classes above c
-  sc->rs.heavy_holds_long = c < length_class(mi::kLongRowThreshold);  // every row beyond the threshold is of a class above c
   // Is the order worth its indirection?  It costs the locality of consecutive rows (rowptr reads, C rows written side by side):
   // 4 M rows of 1 … 8 entries ran 11 – 16 % SLOWER scheduled, 2.4 M rows of ≤ 100 entries around a mean of 50 ran 5 % faster
   // (profiles/r06_degree_skew.log).  Active with heavy rows, or with rows that are long enough to be gather-bound (mean ≥ 16)
@@ -336,7 +346,7 @@ int mi_spmm_schedule_finish(const int32_t* host_out, int32_t* order, int32_t* or
   if (!host_out || M < 0 || K < 0 || nnz < 0 || N < 0 || (M > 0 && !order)) return MI_EINVAL;
   mi_spmm_schedule* sc = new (std::nothrow) mi_spmm_schedule();
   if (!sc) return MI_ENOMEM;
-  sc->rs = mi::RowSchedule{order, M, 0, 0, false, true, nullptr, nullptr, nullptr};
+  sc->rs = mi::RowSchedule{order, M, 0, 0, true, nullptr, nullptr, nullptr};
   sc->nnz = nnz;
   sc->n_width = N;
   sc->locality = false;
@@ -368,7 +378,7 @@ int mi_spmm_schedule_finish(const int32_t* host_out, int32_t* order, int32_t* or
       sc->longest = class_floor(kClasses - 1 - b);
     }
   }
-  set_heavy(sc, heavy_length_for(nnz));
+  set_heavy(sc, heavy_length_for(nnz, M), true);
   // the side stream of the ordinary launch beside the heavy one, and its fork / join events — for a schedule that has heavy or
   // long rows to run beside the rest; an inactive schedule creates nothing (an extra stream is not free: config C3 read 1.7 %
   // slower with one merely EXISTING in the process, A/B on one box)
@@ -427,7 +437,7 @@ int mi_spmm_schedule_info(const mi_spmm_schedule_t* sc, int64_t* info) {
 
 int mi_spmm_schedule_set_heavy(mi_spmm_schedule_t* sc, int32_t heavy_len, int use_side_stream) {
   if (!sc || heavy_len < 0) return MI_EINVAL;
-  set_heavy(sc, heavy_len);
+  set_heavy(sc, heavy_len, false);
   sc->rs.active = true;  // a pinned heavy length is a request to run scheduled
   if (!use_side_stream && sc->rs.side) {  // (tests, A/B: the heavy launch in line, ahead of the rest)
     (void)hipStreamDestroy(sc->rs.side);
