@@ -87,7 +87,7 @@ def test_c3_kernel_stats_agree_with_the_bench_line(rnd):
         # two dispatches per product at C2: the main kernel and the (empty) follow-up — no memset, no scan of rowptr
         c2 = [r["Name"] for r in csv.DictReader(open(PROFILES / f"{rnd}_bench_c2_kernel_stats.csv"))]
         spmm = [n for n in c2 if "spmm_" in n or "find_long" in n or "combine_long" in n]
-        assert len(spmm) == 2 and any("spmm_group_kernel" in n for n in spmm) and any("spmm_long_rows_kernel" in n for n in spmm)
+        assert len(spmm) == 2 and any("spmm_group_kernel" in n for n in spmm) and any("spmm_long_rows_kernel" in n or "spmm_staged_rows_kernel" in n for n in spmm)
 
 
 def test_committed_traffic_is_tied_to_the_sources(tmp_path, monkeypatch):

@@ -38,8 +38,8 @@ for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     per_counter[counter] = {k: sum(v) / len(v) for k, v in by_kernel.items()}
 fetch_kb = sum(per_counter["FETCH_SIZE"].values())
 write_kb = sum(per_counter["WRITE_SIZE"].values())
-# the µs-scale helper launches (find_long_rows / spmm_long_rows with an empty list) ride along
-main = [k for k in per_counter["FETCH_SIZE"] if "long_rows" not in k]
+# the µs-scale helper launches (find_long_rows / the listed-rows kernel with an empty list) ride along
+main = [k for k in per_counter["FETCH_SIZE"] if "long_rows" not in k and "staged_rows" not in k]
 assert len(main) == launches or launches == 1, (per_counter, launches)
 # optional third pass (tools/profile_bench.sh): the DRAM-side share of the reads — requests the L2s sent to HBM
 # (TCC_EA0_RDREQ_DRAM: 32-byte and 64-byte requests, the latter counted apart) as opposed to all fabric reads
