@@ -84,6 +84,59 @@ def committed_traffic(workload, kernel_name=None):
     return rec.get("hbm_bytes_per_product"), rec.get("dram_bytes_per_product")
 
 
+def profiler_attached():
+    """True when this process already runs under a ROCm profiler (tools/profile_bench.sh, the driver's own rocprofv3): no
+    second profiler is started from inside it."""
+    env = os.environ
+    return any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in env) or "rocprofiler" in env.get("LD_PRELOAD", "")
+
+
+def live_traffic(workload, timeout_s=150):
+    """HBM-side bytes per product MEASURED IN THIS RUN: two child processes, one per counter (the guide's HBM / rocprofv3 section:
+    separate --pmc passes), each `rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --workload W --steps 2 …` on the
+    same seeded inputs; per kernel instantiation the mean counter value per launch, summed over the instantiations of one
+    product (one launch of each), FETCH_SIZE (KB) doubled — on gfx950 it counts half the bytes of 16-byte-per-lane reads,
+    MI355X_MICROARCH.md HBM section — and WRITE_SIZE (KB) as it is.  Returns (bytes, {counter: {kernel: KB}}) or (None, reason):
+    any failure (no rocprofv3, a time-out, a refused counter) leaves the bench line to the committed record."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="mi_bench_pmc_", dir="/tmp")
+    per = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, str(REPO / "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-live-pmc"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, f"the {counter} pass took longer than {timeout_s} s"
+            if r.returncode != 0:
+                return None, f"the {counter} pass ended with code {r.returncode}"
+            files = glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"the {counter} pass wrote no counter file"
+            by = {}
+            for row in csv.DictReader(open(max(files, key=os.path.getmtime))):
+                if "spmm" in row["Kernel_Name"] and row.get("Counter_Name", counter) == counter:
+                    k = row["Kernel_Name"].split("(int const")[0].replace("void (anonymous namespace)::", "")
+                    by.setdefault(k, []).append(float(row["Counter_Value"]))
+            if not by:
+                return None, f"the {counter} pass saw no SpMM kernel"
+            per[counter] = {k: sum(v) / len(v) for k, v in by.items()}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch_kb, write_kb = sum(per["FETCH_SIZE"].values()), sum(per["WRITE_SIZE"].values())
+    return (2.0 * fetch_kb + write_kb) * 1024.0, per
+
+
 def committed_beyond_l2_share(workload):
     """Share of a product's algorithmic bytes that left the L2s in the committed PMC passes (profiles/pmc_traffic.json:
     fabric-side bytes / algorithmic bytes, capped at 1) — a property of the matrix and the plan (which gathers meet in an
@@ -371,6 +424,9 @@ def main():
                          "independent direct sends to every peer; try-p2p: as auto, plus p2p if a probe of direct sends in "
                          "its own process group (short timeout) succeeds on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="N = 1: do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes behind the timed "
+                         "region, ~20 s each); the committed record of the same sources is quoted instead, or null")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
@@ -594,6 +650,18 @@ def main():
             kernels_ms_per_step = compute_only_ms
         achieved = local_bytes_alg / (kernels_ms_per_step * 1e-3) / 1e9
         traffic, traffic_dram = committed_traffic(args.workload, kernel_name) if world == 1 else (None, None)
+        traffic_source = None if traffic is None else "profiles/pmc_traffic.json (committed passes of this command at these very sources)"
+        live_detail = None
+        if world == 1 and not args.no_live_pmc and os.environ.get("MI_BENCH_LIVE_PMC", "1") != "0" and not profiler_attached():
+            try:
+                live, live_detail = live_traffic(args.workload)
+            except Exception as e:  # noqa: BLE001  (nothing here may cost the bench line)
+                live, live_detail = None, f"{type(e).__name__}: {e}"
+            if live is not None and any(kernel_name in k for k in live_detail["FETCH_SIZE"]):
+                traffic = live
+                traffic_source = "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run, behind the timed region"
+            elif live is not None:
+                live_detail = f"the passes did not see {kernel_name}"
         cache_resident = 4 * K * N <= (256 << 20)
         peak = CACHE_GATHER_PEAK_GBS if cache_resident else HBM_PEAK_GBS
         beyond_l2 = committed_beyond_l2_share(args.workload) if (cache_resident and world == 1) else None
@@ -674,6 +742,8 @@ def main():
                                  "(FETCH_SIZE counts those hits), priced against the 8 TB/s HBM spec peak; the guide's "
                                  "pure-HBM random-row gather ceiling is 5.5-5.8 TB/s, streaming 6.29 TB/s"),
                 "traffic": traffic, "traffic_dram": traffic_dram,
+                "traffic_source": traffic_source,
+                "traffic_live_detail": live_detail,
                 "frac_dram_only": None if not traffic_dram else round(traffic_dram / (kernels_ms_per_step * 1e-3) / 1e9 / peak, 4),
                 "kernel_ms_per_step": round(kernels_ms_per_step, 4),
                 "kernel_ms_per_step_median": round(float(np.median(step_ms)), 4),
@@ -682,10 +752,11 @@ def main():
                 "algorithmic_bytes_per_step": local_bytes_alg,
                 "note": "achieved = algorithmic bytes of one product / summed duration of its "
                         f"{launches_per_step} back-to-back launch(es) (HIP events on the launch stream); "
-                        "traffic = fabric-side PMC bytes per product (Infinity-Cache hits included), traffic_dram = the "
-                        "DRAM-side share, both from profiles/pmc_traffic.json and null unless that record was taken "
-                        "with these very sources (fingerprint of bench.py + csrc/spmm_* sources) and this kernel; "
-                        "frac_dram_only = traffic_dram / time / peak",
+                        "traffic = fabric-side PMC bytes per product (Infinity-Cache hits included; 2 x FETCH_SIZE + "
+                        "WRITE_SIZE, KB), measured in this run by two rocprofv3 --pmc child passes where traffic_source "
+                        "says live, else from profiles/pmc_traffic.json — null unless that record was taken with these "
+                        "very sources (fingerprint of bench.py + csrc/spmm_* sources) and this kernel; traffic_dram = the "
+                        "DRAM-side share (not observable from rocprofv3 on this part: null); frac_dram_only = traffic_dram / time / peak",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
