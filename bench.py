@@ -91,6 +91,22 @@ def profiler_attached():
     return any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in env) or "rocprofiler" in env.get("LD_PRELOAD", "")
 
 
+def run_group(cmd, cwd, env, timeout_s):
+    """Runs `cmd` in a process group of its own, output discarded; its exit code, or None after `timeout_s` — the whole group
+    (the profiler AND the program it started) is then killed: nothing of a pass that hung may stay on the GPU."""
+    import signal
+    p = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+    try:
+        return p.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
+        p.wait()
+        return None
+
+
 def live_traffic(workload, timeout_s=150):
     """HBM-side bytes per product MEASURED IN THIS RUN: two child processes, one per counter (the guide's HBM / rocprofv3 section:
     separate --pmc passes), each `rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --workload W --steps 2 …` on the
@@ -114,12 +130,11 @@ def live_traffic(workload, timeout_s=150):
                    sys.executable, str(REPO / "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "1",
                    "--no-cpu-baseline", "--no-live-pmc"]
             env = dict(os.environ, TMPDIR="/tmp")
-            try:
-                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
-            except subprocess.TimeoutExpired:
+            rc = run_group(cmd, cwd="/tmp", env=env, timeout_s=timeout_s)
+            if rc is None:
                 return None, f"the {counter} pass took longer than {timeout_s} s"
-            if r.returncode != 0:
-                return None, f"the {counter} pass ended with code {r.returncode}"
+            if rc != 0:
+                return None, f"the {counter} pass ended with code {rc}"
             files = glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True)
             if not files:
                 return None, f"the {counter} pass wrote no counter file"

@@ -115,17 +115,16 @@ def test_live_traffic_sums_one_launch_of_each_instantiation_and_doubles_fetch(mo
     """bench.live_traffic: two child passes (FETCH_SIZE, WRITE_SIZE), per kernel instantiation the mean per launch, one launch
     of each per product, 2 x FETCH + WRITE in KB (the guide's gfx950 correction) — shown on counter files written by a stand-in
     for the child process; a failing pass leaves (None, reason) and never raises."""
-    import subprocess as sp
     bench = _load_bench()
     if not os.path.exists("/opt/rocm/bin/rocprofv3"):
         pytest.skip("no rocprofv3 in this image")
     calls = []
 
-    def fake_run(cmd, **kw):
+    def fake_run(cmd, cwd, env, timeout_s):
         counter = cmd[cmd.index("--pmc") + 1]
         out = Path(cmd[cmd.index("-d") + 1]) / "host" / "1"
         out.mkdir(parents=True)
-        assert cmd[cmd.index("--") + 1] == sys.executable and "--no-live-pmc" in cmd and "--no-cpu-baseline" in cmd and kw["cwd"] == "/tmp"
+        assert cmd[cmd.index("--") + 1] == sys.executable and "--no-live-pmc" in cmd and "--no-cpu-baseline" in cmd and cwd == "/tmp"
         k1 = "void (anonymous namespace)::spmm_wave_row_panel_kernel<false, 1, 8, false>(int const*, int const*)"
         k2 = "void (anonymous namespace)::spmm_wave_row_panel_kernel<true, 1, 8, false>(int const*, int const*)"
         k3 = "void (anonymous namespace)::spmm_staged_rows_kernel<8>(int const*, int const*)"
@@ -136,20 +135,24 @@ def test_live_traffic_sums_one_launch_of_each_instantiation_and_doubles_fetch(mo
             for k, v in rows:
                 f.write(f'"{k}","{counter}",{v}\n')
         calls.append(counter)
-        return sp.CompletedProcess(cmd, 0, b"", b"")
+        return 0
 
-    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(bench, "run_group", fake_run)
     got, detail = bench.live_traffic("c3")
     assert calls == ["FETCH_SIZE", "WRITE_SIZE"]
     assert got == (2.0 * (101.0 + 50.0 + 1.0) + 20.0) * 1024.0
     assert set(detail) == {"FETCH_SIZE", "WRITE_SIZE"} and len(detail["FETCH_SIZE"]) == 3
-    monkeypatch.setattr(bench.subprocess, "run", lambda cmd, **kw: sp.CompletedProcess(cmd, 3, b"", b"boom"))
+    monkeypatch.setattr(bench, "run_group", lambda cmd, cwd, env, timeout_s: 3)
     assert bench.live_traffic("c3") == (None, "the FETCH_SIZE pass ended with code 3")
-
-    def slow(cmd, **kw):
-        raise sp.TimeoutExpired(cmd, kw["timeout"])
-    monkeypatch.setattr(bench.subprocess, "run", slow)
-    assert bench.live_traffic("c3", timeout_s=5)[0] is None
+    monkeypatch.setattr(bench, "run_group", lambda cmd, cwd, env, timeout_s: None)
+    assert bench.live_traffic("c3", timeout_s=5) == (None, "the FETCH_SIZE pass took longer than 5 s")
+    monkeypatch.undo()
+    # the real runner: exit codes pass through; a program that outlives the limit is killed with its whole process group
+    assert bench.run_group([sys.executable, "-c", "import sys; sys.exit(7)"], cwd="/tmp", env=dict(os.environ), timeout_s=60) == 7
+    t0 = __import__("time").time()
+    assert bench.run_group([sys.executable, "-c", "import subprocess, sys, time; subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(60)']); time.sleep(60)"],
+                           cwd="/tmp", env=dict(os.environ), timeout_s=2) is None
+    assert __import__("time").time() - t0 < 30
     monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "x")
     assert bench.profiler_attached()
 
