@@ -81,7 +81,7 @@ def test_schedule_is_a_permutation_by_descending_length_class(cmm, dev):
         cmm.spmm_schedule(t(rowptr, dev)[:-1], nnz, M, 128)
 
 
-@pytest.mark.parametrize("N", [256, 128, 100, 64, 602, 512, 40, 33, 2])
+@pytest.mark.parametrize("N", [256, 128, 100, 64, 602, 512, 40, 33, 2, 8, 16, 320])
 def test_scheduled_product_equals_the_plain_product_and_the_oracle(cmm, dev, oracle_mod, N):
     """Pareto row lengths with empty rows and rows beyond the long-row threshold: the scheduled product has the bits of the
     unscheduled one under every long-row rule and with a bias, with the heavy launch on the side stream, in line, for every
