@@ -208,7 +208,9 @@ const char* mi_spmm_variant_name(int variant);
  *     mi_spmm_schedule_workspace_bytes(M) is only used during the call.  col may be NULL (no locality pass).  Builds on
  *     `stream` and SYNCHRONISES it (reads ≈ 1.5 KiB back: the class table, the window statistics): inspection time, not
  *     capturable.  N: the dense width the schedule will mostly be used with.
- *   Products on one schedule must be ordered on one stream (they share its side stream and fork / join events).
+ *   Products on one schedule must be ordered on one stream (they share its fork / join events).  The side stream itself is ONE per
+ *   device for every schedule of the process (a stream per schedule ran out of hardware queues): unrelated products may see a
+ *   false order between their ordinary launches, nothing else.
  *   mi_spmm_schedule_info: info[12] = {rows, heavy slots, heavy length, non-empty classes, lower bound of the longest row,
  *     flags (1: has a side stream; 2: ACTIVE — an order costs the locality of consecutive rows, so a matrix of short, alike
  *     rows keeps its products unscheduled: active with heavy rows, with a locality order, or mean ≥ 16 entries with ≥ 2 % of the

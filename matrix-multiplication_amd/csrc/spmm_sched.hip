@@ -23,6 +23,8 @@
 // scatter: tiles keep their order inside a bucket, so a later pass by class keeps the earlier pass's column order); creating a
 // schedule reads the class table and two window statistics back (≈ 1.5 KiB) and therefore synchronises the stream —
 // inspection time, like cusparse_inspect's checks.
+#include <map>
+#include <mutex>
 #include <new>
 
 #include "spmm_device.h"
@@ -244,11 +246,33 @@ int32_t heavy_length_for(int64_t nnz, int32_t rows) {
   return (int32_t)(h < 128 ? 128 : (h > mi::kLongRowThreshold ? mi::kLongRowThreshold : h));
 }
 
+// ONE side stream per device for every schedule of the process, created with the first schedule that needs it and never
+// destroyed.  A stream per schedule ran out of hardware queues: the runtime deals streams round-robin to a handful of them, and
+// with a dozen schedules alive (tools/bench_degree_skew.py keeps the automatic ones of its earlier cases) a new schedule's side
+// stream shared its queue with the caller's stream — the launches it was made to run side by side ran one behind the other (reddit-like
+// unclipped: 44.8 ms in the full sweep, 39.2 on its own).  Sharing costs unrelated products a false order between their ordinary
+// launches, never correctness: every product forks into the stream and joins out of it by its own events.
+hipStream_t shared_side_stream(hipError_t* err) {
+  static std::mutex m;
+  static std::map<int, hipStream_t> streams;
+  int dev = 0;
+  *err = hipGetDevice(&dev);
+  if (*err != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(m);
+  auto it = streams.find(dev);
+  if (it != streams.end()) return it->second;
+  hipStream_t s = nullptr;
+  *err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (*err != hipSuccess) return nullptr;
+  streams[dev] = s;
+  return s;
+}
+
 int ensure_side_stream(mi_spmm_schedule* sc) {
-  if (sc->rs.side != nullptr) return MI_OK;
-  hipError_t e = hipStreamCreateWithFlags(&sc->rs.side, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->rs.fork, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->rs.join, hipEventDisableTiming);
+  hipError_t e = hipSuccess;
+  if (sc->rs.side == nullptr) sc->rs.side = shared_side_stream(&e);
+  if (e == hipSuccess && sc->rs.fork == nullptr) e = hipEventCreateWithFlags(&sc->rs.fork, hipEventDisableTiming);
+  if (e == hipSuccess && sc->rs.join == nullptr) e = hipEventCreateWithFlags(&sc->rs.join, hipEventDisableTiming);
   return e == hipSuccess ? MI_OK : mi::record_hip_error(e);
 }
 
@@ -413,7 +437,6 @@ int mi_spmm_schedule_destroy(mi_spmm_schedule_t* sc) {
   if (!sc) return MI_OK;
   if (sc->rs.fork) (void)hipEventDestroy(sc->rs.fork);
   if (sc->rs.join) (void)hipEventDestroy(sc->rs.join);
-  if (sc->rs.side) (void)hipStreamDestroy(sc->rs.side);
   delete sc;
   return MI_OK;
 }
@@ -440,8 +463,7 @@ int mi_spmm_schedule_set_heavy(mi_spmm_schedule_t* sc, int32_t heavy_len, int us
   set_heavy(sc, heavy_len, false);
   sc->rs.active = true;  // a pinned heavy length is a request to run scheduled
   if (!use_side_stream && sc->rs.side) {  // (tests, A/B: the heavy launch in line, ahead of the rest)
-    (void)hipStreamDestroy(sc->rs.side);
-    sc->rs.side = nullptr;
+    sc->rs.side = nullptr;  // (the stream is the process's, not the schedule's)
   }
   if (use_side_stream) return ensure_side_stream(sc);
   return MI_OK;
