@@ -357,6 +357,46 @@ def test_plain_entry_points_build_their_own_schedule_without_synchronising(cmm, 
     cmm.auto_schedule_clear()
 
 
+def test_scheduled_products_fuzz_against_the_plain_product_and_the_oracle(cmm, dev, oracle_mod):
+    """Random skewed matrices through the scheduled product — random widths (every column-part count of the staged kernel, widths
+    that cannot move float4s), a random pinned heavy length (0: every row a heavy slot … none), rows around and beyond the long-row
+    threshold (S = 1 and S > 1), the bias, prepared and scanned lists (long_rows −1 / 1) and the plain chain (0): the bits of the
+    unscheduled product every time, and the oracle's on every third case.  MI_FUZZ_CASES / MI_FUZZ_SEED as the other fuzz tests."""
+    import os
+    g = np.random.Generator(np.random.PCG64(int(os.environ.get("MI_FUZZ_SEED", "909"))))
+    cases = int(os.environ.get("MI_FUZZ_CASES", "10"))
+    thr = cmm.long_row_threshold()
+    for case in range(cases):
+        M = int(g.integers(150, 2500))
+        K = int(g.choice([12_000, 40_000, 70_000]))
+        N = int(g.choice([4, 8, 16, 20, 36, 64, 68, 100, 128, 132, 192, 256, 260, 320, 512, 700, 33, 602]))
+        lens = np.minimum(_pareto_lens(M, int(g.integers(4, 60)), K, seed=int(g.integers(1 << 30))), K)
+        for _ in range(int(g.integers(0, 4))):
+            lens[int(g.integers(0, M))] = min(K, int(g.choice([thr, thr + 1, thr + 700, 3 * thr, 65536, 66000])))
+        while int(lens.sum()) * N > 120_000_000:
+            lens[int(np.argmax(lens))] //= 2
+        rowptr, col, val = _random_rows_csr(M, K, lens, seed=int(g.integers(1 << 30)))
+        B = g.random((K, N), dtype=np.float32) - 0.5
+        bias = g.random(N, dtype=np.float32) if g.integers(0, 3) == 0 else None
+        d_rp, d_col, d_val, d_B = (t(x, dev) for x in (rowptr, col, val, B))
+        d_bias = None if bias is None else t(bias, dev)
+        sched = cmm.spmm_schedule(d_rp, len(val), M, N)
+        heavy = int(g.choice([-1, 0, 8, 40, 300, 3000, 1 << 30]))
+        if heavy >= 0:
+            sched.set_heavy(heavy, bool(g.integers(0, 2)))
+        what = (case, M, K, N, len(val), sorted(int(x) for x in lens if x >= thr), heavy, bias is not None)
+        for long_rows in (-1, 1, 0):
+            kw = {} if bias is None else {"bias": d_bias}
+            plain = _product(cmm, dev, None, d_rp, d_col, d_val, M, K, d_B, long_rows=long_rows, **kw)
+            got = _product(cmm, dev, sched, d_rp, d_col, d_val, M, K, d_B, long_rows=long_rows, **kw)
+            assert torch.equal(got.view(torch.int32), plain.view(torch.int32)), (long_rows,) + what
+            if case % 3 == 0 and long_rows != 1:
+                want = oracle_mod.spmm_csr(rowptr, col, val, M, K, B) if (long_rows == 0 or N < 4) else oracle_mod.spmm_csr_long(rowptr, col, val, M, K, B)
+                if bias is not None:
+                    want = want + bias[None, :]
+                assert np.array_equal(plain.cpu().numpy().view(np.uint32), want.view(np.uint32)), (long_rows,) + what
+
+
 def test_process_exit_with_live_schedules_and_handles():
     """A program that never calls cusparse_clean / auto_schedule_clear must still END cleanly: handles and automatic schedules own
     HIP streams and events, which the extension releases from an atexit hook (left to static destructors they were destroyed
