@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void spmm_wave_row_kernel(
 
   int p = rp[row];
   const int end = rp[row + 1];
-  if (end - p > la.thresh) {  // left to spmm_long_rows_kernel
+  if (end - p > la.thresh) {  // left to the listed-rows launch (spmm_heavy.hip)
     if (lane == 0) long_list_append(la, (int)row, end - p);
     return;
   }
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void spmm_wave_row_vl_kernel(
 
   const int start = rp[row];
   const int end = rp[row + 1];
-  if (end - start > la.thresh) {  // left to spmm_long_rows_kernel
+  if (end - start > la.thresh) {  // left to the listed-rows launch (spmm_heavy.hip)
     if (lane == 0) long_list_append(la, (int)row, end - start);
     return;
   }
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void spmm_group_kernel(
     start = rp[row];
     end = rp[row + 1];
   }
-  const bool skipped = end - start > la.thresh;  // left to spmm_long_rows_kernel
+  const bool skipped = end - start > la.thresh;  // left to the listed-rows launch (spmm_heavy.hip)
   if (skipped) {
     if (lists && gl == 0 && item == 0) long_list_append(la, (int)row, end - start);
     end = start;
@@ -706,7 +706,7 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
     // with more gathers in flight per row, on the schedule's side stream BESIDE the launch(es) of the rest.  Per-row
     // arithmetic is that of the unscheduled plan: the same bits.
     const int heavy_slots = sched->heavy < 0 ? 0 : (sched->heavy > M ? M : sched->heavy);
-    const int heavy = sh.vec4_ok ? heavy_slots : 0;  // the heavy-row kernel moves float4s: other shapes keep every row in the ordinary launch (longest first all the same)
+    const int heavy = N >= 4 ? heavy_slots : 0;  // (narrower products: the narrow kernel, its own order, no heavy launch)
     LongArg lh = la, lr = la;
     lh.order = sched->order, lh.nslots = heavy;
     lh.adapt = nullptr;  // one pass, every column
@@ -718,8 +718,8 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
     const bool early_list = split && !prepared && heavy_slots > 0 && la.ws != nullptr;
     const bool fork = sched->side != nullptr && sched->fork != nullptr && sched->join != nullptr &&
                       (heavy > 0 || (split && prepared) || early_list);
-    // The few big launches — the listed long rows' and the heavy rows' kernel (8 waves + 130 KB of LDS per workgroup; 16-wave
-    // workgroups for shapes that cannot move float4s) — go FIRST and on the caller's stream: a workgroup of that size only finds room on a CU before the
+    // The few big launches — the listed long rows' and the heavy rows' kernel (8 waves + 130 KB of LDS per workgroup) — go FIRST
+    // and on the caller's stream: a workgroup of that size only finds room on a CU before the
     // ordinary launch has filled every wave slot with its small ones.  The ordinary launch(es) follow on the schedule's side
     // stream and fill what is left; the caller's stream then waits for them.
     // (the scan goes BEFORE the fork: the ordinary launch must not get to the CUs ahead of the big workgroups)
@@ -738,19 +738,18 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
       // the counters are zeroed by a memset behind the launch, not by its last workgroup: counting 700 workgroups that have
       // nothing to sum through one atomic held the heavy slots' workgroups back until the ordinary launch had taken the CUs
       // (measured: 245 µs for this launch against 131 with a prepared list)
-      st = heavy > 0 ? launch_staged_rows(ws, lw, false, lh, rowptr, col, val, B, C, N, ldb, ldc, bias, s)
-                     : launch_long_rows(sh.vec4_ok, ws, lw, rowptr, col, val, B, C, N, ldb, ldc, bias, false, s);
+      st = launch_staged_rows(ws, lw, false, lh, rowptr, col, val, B, C, N, ldb, ldc, bias, s);
       if (st != MI_OK) return st;
       MI_HIP_TRY(hipMemsetAsync(ws, 0, 16, s));
       long_rows_done = true;
       lr.ws = nullptr;  // its rows beyond the threshold (a stale schedule may leave some there) are on the list already: skipped only
     // a PREPARED list of the rows beyond the long-row threshold: their kernel needs nothing from this product's other launches
-    } else if (split && prepared && heavy > 0) {  // (heavy > 0: a float4 shape) both in one launch — neither waits for the other
+    } else if (split && prepared && heavy > 0) {  // both in one launch — neither waits for the other
       st = launch_staged_rows(ws, lw, false, lh, rowptr, col, val, B, C, N, ldb, ldc, bias, s);
       if (st != MI_OK) return st;
       long_rows_done = true;
     } else if (split && prepared) {
-      st = launch_long_rows(sh.vec4_ok, ws, lw, rowptr, col, val, B, C, N, ldb, ldc, bias, false, s);
+      st = launch_long_rows(ws, lw, rowptr, col, val, B, C, N, ldb, ldc, bias, false, s);
       if (st != MI_OK) return st;
       long_rows_done = true;
     } else if (heavy > 0) {
@@ -767,7 +766,7 @@ int spmm_dispatch(int variant, const int32_t* rowptr, const int32_t* col, const 
   if (st != MI_OK || !split || long_rows_done) return st;
   // One follow-up launch: the listed rows, their combination (by the last workgroup of each row) and, for a list
   // built by this product, the reset of the counters.  With no long row every workgroup reads three zeros and exits.
-  return launch_long_rows(sh.vec4_ok, ws, lw, rowptr, col, val, B, C, N, ldb, ldc, bias, !prepared, s);
+  return launch_long_rows(ws, lw, rowptr, col, val, B, C, N, ldb, ldc, bias, !prepared, s);
 }
 
 }  // namespace mi

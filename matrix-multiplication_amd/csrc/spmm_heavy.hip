@@ -33,6 +33,10 @@ namespace {
 
 using mi::LongArg;
 
+// four floats of a row of B / C / a partial row at ANY 4-byte alignment (N % 4 != 0, odd leading dimensions, offset views): a
+// dword-aligned global_load / store_dwordx4, which gfx950 serves; where the address is 16-byte aligned it is the same instruction
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
 constexpr int kStageThreads = 512;
 constexpr int kStageCols = 64;                     // columns per workgroup when rows are few: one chain wave, seven loader waves
 constexpr int kStageColsWide = 128;                // … when there are heavy rows enough to fill the chip: two and six
@@ -172,7 +176,8 @@ __device__ __forceinline__ float staged_sum(const int* __restrict__ col, const f
   // `s_waitcnt vmcnt(0)` in front of every one of them: eight dependent trips to memory per chunk instead of one (measured: × 1.6).
   const int lt = tid - CW * 64;
   const int LT = kStageThreads - CW * 64;  // loader threads
-  const int NQ = ncols >> 2;
+  const int NQ = (ncols + 3) >> 2;  // the last quad of a width that is no multiple of four is shifted back to end at the last column: it
+                                    // overlaps its neighbour, the shared columns land twice in the image with the same bits (ncols ≥ 4)
   int qe[KQ], qc[KQ];
 #pragma unroll
   for (int k = 0; k < KQ; ++k) {
@@ -180,7 +185,7 @@ __device__ __forceinline__ float staged_sum(const int* __restrict__ col, const f
     q = q < E * NQ ? q : E * NQ - 1;
     const int blk = q / (8 * NQ), rr = q - blk * 8 * NQ;
     qe[k] = 8 * blk + (rr & 7);
-    qc[k] = rr >> 3;
+    qc[k] = 4 * (rr >> 3) + 4 <= ncols ? 4 * (rr >> 3) : ncols - 4;  // first column of the quad
   }
   // B rows travel two chunks ahead of the chain (register sets xa / xb, taking turns), col / val three chunks ahead
   f32x4 xa[KQ], xb[KQ];
@@ -195,18 +200,18 @@ __device__ __forceinline__ float staged_sum(const int* __restrict__ col, const f
   }
 #define MI_STAGE_ISSUE(X_, XV_)                                                      \
   _Pragma("unroll") for (int k = 0; k < KQ; ++k) {                                   \
-    X_[k] = *reinterpret_cast<const f32x4*>(Bp + (long)cn[k] * ldb + 4 * qc[k]);     \
+    X_[k] = *reinterpret_cast<const f32x4_u*>(Bp + (long)cn[k] * ldb + qc[k]);       \
     XV_[k] = vn[k];                                                                  \
   }
   // (entries of the image beyond a short chunk's count receive copies of its last entry: the chain never reads them)
 #define MI_STAGE_LAND(X_, XV_, IMG_, VALS_)                            \
   _Pragma("unroll") for (int k = 0; k < KQ; ++k) {                     \
-    const int at_ = (IMG_) + 4 * qc[k] * EP + qe[k];                   \
+    const int at_ = (IMG_) + qc[k] * EP + qe[k];                       \
     stage_lds[at_] = X_[k].x;                                          \
     stage_lds[at_ + EP] = X_[k].y;                                     \
     stage_lds[at_ + 2 * EP] = X_[k].z;                                 \
     stage_lds[at_ + 3 * EP] = X_[k].w;                                 \
-    if (qc[k] == 0) stage_lds[(VALS_) + qe[k]] = XV_[k]; /* one lane per entry */ \
+    if (qc[k] == 0) stage_lds[(VALS_) + qe[k]] = XV_[k]; /* one lane per entry: the first quad's */ \
   }
   // One step: chunk A lands from register set X_ in image I_; the barrier; chunk C (two ahead) takes the freed registers,
   // col / val of chunk D (three ahead) follow.
@@ -289,8 +294,9 @@ __device__ __forceinline__ void staged_heavy_unit(const int* __restrict__ rowptr
     if (threadIdx.x == 0 && part == 0) long_list_append(h.la, row, end - start);
     return;
   }
-  const int n0 = part * h.cols;
-  const int ncols = N - n0 < h.cols ? N - n0 : h.cols;
+  int n0 = part * h.cols;
+  int ncols = N - n0 < h.cols ? N - n0 : h.cols;
+  if (ncols < 4) n0 = N - 4, ncols = 4;  // a last part of 1 … 3 columns moves back over its neighbour's (computed twice, the same bits)
   const StageRange r = {start, end, 1L << 40, 1L << 40, 1, h.E};
   const float tot = staged_sum<KQ>(col, val, B + n0, ldb, ncols, r);
   if ((int)threadIdx.x < ncols) {
@@ -300,7 +306,7 @@ __device__ __forceinline__ void staged_heavy_unit(const int* __restrict__ rowptr
   }
 }
 
-// One wave per chain (the form of spmm_long_rows_kernel, for eight waves): group g of a row's S — chains 16g … 16g + 15, two
+// One wave per chain (the form of the 16-wave kernel of rounds 2 – 5, for eight waves): group g of a row's S — chains 16g … 16g + 15, two
 // per wave one after the other, sixteen gathers of whole rows of B in flight per wave — for every column, 256 per pass; the
 // sixteen chain sums meet in LDS and are added in order.  S = 1: the row of C (+ bias); else the group's partial row.
 __device__ __forceinline__ void wave_chain_group(const int* __restrict__ col, const float* __restrict__ val,
@@ -313,8 +319,8 @@ __device__ __forceinline__ void wave_chain_group(const int* __restrict__ col, co
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const long stride = (long)kLongWaves * S * kLongChunk;
   for (int n0 = 0; n0 < N; n0 += 256) {
-    const int c0 = n0 + lane * 4;
-    const bool on = c0 < N;
+    const bool on = n0 + lane * 4 < N;
+    const int c0 = n0 + lane * 4 + 4 <= N ? n0 + lane * 4 : N - 4;  // the partial last quad, shifted back (N ≥ 4)
     for (int h = 0; h < 2; ++h) {
       const int w = 8 * h + wave;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -333,7 +339,7 @@ __device__ __forceinline__ void wave_chain_group(const int* __restrict__ col, co
     _Pragma("unroll") for (int u = 0; u < (U_); ++u) {                                                            \
       const int c = __builtin_amdgcn_readlane(myc, i + u);                                                        \
       v[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), i + u));           \
-      if (on) x[u] = *reinterpret_cast<const f32x4*>(B + (long)c * ldb + c0);                                     \
+      if (on) x[u] = *reinterpret_cast<const f32x4_u*>(B + (long)c * ldb + c0);                                   \
     }                                                                                                             \
     _Pragma("unroll") for (int u = 0; u < (U_); ++u) if (on) acc = fma4(v[u], x[u], acc);                         \
   }
@@ -351,10 +357,10 @@ __device__ __forceinline__ void wave_chain_group(const int* __restrict__ col, co
 #pragma unroll
       for (int w = 1; w < kLongWaves; ++w) tot += part[w * 64 + lane];
       if (S == 1) {
-        if (bias) tot += *reinterpret_cast<const f32x4*>(bias + c0);
-        __builtin_nontemporal_store(tot, reinterpret_cast<f32x4*>(C + (long)row * ldc + c0));
+        if (bias) tot += *reinterpret_cast<const f32x4_u*>(bias + c0);
+        __builtin_nontemporal_store(tot, reinterpret_cast<f32x4_u*>(C + (long)row * ldc + c0));
       } else {
-        *reinterpret_cast<f32x4*>(partial + (long)(pb + g) * N + c0) = tot;
+        *reinterpret_cast<f32x4_u*>(partial + (long)(pb + g) * N + c0) = tot;
       }
     }
     __syncthreads();
@@ -365,8 +371,8 @@ __device__ __forceinline__ void wave_chain_group(const int* __restrict__ col, co
 // work is (slot t, column part) — group g of its row's S, chains 16g … 16g + 15 one after the other at the CU's gather rate,
 // added in that order, for one part of the columns.  S = 1: that is the row's sum.  Else the S group sums meet in the workspace
 // and whichever of the S · parts units delivers LAST adds them in order g = 0 … S−1 for every column (an arrival counter per
-// row; agent-scope release by every deliverer, acquire by the last) — the arithmetic of spmm_long_rows_kernel, which sums these
-// rows with one wave per chain and remains for the shapes that cannot move float4s.
+// row; agent-scope release by every deliverer, acquire by the last) — the arithmetic of the 16-wave kernel of rounds 2 – 5 (one wave
+// per chain), which this one replaces for every width.
 template <int KQ>
 __device__ __forceinline__ void staged_list_units(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                   const float* __restrict__ val, const float* __restrict__ B,
@@ -396,8 +402,9 @@ __device__ __forceinline__ void staged_list_units(const int* __restrict__ rowptr
     if (bulk) {
       wave_chain_group(col, val, B, C, N, ldb, ldc, bias, partial, row, start, end, g, S, pb);
     } else {
-      const int n0 = part * kStageCols;
-      const int ncols = N - n0 < kStageCols ? N - n0 : kStageCols;
+      int n0 = part * kStageCols;
+      int ncols = N - n0 < kStageCols ? N - n0 : kStageCols;
+      if (ncols < 4) n0 = N - 4, ncols = 4;  // (as the heavy slots' last part)
       const StageRange r = {start + (long)g * kLongWaves * kLongChunk, end, kLongChunk, (long)kLongWaves * S * kLongChunk,
                             kLongWaves, E};
       const float tot = staged_sum<KQ>(col, val, B + n0, ldb, ncols, r);
@@ -482,7 +489,7 @@ StageShape stage_shape(int N, int cols_per_wg) {
   StageShape sh;
   sh.parts = (N + cols_per_wg - 1) / cols_per_wg;
   const int cols = N < cols_per_wg ? N : cols_per_wg;
-  const int nq = cols / 4;
+  const int nq = (cols + 3) / 4;
   const long loaders = kStageThreads - 64 * ((cols + 63) / 64);
   int E = kStageMaxE;
   if ((long)(E + 4) * cols > kStageFloats) E = kStageFloats / cols - 4;
@@ -518,7 +525,7 @@ namespace mi {
 int launch_staged_rows(int* ws, const LongWs& lw, bool reset, const LongArg& heavy, const int32_t* rowptr, const int32_t* col,
                        const float* val, const float* B, float* C, int32_t N, int64_t ldb, int64_t ldc, const float* bias,
                        hipStream_t s) {
-  if (N < 4 || N % 4 != 0) return MI_EINVAL;  // (the dispatcher sends float4 shapes)
+  if (N < 4) return MI_EINVAL;  // (narrower products keep the narrow kernel's own order: the dispatcher never sends them)
   const int force = forced_cols();
   StagedList l = {};
   StagedHeavy h = {};

@@ -15,7 +15,7 @@ constexpr int kAdaptVerdicts = 16;       // ints the locality probe writes behin
 // What the kernels get: which rows to leave to the long-row kernel, where to list them, the locality verdicts, and —
 // scheduled launches — the order in which row slots map to rows.
 struct LongArg {
-  int thresh;               // rows with more non-zeros are left to spmm_long_rows_kernel
+  int thresh;               // rows with more non-zeros are left to the listed-rows launch (spmm_heavy.hip)
   int cap_e, cap_s, cap_p;  // list capacities (hold for any rowptr consistent with nnz)
   int* ws;                  // the list; nullptr: skip only (the list was prepared beforehand) or nothing is skipped
   const int* adapt;         // kAdaptSlots verdicts of spmm_locality_probe_kernel (L2-level panel plans with a workspace), or nullptr
@@ -33,12 +33,10 @@ LongWs long_ws_layout(int64_t nnz, int32_t N);
 // products without a prepared list)
 int launch_find_long_rows(const int32_t* rowptr, int32_t M, const LongArg& la, hipStream_t s);
 // the follow-up launch of a product that splits its long rows: sums the listed rows, combines, resets the counters
-int launch_long_rows(bool vec4, int* ws, const LongWs& lw, const int32_t* rowptr, const int32_t* col, const float* val,
-                     const float* B, float* C, int32_t N, int64_t ldb, int64_t ldc, const float* bias, bool reset,
-                     hipStream_t s);
-
-// the same sums for float4 shapes (N % 4 == 0, 16-byte aligned operands): one 8-wave workgroup per group of 16 chains and 64
-// columns, the chains staged through LDS at the CU's gather rate (spmm_heavy.hip); launch_long_rows sends vec4 shapes here
+int launch_long_rows(int* ws, const LongWs& lw, const int32_t* rowptr, const int32_t* col, const float* val, const float* B,
+                     float* C, int32_t N, int64_t ldb, int64_t ldc, const float* bias, bool reset, hipStream_t s);
+// (its body: one 8-wave workgroup per group of 16 chains and 64 columns, the chains staged through LDS at the CU's gather rate, or
+// one wave per chain once the list is long — spmm_heavy.hip; any width ≥ 4, any 4-byte alignment)
 int launch_long_rows_staged(int* ws, const LongWs& lw, const int32_t* rowptr, const int32_t* col, const float* val,
                             const float* B, float* C, int32_t N, int64_t ldb, int64_t ldc, const float* bias, bool reset,
                             hipStream_t s);
@@ -58,8 +56,7 @@ int launch_group_panels(int panels, const int* rowptr, const int* col, const flo
 // ---- heavy rows of a schedule (spmm_heavy.hip) ----------------------------------------------------------------------
 // One 8-wave workgroup per slot of la.order and 64 columns: the row's B rows gathered by the loader waves into LDS, up to 224
 // entries at a time, and summed from there by the chain wave — ONE chain per output element in CSR order (the same bits as every
-// other kernel).  N % 4 == 0, 16-byte aligned operands (the caller checks); rows beyond la.thresh are skipped and listed as
-// everywhere else.
+// other kernel).  N ≥ 4, any 4-byte alignment; rows beyond la.thresh are skipped and listed as everywhere else.
 int launch_heavy_rows(const int32_t* rowptr, const int32_t* col, const float* val, int32_t M, int32_t N, const float* B,
                       int64_t ldb, float* C, int64_t ldc, const float* bias, LongArg la, hipStream_t s);
 // both in ONE launch (a prepared list beside a schedule's heavy slots would otherwise wait for each other on the stream):

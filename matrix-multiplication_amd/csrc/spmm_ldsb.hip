@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_ldsb_kernel(
         st = rp[row];
         en = rp[row + 1];
       }
-      skip = en - st > long_thresh;  // left to spmm_long_rows_kernel
+      skip = en - st > long_thresh;  // left to the listed-rows launch (spmm_heavy.hip)
       if (skip) en = st;
     };
     // an entry travels as {byte offset of its B row in LDS, value}; positions beyond the row's end read as value −0 on
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_ldsq_kernel(
     st = *reinterpret_cast<const int*>(rp + o);
     en = *reinterpret_cast<const int*>(rp + (there ? o + 4u : 0u));
   };
-  auto finish_bounds = [&](int& st, int& en, bool& skip) {  // (skip: left to spmm_long_rows_kernel)
+  auto finish_bounds = [&](int& st, int& en, bool& skip) {  // (skip: left to the listed-rows launch (spmm_heavy.hip))
     skip = en - st > long_thresh;
     if (skip) en = st;
   };

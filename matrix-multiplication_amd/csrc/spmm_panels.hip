@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void spmm_wave_row_panel_kernel(
   float* Cl = C + row * ldc + lane * 4;
   const int start = rowptr[row];
   const int end = rowptr[row + 1];
-  if (end - start > la.thresh) {  // left to spmm_long_rows_kernel (in every pass)
+  if (end - start > la.thresh) {  // left to the listed-rows launch (spmm_heavy.hip) (in every pass)
     if (lists && lane == 0) long_list_append(la, (int)row, end - start);
     return;
   }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void spmm_group_panel_kernel(
     start = rowptr[row];
     end = rowptr[row + 1];
   }
-  const bool skipped = end - start > la.thresh;  // left to spmm_long_rows_kernel (in every pass)
+  const bool skipped = end - start > la.thresh;  // left to the listed-rows launch (spmm_heavy.hip) (in every pass)
   if (skipped) {
     if (FIRST && gl == 0) long_list_append(la, (int)row, end - start);
     end = start;

@@ -14,6 +14,7 @@ from bench_degree_skew import csr_from_lengths, pareto_lengths  # noqa: E402
 SHAPES = {"arxiv": (170_000, 128, 14), "reddit": (233_000, 602, 490), "products": (2_400_000, 100, 50), "c3skew": (1 << 20, 256, 105)}
 name, clip = sys.argv[1], int(sys.argv[2])
 M, N, mean = SHAPES[name]
+N = int(__import__('os').environ.get('MI_SKEW_N', N))  # (another dense width on the same matrix)
 dev = torch.device("cuda")
 lens = pareto_lengths(M, mean, clip, M, seed=3)
 rowptr, col, val = csr_from_lengths(lens, M, seed=4)
